@@ -1,0 +1,113 @@
+"""ctypes access to the CPU checkers (test infrastructure):
+
+  * `oracle/libwg_oracle.so`     -- this repo's C restatement (oracle/*.c)
+  * `oracle/_ref/libqld_ref.so`  -- the reference's own qld.cpp, compiled by
+                                    oracle/Makefile (present where the
+                                    reference tree was available at build time)
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+ORACLE_SO = os.path.join(ORACLE_DIR, "libwg_oracle.so")
+REF_SO = os.path.join(ORACLE_DIR, "_ref", "libqld_ref.so")
+REF_SYM = "_Z7ql0001_PiS_S_S_S_S_PdS0_S0_S0_S0_S0_S0_S0_S_S_S_S0_S_S_S_S0_"
+
+_dp = C.POINTER(C.c_double)
+_ip = C.POINTER(C.c_int)
+
+
+def _d(a):
+    return a.ctypes.data_as(_dp)
+
+
+def _i(a):
+    return a.ctypes.data_as(_ip)
+
+
+def build_oracle():
+    """(Re)build the oracle .so if a source is newer than it."""
+    srcs = [os.path.join(ORACLE_DIR, f) for f in os.listdir(ORACLE_DIR) if f.endswith((".c", ".h"))]
+    if (not os.path.exists(ORACLE_SO)) or any(os.path.getmtime(s) > os.path.getmtime(ORACLE_SO) for s in srcs):
+        subprocess.check_call(["make", "-s", "-C", ORACLE_DIR, "libwg_oracle.so"])
+    return ORACLE_SO
+
+
+_oracle = None
+_ref = None
+
+
+def oracle():
+    global _oracle
+    if _oracle is None:
+        _oracle = C.CDLL(build_oracle())
+    return _oracle
+
+
+def have_ref():
+    return os.path.exists(REF_SO)
+
+
+def ref():
+    global _ref
+    if _ref is None:
+        _ref = C.CDLL(REF_SO)
+    return _ref
+
+
+def oracle_ql(q, eps=1e-8, hist_cap=4096):
+    """Run the oracle's QL restatement on a qpgen dict."""
+    n, m = q["n"], q["m"]
+    x = np.zeros(n)
+    u = np.zeros(m + 2 * n)
+    ifail = C.c_int(-99)
+    iact = np.zeros(n, dtype=np.int32)
+    nact = C.c_int(0)
+    nit = C.c_int(0)
+    hist = np.zeros(hist_cap, dtype=np.int32)
+    hlen = C.c_int(0)
+    oracle().wgo_ql_solve(C.c_int(m), C.c_int(q["me"]), C.c_int(q["mmax"]), C.c_int(n), C.c_int(q["nmax"]),
+                          _d(q["C"]), _d(q["d"]), _d(q["A"]), _d(q["b"]), _d(q["xl"]), _d(q["xu"]),
+                          C.c_double(eps), _d(x), _d(u), C.byref(ifail), _i(iact), C.byref(nact),
+                          C.byref(nit), _i(hist), C.c_int(hist_cap), C.byref(hlen))
+    return dict(x=x, u=u, ifail=ifail.value, iact=iact[:nact.value].copy(), nact=nact.value,
+                n_iter=nit.value, hist=hist[:min(hlen.value, hist_cap)].copy(), hist_len=hlen.value)
+
+
+def ref_ql(q, eps=1e-8):
+    """Run the compiled reference ql0001_ (argument order of qld.hh:27-31;
+    workspace sizes as qp-problem.cpp:256-263).  Not re-entrant (static locals)."""
+    n, m = q["n"], q["m"]
+    Cc = q["C"].copy(order="F")
+    x = np.zeros(n)
+    mnn = m + 2 * n
+    u = np.zeros(mnn)
+    lwar = 2 * (3 * n * n // 2 + 10 * n + 2 * (m + 1) + 20000)
+    war = np.zeros(lwar)
+    liwar = 2 * n + 1000
+    iwar = np.zeros(liwar, dtype=np.int32)
+    iwar[0] = 1
+    ci = lambda v: C.byref(C.c_int(v))
+    ifail = C.c_int(-99)
+    fn = getattr(ref(), REF_SYM)
+    d = q["d"].copy()
+    A = q["A"].copy(order="F")
+    b = q["b"].copy()
+    xl = q["xl"].copy()
+    xu = q["xu"].copy()
+    fn(ci(m), ci(q["me"]), ci(q["mmax"]), ci(n), ci(q["nmax"]), ci(mnn),
+       _d(Cc), _d(d), _d(A), _d(b), _d(xl), _d(xu), _d(x), _d(u), ci(0), C.byref(ifail), ci(0),
+       _d(war), ci(lwar), _i(iwar), ci(liwar), C.byref(C.c_double(eps)))
+    # the final ordered active set is left in iwar[0..nact); nact itself is a
+    # static local, so recover it from the non-zero multipliers' count bound
+    return dict(x=x, u=u, ifail=ifail.value, iwar=iwar[:n].copy(), C_after=Cc)
+
+
+def same_bits(a, b):
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    b = np.ascontiguousarray(b, dtype=np.float64)
+    return a.shape == b.shape and np.array_equal(a.view(np.uint64), b.view(np.uint64))
