@@ -1,0 +1,236 @@
+// wg_capi.hip -- C ABI (include/wg_mpc.h) over the HIP kernels.  gfx950 only.
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/wg_mpc.h"
+#include "wg_ql_device.hpp"
+
+namespace {
+
+thread_local std::string g_err;
+int g_device = -1;
+int g_num_cu = 256;
+std::mutex g_mu;
+
+int fail(int code, const char *fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  g_err = buf;
+  return code;
+}
+
+#define HIP_TRY(expr)                                                            \
+  do {                                                                           \
+    hipError_t e_ = (expr);                                                      \
+    if (e_ != hipSuccess) return fail(WG_ERR_HIP, "%s: %s", #expr, hipGetErrorString(e_)); \
+  } while (0)
+
+int ensure_device() {
+  if (g_device >= 0) return WG_OK;
+  return wg_init(0);
+}
+
+// grow-only device scratch for the host-pointer entry points
+struct DevBuf {
+  void *p = nullptr;
+  size_t cap = 0;
+  int reserve(size_t bytes) {
+    if (bytes <= cap) return WG_OK;
+    if (p) (void)hipFree(p);
+    p = nullptr; cap = 0;
+    hipError_t e = hipMalloc(&p, bytes);
+    if (e != hipSuccess) return fail(WG_ERR_HIP, "hipMalloc(%zu): %s", bytes, hipGetErrorString(e));
+    cap = bytes;
+    return WG_OK;
+  }
+  void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+};
+DevBuf g_in, g_out;
+
+}  // namespace
+
+// ---------------------------------------------------------------------------
+// Dense batched QP kernel: one wavefront (= one workgroup) per QP, grid-stride.
+// Replaces ql0001_ (qld.hh:27-31) for B problems at once.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void wg_ql_dense_kernel(
+    int B, int nmax, int mmax, const int *__restrict__ n_arr, const int *__restrict__ m_arr,
+    const int *__restrict__ me_arr, const double *__restrict__ C, const double *__restrict__ dvec,
+    const double *__restrict__ A, const double *__restrict__ bvec, const double *__restrict__ xl,
+    const double *__restrict__ xu, double eps, double *__restrict__ x, double *__restrict__ u,
+    int *__restrict__ ifail, int *__restrict__ n_iter, int *__restrict__ iact, int *__restrict__ nact,
+    int *__restrict__ hist, int hist_cap, int *__restrict__ hist_len) {
+  extern __shared__ __attribute__((aligned(16))) double wg_lds[];
+  const int lane = threadIdx.x & 63;
+  for (int qp = blockIdx.x; qp < B; qp += gridDim.x) {
+    const int n = n_arr ? n_arr[qp] : nmax;
+    const int m = m_arr ? m_arr[qp] : mmax - 1;
+    const int me = me_arr ? me_arr[qp] : 0;
+    wg::QlDims D(n, m, m);
+    wg::QlView q;
+    q.carve(wg_lds, D, me);
+
+    // ---- stage the problem into LDS (coalesced 8-byte lanes) ----
+    const double *Cg = C + (size_t)qp * nmax * nmax;
+    const double *Ag = A + (size_t)qp * mmax * nmax;
+    for (int j = 0; j < n; ++j)
+      for (int i = lane; i < n; i += 64) Gm(i, j) = Cg[i + (size_t)j * nmax];
+    for (int i = 0; i < n; ++i)
+      for (int k = lane; k < m; k += 64) Am(k, i) = Ag[k + (size_t)i * mmax];
+    for (int i = lane; i < n; i += 64) {
+      q.d[i] = dvec[(size_t)qp * nmax + i];
+      q.xl[i] = xl[(size_t)qp * nmax + i];
+      q.xu[i] = xu[(size_t)qp * nmax + i];
+    }
+    for (int k = lane; k < m; k += 64) q.b[k] = -bvec[(size_t)qp * mmax + k];   // qld.cpp:469-475
+    WG_WSYNC();
+    // qld.cpp:442-444: c(nmax,nmax) == 0 -> eps (inside the n x n block only if nmax == n)
+    if (nmax == n && lane == 0 && fabs(Gm(n - 1, n - 1)) == 0.0) Gm(n - 1, n - 1) = eps;
+    WG_WSYNC();
+
+    int *hq = hist ? hist + (size_t)qp * hist_cap : nullptr;
+    wg::QlResult r = wg::ql_solve(q, eps, hq, hist_cap);
+
+    // ---- results ----
+    for (int i = lane; i < n; i += 64) x[(size_t)qp * nmax + i] = q.x[i];
+    if (u) {
+      double *uq = u + (size_t)qp * (mmax + 2 * nmax);
+      if (r.ifail == 0) {                                   // qld.cpp:520-536
+        for (int j = lane; j < m + 2 * n; j += 64) uq[j] = 0.0;
+        WG_WSYNC();
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        for (int i = lane; i < r.nact; i += 64) uq[q.iact[i] - 1] = q.lam[i];
+      }
+    }
+    if (iact)
+      for (int i = lane; i < nmax; i += 64) iact[(size_t)qp * nmax + i] = (i < r.nact) ? q.iact[i] : 0;
+    if (lane == 0) {
+      ifail[qp] = r.ifail;
+      if (n_iter) n_iter[qp] = r.n_iter;
+      if (nact) nact[qp] = r.nact;
+      if (hist_len) hist_len[qp] = r.hist_len;
+    }
+    WG_WSYNC();
+  }
+}
+
+extern "C" {
+
+int wg_abi_version(void) { return 1; }
+
+const char *wg_last_error(void) { return g_err.c_str(); }
+
+int wg_init(int device_ordinal) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  int count = 0;
+  hipError_t e = hipGetDeviceCount(&count);
+  if (e != hipSuccess || count <= 0)
+    return fail(WG_ERR_NO_DEVICE, "no HIP device available (%s); this library has no CPU path",
+                e == hipSuccess ? "count = 0" : hipGetErrorString(e));
+  if (device_ordinal < 0 || device_ordinal >= count)
+    return fail(WG_ERR_BAD_ARG, "device ordinal %d out of range [0,%d)", device_ordinal, count);
+  HIP_TRY(hipSetDevice(device_ordinal));
+  hipDeviceProp_t prop;
+  HIP_TRY(hipGetDeviceProperties(&prop, device_ordinal));
+  g_num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  g_device = device_ordinal;
+  return WG_OK;
+}
+
+void wg_shutdown(void) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  g_in.release();
+  g_out.release();
+  g_device = -1;
+}
+
+size_t wg_qp_lds_bytes(int n, int m) { return wg::QlDims(n, m, m).bytes(); }
+
+int wg_qp_solve_batch_dev(int B, int nmax, int mmax, const int *n, const int *m, const int *me,
+                          const double *C, const double *d, const double *A, const double *b,
+                          const double *xl, const double *xu, double eps, double *x, double *u,
+                          int *ifail, int *n_iter, int *iact, int *nact, int *hist, int hist_cap,
+                          int *hist_len, void *hip_stream) {
+  if (int rc = ensure_device()) return rc;
+  if (B < 0 || nmax <= 0 || mmax <= 0) return fail(WG_ERR_BAD_ARG, "bad sizes B=%d nmax=%d mmax=%d", B, nmax, mmax);
+  if (!C || !d || !A || !b || !xl || !xu || !x || !ifail) return fail(WG_ERR_BAD_ARG, "null required pointer");
+  if (hist && (!hist_len || hist_cap <= 0)) return fail(WG_ERR_BAD_ARG, "hist needs hist_len and hist_cap > 0");
+  if (B == 0) return WG_OK;
+  const int m_cap = m ? mmax : mmax - 1;
+  size_t lds = wg::QlDims(nmax, m_cap, m_cap).bytes();
+  if (lds > 160 * 1024) return fail(WG_ERR_TOO_LARGE, "QP (n=%d, m=%d) needs %zu B of LDS > 160 KiB", nmax, m_cap, lds);
+  if (lds > 64 * 1024)
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(wg_ql_dense_kernel),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  int per_cu = (int)((160 * 1024) / lds);
+  if (per_cu < 1) per_cu = 1;
+  if (per_cu > 16) per_cu = 16;
+  int grid = g_num_cu * per_cu;
+  if (grid > B) grid = B;
+  hipStream_t st = reinterpret_cast<hipStream_t>(hip_stream);
+  hipLaunchKernelGGL(wg_ql_dense_kernel, dim3(grid), dim3(64), lds, st, B, nmax, mmax, n, m, me, C, d, A, b,
+                     xl, xu, eps, x, u, ifail, n_iter, iact, nact, hist, hist_cap, hist_len);
+  HIP_TRY(hipGetLastError());
+  return WG_OK;
+}
+
+int wg_qp_solve_batch(int B, int nmax, int mmax, const int *n, const int *m, const int *me,
+                      const double *C, const double *d, const double *A, const double *b,
+                      const double *xl, const double *xu, double eps, double *x, double *u, int *ifail,
+                      int *n_iter, int *iact, int *nact, int *hist, int hist_cap, int *hist_len) {
+  if (int rc = ensure_device()) return rc;
+  if (B < 0 || nmax <= 0 || mmax <= 0) return fail(WG_ERR_BAD_ARG, "bad sizes B=%d nmax=%d mmax=%d", B, nmax, mmax);
+  if (!C || !d || !A || !b || !xl || !xu || !x || !ifail) return fail(WG_ERR_BAD_ARG, "null required pointer");
+  if (B == 0) return WG_OK;
+  std::lock_guard<std::mutex> lk(g_mu);
+  const size_t sB = (size_t)B;
+  // input arena
+  struct Seg { const void *h; size_t bytes; size_t off; };
+  std::vector<Seg> in = {
+      {C, sB * nmax * nmax * 8, 0}, {d, sB * nmax * 8, 0},  {A, sB * mmax * nmax * 8, 0},
+      {b, sB * mmax * 8, 0},        {xl, sB * nmax * 8, 0}, {xu, sB * nmax * 8, 0},
+      {n, n ? sB * 4 : 0, 0},       {m, m ? sB * 4 : 0, 0}, {me, me ? sB * 4 : 0, 0}};
+  size_t tot = 0;
+  for (auto &s : in) { s.off = tot; tot += (s.bytes + 255) & ~(size_t)255; }
+  if (int rc = g_in.reserve(tot)) return rc;
+  char *din = static_cast<char *>(g_in.p);
+  for (auto &s : in)
+    if (s.bytes) HIP_TRY(hipMemcpy(din + s.off, s.h, s.bytes, hipMemcpyHostToDevice));
+  struct OSeg { void *h; size_t bytes; size_t off; };
+  std::vector<OSeg> out = {{x, sB * nmax * 8, 0},
+                           {u, u ? sB * (mmax + 2 * (size_t)nmax) * 8 : 0, 0},
+                           {ifail, sB * 4, 0},
+                           {n_iter, n_iter ? sB * 4 : 0, 0},
+                           {iact, iact ? sB * nmax * 4 : 0, 0},
+                           {nact, nact ? sB * 4 : 0, 0},
+                           {hist, hist ? sB * hist_cap * 4 : 0, 0},
+                           {hist_len, hist_len ? sB * 4 : 0, 0}};
+  size_t otot = 0;
+  for (auto &s : out) { s.off = otot; otot += (s.bytes + 255) & ~(size_t)255; }
+  if (int rc = g_out.reserve(otot)) return rc;
+  char *dout = static_cast<char *>(g_out.p);
+  HIP_TRY(hipMemset(dout, 0, otot));
+  auto ip = [&](int k) { return in[k].bytes ? din + in[k].off : nullptr; };
+  auto op = [&](int k) { return out[k].bytes ? dout + out[k].off : nullptr; };
+  int rc = wg_qp_solve_batch_dev(B, nmax, mmax, (const int *)ip(6), (const int *)ip(7), (const int *)ip(8),
+                                 (const double *)ip(0), (const double *)ip(1), (const double *)ip(2),
+                                 (const double *)ip(3), (const double *)ip(4), (const double *)ip(5), eps,
+                                 (double *)op(0), (double *)op(1), (int *)op(2), (int *)op(3), (int *)op(4),
+                                 (int *)op(5), (int *)op(6), hist_cap, (int *)op(7), nullptr);
+  if (rc) return rc;
+  HIP_TRY(hipDeviceSynchronize());
+  for (auto &s : out)
+    if (s.bytes) HIP_TRY(hipMemcpy(s.h, dout + s.off, s.bytes, hipMemcpyDeviceToHost));
+  return WG_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,784 @@
+// wg_ql_device.hpp -- one dense convex QP per wavefront, all factors in LDS.
+//
+// Device-side replacement for the solver on the reference's Herdt-2010 path:
+//   ql0001_ / ql0002_   /root/reference/src/Mathematics/qld.cpp:378-612, 621-2091
+// (Powell / Schittkowski dual active-set method; called from
+//  QPProblem::solve, src/ZMPRefTrajectoryGeneration/qp-problem.cpp:245-294.)
+//
+// Design (gfx950 / CDNA4):
+//   * one 64-lane wavefront owns one QP; a workgroup is exactly one wave, so
+//     no s_barrier is ever needed -- LDS traffic of one wave is processed in
+//     order, only the compiler has to be fenced (WG_WSYNC);
+//   * Hessian G, Z (= R^-1, later rotated), packed R, the constraint matrix A
+//     and all vectors live in the wave's LDS slice; leading dimensions are odd
+//     so that both row and column sweeps are bank-conflict free for 8-byte
+//     accesses;
+//   * lanes parallelise over *independent outputs* only (rows of Z, columns of
+//     R, constraint rows of A); every inner sum runs sequentially inside one
+//     lane in the reference's order, so every double is bit-identical to the
+//     CPU solver and the active-set add/drop sequence is reproduced exactly;
+//   * order-insensitive reductions (max, arg-max with first-index tie-break,
+//     "any") use wave shuffles;
+//   * the long scalar chains (Givens sweep norms, triangular solves) are
+//     executed redundantly by all lanes on LDS-broadcast operands.
+// Compile with -ffp-contract=off: the reference build has no FMA contraction.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace wg {
+
+#define WG_WSYNC()                                          \
+  do {                                                      \
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  \
+    __builtin_amdgcn_wave_barrier();                        \
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");  \
+  } while (0)
+
+__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ double uni(double v) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_readfirstlane(lo);
+  hi = __builtin_amdgcn_readfirstlane(hi);
+  return __hiloint2double(hi, lo);
+}
+// f2c.h max/min (qld.cpp:269-270)
+__device__ __forceinline__ double maxd(double a, double b) { return a >= b ? a : b; }
+__device__ __forceinline__ double mind(double a, double b) { return a <= b ? a : b; }
+
+// LDS footprint of one QP (in doubles, then ints).  Host and device agree on it.
+struct QlDims {
+  int n, m, mmax;
+  int ldg, ldz, lda;
+  __host__ __device__ QlDims(int n_, int m_, int mmax_)
+      : n(n_), m(m_), mmax(mmax_), ldg(n_ | 1), ldz(n_ | 1), lda(mmax_ | 1) {}
+  __host__ __device__ int r_len() const { return n * (n + 1) / 2 + n; }
+  __host__ __device__ int n_doubles() const {
+    return n * ldg + n * ldz + r_len() + n * lda   // G, Z, R, A
+           + 8 * n                                  // x d ww wd wx lam xl xu
+           + (m + n) + m                            // wa, b (inner)
+           + 4 * n + 8;                             // scratch + scalar slots
+  }
+  __host__ __device__ size_t bytes() const {
+    return (size_t)n_doubles() * 8 + (size_t)((n + 1) & ~1) * 4;
+  }
+};
+
+struct QlView {
+  int n, m, me, mn, ldg, ldz, lda;
+  double *G, *Z, *R, *A;
+  double *x, *d, *ww, *wd, *wx, *lam, *xl, *xu, *wa, *b;
+  double *sc0, *sc1, *sc2, *sc3, *slot;
+  int *iact;
+  __device__ void carve(double *base, const QlDims &D, int me_) {
+    n = D.n; m = D.m; me = me_; mn = D.m + D.n; ldg = D.ldg; ldz = D.ldz; lda = D.lda;
+    double *p = base;
+    G = p; p += n * ldg;
+    Z = p; p += n * ldz;
+    R = p; p += D.r_len();
+    A = p; p += n * lda;
+    x = p; p += n;  d = p; p += n;  ww = p; p += n;  wd = p; p += n;
+    wx = p; p += n; lam = p; p += n; xl = p; p += n; xu = p; p += n;
+    wa = p; p += m + n;
+    b = p; p += m;
+    sc0 = p; p += n; sc1 = p; p += n; sc2 = p; p += n; sc3 = p; p += n;
+    slot = p; p += 8;
+    iact = reinterpret_cast<int *>(p);
+  }
+};
+
+#define Gm(i, j) q.G[(i) + (j) * q.ldg]
+#define Zm(i, j) q.Z[(i) + (j) * q.ldz]
+#define Am(k, i) q.A[(k) + (i) * q.lda]
+#define Rp(i, j) q.R[(j) * ((j) + 1) / 2 + (i)]
+
+struct QlResult {
+  int ifail, n_iter, nact, hist_len;
+};
+
+// arg-max over the wave: larger v wins, equal v -> smaller idx.  idx < 0 = no candidate.
+__device__ __forceinline__ void wave_argmax_first(double &v, int &idx) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) {
+    double ov = __shfl_xor(v, off);
+    int oi = __shfl_xor(idx, off);
+    bool take = (oi >= 0) && (idx < 0 || ov > v || (ov == v && oi < idx));
+    if (take) { v = ov; idx = oi; }
+  }
+}
+__device__ __forceinline__ double wave_max(double v) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) v = maxd(v, __shfl_xor(v, off));
+  return v;
+}
+__device__ __forceinline__ int wave_min_int(int v) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) { int o = __shfl_xor(v, off); v = o < v ? o : v; }
+  return v;
+}
+
+// qld.cpp:1921-1930 / 2005-2014
+__device__ __forceinline__ void givens(double p, double qq, double &ga, double &gb, double &nrm) {
+  double t = maxd(fabs(p), fabs(qq));
+  double d1 = p / t, d2 = qq / t;
+  double sum = t * sqrt(d1 * d1 + d2 * d2);
+  ga = p / sum;
+  gb = qq / sum;
+  nrm = sum;
+}
+// norm only (the part of the rotation that sits on the sequential chain)
+__device__ __forceinline__ double givens_norm(double p, double qq) {
+  double t = maxd(fabs(p), fabs(qq));
+  double d1 = p / t, d2 = qq / t;
+  return t * sqrt(d1 * d1 + d2 * d2);
+}
+__device__ __forceinline__ bool significant(double base, double delta_abs) {
+  double temp = base + delta_abs * .1;
+  double tempa = base + delta_abs * .2;
+  if (temp <= base) return false;
+  if (tempa <= temp) return false;
+  return true;
+}
+
+// s[i] = sum_j Z(j,i) * ww[j]   (qld.cpp:2071-2085); lane i owns s[i]
+__device__ __forceinline__ void zt_times_ww(const QlView &q, double *s, int lane) {
+  const int n = q.n;
+  for (int i = lane; i < n; i += 64) {
+    double acc = 0.0;
+    for (int j = 0; j < n; ++j) acc += Zm(j, i) * q.ww[j];
+    s[i] = acc;
+  }
+  WG_WSYNC();
+}
+
+// ww[0..nact) = R^-1 s[0..nact)   (qld.cpp:1824-1851).  Sequential chain,
+// executed redundantly by every lane on broadcast operands.
+__device__ __forceinline__ void backsub(const QlView &q, const double *s, int nact, int lane) {
+  for (int i = nact - 1; i >= 0; --i) {
+    double sum = 0.0;
+    for (int j = i + 1; j < nact; ++j) sum += Rp(i, j) * q.ww[j];
+    double v = (s[i] - sum) / Rp(i, i);
+    if (lane == 0) q.ww[i] = v;
+    WG_WSYNC();
+  }
+}
+
+// qld.cpp:1861-1889.  Returns kdrop (0-based) or -1; ratio updated when found.
+__device__ __forceinline__ int pick_drop(const QlView &q, int nact, double res, double &ratio, int lane) {
+  double best = 0.0, bestt = 0.0;
+  int bidx = -1;
+  for (int k = lane; k < nact; k += 64) {
+    if (q.iact[k] <= q.me) continue;
+    double w = q.ww[k];
+    if (res * w >= 0.0) continue;
+    double temp = q.lam[k] / w;
+    double key = -fabs(temp);          // smaller |temp| wins, first index on ties
+    if (bidx < 0 || key > best) { best = key; bestt = temp; bidx = k; }
+  }
+  int idx = bidx;
+  double v = best;
+  wave_argmax_first(v, idx);
+  if (idx < 0) return -1;
+  // fetch the winning lane's temp
+  double t = __shfl(bestt, idx & 63);
+  ratio = t;
+  return idx;
+}
+
+// qld.cpp:2039-2058 (lql): per-lane terms, then the sum in index order.
+__device__ __forceinline__ double xmag_sum(const QlView &q, double vfact, int lane) {
+  const int n = q.n;
+  for (int i = lane; i < n; i += 64) {
+    double xi = q.x[i];
+    q.sc3[i] = fabs(xi) * vfact * (fabs(q.d[i]) + fabs(Gm(i, i) * xi));
+  }
+  WG_WSYNC();
+  double sum = 0.0;
+  for (int i = 0; i < n; ++i) sum += q.sc3[i];
+  return sum;
+}
+
+// qld.cpp:1992-2030.  Three phases: (1) the chain of rotation norms, all lanes
+// redundantly; (2) ga/gb of every rotation, one lane each; (3) every lane
+// carries its own row of Z through the whole rotation sequence.
+__device__ __forceinline__ void sweep(const QlView &q, double *s, int nu, int nact, int lane) {
+  const int n = q.n;
+  if (nu - 1 <= nact) return;
+  // phase 1: sc0[c] = p (s[c-1] before), sc1[c] = q (s[c] current), sc2[c] = norm; sc2[c] = 0 marks "skipped"
+  {
+    double cur = s[nu - 1];
+    for (int c = nu - 1; c > nact; --c) {
+      double p = s[c - 1];
+      double nrm;
+      if (cur == 0.0) { nrm = 0.0; cur = p; }
+      else { nrm = givens_norm(p, cur); if (lane == 0) { q.sc0[c] = p; q.sc1[c] = cur; } cur = nrm; }
+      if (lane == 0) q.sc2[c] = nrm;
+    }
+    WG_WSYNC();
+  }
+  // phase 2: rotation coefficients
+  for (int c = nact + 1 + lane; c < nu; c += 64) {
+    double nrm = q.sc2[c];
+    if (nrm != 0.0) {
+      double p = q.sc0[c], qq = q.sc1[c];
+      q.sc0[c] = p / nrm;   // ga
+      q.sc1[c] = qq / nrm;  // gb
+      s[c - 1] = nrm;
+    }
+  }
+  WG_WSYNC();
+  // phase 3: rows of Z
+  for (int i = lane; i < n; i += 64) {
+    double carry = Zm(i, nu - 1);
+    for (int c = nu - 1; c > nact; --c) {
+      if (q.sc2[c] == 0.0) { Zm(i, c) = carry; carry = Zm(i, c - 1); continue; }
+      double ga = q.sc0[c], gb = q.sc1[c];
+      double zl = Zm(i, c - 1);
+      double t = ga * zl + gb * carry;
+      Zm(i, c) = ga * carry - gb * zl;
+      carry = t;
+    }
+    Zm(i, nact) = carry;
+  }
+  WG_WSYNC();
+}
+
+// qld.cpp:1903-1982.  nu = number of R columns taking part (nact, or nact+1
+// when the S column rides along).  Returns the new nact.
+__device__ __forceinline__ int drop_constraint(const QlView &q, int kdrop, int nu, int nact, int lane) {
+  const int n = q.n;
+  if (lane == 0) {
+    int code = q.iact[kdrop];
+    int ia = code - 1;
+    if (code > q.mn) ia -= n;
+    q.wa[ia] = -q.wa[ia];
+  }
+  WG_WSYNC();
+  for (int k = kdrop; k < nact - 1; ++k) {
+    double ga, gb, nrm;
+    givens(Rp(k, k + 1), Rp(k + 1, k + 1), ga, gb, nrm);   // redundant on all lanes
+    WG_WSYNC();
+    for (int i = lane; i <= k; i += 64) {
+      double t = Rp(i, k + 1);
+      Rp(i, k + 1) = Rp(i, k);
+      Rp(i, k) = t;
+    }
+    WG_WSYNC();
+    if (lane == 0) { Rp(k + 1, k + 1) = 0.0; Rp(k, k) = nrm; }
+    WG_WSYNC();
+    for (int c = k + 1 + lane; c < nu; c += 64) {
+      double rk = Rp(k, c), rk1 = Rp(k + 1, c);
+      double t = ga * rk + gb * rk1;
+      Rp(k + 1, c) = ga * rk1 - gb * rk;
+      Rp(k, c) = t;
+    }
+    for (int i = lane; i < n; i += 64) {
+      double zk = Zm(i, k), zk1 = Zm(i, k + 1);
+      double t = ga * zk + gb * zk1;
+      Zm(i, k + 1) = ga * zk1 - gb * zk;
+      Zm(i, k) = t;
+    }
+    if (lane == 0) { q.iact[k] = q.iact[k + 1]; q.lam[k] = q.lam[k + 1]; }
+    WG_WSYNC();
+  }
+  return nact - 1;
+}
+
+// qld.cpp:1547-1658
+__device__ __forceinline__ bool independent_coordinate(const QlView &q, int knext, int nact, double vsmall, int lane) {
+  const int n = q.n, m = q.m;
+  int k1 = 0;
+  if (knext > m) { k1 = knext - m; if (k1 > n) k1 -= n; }
+  bool found = false;
+  for (int i = 1 + lane; i <= n; i += 64) {
+    double suma;
+    if (knext <= m) suma = Am(knext - 1, i - 1);
+    else { suma = 0.0; if (i == k1) suma = (knext > q.mn) ? -1.0 : 1.0; }
+    double sumb = fabs(suma);
+    for (int k = 0; k < nact; ++k) {
+      int kk = q.iact[k];
+      double temp;
+      if (kk <= m) temp = q.ww[k] * Am(kk - 1, i - 1);
+      else {
+        kk -= m; temp = 0.0;
+        if (kk == i) temp = q.ww[kk - 1];
+        kk -= n;
+        if (kk == i) temp = -q.ww[kk - 1];
+      }
+      suma -= temp;
+      sumb += fabs(temp);
+    }
+    if (knext <= m && suma <= vsmall) continue;
+    if (significant(sumb, fabs(suma))) found = true;
+  }
+  return __any(found) != 0;
+}
+
+// The solver.  Problem data must already be in LDS: G (copy of C, patched per
+// qld.cpp:442-444), A, d, b (INNER sign: b = -b_user, qld.cpp:469-475), xl, xu.
+// hist: optional global add(+code)/drop(-code) log written by lane 0.
+__device__ inline QlResult ql_solve(const QlView &q, double vsmall, int *hist, int hist_cap) {
+  const int lane = threadIdx.x & 63;
+  const int n = q.n, m = q.m, me = q.me, mn = q.mn;
+  QlResult out;
+  out.hist_len = 0;
+  int nact = 0, info = 0, iterc = 1, itref = 0, iflag = 0;
+  const int maxit = (m + n) * 40;                       // :459
+  const double onha = 1.5, xmagr = .01, diagr = 2.0;
+  const int ifinc = 3, kfinc = n > 10 ? n : 10;
+  int jfinc = -kfinc;
+  double xmag = 0.0, vfact = 1.0, res = 0.0, ratio = 0.0, diag = 0.0;
+  int knext = 0;
+  const int s_tail = n * (n + 1) / 2;
+  double *s = q.R + s_tail;
+  bool early_exit = false;
+
+#define LOG_EVENT(code)                                                   \
+  do {                                                                    \
+    if (lane == 0 && hist && out.hist_len < hist_cap) hist[out.hist_len] = (code); \
+    out.hist_len++;                                                       \
+  } while (0)
+
+  // ---- reciprocal lengths of the constraint normals, :769-807 ----
+  {
+    int fatal = 0x7fffffff;
+    for (int k = lane; k < m; k += 64) {
+      double sum = 0.0;
+      for (int i = 0; i < n; ++i) { double a = Am(k, i); sum += a * a; }
+      if (sum > 0.0) sum = 1.0 / sqrt(sum);
+      else if (q.b[k] == 0.0) {}
+      else if (k + 1 <= me || q.b[k] > 0.0) fatal = k + 1 < fatal ? k + 1 : fatal;
+      q.wa[k] = sum;
+    }
+    for (int k = lane; k < n; k += 64) q.wa[m + k] = 1.0;
+    fatal = wave_min_int(fatal);
+    if (fatal != 0x7fffffff) { info = -fatal; early_exit = true; }
+  }
+
+  if (!early_exit) {
+    // ---- make the Hessian numerically positive definite, :814-854 ----
+    for (int i = lane; i < n; i += 64) q.wd[i] = Gm(i, i);
+    WG_WSYNC();
+    {
+      double dl = 0.0;
+      for (int i = lane; i < n; i += 64) {
+        double wdi = q.wd[i];
+        dl = maxd(dl, vsmall - wdi);
+        for (int j = i + 1; j < n; ++j) {
+          double gjj = q.wd[j], gij = Gm(i, j);
+          double ga = -mind(wdi, gjj);
+          double gb = fabs(wdi - gjj) + fabs(gij);
+          if (gb > 0.0) ga += gij * gij / gb;
+          dl = maxd(dl, ga);
+        }
+      }
+      diag = wave_max(dl);
+    }
+    bool need_shift = diag > 0.0;
+    for (;;) {
+      if (need_shift) {
+        diag = diagr * diag;
+        for (int i = lane; i < n; i += 64) Gm(i, i) = diag + q.wd[i];
+        WG_WSYNC();
+      }
+      // ---- Cholesky, row by row (same sums as the column order of :859-890) ----
+      int jfail = -1;
+      double tfail = 0.0;
+      for (int i = 0; i < n; ++i) {
+        for (int j = i + lane; j < n; j += 64) {
+          double temp = Gm(i, j);
+          for (int k = 0; k < i; ++k) temp -= Rp(k, j) * Rp(k, i);
+          if (j == i) {
+            if (temp < vsmall) { q.slot[0] = 1.0; q.slot[1] = temp; }
+            else { q.slot[0] = 0.0; Rp(i, i) = sqrt(temp); }
+          } else q.sc0[j] = temp;
+        }
+        WG_WSYNC();
+        if (q.slot[0] != 0.0) { jfail = i; tfail = q.slot[1]; break; }
+        double rii = Rp(i, i);
+        for (int j = i + 1 + lane; j < n; j += 64) Rp(i, j) = q.sc0[j] / rii;
+        WG_WSYNC();
+      }
+      jfail = uni(jfail);
+      if (jfail < 0) break;
+      // ---- :895-918 further diagonal shift (rare; lane 0, serial) ----
+      if (lane == 0) {
+        double dnew;
+        if (jfail == 0) dnew = diag + vsmall - tfail;
+        else {
+          double *v = q.lam;
+          double sumx = 1.0;
+          v[jfail] = 1.0;
+          for (int k = jfail; k >= 1; --k) {
+            double sum = 0.0;
+            for (int i = k; i <= jfail; ++i) sum -= Rp(k - 1, i) * v[i];
+            v[k - 1] = sum / Rp(k - 1, k - 1);
+            sumx += v[k - 1] * v[k - 1];
+          }
+          dnew = diag + vsmall - tfail / sumx;
+        }
+        q.slot[2] = dnew;
+      }
+      WG_WSYNC();
+      diag = q.slot[2];
+      need_shift = true;
+    }
+
+    // ---- Z = R^-1, :937-975 ----
+    for (int i = lane; i < n; i += 64) {
+      for (int j = 0; j < i; ++j) Zm(i, j) = 0.0;
+      Zm(i, i) = 1.0 / Rp(i, i);
+    }
+    {
+      // aligned form: all lanes walk (c, k) together so R(k,c) is a broadcast
+      const int i0 = lane, i1 = lane + 64;
+      double sum0, sum1;
+      for (int c = 1; c < n; ++c) {
+        sum0 = 0.0; sum1 = 0.0;
+        for (int k = 0; k < c; ++k) {
+          double rkc = Rp(k, c);
+          if (i0 <= k) sum0 += Zm(i0, k) * rkc;
+          if (i1 <= k) sum1 += Zm(i1, k) * rkc;
+        }
+        double rcc = Rp(c, c);
+        if (i0 < c) Zm(i0, c) = -sum0 / rcc;
+        if (i1 < c) Zm(i1, c) = -sum1 / rcc;
+      }
+    }
+    WG_WSYNC();
+  }
+
+  enum { ST_RESET, ST_RESID, ST_SCAN, ST_CONVERGED, ST_FINISH };
+  int st = early_exit ? ST_FINISH : ST_RESET;
+  while (st != ST_FINISH) {
+    if (st == ST_RESET || st == ST_RESID) {
+      s = q.R + s_tail;
+      if (st == ST_RESET) {                                 // :989-1027
+        iflag = 1;
+        for (int i = lane; i < n; i += 64) {
+          q.x[i] = 0.0;
+          q.ww[i] = q.d[i];
+          if (i >= nact) continue;
+          q.lam[i] = 0.0;
+          int k = q.iact[i];
+          if (k <= m) s[i] = q.b[k - 1];
+          else if (k > mn) s[i] = -q.xu[k - mn - 1];
+          else s[i] = q.xl[k - m - 1];
+        }
+        xmag = 0.0;
+        vfact = 1.0;
+        WG_WSYNC();
+      } else {                                              // :1031-1099
+        iflag = 2;
+        for (int i = lane; i < n; i += 64) {
+          double acc = q.d[i];
+          for (int j = 0; j < n; ++j) acc += Gm(i, j) * q.x[j];
+          for (int k = 0; k < nact; ++k) {
+            int kk = q.iact[k];
+            if (kk <= m) acc -= q.lam[k] * Am(kk - 1, i);
+            else if (kk <= mn) { if (kk - m - 1 == i) acc -= q.lam[k]; }
+            else { if (kk - mn - 1 == i) acc += q.lam[k]; }
+          }
+          q.ww[i] = acc;
+        }
+        for (int k = lane; k < nact; k += 64) {
+          int kk = q.iact[k];
+          double sk;
+          if (kk <= m) {
+            sk = q.b[kk - 1];
+            for (int i = 0; i < n; ++i) sk -= q.x[i] * Am(kk - 1, i);
+          } else if (kk <= mn) { int k1 = kk - m - 1; sk = q.xl[k1] - q.x[k1]; }
+          else { int k1 = kk - mn - 1; sk = -q.xu[k1] + q.x[k1]; }
+          s[k] = sk;
+        }
+        WG_WSYNC();
+      }
+      if (nact > 0) {                                       // :1104-1170
+        // forward substitution with R^T, column oriented (sums ascend in j)
+        {
+          double sum0 = 0.0, sum1 = 0.0;
+          const int i0 = lane, i1 = lane + 64;
+          for (int j = 0; j < nact; ++j) {
+            if (i0 == j) s[j] = (s[j] - sum0) / Rp(j, j);
+            if (i1 == j) s[j] = (s[j] - sum1) / Rp(j, j);
+            WG_WSYNC();
+            double sj = s[j];
+            if (i0 > j && i0 < nact) sum0 += Rp(j, i0) * sj;
+            if (i1 > j && i1 < nact) sum1 += Rp(j, i1) * sj;
+          }
+        }
+        for (int i = lane; i < n; i += 64) {
+          double sum = 0.0;
+          for (int j = 0; j < nact; ++j) sum += s[j] * Zm(i, j);
+          q.x[i] += sum;
+          q.sc0[i] = sum;
+        }
+        WG_WSYNC();
+        for (int j = lane; j < n; j += 64) {
+          double acc = q.ww[j];
+          for (int i = 0; i < n; ++i) acc += q.sc0[i] * Gm(i, j);
+          q.ww[j] = acc;
+        }
+        WG_WSYNC();
+      }
+      zt_times_ww(q, s, lane);                              // :1175-1177
+      if (nact != n) {                                      // :1186-1201
+        for (int i = lane; i < n; i += 64) {
+          double sum = 0.0;
+          for (int j = nact; j < n; ++j) sum += Zm(i, j) * s[j];
+          q.x[i] -= sum;
+        }
+        info = 0;
+        WG_WSYNC();
+      }
+      if (nact != 0) {                                      // :1208-1217
+        backsub(q, s, nact, lane);
+        for (int k = lane; k < nact; k += 64) q.lam[k] += q.ww[k];
+        WG_WSYNC();
+      }
+      { double sm = xmag_sum(q, vfact, lane); xmag = maxd(xmag, sm); }
+      if (iflag == itref) { st = ST_RESID; continue; }      // :1226
+      // first inequality with a negative multiplier, :1233-1249
+      int kd = 0x7fffffff;
+      for (int k = lane; k < nact; k += 64)
+        if (q.lam[k] < 0.0 && q.iact[k] > me) { kd = k < kd ? k : kd; }
+      kd = wave_min_int(kd);
+      if (kd != 0x7fffffff) {
+        LOG_EVENT(-q.iact[kd]);
+        nact = drop_constraint(q, kd, nact, nact, lane);
+        st = ST_RESID;
+        continue;
+      }
+      st = ST_SCAN;
+    }
+
+    if (st == ST_SCAN) {
+      // ---- most violated normalised constraint, :1255-1331 ----
+      double bestv = 0.0, bestres = 0.0;
+      int bidx = -1;
+      for (int k = lane; k < m; k += 64) {
+        double wak = q.wa[k];
+        if (wak <= 0.0) continue;
+        double bk = q.b[k];
+        double sum = -bk;
+        for (int i = 0; i < n; ++i) sum += q.x[i] * Am(k, i);
+        double sumx = -sum * wak;
+        if (k + 1 <= me) sumx = fabs(sumx);
+        if (sumx <= 0.0) continue;              // cvmax starts at 0 (:1256)
+        if (bidx >= 0 && sumx <= bestv) continue;
+        double temp = fabs(bk);
+        for (int i = 0; i < n; ++i) temp += fabs(q.x[i] * Am(k, i));
+        double tempa = temp + fabs(sum);
+        if (tempa <= temp) continue;
+        temp += onha * fabs(sum);
+        if (temp <= tempa) continue;
+        bestv = sumx; bestres = sum; bidx = k + 1;
+      }
+      for (int k = lane; k < n; k += 64) {
+        if (q.wa[m + k] <= 0.0) continue;
+        bool lower = true;
+        double sum = q.xl[k] - q.x[k];
+        if (sum == 0.0) continue;
+        if (sum < 0.0) { sum = q.x[k] - q.xu[k]; lower = false; }
+        if (sum <= 0.0) continue;               // cvmax starts at 0
+        if (bidx >= 0 && sum <= bestv) continue;
+        bestv = sum; bestres = -sum; bidx = lower ? k + 1 + m : k + 1 + mn;
+      }
+      {
+        // order key: general rows 1..m, then bounds by variable; lower/upper of one
+        // variable never compete.  knext codes > mn (upper) must sort by variable.
+        int key = bidx < 0 ? -1 : (bidx > mn ? bidx - n : bidx);
+        double v = bestv;
+        int kk = key;
+        wave_argmax_first(v, kk);
+        if (kk < 0) { bestv = 0.0; bidx = -1; }
+        else {
+          int src = -1;
+          // the lane that owns the winning key
+          unsigned long long mask = __ballot(key == kk);
+          src = __ffsll((long long)mask) - 1;
+          bestv = __shfl(bestv, src);
+          bestres = __shfl(bestres, src);
+          bidx = __shfl(bidx, src);
+        }
+      }
+      double cvmax = bestv;
+      if (bidx >= 0) { res = bestres; knext = bidx; }
+      info = 0;
+      if (cvmax <= vsmall) { st = ST_CONVERGED; continue; }  // :1336
+
+      // ---- has the objective stopped increasing?  :1343-1408 ----
+      ++jfinc;
+      if (jfinc == 0 || jfinc == ifinc) {
+        if (jfinc == ifinc) {
+          for (int i = lane; i < n; i += 64) {
+            double sum = 2.0 * q.d[i];
+            double sumx = fabs(sum);
+            for (int j = 0; j < n; ++j) {
+              double temp = Gm(i, j) * (q.wx[j] + q.x[j]);
+              sum += temp;
+              sumx += fabs(temp);
+            }
+            double dx = q.x[i] - q.wx[i];
+            q.sc0[i] = sum * dx;
+            q.sc1[i] = sumx * fabs(dx);
+          }
+          WG_WSYNC();
+          double fdiff = 0.0, fdiffa = 0.0;
+          for (int i = 0; i < n; ++i) { fdiff += q.sc0[i]; fdiffa += q.sc1[i]; }
+          info = 2;
+          double sum = fdiffa + fdiff;
+          if (sum <= fdiffa) { st = ST_CONVERGED; continue; }
+          double temp = fdiffa + onha * fdiff;
+          if (temp <= sum) { st = ST_CONVERGED; continue; }
+          jfinc = 0;
+          info = 0;
+        }
+        for (int i = lane; i < n; i += 64) q.wx[i] = q.x[i];
+        WG_WSYNC();
+      }
+
+      ++iterc;                                              // :1415-1420
+      if (iterc > maxit) { info = 1; st = ST_FINISH; continue; }
+
+      // ---- new normal and its products with the columns of Z, :1422-1470 ----
+      s = q.R + nact * (nact + 1) / 2;
+      if (knext <= m) {
+        for (int i = lane; i < n; i += 64) q.ww[i] = Am(knext - 1, i);
+        WG_WSYNC();
+        zt_times_ww(q, s, lane);
+      } else {
+        int k1 = knext - m;
+        double sg = 1.0;
+        if (k1 > n) { k1 = knext - mn; sg = -1.0; }
+        for (int i = lane; i < n; i += 64) {
+          q.ww[i] = (i == k1 - 1) ? sg : 0.0;
+          double z = Zm(k1 - 1, i);
+          s[i] = (sg > 0.0) ? z : -z;
+        }
+        WG_WSYNC();
+      }
+      double parnew = 0.0, parinc = 0.0, step = 0.0, sumy;
+      int kdrop = -1;
+      int route;   // 0 step, 1 dependent (multipliers needed), 2 dependent (multipliers in ww)
+      if (nact == n) route = 1;                             // :1477
+      else {
+        sweep(q, s, n, nact, lane);                         // :1480-1482
+        if (nact == 0) route = 0;                           // :1488
+        else {                                              // :1491-1532
+          double suma = 0.0, sumb = 0.0, sumc = 0.0;
+          for (int i = 0; i < n; ++i) {
+            double zi = Zm(i, nact), wi = q.ww[i];
+            suma += wi * zi;
+            sumb += fabs(wi * zi);
+            sumc += zi * zi;
+          }
+          if (!significant(sumb, fabs(suma)) || !(sumb > vsmall)) route = 1;
+          else {
+            sumc = sqrt(sumc);
+            if (knext <= m) sumc /= q.wa[knext - 1];
+            if (significant(sumc, fabs(suma))) route = 0;
+            else {                                          // :1538-1540
+              backsub(q, s, nact, lane);
+              route = independent_coordinate(q, knext, nact, vsmall, lane) ? 0 : 2;
+            }
+          }
+        }
+      }
+      route = uni(route);
+      if (route != 0) {
+        if (route == 1) backsub(q, s, nact, lane);
+        kdrop = pick_drop(q, nact, res, ratio, lane);
+        info = -knext;                                      // :1663
+        if (kdrop < 0) { st = ST_CONVERGED; continue; }
+        parinc = ratio;
+        parnew = parinc;
+      }
+
+      // ---- partial steps, each ending in a deletion, :1673-1759 ----
+      bool dual_only = (route != 0);
+      for (;;) {
+        if (!dual_only) {
+          sumy = s[nact];                                   // :1718-1720
+          step = -res / sumy;
+          parinc = step / sumy;
+          kdrop = -1;
+          if (nact > 0) {
+            backsub(q, s, nact, lane);
+            kdrop = pick_drop(q, nact, res, ratio, lane);
+            if (kdrop >= 0) {                               // :1734-1743
+              double temp = 1.0 - ratio / parinc;
+              if (temp <= 0.0) kdrop = -1;
+              else { step = ratio * sumy; parinc = ratio; res = temp * res; }
+            }
+          }
+          for (int i = lane; i < n; i += 64) q.x[i] += step * Zm(i, nact);   // :1749-1755
+          parnew += parinc;
+          WG_WSYNC();
+          if (nact < 1) break;
+        }
+        dual_only = false;
+        for (int k = lane; k < nact; k += 64) {             // :1677-1687
+          double l = q.lam[k] - parinc * q.ww[k];
+          if (q.iact[k] > me) l = maxd(0.0, l);
+          q.lam[k] = l;
+        }
+        WG_WSYNC();
+        if (kdrop < 0) break;
+        {                                                   // :1697-1711
+          int nu = nact + 1;
+          LOG_EVENT(-q.iact[kdrop]);
+          nact = drop_constraint(q, kdrop, nu, nact, lane);
+          double *snew = s - (nact + 1);
+          if (nu > n) nu = n;
+          // ascending copy, source ahead of destination: lanes in index order
+          for (int i0 = 0; i0 < nu; i0 += 64) {
+            int i = i0 + lane;
+            double v = (i < nu) ? s[i] : 0.0;
+            WG_WSYNC();
+            if (i < nu) snew[i] = v;
+            WG_WSYNC();
+          }
+          s = snew;
+          sweep(q, s, nu, nact, lane);
+        }
+      }
+
+      // ---- add the new constraint, :1764-1771 ----
+      if (lane == 0) {
+        q.lam[nact] = parnew;
+        q.iact[nact] = knext;
+        int ia = knext - 1;
+        if (knext > mn) ia -= n;
+        q.wa[ia] = -q.wa[ia];
+      }
+      nact++;
+      LOG_EVENT(knext);
+      WG_WSYNC();
+      double sm = xmag_sum(q, vfact, lane);                 // :1776-1786
+      xmag = maxd(xmag, sm);
+      if (sm < xmagr * xmag) st = ST_RESET;
+      else if (itref <= 0) st = ST_SCAN;
+      else st = ST_RESID;
+      continue;
+    }
+
+    if (st == ST_CONVERGED) {                               // :1791-1799
+      ++itref;
+      jfinc = -1;
+      if (itref == 1) { st = ST_RESID; continue; }
+      st = ST_FINISH;
+    }
+  }
+#undef LOG_EVENT
+
+  // ---- ql0001 epilogue, :497-608 ----
+  out.ifail = 0;
+  if (info == 1) out.ifail = 1;
+  else if (info == 2) out.ifail = 2;
+  else if (info < 0) out.ifail = -info + 10;
+  out.n_iter = iterc;
+  out.nact = nact;
+  return out;
+}
+
+}  // namespace wg

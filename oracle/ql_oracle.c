@@ -301,7 +301,8 @@ int wgo_ql_solve(int m, int me, int mmax, int n, int nmax,
   for (int j = 0; j < n; ++j)
     for (int i = 0; i < n; ++i) G(i, j) = c[i + (size_t)j * nmax];
   /* qld.cpp:442-444 (the reference patches the caller's array; we patch the copy) */
-  if (fabs(G(n - 1, n - 1)) == 0.0) G(n - 1, n - 1) = eps;
+  /* the element patched is c(nmax,nmax): inside the n x n block only if nmax == n */
+  if (nmax == n && fabs(G(n - 1, n - 1)) == 0.0) G(n - 1, n - 1) = eps;
   for (int j = 0; j < m; ++j) binner[j] = -b[j];            /* :469-475 */
   const int maxit = (m + n) * 40;                           /* :459 */
 
