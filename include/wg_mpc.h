@@ -95,6 +95,114 @@ int wg_qp_solve_batch_dev(int B, int nmax, int mmax, const int *n, const int *m,
                           int *hist, int hist_cap, int *hist_len,
                           void *hip_stream);
 
+
+/* ------------------------------------------------------------------------
+ * Herdt-2010 MPC tick, batched over independent gaits
+ *
+ * One "tick" = one execution of the body of
+ *     ZMPVelocityReferencedQP::OnLine            (ZMPVelocityReferencedQP.cpp:346-452)
+ * for one gait: support-state preview, orientation preview, QP assembly,
+ * QL solve, LIPM interpolation + state step, trunk and feet interpolation.
+ * The reference keeps this state in C++ objects and four deques; here it is a
+ * flat POD per gait so that B gaits sit in one HBM array.
+ * ---------------------------------------------------------------------- */
+
+/* FootAbsolutePosition without time/stepType (include/jrl/walkgen/pgtypes.hh:137-154);
+ * x,y,z in metres, angles in DEGREES like the reference. */
+typedef struct wg_foot_sample {
+  double x, y, z, theta, omega, omega2;
+  double dx, dy, dz, dtheta, domega, domega2;
+  double ddx, ddy, ddz, ddtheta, ddomega, ddomega2;
+} wg_foot_sample_t;
+
+enum { WG_LEFT = 0, WG_RIGHT = 1 };   /* foot_type_e, privatepgtypes.hh:47-50 */
+enum { WG_SS = 0, WG_DS = 1 };        /* PhaseType,   privatepgtypes.hh:65-68 */
+
+/* Robot / algorithm constants (what the path reads from CjrlHumanoidDynamicRobot
+ * plus the constants hard-coded in the reference's constructors). */
+typedef struct wg_model {
+  int N;                    /* QP_N_ = 16            ZMPVelocityReferencedQP.cpp:64  */
+  int flags;                /* WG_FLAG_* below */
+  double T;                 /* QP_T_ = 0.1                                     :63  */
+  double Tctrl;             /* m_SamplingPeriod = 0.005                        :65  */
+  double com_height_qp;     /* 0.814                                      :103,114  */
+  double alpha, beta, gamma;/* 1.0, 1e-5, 1e-6 (INSTANT_VELOCITY, JERK_MIN, COP_CENTERING) :116-118 */
+  double sole_w, sole_h;    /* CjrlFoot::getSoleSize outputs, relative-feet-inequalities.cpp:158-172 */
+  double margin_x, margin_y;/* 0.04, 0.04                                      :48-49 */
+  double ds_feet_distance;  /* 0.2                                             :47   */
+  double hip_l_lo, hip_l_hi, hip_r_lo, hip_r_hi; /* hip-yaw limits, OrientationsPreview.cpp:42-66 */
+  double hip_vmax;          /* |upperVelocityBound|                            :68   */
+  double hip_amax;          /* 0.1                                             :71   */
+  double feet_cross_max;    /* 5 deg in rad                                    :73   */
+  double step_period;       /* 0.8   SupportFSM, ZMPVelocityReferencedQP.cpp:76     */
+  double ds_period;         /* 1e9                                             :77   */
+  double dsss_period;       /* 0.8                                             :78   */
+  double t_single;          /* 0.7   rigid-body-system.cpp:60                        */
+  double t_double;          /* = T   rigid-body-system.cpp:61                        */
+  double step_height;       /* 0.05  rigid-body-system.cpp:66                        */
+  double feet_distance;     /* 0.2   rigid-body-system.cpp:65                        */
+} wg_model_t;
+
+/* wg_model_t.flags */
+#define WG_FLAG_NO_STOP_CENTERING 1  /* skip the "go to the feet centre when NbStepsLeft == 0" branch
+                                        (ZMPVelocityReferencedQP.cpp:410-421).  That branch was added
+                                        after the reference's golden .datref was recorded (ChangeLog
+                                        [3.1.8] "Put the CoM at the center of the feet when stopping");
+                                        the flag exists so the golden file can be replayed. */
+
+/* Per-gait state carried from tick to tick. */
+typedef struct wg_gait_state {
+  /* scheduling: ZMPVelocityReferencedQP members + the caller's 5 ms clock */
+  double clock;             /* m_InternalClock at which the NEXT tick fires */
+  double upper_time_limit;  /* UpperTimeLimitToUpdate_ */
+  double time_to_stop;      /* TimeToStopOnLineMode_ */
+  int tick_count;
+  int running;              /* Running_ */
+  int ending_phase;         /* EndingPhase_ (":stoppg") */
+  int online;               /* m_OnLineMode */
+  /* NewVelRef_.Local */
+  double vref[3];
+  /* LinearizedInvertedPendulum2D state; com_z = starting CoM height (:303) */
+  double com_x[3], com_y[3], com_z;
+  /* IntermedData_->SupportState()  (support_state_t, privatepgtypes.hh:291-320) */
+  int phase, foot, nb_steps_left, step_number, state_changed, pad0_;
+  double time_limit, start_time, sup_x, sup_y, sup_yaw;
+  /* SupportFSM rotation bookkeeping (SupportFSM.hh:117-134) */
+  int in_translation, in_rotation, nb_steps_after_rotation, rot_support_foot,
+      post_rotation_phase, nb_steps_ssds;
+  /* OrientationsPreview::TrunkState_ / TrunkStateT_ (yaw only) */
+  double trunk_yaw[3], trunkT_yaw[3];
+  /* what the tick reads from the four deques: with the reference's cadence
+   * (20 samples pushed per tick, one popped per 5 ms call) deque.front() is the
+   * previous tick's sample #11, deque[size-2] its #18 and deque.back() its #19 */
+  wg_foot_sample_t lf[3], rf[3];          /* [0] front, [1] back-1, [2] back */
+  double front_com_x[3], front_com_y[3];  /* FinalCOMTraj_deq[0] */
+  /* swing-foot height polynomial, set only when the support state changes
+   * (OnLineFootTrajectoryGeneration.cpp:285-286) */
+  double poly_z[5];
+} wg_gait_state_t;
+
+#define WG_SAMPLES_PER_TICK 20   /* QP_T_ / m_SamplingPeriod */
+
+/* What one tick appends to the four deques + solver diagnostics. */
+typedef struct wg_tick_out {
+  double jerk_x, jerk_y;                       /* control applied to the LIPM */
+  int ifail, n_iter, nact, n, m, nb_prw_steps; /* QP dimensions: n = 2N+2s, m = 1+4N+5s */
+  double com_x[WG_SAMPLES_PER_TICK][3], com_y[WG_SAMPLES_PER_TICK][3];
+  double com_yaw[WG_SAMPLES_PER_TICK][2];
+  double zmp_x[WG_SAMPLES_PER_TICK], zmp_y[WG_SAMPLES_PER_TICK];
+  wg_foot_sample_t lf[WG_SAMPLES_PER_TICK], rf[WG_SAMPLES_PER_TICK];
+} wg_tick_out_t;
+
+/* Defaults of every constant the reference hard-codes; caller fills the robot part. */
+void wg_model_defaults(wg_model_t *model);
+
+/* State after ZMPVelocityReferencedQP::InitOnLine (:212-319): standing in double
+ * support on the left foot, queues holding the 8 start samples. */
+void wg_gait_init(const wg_model_t *model, wg_gait_state_t *state,
+                  const double com0[3] /* x y z */, const double left_xyt[3],
+                  const double right_xyt[3] /* x y theta[deg] */);
+
 #ifdef __cplusplus
 }
 #endif

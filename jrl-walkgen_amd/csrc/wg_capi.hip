@@ -3,6 +3,7 @@
 
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <string>
@@ -153,6 +154,16 @@ void wg_shutdown(void) {
   g_device = -1;
 }
 
+#ifdef WG_PROFILE
+// diagnostic build only: read-and-reset the in-kernel phase timers (shader cycles)
+int wg_prof_read(unsigned long long *out24) {
+  if (hipMemcpyFromSymbol(out24, HIP_SYMBOL(wg::g_prof), 24 * sizeof(unsigned long long)) != hipSuccess) return -1;
+  unsigned long long z[24] = {0};
+  if (hipMemcpyToSymbol(HIP_SYMBOL(wg::g_prof), z, sizeof z) != hipSuccess) return -1;
+  return 0;
+}
+#endif
+
 size_t wg_qp_lds_bytes(int n, int m) { return wg::QlDims(n, m, m).bytes(); }
 
 int wg_qp_solve_batch_dev(int B, int nmax, int mmax, const int *n, const int *m, const int *me,
@@ -174,6 +185,7 @@ int wg_qp_solve_batch_dev(int B, int nmax, int mmax, const int *n, const int *m,
   int per_cu = (int)((160 * 1024) / lds);
   if (per_cu < 1) per_cu = 1;
   if (per_cu > 16) per_cu = 16;
+  if (const char *ov = getenv("WG_WAVES_PER_CU")) { int v = atoi(ov); if (v > 0) per_cu = v; }  // tuning knob
   int grid = g_num_cu * per_cu;
   if (grid > B) grid = B;
   hipStream_t st = reinterpret_cast<hipStream_t>(hip_stream);

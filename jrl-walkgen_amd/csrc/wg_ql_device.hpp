@@ -27,6 +27,13 @@
 
 namespace wg {
 
+#ifndef WG_UNROLL_N
+#define WG_UNROLL_N 4
+#endif
+#define WG_PRAGMA(x) _Pragma(#x)
+#define WG_UNROLL_(n) WG_PRAGMA(unroll n)
+#define WG_UNROLL WG_UNROLL_(WG_UNROLL_N)
+
 #define WG_WSYNC()                                          \
   do {                                                      \
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  \
@@ -91,6 +98,18 @@ struct QlView {
 #define Am(k, i) q.A[(k) + (i) * q.lda]
 #define Rp(i, j) q.R[(j) * ((j) + 1) / 2 + (i)]
 
+// ---- optional in-kernel phase timers (diagnostic build only: -DWG_PROFILE) ----
+#ifdef WG_PROFILE
+__device__ unsigned long long g_prof[24];
+#define PT_DECL unsigned long long pt_acc[24] = {0}; unsigned long long pt_last = clock64();
+#define PT(k) do { unsigned long long t_ = clock64(); pt_acc[k] += t_ - pt_last; pt_last = t_; } while (0)
+#define PT_FLUSH do { if ((threadIdx.x & 63) == 0) for (int k_ = 0; k_ < 24; ++k_) atomicAdd(&g_prof[k_], pt_acc[k_]); } while (0)
+#else
+#define PT_DECL
+#define PT(k) do {} while (0)
+#define PT_FLUSH do {} while (0)
+#endif
+
 struct QlResult {
   int ifail, n_iter, nact, hist_len;
 };
@@ -144,6 +163,7 @@ __device__ __forceinline__ void zt_times_ww(const QlView &q, double *s, int lane
   const int n = q.n;
   for (int i = lane; i < n; i += 64) {
     double acc = 0.0;
+    WG_UNROLL
     for (int j = 0; j < n; ++j) acc += Zm(j, i) * q.ww[j];
     s[i] = acc;
   }
@@ -155,6 +175,7 @@ __device__ __forceinline__ void zt_times_ww(const QlView &q, double *s, int lane
 __device__ __forceinline__ void backsub(const QlView &q, const double *s, int nact, int lane) {
   for (int i = nact - 1; i >= 0; --i) {
     double sum = 0.0;
+    WG_UNROLL
     for (int j = i + 1; j < nact; ++j) sum += Rp(i, j) * q.ww[j];
     double v = (s[i] - sum) / Rp(i, i);
     if (lane == 0) q.ww[i] = v;
@@ -193,6 +214,7 @@ __device__ __forceinline__ double xmag_sum(const QlView &q, double vfact, int la
   }
   WG_WSYNC();
   double sum = 0.0;
+  WG_UNROLL
   for (int i = 0; i < n; ++i) sum += q.sc3[i];
   return sum;
 }
@@ -206,6 +228,7 @@ __device__ __forceinline__ void sweep(const QlView &q, double *s, int nu, int na
   // phase 1: sc0[c] = p (s[c-1] before), sc1[c] = q (s[c] current), sc2[c] = norm; sc2[c] = 0 marks "skipped"
   {
     double cur = s[nu - 1];
+    WG_UNROLL
     for (int c = nu - 1; c > nact; --c) {
       double p = s[c - 1];
       double nrm;
@@ -229,6 +252,7 @@ __device__ __forceinline__ void sweep(const QlView &q, double *s, int nu, int na
   // phase 3: rows of Z
   for (int i = lane; i < n; i += 64) {
     double carry = Zm(i, nu - 1);
+    WG_UNROLL
     for (int c = nu - 1; c > nact; --c) {
       if (q.sc2[c] == 0.0) { Zm(i, c) = carry; carry = Zm(i, c - 1); continue; }
       double ga = q.sc0[c], gb = q.sc1[c];
@@ -294,6 +318,7 @@ __device__ __forceinline__ bool independent_coordinate(const QlView &q, int knex
     if (knext <= m) suma = Am(knext - 1, i - 1);
     else { suma = 0.0; if (i == k1) suma = (knext > q.mn) ? -1.0 : 1.0; }
     double sumb = fabs(suma);
+    WG_UNROLL
     for (int k = 0; k < nact; ++k) {
       int kk = q.iact[k];
       double temp;
@@ -331,6 +356,7 @@ __device__ inline QlResult ql_solve(const QlView &q, double vsmall, int *hist, i
   const int s_tail = n * (n + 1) / 2;
   double *s = q.R + s_tail;
   bool early_exit = false;
+  PT_DECL
 
 #define LOG_EVENT(code)                                                   \
   do {                                                                    \
@@ -343,6 +369,7 @@ __device__ inline QlResult ql_solve(const QlView &q, double vsmall, int *hist, i
     int fatal = 0x7fffffff;
     for (int k = lane; k < m; k += 64) {
       double sum = 0.0;
+      WG_UNROLL
       for (int i = 0; i < n; ++i) { double a = Am(k, i); sum += a * a; }
       if (sum > 0.0) sum = 1.0 / sqrt(sum);
       else if (q.b[k] == 0.0) {}
@@ -353,6 +380,7 @@ __device__ inline QlResult ql_solve(const QlView &q, double vsmall, int *hist, i
     fatal = wave_min_int(fatal);
     if (fatal != 0x7fffffff) { info = -fatal; early_exit = true; }
   }
+  PT(0);
 
   if (!early_exit) {
     // ---- make the Hessian numerically positive definite, :814-854 ----
@@ -363,6 +391,7 @@ __device__ inline QlResult ql_solve(const QlView &q, double vsmall, int *hist, i
       for (int i = lane; i < n; i += 64) {
         double wdi = q.wd[i];
         dl = maxd(dl, vsmall - wdi);
+        WG_UNROLL
         for (int j = i + 1; j < n; ++j) {
           double gjj = q.wd[j], gij = Gm(i, j);
           double ga = -mind(wdi, gjj);
@@ -374,6 +403,7 @@ __device__ inline QlResult ql_solve(const QlView &q, double vsmall, int *hist, i
       diag = wave_max(dl);
     }
     bool need_shift = diag > 0.0;
+    PT(1);
     for (;;) {
       if (need_shift) {
         diag = diagr * diag;
@@ -386,6 +416,7 @@ __device__ inline QlResult ql_solve(const QlView &q, double vsmall, int *hist, i
       for (int i = 0; i < n; ++i) {
         for (int j = i + lane; j < n; j += 64) {
           double temp = Gm(i, j);
+          WG_UNROLL
           for (int k = 0; k < i; ++k) temp -= Rp(k, j) * Rp(k, i);
           if (j == i) {
             if (temp < vsmall) { q.slot[0] = 1.0; q.slot[1] = temp; }
@@ -410,6 +441,7 @@ __device__ inline QlResult ql_solve(const QlView &q, double vsmall, int *hist, i
           v[jfail] = 1.0;
           for (int k = jfail; k >= 1; --k) {
             double sum = 0.0;
+            WG_UNROLL
             for (int i = k; i <= jfail; ++i) sum -= Rp(k - 1, i) * v[i];
             v[k - 1] = sum / Rp(k - 1, k - 1);
             sumx += v[k - 1] * v[k - 1];
@@ -423,8 +455,10 @@ __device__ inline QlResult ql_solve(const QlView &q, double vsmall, int *hist, i
       need_shift = true;
     }
 
+    PT(2);
     // ---- Z = R^-1, :937-975 ----
     for (int i = lane; i < n; i += 64) {
+      WG_UNROLL
       for (int j = 0; j < i; ++j) Zm(i, j) = 0.0;
       Zm(i, i) = 1.0 / Rp(i, i);
     }
@@ -434,6 +468,7 @@ __device__ inline QlResult ql_solve(const QlView &q, double vsmall, int *hist, i
       double sum0, sum1;
       for (int c = 1; c < n; ++c) {
         sum0 = 0.0; sum1 = 0.0;
+        WG_UNROLL
         for (int k = 0; k < c; ++k) {
           double rkc = Rp(k, c);
           if (i0 <= k) sum0 += Zm(i0, k) * rkc;
@@ -447,6 +482,7 @@ __device__ inline QlResult ql_solve(const QlView &q, double vsmall, int *hist, i
     WG_WSYNC();
   }
 
+  PT(3);
   enum { ST_RESET, ST_RESID, ST_SCAN, ST_CONVERGED, ST_FINISH };
   int st = early_exit ? ST_FINISH : ST_RESET;
   while (st != ST_FINISH) {
@@ -471,7 +507,9 @@ __device__ inline QlResult ql_solve(const QlView &q, double vsmall, int *hist, i
         iflag = 2;
         for (int i = lane; i < n; i += 64) {
           double acc = q.d[i];
+          WG_UNROLL
           for (int j = 0; j < n; ++j) acc += Gm(i, j) * q.x[j];
+          WG_UNROLL
           for (int k = 0; k < nact; ++k) {
             int kk = q.iact[k];
             if (kk <= m) acc -= q.lam[k] * Am(kk - 1, i);
@@ -485,6 +523,7 @@ __device__ inline QlResult ql_solve(const QlView &q, double vsmall, int *hist, i
           double sk;
           if (kk <= m) {
             sk = q.b[kk - 1];
+            WG_UNROLL
             for (int i = 0; i < n; ++i) sk -= q.x[i] * Am(kk - 1, i);
           } else if (kk <= mn) { int k1 = kk - m - 1; sk = q.xl[k1] - q.x[k1]; }
           else { int k1 = kk - mn - 1; sk = -q.xu[k1] + q.x[k1]; }
@@ -508,6 +547,7 @@ __device__ inline QlResult ql_solve(const QlView &q, double vsmall, int *hist, i
         }
         for (int i = lane; i < n; i += 64) {
           double sum = 0.0;
+          WG_UNROLL
           for (int j = 0; j < nact; ++j) sum += s[j] * Zm(i, j);
           q.x[i] += sum;
           q.sc0[i] = sum;
@@ -515,27 +555,34 @@ __device__ inline QlResult ql_solve(const QlView &q, double vsmall, int *hist, i
         WG_WSYNC();
         for (int j = lane; j < n; j += 64) {
           double acc = q.ww[j];
+          WG_UNROLL
           for (int i = 0; i < n; ++i) acc += q.sc0[i] * Gm(i, j);
           q.ww[j] = acc;
         }
         WG_WSYNC();
       }
+      PT(4);
       zt_times_ww(q, s, lane);                              // :1175-1177
+      PT(5);
       if (nact != n) {                                      // :1186-1201
         for (int i = lane; i < n; i += 64) {
           double sum = 0.0;
+          WG_UNROLL
           for (int j = nact; j < n; ++j) sum += Zm(i, j) * s[j];
           q.x[i] -= sum;
         }
         info = 0;
         WG_WSYNC();
       }
+      PT(6);
       if (nact != 0) {                                      // :1208-1217
         backsub(q, s, nact, lane);
         for (int k = lane; k < nact; k += 64) q.lam[k] += q.ww[k];
         WG_WSYNC();
       }
+      PT(7);
       { double sm = xmag_sum(q, vfact, lane); xmag = maxd(xmag, sm); }
+      PT(8);
       if (iflag == itref) { st = ST_RESID; continue; }      // :1226
       // first inequality with a negative multiplier, :1233-1249
       int kd = 0x7fffffff;
@@ -560,12 +607,14 @@ __device__ inline QlResult ql_solve(const QlView &q, double vsmall, int *hist, i
         if (wak <= 0.0) continue;
         double bk = q.b[k];
         double sum = -bk;
+        WG_UNROLL
         for (int i = 0; i < n; ++i) sum += q.x[i] * Am(k, i);
         double sumx = -sum * wak;
         if (k + 1 <= me) sumx = fabs(sumx);
         if (sumx <= 0.0) continue;              // cvmax starts at 0 (:1256)
         if (bidx >= 0 && sumx <= bestv) continue;
         double temp = fabs(bk);
+        WG_UNROLL
         for (int i = 0; i < n; ++i) temp += fabs(q.x[i] * Am(k, i));
         double tempa = temp + fabs(sum);
         if (tempa <= temp) continue;
@@ -603,6 +652,7 @@ __device__ inline QlResult ql_solve(const QlView &q, double vsmall, int *hist, i
       }
       double cvmax = bestv;
       if (bidx >= 0) { res = bestres; knext = bidx; }
+      PT(9);
       info = 0;
       if (cvmax <= vsmall) { st = ST_CONVERGED; continue; }  // :1336
 
@@ -613,6 +663,7 @@ __device__ inline QlResult ql_solve(const QlView &q, double vsmall, int *hist, i
           for (int i = lane; i < n; i += 64) {
             double sum = 2.0 * q.d[i];
             double sumx = fabs(sum);
+            WG_UNROLL
             for (int j = 0; j < n; ++j) {
               double temp = Gm(i, j) * (q.wx[j] + q.x[j]);
               sum += temp;
@@ -624,6 +675,7 @@ __device__ inline QlResult ql_solve(const QlView &q, double vsmall, int *hist, i
           }
           WG_WSYNC();
           double fdiff = 0.0, fdiffa = 0.0;
+          WG_UNROLL
           for (int i = 0; i < n; ++i) { fdiff += q.sc0[i]; fdiffa += q.sc1[i]; }
           info = 2;
           double sum = fdiffa + fdiff;
@@ -637,6 +689,7 @@ __device__ inline QlResult ql_solve(const QlView &q, double vsmall, int *hist, i
         WG_WSYNC();
       }
 
+      PT(10);
       ++iterc;                                              // :1415-1420
       if (iterc > maxit) { info = 1; st = ST_FINISH; continue; }
 
@@ -657,15 +710,18 @@ __device__ inline QlResult ql_solve(const QlView &q, double vsmall, int *hist, i
         }
         WG_WSYNC();
       }
+      PT(11);
       double parnew = 0.0, parinc = 0.0, step = 0.0, sumy;
       int kdrop = -1;
       int route;   // 0 step, 1 dependent (multipliers needed), 2 dependent (multipliers in ww)
       if (nact == n) route = 1;                             // :1477
       else {
         sweep(q, s, n, nact, lane);                         // :1480-1482
+        PT(12);
         if (nact == 0) route = 0;                           // :1488
         else {                                              // :1491-1532
           double suma = 0.0, sumb = 0.0, sumc = 0.0;
+          WG_UNROLL
           for (int i = 0; i < n; ++i) {
             double zi = Zm(i, nact), wi = q.ww[i];
             suma += wi * zi;
@@ -685,6 +741,7 @@ __device__ inline QlResult ql_solve(const QlView &q, double vsmall, int *hist, i
         }
       }
       route = uni(route);
+      PT(13);
       if (route != 0) {
         if (route == 1) backsub(q, s, nact, lane);
         kdrop = pick_drop(q, nact, res, ratio, lane);
@@ -703,8 +760,11 @@ __device__ inline QlResult ql_solve(const QlView &q, double vsmall, int *hist, i
           parinc = step / sumy;
           kdrop = -1;
           if (nact > 0) {
+            PT(14);
             backsub(q, s, nact, lane);
+            PT(15);
             kdrop = pick_drop(q, nact, res, ratio, lane);
+            PT(16);
             if (kdrop >= 0) {                               // :1734-1743
               double temp = 1.0 - ratio / parinc;
               if (temp <= 0.0) kdrop = -1;
@@ -743,6 +803,7 @@ __device__ inline QlResult ql_solve(const QlView &q, double vsmall, int *hist, i
         }
       }
 
+      PT(17);
       // ---- add the new constraint, :1764-1771 ----
       if (lane == 0) {
         q.lam[nact] = parnew;
@@ -754,8 +815,10 @@ __device__ inline QlResult ql_solve(const QlView &q, double vsmall, int *hist, i
       nact++;
       LOG_EVENT(knext);
       WG_WSYNC();
+      PT(18);
       double sm = xmag_sum(q, vfact, lane);                 // :1776-1786
       xmag = maxd(xmag, sm);
+      PT(19);
       if (sm < xmagr * xmag) st = ST_RESET;
       else if (itref <= 0) st = ST_SCAN;
       else st = ST_RESID;
@@ -771,6 +834,8 @@ __device__ inline QlResult ql_solve(const QlView &q, double vsmall, int *hist, i
   }
 #undef LOG_EVENT
 
+  PT(20);
+  PT_FLUSH;
   // ---- ql0001 epilogue, :497-608 ----
   out.ifail = 0;
   if (info == 1) out.ifail = 1;

@@ -28,6 +28,28 @@ int wgo_ql_solve(int m, int me, int mmax, int n, int nmax,
                  int *nact_out, int *n_iter, int *hist, int hist_cap,
                  int *hist_len);
 
+/* ---- Herdt-2010 tick restatement (herdt_oracle.c) ------------------------- */
+#include "../include/wg_mpc.h"   /* POD layouts only (wg_model_t, wg_gait_state_t, wg_tick_out_t) */
+
+#define WGO_HIST_CAP 512
+#define WGO_DUMP_C (80 * 80)
+#define WGO_DUMP_A (200 * 80)
+/* optional per-tick introspection: the assembled QP exactly as it is handed to QL */
+typedef struct wgo_qp_dump {
+  int n, m, mmax, ifail, nact, n_iter, hist_len;
+  int iact[128];
+  int hist[WGO_HIST_CAP];
+  double C[WGO_DUMP_C], A[WGO_DUMP_A], d[80], b[200], x[80];
+  wg_foot_sample_t lf_back_rewritten, rf_back_rewritten;
+} wgo_qp_dump_t;
+
+void wgo_model_defaults(wg_model_t *model);
+void wgo_gait_init(const wg_model_t *model, wg_gait_state_t *state, const double com0[3],
+                   const double left_xyt[3], const double right_xyt[3]);
+/* one tick at time state->clock (the caller advances the clock, see tests/herdt_replay.py);
+ * out and dump may be NULL.  Returns 0, or <0 if the sizes are unsupported. */
+int wgo_mpc_tick(const wg_model_t *model, wg_gait_state_t *state, wg_tick_out_t *out, wgo_qp_dump_t *dump);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,190 @@
+"""Replays the reference's 5 ms control loop around a tick function.
+
+Mirrors PatternGeneratorInterfacePrivate::RunOneStepOfTheControlLoop
+(src/PatternGeneratorInterfacePrivate.cpp:1246-1514, Herdt branch :1316-1327)
+plus CoMAndFootOnlyStrategy::OneGlobalStepOfControl
+(src/GlobalStrategyManagers/CoMAndFootOnlyStrategy.cpp:56-127) and the event
+loop of tests/TestObject.cpp:515-605: the four deques, one pop per call, one
+tick whenever  clock + 1e-5 > UpperTimeLimitToUpdate_.  The tick itself is a
+callable so that the same replay drives the CPU oracle and the HIP path.
+
+Row layout = the 38 columns of tests/TestObject.cpp:344-385.
+"""
+import ctypes as C
+
+import numpy as np
+
+import oraclelib as ol
+
+SAMPLES = 20
+
+
+class FootSample(C.Structure):
+    _fields_ = [(k, C.c_double) for k in
+                ("x", "y", "z", "theta", "omega", "omega2", "dx", "dy", "dz", "dtheta", "domega", "domega2",
+                 "ddx", "ddy", "ddz", "ddtheta", "ddomega", "ddomega2")]
+
+
+class Model(C.Structure):
+    _fields_ = [("N", C.c_int), ("flags", C.c_int)] + [(k, C.c_double) for k in
+                ("T", "Tctrl", "com_height_qp", "alpha", "beta", "gamma", "sole_w", "sole_h", "margin_x", "margin_y",
+                 "ds_feet_distance", "hip_l_lo", "hip_l_hi", "hip_r_lo", "hip_r_hi", "hip_vmax", "hip_amax",
+                 "feet_cross_max", "step_period", "ds_period", "dsss_period", "t_single", "t_double", "step_height",
+                 "feet_distance")]
+
+
+class GaitState(C.Structure):
+    _fields_ = [("clock", C.c_double), ("upper_time_limit", C.c_double), ("time_to_stop", C.c_double),
+                ("tick_count", C.c_int), ("running", C.c_int), ("ending_phase", C.c_int), ("online", C.c_int),
+                ("vref", C.c_double * 3),
+                ("com_x", C.c_double * 3), ("com_y", C.c_double * 3), ("com_z", C.c_double),
+                ("phase", C.c_int), ("foot", C.c_int), ("nb_steps_left", C.c_int), ("step_number", C.c_int),
+                ("state_changed", C.c_int), ("pad0_", C.c_int),
+                ("time_limit", C.c_double), ("start_time", C.c_double), ("sup_x", C.c_double), ("sup_y", C.c_double),
+                ("sup_yaw", C.c_double),
+                ("in_translation", C.c_int), ("in_rotation", C.c_int), ("nb_steps_after_rotation", C.c_int),
+                ("rot_support_foot", C.c_int), ("post_rotation_phase", C.c_int), ("nb_steps_ssds", C.c_int),
+                ("trunk_yaw", C.c_double * 3), ("trunkT_yaw", C.c_double * 3),
+                ("lf", FootSample * 3), ("rf", FootSample * 3),
+                ("front_com_x", C.c_double * 3), ("front_com_y", C.c_double * 3),
+                ("poly_z", C.c_double * 5)]
+
+
+class TickOut(C.Structure):
+    _fields_ = [("jerk_x", C.c_double), ("jerk_y", C.c_double),
+                ("ifail", C.c_int), ("n_iter", C.c_int), ("nact", C.c_int), ("n", C.c_int), ("m", C.c_int),
+                ("nb_prw_steps", C.c_int),
+                ("com_x", (C.c_double * 3) * SAMPLES), ("com_y", (C.c_double * 3) * SAMPLES),
+                ("com_yaw", (C.c_double * 2) * SAMPLES),
+                ("zmp_x", C.c_double * SAMPLES), ("zmp_y", C.c_double * SAMPLES),
+                ("lf", FootSample * SAMPLES), ("rf", FootSample * SAMPLES)]
+
+
+HIST_CAP = 512
+
+
+class QpDump(C.Structure):
+    _fields_ = [("n", C.c_int), ("m", C.c_int), ("mmax", C.c_int), ("ifail", C.c_int), ("nact", C.c_int),
+                ("n_iter", C.c_int), ("hist_len", C.c_int), ("iact", C.c_int * 128), ("hist", C.c_int * HIST_CAP),
+                ("C", C.c_double * (80 * 80)), ("A", C.c_double * (200 * 80)), ("d", C.c_double * 80),
+                ("b", C.c_double * 200), ("x", C.c_double * 80),
+                ("lf_back_rewritten", FootSample), ("rf_back_rewritten", FootSample)]
+
+
+def default_model():
+    m = Model()
+    ol.oracle().wgo_model_defaults(C.byref(m))
+    return m
+
+
+def init_state(model, com0, left_xyt, right_xyt):
+    s = GaitState()
+    a3 = lambda v: (C.c_double * 3)(*v)
+    ol.oracle().wgo_gait_init(C.byref(model), C.byref(s), a3(com0), a3(left_xyt), a3(right_xyt))
+    return s
+
+
+def oracle_tick(model, state, want_dump=False):
+    out = TickOut()
+    dump = QpDump() if want_dump else None
+    rc = ol.oracle().wgo_mpc_tick(C.byref(model), C.byref(state), C.byref(out), C.byref(dump) if dump else None)
+    assert rc == 0, rc
+    return out, dump
+
+
+def _foot_row(f):
+    return [f.x, f.y, f.z, f.dx, f.dy, f.dz, f.ddx, f.ddy, f.ddz, f.theta, f.omega, f.omega2]
+
+
+def _copy_foot(f):
+    g = FootSample()
+    C.memmove(C.byref(g), C.byref(f), C.sizeof(FootSample))
+    return g
+
+
+def replay(model, state, events, max_calls, tick=oracle_tick, zmp0=(0.0, 0.0), on_tick=None,
+           legacy_running=False):
+    """events: {iteration: callable(state)} applied after that call like TestObject::generateEvent.
+    legacy_running: rows are produced until the queues run dry (behaviour of the revision that recorded
+    the golden file; today RunOneStepOfTheControlLoop returns ZMPVelocityReferencedQP::Running()).
+    Returns an (n_calls x 38) array."""
+    dt = model.Tctrl
+    # InitOnLine: 8 start samples in every queue (ZMPVelocityReferencedQP.cpp:240-275)
+    nbuf = int(0.04 / dt)
+    com_q = [dict(x=[state.com_x[0], 0.0, 0.0], y=[state.com_y[0], 0.0, 0.0], z=state.com_z, yaw=0.0) for _ in range(nbuf)]
+    zmp_q = [tuple(zmp0) for _ in range(nbuf)]
+    lf_q = [_copy_foot(state.lf[2]) for _ in range(nbuf)]
+    rf_q = [_copy_foot(state.rf[2]) for _ in range(nbuf)]
+    clock = 0.0
+    rows = []
+    for it in range(1, max_calls + 1):
+        clock += dt
+        was_online = bool(state.online)                                            # :332-335
+        if was_online and state.ending_phase and clock >= state.time_to_stop:      # :338-340
+            state.online = 0       # (the call that switches on-line mode off still runs its tick)
+        if was_online and clock + 0.00001 > state.upper_time_limit:                # :346
+            state.clock = clock
+            res = tick(model, state, True)
+            out, dump = res
+            if on_tick:
+                on_tick(it, clock, state, out, dump)
+            if dump is not None:
+                lf_q[-1] = _copy_foot(dump.lf_back_rewritten)
+                rf_q[-1] = _copy_foot(dump.rf_back_rewritten)
+            for k in range(SAMPLES):
+                com_q.append(dict(x=list(out.com_x[k]), y=list(out.com_y[k]), z=state.com_z, yaw=out.com_yaw[k][0]))
+                zmp_q.append((out.zmp_x[k], out.zmp_y[k]))
+                lf_q.append(_copy_foot(out.lf[k]))
+                rf_q.append(_copy_foot(out.rf[k]))
+        running = bool(state.running) or legacy_running
+        if not com_q:
+            break
+        c = com_q.pop(0); z = zmp_q.pop(0); lf = lf_q.pop(0); rf = rf_q.pop(0)
+        if not running:
+            break
+        row = [it * 0.005, c["x"][0], c["y"][0], c["z"], c["yaw"], c["x"][1], c["y"][1], 0.0, z[0], z[1]]
+        row += _foot_row(lf) + _foot_row(rf) + [z[0], z[1], 0.0, 0.0]
+        rows.append(row)
+        if it in events:
+            events[it](state)
+    return np.array(rows)
+
+
+def emergency_stop_events():
+    """tests/TestHerdt2010.cpp:260-265 (+ handlers :128-200)."""
+    def vel(x, y, w):
+        def f(s):
+            s.vref[0], s.vref[1], s.vref[2] = x, y, w
+        return f
+
+    def stop(s):
+        s.vref[0], s.vref[1], s.vref[2] = 0.0, 0.0, 0.0
+        s.ending_phase = 1
+    return {int(5 * 200): vel(0.0, 0.0, 0.4), int(10 * 200): vel(0.2, 0.0, -0.2), int(15.2 * 200): vel(0.0, 0.0, 0.0),
+            int(20.8 * 200): stop}
+
+
+def load_datref(path):
+    return np.loadtxt(path)
+
+
+def emergency_stop_setup(datref):
+    """Model / start state / events of TestHerdt2010's EmergencyStop profile on jrl-dynamics' sample robot.
+
+    Robot constants that the reference reads from the (absent) sample model were identified from the
+    golden file itself: sole 0.25 x 0.14 m, no hip-yaw limits (fallback -30/+45 deg on both
+    legs, zero velocity bound), start CoM (0.0316055, 0, 0.7116911), feet at (0, +-0.09).
+    Two things in the golden file predate the current reference source (ChangeLog [3.1.8]):
+      * the initial support state had Y hard-coded to 0.1 (half the default feet distance) instead of the
+        left foot's y,
+      * the "move the CoM to the feet centre when stopping" branch did not exist, and rows were written
+        until the queues ran dry.
+    """
+    m = default_model()
+    m.flags = 1                      # WG_FLAG_NO_STOP_CENTERING
+    s = init_state(m, [datref[0, 1], datref[0, 2], datref[0, 3]], [datref[0, 10], datref[0, 11], 0.0],
+                   [datref[0, 22], datref[0, 23], 0.0])
+    s.nb_steps_left = 2              # ":numberstepsbeforestop 2"  (ZMPVelocityReferencedQP.cpp:197-202)
+    s.nb_steps_ssds = 2
+    s.sup_y = 0.1
+    return m, s, emergency_stop_events()
