@@ -192,9 +192,12 @@ typedef struct wg_tick_out {
   double com_yaw[WG_SAMPLES_PER_TICK][2];
   double zmp_x[WG_SAMPLES_PER_TICK], zmp_y[WG_SAMPLES_PER_TICK];
   wg_foot_sample_t lf[WG_SAMPLES_PER_TICK], rf[WG_SAMPLES_PER_TICK];
+  /* the newest sample ALREADY in the feet queues before this tick: the double-support branch of
+   * interpolate_feet_positions rewrites it (OnLineFootTrajectoryGeneration.cpp:333-336, k = 0) */
+  wg_foot_sample_t lf_back, rf_back;
 } wg_tick_out_t;
 
-/* Defaults of every constant the reference hard-codes; caller fills the robot part. */
+/* Defaults of every constant the reference hard-codes; robot part = jrl-dynamics' sample robot. */
 void wg_model_defaults(wg_model_t *model);
 
 /* State after ZMPVelocityReferencedQP::InitOnLine (:212-319): standing in double
@@ -202,6 +205,34 @@ void wg_model_defaults(wg_model_t *model);
 void wg_gait_init(const wg_model_t *model, wg_gait_state_t *state,
                   const double com0[3] /* x y z */, const double left_xyt[3],
                   const double right_xyt[3] /* x y theta[deg] */);
+
+
+/* Upload the model and build, on the device, what the reference builds once per gait in the
+ * ZMPVelocityReferencedQP constructor and InitOnLine: the condensed cart-table maps S/U
+ * (RigidBodySystem::compute_dyn_cjerk, rigid-body-system.cpp:377-452) and the invariant Hessian block
+ * beta*I + alpha*Uv'Uv + gamma*Uz'Uz (GeneratorVelRef::build_invariant_part, generator-vel-ref.cpp:587-614).
+ * These tables are constants of the model (a few KiB, 3 x 2N^3 flop once per process); they are formed on
+ * the host in the reference's exact summation order -- so that the per-tick QPs are bit-identical to the
+ * reference's -- and uploaded once. */
+int wg_mpc_configure(const wg_model_t *model);
+
+/* One MPC tick for each of B gaits (replaces B calls of ZMPVelocityReferencedQP::OnLine with
+ * time + 1e-5 > UpperTimeLimitToUpdate_, ZMPVelocityReferencedQP.cpp:346-452).
+ *   states  B structs, read and written; state->clock must hold the control-loop time of the tick
+ *           (`advance_calls` > 0 adds that many control periods to it first, the way
+ *           RunOneStepOfTheControlLoop does, PatternGeneratorInterfacePrivate.cpp:1256)
+ *   outs    B structs or NULL (NULL: only the state is advanced)
+ *   diag    B x 6 ints {ifail, n_iter, nact, n, m, nb_prw_steps} or NULL
+ *   hist    B x hist_cap active-set add(+)/drop(-) log or NULL, hist_len B or NULL */
+int wg_mpc_tick_batch(int B, wg_gait_state_t *states, wg_tick_out_t *outs, int *diag, int advance_calls,
+                      int *hist, int hist_cap, int *hist_len);
+int wg_mpc_tick_batch_dev(int B, wg_gait_state_t *states, wg_tick_out_t *outs, int *diag, int advance_calls,
+                          int *hist, int hist_cap, int *hist_len, void *hip_stream);
+/* NewVelRef_ <- (vx, vy, vyaw) for every gait (":setVelReference", ZMPVelocityReferencedQP.hh:103-114);
+ * vref = B x 3 doubles, DEVICE pointers. */
+int wg_mpc_set_velref_dev(int B, wg_gait_state_t *states, const double *vref, void *hip_stream);
+/* LDS bytes one gait occupies in the tick kernel for the configured model. */
+size_t wg_mpc_tick_lds_bytes(void);
 
 #ifdef __cplusplus
 }

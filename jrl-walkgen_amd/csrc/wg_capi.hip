@@ -246,3 +246,181 @@ int wg_qp_solve_batch(int B, int nmax, int mmax, const int *n, const int *m, con
 }
 
 }  // extern "C"
+
+// ===========================================================================
+// Herdt-2010 MPC tick, batched (include/wg_mpc.h, second half)
+// ===========================================================================
+#include "wg_tick_device.hpp"
+
+namespace {
+wg_model_t g_model;
+bool g_model_set = false;
+wg::TickTables *g_tables_dev = nullptr;
+DevBuf g_tick_state, g_tick_out, g_tick_aux;
+
+inline int tick_max_n(const wg_model_t &m) { return 2 * m.N + 2 * wg::kSMax; }
+inline int tick_max_m(const wg_model_t &m) { return 1 + 4 * m.N + 5 * wg::kSMax; }
+inline size_t tick_ql_bytes(const wg_model_t &m) {
+  size_t b = wg::QlDims(tick_max_n(m), tick_max_m(m), tick_max_m(m)).bytes();
+  return (b + 15) & ~(size_t)15;
+}
+}  // namespace
+
+__global__ __launch_bounds__(64) void wg_mpc_tick_kernel(int B, wg_model_t model, const wg::TickTables *__restrict__ tb,
+                                                         wg_gait_state_t *__restrict__ states,
+                                                         wg_tick_out_t *__restrict__ outs, int *__restrict__ diag,
+                                                         int advance_calls, int *__restrict__ hist, int hist_cap,
+                                                         int *__restrict__ hist_len, unsigned ql_bytes) {
+  extern __shared__ __attribute__((aligned(16))) double wg_lds[];
+  const int lane = threadIdx.x & 63;
+  for (int g = blockIdx.x; g < B; g += gridDim.x) {
+    if (advance_calls > 0) {
+      if (lane == 0) {
+        double c = states[g].clock;
+        for (int k = 0; k < advance_calls; ++k) c += model.Tctrl;   // PatternGeneratorInterfacePrivate.cpp:1256
+        states[g].clock = c;
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      WG_WSYNC();
+    }
+    wg::TickDiag dg = wg::mpc_tick(model, tb, states + g, outs ? outs + g : nullptr, wg_lds,
+                                   reinterpret_cast<char *>(wg_lds) + ql_bytes, hist ? hist + (size_t)g * hist_cap : nullptr,
+                                   hist_cap, hist_len ? hist_len + g : nullptr);
+    if (diag && lane == 0) {
+      int *dq = diag + (size_t)g * 6;
+      dq[0] = dg.ifail; dq[1] = dg.n_iter; dq[2] = dg.nact; dq[3] = dg.n; dq[4] = dg.m; dq[5] = dg.ns;
+    }
+    WG_WSYNC();
+  }
+}
+
+__global__ void wg_set_velref_kernel(int B, wg_gait_state_t *states, const double *vref) {
+  const int g = blockIdx.x * blockDim.x + threadIdx.x;
+  if (g < B) {
+    states[g].vref[0] = vref[3 * g + 0];
+    states[g].vref[1] = vref[3 * g + 1];
+    states[g].vref[2] = vref[3 * g + 2];
+  }
+}
+
+extern "C" {
+
+void wg_model_defaults(wg_model_t *m) {
+  memset(m, 0, sizeof *m);
+  m->N = 16; m->flags = 0; m->T = 0.1; m->Tctrl = 0.005; m->com_height_qp = 0.814;
+  m->alpha = 1.0; m->beta = 0.00001; m->gamma = 0.000001;
+  m->sole_w = 0.25; m->sole_h = 0.14;
+  m->margin_x = 0.04; m->margin_y = 0.04; m->ds_feet_distance = 0.2;
+  m->hip_l_lo = -30.0 / 180.0 * wg::kPi; m->hip_l_hi = 45.0 / 180.0 * wg::kPi;
+  m->hip_r_lo = -30.0 / 180.0 * wg::kPi; m->hip_r_hi = 45.0 / 180.0 * wg::kPi;
+  m->hip_vmax = 0.0; m->hip_amax = 0.1; m->feet_cross_max = 5.0 / 180.0 * wg::kPi;
+  m->step_period = 0.8; m->ds_period = 1e9; m->dsss_period = 0.8;
+  m->t_single = 0.7; m->t_double = 0.1; m->step_height = 0.05; m->feet_distance = 0.2;
+}
+
+void wg_gait_init(const wg_model_t *, wg_gait_state_t *s, const double com0[3], const double left_xyt[3],
+                  const double right_xyt[3]) {
+  memset(s, 0, sizeof *s);
+  s->online = 1; s->time_to_stop = -1.0;
+  for (int k = 0; k < 3; k++) {
+    s->lf[k].x = left_xyt[0]; s->lf[k].y = left_xyt[1]; s->lf[k].theta = left_xyt[2];
+    s->rf[k].x = right_xyt[0]; s->rf[k].y = right_xyt[1]; s->rf[k].theta = right_xyt[2];
+  }
+  s->phase = WG_DS; s->foot = WG_LEFT; s->time_limit = 1000000000; s->nb_steps_left = 1;
+  s->sup_x = left_xyt[0]; s->sup_y = left_xyt[1]; s->sup_yaw = left_xyt[2] * wg::kPi / 180;
+  s->com_x[0] = com0[0]; s->com_y[0] = com0[1]; s->com_z = com0[2];
+  s->front_com_x[0] = com0[0]; s->front_com_y[0] = com0[1];
+  s->nb_steps_ssds = 2; s->rot_support_foot = WG_LEFT;
+}
+
+int wg_mpc_configure(const wg_model_t *model) {
+  if (int rc = ensure_device()) return rc;
+  if (!model) return fail(WG_ERR_BAD_ARG, "null model");
+  if (model->N < 2 || model->N > wg::kNMaxH) return fail(WG_ERR_BAD_ARG, "N=%d outside [2,%d]", model->N, wg::kNMaxH);
+  if ((int)(model->T / model->Tctrl) != WG_SAMPLES_PER_TICK)
+    return fail(WG_ERR_BAD_ARG, "T/Tctrl must be %d", WG_SAMPLES_PER_TICK);
+  size_t lds = tick_ql_bytes(*model) + wg::TickLds::bytes(model->N);
+  if (lds > 160 * 1024) return fail(WG_ERR_TOO_LARGE, "tick needs %zu B of LDS > 160 KiB", lds);
+  std::lock_guard<std::mutex> lk(g_mu);
+  static wg::TickTables host_tables;
+  wg::build_tables(*model, host_tables);
+  if (!g_tables_dev) HIP_TRY(hipMalloc(reinterpret_cast<void **>(&g_tables_dev), sizeof(wg::TickTables)));
+  HIP_TRY(hipMemcpy(g_tables_dev, &host_tables, sizeof host_tables, hipMemcpyHostToDevice));
+  g_model = *model;
+  g_model_set = true;
+  return WG_OK;
+}
+
+size_t wg_mpc_tick_lds_bytes(void) {
+  if (!g_model_set) return 0;
+  return tick_ql_bytes(g_model) + wg::TickLds::bytes(g_model.N);
+}
+
+int wg_mpc_tick_batch_dev(int B, wg_gait_state_t *states, wg_tick_out_t *outs, int *diag, int advance_calls, int *hist,
+                          int hist_cap, int *hist_len, void *hip_stream) {
+  if (int rc = ensure_device()) return rc;
+  if (!g_model_set) return fail(WG_ERR_BAD_ARG, "wg_mpc_configure() has not been called");
+  if (B < 0 || !states) return fail(WG_ERR_BAD_ARG, "bad arguments");
+  if (hist && (!hist_len || hist_cap <= 0)) return fail(WG_ERR_BAD_ARG, "hist needs hist_len and hist_cap > 0");
+  if (B == 0) return WG_OK;
+  const size_t qlb = tick_ql_bytes(g_model);
+  const size_t lds = qlb + wg::TickLds::bytes(g_model.N);
+  if (lds > 64 * 1024)
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(wg_mpc_tick_kernel),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  int per_cu = (int)((160 * 1024) / lds);
+  if (per_cu < 1) per_cu = 1;
+  per_cu *= 2;                                    // a few blocks in flight per slot evens out solver iteration counts
+  if (const char *ov = getenv("WG_WAVES_PER_CU")) { int v = atoi(ov); if (v > 0) per_cu = v; }
+  int grid = g_num_cu * per_cu;
+  if (grid > B) grid = B;
+  hipStream_t st = reinterpret_cast<hipStream_t>(hip_stream);
+  hipLaunchKernelGGL(wg_mpc_tick_kernel, dim3(grid), dim3(64), lds, st, B, g_model, g_tables_dev, states, outs, diag,
+                     advance_calls, hist, hist_cap, hist_len, (unsigned)qlb);
+  HIP_TRY(hipGetLastError());
+  return WG_OK;
+}
+
+int wg_mpc_tick_batch(int B, wg_gait_state_t *states, wg_tick_out_t *outs, int *diag, int advance_calls, int *hist,
+                      int hist_cap, int *hist_len) {
+  if (int rc = ensure_device()) return rc;
+  if (!g_model_set) return fail(WG_ERR_BAD_ARG, "wg_mpc_configure() has not been called");
+  if (B < 0 || !states) return fail(WG_ERR_BAD_ARG, "bad arguments");
+  if (B == 0) return WG_OK;
+  std::lock_guard<std::mutex> lk(g_mu);
+  const size_t sB = (size_t)B;
+  if (int rc = g_tick_state.reserve(sB * sizeof(wg_gait_state_t))) return rc;
+  if (outs) if (int rc = g_tick_out.reserve(sB * sizeof(wg_tick_out_t))) return rc;
+  const size_t aux_bytes = sB * 6 * 4 + (hist ? sB * hist_cap * 4 + sB * 4 : 0);
+  if (int rc = g_tick_aux.reserve(aux_bytes)) return rc;
+  HIP_TRY(hipMemcpy(g_tick_state.p, states, sB * sizeof(wg_gait_state_t), hipMemcpyHostToDevice));
+  int *d_diag = static_cast<int *>(g_tick_aux.p);
+  int *d_hist = hist ? d_diag + sB * 6 : nullptr;
+  int *d_hlen = hist ? d_hist + sB * hist_cap : nullptr;
+  HIP_TRY(hipMemset(g_tick_aux.p, 0, aux_bytes));
+  int rc = wg_mpc_tick_batch_dev(B, static_cast<wg_gait_state_t *>(g_tick_state.p),
+                                 outs ? static_cast<wg_tick_out_t *>(g_tick_out.p) : nullptr, d_diag, advance_calls,
+                                 d_hist, hist_cap, d_hlen, nullptr);
+  if (rc) return rc;
+  HIP_TRY(hipDeviceSynchronize());
+  HIP_TRY(hipMemcpy(states, g_tick_state.p, sB * sizeof(wg_gait_state_t), hipMemcpyDeviceToHost));
+  if (outs) HIP_TRY(hipMemcpy(outs, g_tick_out.p, sB * sizeof(wg_tick_out_t), hipMemcpyDeviceToHost));
+  if (diag) HIP_TRY(hipMemcpy(diag, d_diag, sB * 6 * 4, hipMemcpyDeviceToHost));
+  if (hist) {
+    HIP_TRY(hipMemcpy(hist, d_hist, sB * hist_cap * 4, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(hist_len, d_hlen, sB * 4, hipMemcpyDeviceToHost));
+  }
+  return WG_OK;
+}
+
+int wg_mpc_set_velref_dev(int B, wg_gait_state_t *states, const double *vref, void *hip_stream) {
+  if (int rc = ensure_device()) return rc;
+  if (B < 0 || !states || !vref) return fail(WG_ERR_BAD_ARG, "bad arguments");
+  if (B == 0) return WG_OK;
+  hipLaunchKernelGGL(wg_set_velref_kernel, dim3((B + 255) / 256), dim3(256), 0, reinterpret_cast<hipStream_t>(hip_stream),
+                     B, states, vref);
+  HIP_TRY(hipGetLastError());
+  return WG_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,773 @@
+// wg_tick_device.hpp -- one Herdt-2010 MPC tick per wavefront.
+//
+// Device-side replacement for the body of
+//   ZMPVelocityReferencedQP::OnLine   src/ZMPRefTrajectoryGeneration/ZMPVelocityReferencedQP.cpp:346-452
+// and what it calls on the reference's CPU path:
+//   SupportFSM                        src/PreviewControl/SupportFSM.cpp:57-153
+//   GeneratorVelRef                   src/ZMPRefTrajectoryGeneration/generator-vel-ref.cpp:70-229, 284-474, 554-674
+//   OrientationsPreview               src/ZMPRefTrajectoryGeneration/OrientationsPreview.cpp:79-418
+//   RelativeFeetInequalities          src/Mathematics/relative-feet-inequalities.cpp:185-319
+//   QPProblem::solve -> ql0001_       (wg_ql_device.hpp)
+//   LinearizedInvertedPendulum2D      src/PreviewControl/LinearizedInvertedPendulum2D.cpp:157-264
+//   OnLineFootTrajectoryGeneration    src/FootTrajectoryGeneration/OnLineFootTrajectoryGeneration.cpp:50-346
+//
+// One wave owns one gait.  The branchy scalar bookkeeping (support FSM, orientation
+// preview, polygon edges) runs on lane 0 and leaves its results in LDS; QP assembly,
+// the solve and the sample interpolation are lane-parallel.  Every floating-point
+// expression keeps the reference's evaluation order (ublas prod sums k ascending from
+// 0.0, compute_term scales after the product, add_term_to accumulates with +=).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "../../include/wg_mpc.h"
+#define WG_TRIG_FN __host__ __device__ static inline
+#include "../../include/wg_trig.h"
+#include "wg_ql_device.hpp"
+
+namespace wg {
+
+constexpr int kNMaxH = 32;   // largest horizon
+constexpr int kSMax = 4;     // largest number of previewed steps
+constexpr double kPi = 3.14159265358979323846;
+
+// Condensed cart-table maps + invariant Hessian block, built once per model on the host
+// (RigidBodySystem::compute_dyn_cjerk, rigid-body-system.cpp:377-452;
+//  GeneratorVelRef::build_invariant_part, generator-vel-ref.cpp:587-614).
+struct TickTables {
+  double Sv[kNMaxH][3], Sz[kNMaxH][3];
+  double Uv[kNMaxH][kNMaxH], Uz[kNMaxH][kNMaxH];
+  double Qb[kNMaxH][kNMaxH];
+};
+
+inline void build_tables(const wg_model_t &m, TickTables &t) {
+  const int N = m.N;
+  const double T = m.T, h = m.com_height_qp;
+  for (unsigned i = 0; i < (unsigned)kNMaxH; i++)
+    for (unsigned j = 0; j < (unsigned)kNMaxH; j++) { t.Uv[i][j] = 0.0; t.Uz[i][j] = 0.0; t.Qb[i][j] = 0.0; }
+  for (unsigned i = 0; i < (unsigned)N; i++) {
+    t.Sv[i][0] = 0.0; t.Sv[i][1] = 1.0; t.Sv[i][2] = (i + 1) * T;
+    t.Sz[i][0] = 1.0; t.Sz[i][1] = (i + 1) * T;
+    t.Sz[i][2] = (i + 1) * (i + 1) * T * T * 0.5 - h / 9.81;
+    for (unsigned j = 0; j <= i; j++) {
+      t.Uv[i][j] = (2 * (i - j) + 1) * T * T * 0.5;
+      t.Uz[i][j] = (1 + 3 * (i - j) + 3 * (i - j) * (i - j)) * T * T * T / 6.0 - T * h / 9.81;
+    }
+  }
+  for (int i = 0; i < N; i++)
+    for (int j = 0; j < N; j++) {
+      double pj = 0.0, pv = 0.0, pz = 0.0;
+      for (int k = 0; k < N; k++) {
+        pj += ((k == i) ? 1.0 : 0.0) * ((k == j) ? 1.0 : 0.0);
+        pv += t.Uv[k][i] * t.Uv[k][j];
+        pz += t.Uz[k][i] * t.Uz[k][j];
+      }
+      double q = 0.0;
+      q += pj * m.beta;
+      q += pv * m.alpha;
+      q += pz * m.gamma;
+      t.Qb[i][j] = q;
+    }
+}
+
+struct Sup {
+  int phase, foot, nb_steps_left, step_number, state_changed, pad;
+  double time_limit, start_time, x, y, yaw;
+};
+
+// LDS scratch of the tick (besides the solver's QlView)
+struct TickLds {
+  Sup *sup;                       // [N+1]
+  int *stepidx;                   // [N]
+  double *VcX, *VcY;              // [N]
+  double *Vc_fX, *Vc_fY;          // [kSMax]
+  double *V_f;                    // [kSMax*kSMax]
+  double *sup_angles;             // [8]
+  double *trunk;                  // [N+1]
+  double *refx, *refy;            // [N]
+  double *svx, *svy, *szx, *szy;  // [N]
+  double *rowA, *rowB, *rowD;     // [m]  polygon edge per constraint row
+  int *rowK;                      // [m]  instant (CoP rows) or step (foot rows)
+  double *misc;                   // [16] scalars handed from lane 0 to the wave
+  wg_gait_state_t *st;            // working copy of the state
+  __host__ __device__ static size_t bytes(int N) {
+    const int m = 1 + 4 * N + 5 * kSMax;
+    size_t b = sizeof(Sup) * (N + 1) + 8 * (size_t)(2 * N + 2 * kSMax + kSMax * kSMax + 8 + (N + 1) + 6 * N + 3 * m + 16) +
+               4 * (size_t)(((N + 1) & ~1) + ((m + 1) & ~1)) + ((sizeof(wg_gait_state_t) + 15) & ~(size_t)15);
+    return (b + 15) & ~(size_t)15;
+  }
+  __device__ void carve(char *base, int N) {
+    const int m = 1 + 4 * N + 5 * kSMax;
+    char *p = base;
+    st = reinterpret_cast<wg_gait_state_t *>(p); p += (sizeof(wg_gait_state_t) + 15) & ~(size_t)15;
+    sup = reinterpret_cast<Sup *>(p); p += sizeof(Sup) * (N + 1);
+    double *d = reinterpret_cast<double *>(p);
+    VcX = d; d += N; VcY = d; d += N; Vc_fX = d; d += kSMax; Vc_fY = d; d += kSMax; V_f = d; d += kSMax * kSMax;
+    sup_angles = d; d += 8; trunk = d; d += N + 1; refx = d; d += N; refy = d; d += N;
+    svx = d; d += N; svy = d; d += N; szx = d; d += N; szy = d; d += N;
+    rowA = d; d += m; rowB = d; d += m; rowD = d; d += m; misc = d; d += 16;
+    int *ip = reinterpret_cast<int *>(d);
+    stepidx = ip; ip += (N + 1) & ~1; rowK = ip;
+  }
+};
+
+// ---------------------------------------------------------------------------
+// lane-0 scalar code
+// ---------------------------------------------------------------------------
+#define WG_FSM_EPS 1e-6
+#define WG_OP_EPS 0.00000001
+
+// SupportFSM::update_vel_reference, SupportFSM.cpp:57-90
+__device__ inline void fsm_update_vel_reference(wg_gait_state_t *s, double *ref, int cur_foot) {
+  s->in_translation = (fabs(ref[0]) > 2 * WG_FSM_EPS || fabs(ref[1]) > 2 * WG_FSM_EPS) ? 1 : 0;
+  if (fabs(ref[2]) > WG_FSM_EPS) s->in_rotation = 1;
+  else if (s->in_rotation && !s->in_translation) {
+    ref[0] = 2 * WG_FSM_EPS; ref[1] = 2 * WG_FSM_EPS;
+    if (!s->post_rotation_phase) {
+      s->rot_support_foot = cur_foot; s->nb_steps_after_rotation = 0; s->post_rotation_phase = 1;
+    } else {
+      if (s->rot_support_foot != cur_foot) { s->rot_support_foot = cur_foot; ++s->nb_steps_after_rotation; }
+      if (s->nb_steps_after_rotation > 2) { s->in_rotation = 0; s->post_rotation_phase = 0; }
+    }
+  } else s->in_rotation = 0;
+}
+
+// SupportFSM::set_support_state, SupportFSM.cpp:93-153
+__device__ inline void fsm_set_support_state(const wg_model_t &m, int nb_steps_ssds, double time, unsigned pi, Sup &S,
+                                             const double *ref) {
+  const double T = m.T;
+  S.state_changed = 0;
+  const bool given = fabs(ref[0]) > WG_FSM_EPS || fabs(ref[1]) > WG_FSM_EPS || fabs(ref[2]) > WG_FSM_EPS;
+  if (given && S.phase == WG_DS && (S.time_limit - time - WG_FSM_EPS) > m.dsss_period) {
+    S.time_limit = time + m.dsss_period - T / 10.0;
+    S.nb_steps_left = nb_steps_ssds;
+  }
+  if (time + WG_FSM_EPS + pi * T >= S.time_limit) {
+    if (S.phase == WG_SS && !given && S.nb_steps_left == 0) {
+      S.phase = WG_DS;
+      S.time_limit = time + pi * T + m.ds_period - T / 10.0;
+      S.state_changed = 1;
+    } else if ((S.phase == WG_DS && given) || (S.phase == WG_DS && S.nb_steps_left > 0)) {
+      S.phase = WG_SS;
+      S.time_limit = time + pi * T + m.step_period - T / 10.0;
+      S.nb_steps_left = nb_steps_ssds;
+      S.state_changed = 1;
+    } else if ((S.phase == WG_SS && S.nb_steps_left > 0) || (S.nb_steps_left == 0 && given)) {
+      S.foot = (S.foot == WG_LEFT) ? WG_RIGHT : WG_LEFT;
+      S.state_changed = 1;
+      S.time_limit = time + pi * T + m.step_period - T / 10.0;
+      if (pi != 1) ++S.step_number;
+      if (!given) S.nb_steps_left = S.nb_steps_left - 1;
+      if (given) S.nb_steps_left = nb_steps_ssds;
+    }
+  }
+}
+
+struct Hull { int nv; double X[5], Y[5], A[5], B[5], D[5]; };
+
+// RelativeFeetInequalities::set_vertices (:185-234) on the hulls of init_convex_hulls (:88-149)
+__device__ inline void hull_set_vertices(const wg_model_t &m, Hull &H, int foot, int phase, double yaw, bool feet) {
+  if (!feet) {
+    const double lx[4] = {1.0, 1.0, -1.0, -1.0};
+    const double lyr[4] = {-1.0, 1.0, 1.0, -1.0}, lyl[4] = {1.0, -1.0, -1.0, 1.0};
+    double hw = 0.5 * m.sole_w; hw -= m.margin_x;      // FootHalfSize.cpp:62-70
+    double hh = 0.5 * m.sole_h; hh -= m.margin_y;
+    const double hhds = hh + m.ds_feet_distance / 2.0;
+    H.nv = 4;
+    for (int j = 0; j < 4; j++) {
+      H.X[j] = lx[j] * hw;
+      if (foot == WG_LEFT) H.Y[j] = (phase == WG_DS) ? lyl[j] * hhds - m.ds_feet_distance / 2.0 : lyl[j] * hh;
+      else H.Y[j] = (phase == WG_DS) ? lyr[j] * hhds + m.ds_feet_distance / 2.0 : lyr[j] * hh;
+    }
+  } else {
+    const double px[5] = {-0.28, -0.2, 0.0, 0.2, 0.28};
+    const double py[5] = {-0.2, -0.3, -0.4, -0.3, -0.2};
+    H.nv = 5;
+    for (int j = 0; j < 5; j++) { H.X[j] = px[j]; H.Y[j] = (foot == WG_LEFT) ? py[j] : -py[j]; }
+  }
+  const double c = wg_cos(yaw), s = wg_sin(yaw);        // convex_hull_t::rotate, privatepgtypes.cpp:157-185
+  for (int j = 0; j < H.nv; j++) {
+    const double xo = H.X[j], yo = H.Y[j];
+    H.X[j] = (xo * c - yo * s);
+    H.Y[j] = (xo * s + yo * c);
+  }
+}
+
+// compute_linear_system :264-319
+__device__ inline void hull_linear_system(Hull &H, int foot) {
+  const double sign = (foot == WG_LEFT) ? 1.0 : -1.0;
+  for (int i = 0; i < H.nv; i++) {
+    const int i2 = (i + 1 == H.nv) ? 0 : i + 1;
+    const double y1 = H.Y[i], y2 = H.Y[i2], x1 = H.X[i], x2 = H.X[i2];
+    const double dx = y1 - y2, dy = x2 - x1;
+    const double dc = dx * x1 + dy * y1;
+    H.A[i] = sign * dx; H.B[i] = sign * dy; H.D[i] = sign * dc;
+  }
+}
+
+// OrientationsPreview::verify_angle_hip_joint :273-303
+__device__ inline bool op_verify_angle(const wg_model_t &m, wg_gait_state_t *s, double sup_time_passed, const Sup &cur,
+                                       double trunk_end, double cur_sup_angle, unsigned step_number) {
+  double ul, ll;
+  if (cur.foot == WG_LEFT) { ul = m.hip_l_hi; ll = m.hip_l_lo; } else { ul = m.hip_r_hi; ll = m.hip_r_lo; }
+  const double lim = (s->trunkT_yaw[1] < 0.0) ? ll : ul;
+  if (fabs(trunk_end - cur_sup_angle) > fabs(lim)) {
+    s->trunkT_yaw[1] = (cur_sup_angle + 0.9 * lim - s->trunk_yaw[0] - s->trunk_yaw[1] * m.T / 2.0) /
+                       (sup_time_passed + step_number * m.step_period - m.T / 2.0);
+    return false;
+  }
+  return true;
+}
+
+// OrientationsPreview::preview_orientations :79-251
+__device__ inline void op_preview(const wg_model_t &m, wg_gait_state_t *s, double time, const double *ref, Sup *sup,
+                                  double *sup_angles, double *trunk) {
+  const int N = m.N;
+  const double T = m.T, SSP = m.step_period;
+  const Sup cur = sup[0];
+  if (cur.phase != WG_DS) {                                  // verify_acceleration_hip_joint :254-270
+    if (fabs(ref[2] - s->trunk_yaw[1]) > 2.0 / 3.0 * T * m.hip_amax) {
+      const double sg = (ref[2] - s->trunk_yaw[1] < 0.0) ? -1.0 : 1.0;
+      s->trunkT_yaw[1] = s->trunk_yaw[1] + sg * 2.0 / 3.0 * T * m.hip_amax;
+    } else s->trunkT_yaw[1] = ref[2];
+  } else s->trunkT_yaw[1] = 0.0;
+
+  bool vel_ok = false, angle_ok = false;
+  double first_prw = 0.0;
+  const double sign_rot_vel = (s->trunkT_yaw[1] < 0.0) ? -1.0 : 1.0;
+  double sup_time_passed = 0.0;
+  unsigned step_number = 0;
+  double trunk_end = 0.0;
+  int na = 0;
+  const unsigned last = (unsigned)((int)ceil((N + 1) * T / SSP));
+  int guard = 0;
+  while (!vel_ok && guard++ < 64) {
+    const double cur_sup_angle = (cur.foot == WG_LEFT) ? s->lf[0].theta * kPi / 180.0 : s->rf[0].theta * kPi / 180.0;
+    if (cur.phase != WG_DS) {
+      angle_ok = false;
+      int g2 = 0;
+      while (!angle_ok && g2++ < 64) {
+        if (fabs(s->trunkT_yaw[1] - s->trunk_yaw[1]) > WG_OP_EPS) {
+          const double a = s->trunk_yaw[0], b = s->trunk_yaw[1], c = 0.0;
+          const double d = 3.0 * (s->trunkT_yaw[1] - s->trunk_yaw[1]) / (T * T);
+          const double e = -2.0 * d / (3.0 * T);
+          s->trunkT_yaw[0] = a + b * T + 1.0 / 2.0 * c * T * T + 1.0 / 3.0 * d * T * T * T + 1.0 / 4.0 * e * T * T * T * T;
+        } else s->trunkT_yaw[0] = s->trunk_yaw[0] + s->trunk_yaw[1] * T;
+        sup_time_passed = cur.time_limit - time;
+        trunk_end = s->trunkT_yaw[0] + s->trunkT_yaw[1] * (sup_time_passed - T);
+        angle_ok = op_verify_angle(m, s, sup_time_passed, cur, trunk_end, cur_sup_angle, step_number);
+      }
+    } else {
+      sup_time_passed = cur.time_limit + SSP - time;
+      first_prw = 1;
+      sup_angles[na++] = cur_sup_angle;
+      s->trunkT_yaw[0] = trunk_end = s->trunk_yaw[0];
+    }
+    double prev_sup_angle = cur_sup_angle;
+    double prw_foot = (cur.foot == WG_LEFT) ? 1.0 : -1.0;
+    for (step_number = (unsigned)first_prw; step_number <= last; step_number++) {
+      prw_foot = -prw_foot;
+      double prw_angle = trunk_end + s->trunkT_yaw[1] * SSP / 2.0;
+      // verify_velocity_hip_joint (:306-365) receives its angle by value: no effect
+      if ((double)prw_foot * (prev_sup_angle - prw_angle) - WG_OP_EPS > m.feet_cross_max)
+        prw_angle = prev_sup_angle + (double)sign_rot_vel * m.feet_cross_max;
+      else if (fabs(prw_angle - prev_sup_angle) > m.hip_vmax * SSP)
+        prw_angle = prev_sup_angle + (double)prw_foot * m.hip_vmax * (SSP - T);
+      angle_ok = op_verify_angle(m, s, sup_time_passed, cur, trunk_end, cur_sup_angle, step_number);
+      if (!angle_ok) { na = 0; vel_ok = false; break; }
+      else if (na < 8) sup_angles[na++] = prw_angle;
+      trunk_end = trunk_end + SSP * s->trunkT_yaw[1];
+      prev_sup_angle = prw_angle;
+      vel_ok = true;
+    }
+  }
+  trunk[0] = s->trunk_yaw[0];
+  trunk[1] = s->trunkT_yaw[0];
+  for (int i = 1; i < N; i++) trunk[i + 1] = s->trunkT_yaw[0] + s->trunkT_yaw[1] * T;
+  double sup_angle = sup[0].yaw;
+  int j = 0;
+  for (int i = 1; i <= N; i++) {
+    if (sup[i].state_changed) { sup_angle = sup_angles[j]; j++; }
+    sup[i].yaw = sup_angle;
+  }
+}
+
+// polynomial helpers, Polynome.cpp:44-76, PolynomeFoot.cpp:59-79, 100-120, 226-240
+__device__ inline double poly_eval(const double *c, int deg, double t) {
+  double r = 0.0, pt = 1.0;
+  for (int i = 0; i <= deg; i++) { r += c[i] * pt; pt *= t; }
+  return r;
+}
+__device__ inline double poly_d1(const double *c, int deg, double t) {
+  double r = 0, pt = 1;
+  for (int i = 1; i <= deg; i++) { r += i * c[i] * pt; pt *= t; }
+  return r;
+}
+__device__ inline double poly_d2(const double *c, int deg, double t) {
+  double r = 0, pt = 1;
+  for (int i = 2; i <= deg; i++) { r += i * (i - 1) * c[i] * pt; pt *= t; }
+  return r;
+}
+__device__ inline void poly5_set(double *c, double FT, double FP, double p0, double v0, double a0) {
+  double tmp;
+  c[0] = p0; c[1] = v0; c[2] = a0 / 2.0;
+  tmp = FT * FT * FT;
+  c[3] = (-3.0 / 2.0 * a0 * FT * FT - 6.0 * v0 * FT - 10.0 * p0 + 10.0 * FP) / tmp;
+  tmp = tmp * FT;
+  c[4] = (3.0 / 2.0 * a0 * FT * FT + 8.0 * v0 * FT + 15.0 * p0 - 15.0 * FP) / tmp;
+  tmp = tmp * FT;
+  c[5] = (-1.0 / 2.0 * a0 * FT * FT - 3.0 * v0 * FT - 6.0 * p0 + 6.0 * FP) / tmp;
+}
+__device__ inline void poly4_set(double *c, double FT, double MP) {
+  double tmp;
+  c[0] = 0.0; c[1] = 0.0;
+  tmp = FT * FT;
+  if (MP == 0.0 || tmp == 0.0) { c[2] = 0.0; c[3] = 0.0; c[4] = 0.0; }
+  else {
+    c[2] = 16.0 * MP / tmp;
+    tmp = tmp * FT;
+    c[3] = -32.0 * MP / tmp;
+    tmp = tmp * FT;
+    c[4] = 16.0 * MP / tmp;
+  }
+}
+__device__ inline void poly3_set(double *c, double FT, double FP, double p0, double v0) {
+  double tmp;
+  c[0] = p0; c[1] = v0;
+  tmp = FT * FT;
+  if (FT == 0.0) { c[2] = 0.0; c[3] = 0.0; }
+  else {
+    c[2] = (3 * FP - 3 * p0 - 2 * v0 * FT) / tmp;
+    c[3] = (v0 * FT + 2 * p0 - 2 * FP) / (tmp * FT);
+  }
+}
+
+// ---------------------------------------------------------------------------
+// the tick: executed by one wave.  `lds` = QlView area followed by TickLds area.
+// ---------------------------------------------------------------------------
+struct TickDiag { int ifail, n_iter, nact, n, m, ns; };
+
+__device__ inline TickDiag mpc_tick(const wg_model_t &m, const TickTables *__restrict__ tb, wg_gait_state_t *gstate,
+                                    wg_tick_out_t *out, double *lds_ql, char *lds_tick, int *hist, int hist_cap,
+                                    int *hist_len) {
+  const int lane = threadIdx.x & 63;
+  const int N = m.N;
+  const double T = m.T;
+  const int K = WG_SAMPLES_PER_TICK;
+  TickLds L;
+  L.carve(lds_tick, N);
+  wg_gait_state_t *s = L.st;
+
+  // ---- state: HBM -> LDS (coalesced 8-byte lanes) ----
+  {
+    const double *src = reinterpret_cast<const double *>(gstate);
+    double *dst = reinterpret_cast<double *>(s);
+    for (int i = lane; i < (int)(sizeof(wg_gait_state_t) / 8); i += 64) dst[i] = src[i];
+  }
+  WG_WSYNC();
+  const double time = s->clock;
+
+  // ---- lane 0: support FSM, selection, orientations, polygon edges ----
+  if (lane == 0) {
+    double ref[3] = {s->vref[0], s->vref[1], s->vref[2]};
+    fsm_update_vel_reference(s, ref, s->foot);                       // :353-357
+    Sup cur;
+    cur.phase = s->phase; cur.foot = s->foot; cur.nb_steps_left = s->nb_steps_left; cur.step_number = s->step_number;
+    cur.state_changed = s->state_changed; cur.pad = 0; cur.time_limit = s->time_limit; cur.start_time = s->start_time;
+    cur.x = s->sup_x; cur.y = s->sup_y; cur.yaw = s->sup_yaw;
+    // preview_support_states, generator-vel-ref.cpp:70-134
+    fsm_set_support_state(m, s->nb_steps_ssds, time, 0, cur, ref);
+    if (cur.state_changed) {
+      const wg_foot_sample_t *f = (cur.foot == WG_LEFT) ? &s->lf[0] : &s->rf[0];
+      cur.x = f->x; cur.y = f->y; cur.yaw = f->theta * kPi / 180.0; cur.start_time = time;
+    }
+    L.sup[0] = cur;
+    s->phase = cur.phase; s->foot = cur.foot; s->nb_steps_left = cur.nb_steps_left; s->step_number = cur.step_number;
+    s->state_changed = cur.state_changed; s->time_limit = cur.time_limit; s->start_time = cur.start_time;
+    s->sup_x = cur.x; s->sup_y = cur.y; s->sup_yaw = cur.yaw;
+    {
+      Sup prw = cur;
+      prw.step_number = 0;
+      for (unsigned pi = 1; pi <= (unsigned)N; pi++) {
+        fsm_set_support_state(m, s->nb_steps_ssds, time, pi, prw, ref);
+        if (prw.state_changed) {
+          if (pi == 1) {
+            const wg_foot_sample_t *f = (prw.foot == WG_LEFT) ? &s->lf[2] : &s->rf[2];
+            prw.x = f->x; prw.y = f->y; prw.yaw = f->theta * kPi / 180.0; prw.start_time = time + pi * T;
+          }
+          if (prw.step_number > 0) { prw.x = 0.0; prw.y = 0.0; }
+        }
+        L.sup[pi] = prw;
+      }
+    }
+    int ns = L.sup[N].step_number;
+    if (ns > kSMax) ns = kSMax;        // cannot happen for N*T <= kSMax*step_period; keeps indices in range
+    // generate_selection_matrices :137-208
+    for (int k = 0; k < kSMax; k++) { L.Vc_fX[k] = 0.0; L.Vc_fY[k] = 0.0; }
+    for (int k = 0; k < kSMax * kSMax; k++) L.V_f[k] = 0.0;
+    for (int i = 0; i < N; i++) {
+      const Sup &S = L.sup[i + 1];
+      L.VcX[i] = 0.0; L.VcY[i] = 0.0; L.stepidx[i] = 0;
+      if (S.step_number > 0) {
+        L.stepidx[i] = S.step_number;
+        if (S.step_number == 1 && S.state_changed && S.phase == WG_SS) {
+          L.Vc_fX[0] = L.sup[i].x; L.Vc_fY[0] = L.sup[i].y;
+          L.V_f[0] = 1.0;
+        } else if (S.step_number > 1 && S.step_number <= kSMax) {
+          L.V_f[(S.step_number - 1) * kSMax + (S.step_number - 2)] = -1.0;
+          L.V_f[(S.step_number - 1) * kSMax + (S.step_number - 1)] = 1.0;
+        }
+      } else { L.VcX[i] = S.x; L.VcY[i] = S.y; }
+    }
+    op_preview(m, s, time, ref, L.sup, L.sup_angles, L.trunk);
+    // compute_global_reference :211-229 (only 3 distinct yaw values occur)
+    for (int i = 0; i < N; i++) {
+      const double yt = L.trunk[i];
+      const double c = wg_cos(yt), sn = wg_sin(yt);
+      L.refx[i] = ref[0] * c - ref[1] * sn;
+      L.refy[i] = ref[1] * c + ref[0] * sn;
+    }
+    // polygon edges per constraint row: build_inequalities_cop :284-314, build_inequalities_feet :317-354
+    const int mq = 1 + 4 * N + 5 * ns;
+    L.rowA[0] = 0.0; L.rowB[0] = 0.0; L.rowD[0] = 0.0; L.rowK[0] = -1;
+    Hull H;
+    hull_set_vertices(m, H, L.sup[0].foot, L.sup[0].phase, L.sup[0].yaw, false);
+    for (int i = 0; i < N; i++) {
+      const Sup &S = L.sup[i + 1];
+      if (S.state_changed) hull_set_vertices(m, H, S.foot, S.phase, S.yaw, false);
+      hull_linear_system(H, S.foot);
+      for (int e = 0; e < 4; e++) {
+        const int r = 1 + 4 * i + e;
+        L.rowA[r] = H.A[e]; L.rowB[r] = H.B[e]; L.rowD[r] = H.D[e]; L.rowK[r] = i;
+      }
+    }
+    for (int r = 1 + 4 * N; r < mq; r++) { L.rowA[r] = 0.0; L.rowB[r] = 0.0; L.rowD[r] = 0.0; L.rowK[r] = -1; }
+    for (int i = 0; i < N; i++) {
+      const Sup &S = L.sup[i + 1];
+      if (S.state_changed && S.step_number > 0 && S.step_number <= ns && S.phase != WG_DS) {
+        hull_set_vertices(m, H, L.sup[i].foot, L.sup[i].phase, L.sup[i].yaw, true);
+        hull_linear_system(H, S.foot);
+        const int k = S.step_number - 1;
+        for (int e = 0; e < 5; e++) {
+          const int r = 1 + 4 * N + 5 * k + e;
+          L.rowA[r] = H.A[e]; L.rowB[r] = H.B[e]; L.rowD[r] = H.D[e]; L.rowK[r] = k;
+        }
+      }
+    }
+    L.misc[0] = (double)ns;
+    L.misc[1] = ref[0]; L.misc[2] = ref[1]; L.misc[3] = ref[2];
+  }
+  WG_WSYNC();
+
+  const int ns = (int)L.misc[0];
+  const int n = 2 * N + 2 * ns;
+  const int mq = 1 + 4 * N + 5 * ns;     // rows incl. the dummy row 0 (qp-problem.cpp:248)
+  QlDims D(n, mq, mq);
+  QlView q;
+  q.carve(lds_ql, D, 0);
+
+  // ---- S*c products (MV2_ = prod(S, CoM), generator-vel-ref.cpp:780-787) ----
+  for (int i = lane; i < N; i += 64) {
+    double ax = 0.0, ay = 0.0, bx = 0.0, by = 0.0;
+    for (int k = 0; k < 3; k++) {
+      ax += tb->Sv[i][k] * s->com_x[k]; ay += tb->Sv[i][k] * s->com_y[k];
+      bx += tb->Sz[i][k] * s->com_x[k]; by += tb->Sz[i][k] * s->com_y[k];
+    }
+    L.svx[i] = ax; L.svy[i] = ay; L.szx[i] = bx; L.szy[i] = by;
+  }
+  WG_WSYNC();
+
+  // ---- gradient, update_problem :617-674 ----
+  for (int i = lane; i < N; i += 64) {
+    double t1x = 0.0, t1y = 0.0, t2x = 0.0, t2y = 0.0;
+    for (int k = 0; k < N; k++) {
+      const double u = tb->Uv[k][i];
+      t1x += u * L.svx[k]; t1y += u * L.svy[k];
+      t2x += u * L.refx[k]; t2y += u * L.refy[k];
+    }
+    double dx = 0.0, dy = 0.0;
+    dx += t1x * m.alpha; dy += t1y * m.alpha;
+    dx += t2x * (-m.alpha); dy += t2y * (-m.alpha);
+    q.d[i] = dx; q.d[N + i] = dy;
+  }
+  for (int j = lane; j < ns; j += 64) {
+    double px = 0.0, py = 0.0, qx = 0.0, qy = 0.0;
+    for (int k = 0; k < N; k++) {
+      const double v = (L.stepidx[k] == j + 1) ? 1.0 : 0.0;
+      px += v * L.szx[k]; py += v * L.szy[k];
+      qx += v * L.VcX[k]; qy += v * L.VcY[k];
+    }
+    double dx = 0.0, dy = 0.0;
+    dx += px * (-m.gamma); dy += py * (-m.gamma);
+    dx += qx * m.gamma; dy += qy * m.gamma;
+    q.d[2 * N + j] = dx; q.d[2 * N + ns + j] = dy;
+  }
+  for (int i = lane; i < n; i += 64) { q.xl[i] = -1e8; q.xu[i] = 1e8; }   // qp-problem.cpp:118-121
+
+  // ---- Hessian: invariant blocks + variant columns ----
+  for (int e = lane; e < n * n; e += 64) {
+    const int i = e % n, j = e / n;
+    double v = 0.0;
+    if (i < N && j < N) v = tb->Qb[i][j];
+    else if (i >= N && i < 2 * N && j >= N && j < 2 * N) v = tb->Qb[i - N][j - N];
+    Gm(i, j) = v;
+  }
+  WG_WSYNC();
+  for (int e = lane; e < N * ns; e += 64) {
+    const int i = e % N, j = e / N;
+    double p = 0.0, pt = 0.0;
+    for (int k = 0; k < N; k++) {
+      const double v = (L.stepidx[k] == j + 1) ? 1.0 : 0.0;
+      p += tb->Uz[k][i] * v;
+      pt += v * tb->Uz[k][i];
+    }
+    p *= -m.gamma; pt *= -m.gamma;
+    Gm(i, 2 * N + j) += p; Gm(N + i, 2 * N + ns + j) += p;
+    Gm(2 * N + j, i) += pt; Gm(2 * N + ns + j, N + i) += pt;
+  }
+  for (int e = lane; e < ns * ns; e += 64) {
+    const int i = e % ns, j = e / ns;
+    double p = 0.0;
+    for (int k = 0; k < N; k++) {
+      const double vi = (L.stepidx[k] == i + 1) ? 1.0 : 0.0, vj = (L.stepidx[k] == j + 1) ? 1.0 : 0.0;
+      p += vi * vj;
+    }
+    p *= m.gamma;
+    Gm(2 * N + i, 2 * N + j) += p; Gm(2 * N + ns + i, 2 * N + ns + j) += p;
+  }
+
+  // ---- constraints, build_constraints_cop :393-448, build_constraints_feet :451-474 ----
+  for (int r = lane; r < mq; r += 64) {
+    const double a = L.rowA[r], bb = L.rowB[r];
+    const int kk = L.rowK[r];
+    double bacc = 0.0;
+    if (r >= 1 && r <= 4 * N) {
+      const int i = kk;
+      for (int c = 0; c < N; c++) {
+        const double u = tb->Uz[i][c];
+        const double px = 0.0 + a * u, py = 0.0 + bb * u;
+        Am(r, c) = 0.0 + px * -1.0; Am(r, N + c) = 0.0 + py * -1.0;
+      }
+      for (int j = 0; j < ns; j++) {
+        const double v = (L.stepidx[i] == j + 1) ? 1.0 : 0.0;
+        const double px = 0.0 + a * v, py = 0.0 + bb * v;
+        Am(r, 2 * N + j) = 0.0 + px * 1.0; Am(r, 2 * N + ns + j) = 0.0 + py * 1.0;
+      }
+      bacc += L.rowD[r];
+      bacc += (0.0 + a * L.szx[i]) * -1.0;
+      bacc += (0.0 + bb * L.szy[i]) * -1.0;
+      bacc += (0.0 + a * L.VcX[i]) * 1.0;
+      bacc += (0.0 + bb * L.VcY[i]) * 1.0;
+    } else {
+      for (int c = 0; c < n; c++) Am(r, c) = 0.0;
+      if (r > 4 * N && kk >= 0) {
+        const int k = kk;
+        for (int j = 0; j < ns; j++) {
+          const double vf = L.V_f[k * kSMax + j];
+          const double px = 0.0 + a * vf, py = 0.0 + bb * vf;
+          Am(r, 2 * N + j) = 0.0 + px * -1.0; Am(r, 2 * N + ns + j) = 0.0 + py * -1.0;
+        }
+        bacc += L.rowD[r];
+        bacc += (0.0 + a * L.Vc_fX[k]) * 1.0;
+        bacc += (0.0 + bb * L.Vc_fY[k]) * 1.0;
+      }
+    }
+    q.b[r] = -bacc;                 // inner sign, qld.cpp:469-475
+  }
+  WG_WSYNC();
+  if (lane == 0 && fabs(Gm(n - 1, n - 1)) == 0.0) Gm(n - 1, n - 1) = 1e-8;   // qld.cpp:442-444 (nmax == n)
+  WG_WSYNC();
+
+  // ---- QPProblem::solve -> ql0001_ (eps = 1e-8, qp-problem.cpp:260) ----
+  QlResult qr = ql_solve(q, 1e-8, hist, hist_cap);
+  if (hist_len && lane == 0) *hist_len = qr.hist_len;
+
+  // ---- CoM: jerk, 20 interpolated samples, state step (ZMPVelocityReferencedQP.cpp:405-428) ----
+  double jx, jy;
+  const bool stop_branch = (L.sup[0].nb_steps_left == 0) && !(m.flags & WG_FLAG_NO_STOP_CENTERING);
+  if (stop_branch) {
+    jx = (s->lf[0].x + s->rf[0].x) / 2 - s->front_com_x[0];
+    jy = (s->lf[0].y + s->rf[0].y) / 2 - s->front_com_y[0];
+    const bool arrived = fabs(jx) < 1e-3 && fabs(jy) < 1e-3;
+    const double tf = 0.75;
+    jx = 6 / (tf * tf * tf) * (jx - tf * s->front_com_x[1] - (tf * tf / 2) * s->front_com_x[2]);
+    jy = 6 / (tf * tf * tf) * (jy - tf * s->front_com_y[1] - (tf * tf / 2) * s->front_com_y[2]);
+    WG_WSYNC();
+    if (lane == 0 && arrived) s->running = 0;
+  } else {
+    jx = q.x[0]; jy = q.x[N];
+    WG_WSYNC();
+    if (lane == 0) s->running = 1;
+  }
+  {
+    const double cx[3] = {s->com_x[0], s->com_x[1], s->com_x[2]}, cy[3] = {s->com_y[0], s->com_y[1], s->com_y[2]};
+    const double c02 = -s->com_z / 9.81;
+    WG_WSYNC();
+    if (lane < K) {                                       // Interpolation :157-227
+      const int lk = lane;
+      const double t = (lk + 1) * m.Tctrl;
+      const double x0 = cx[0] + t * cx[1] + 0.5 * t * t * cx[2] + t * t * t * jx / 6.0;
+      const double x1 = cx[1] + t * cx[2] + 0.5 * t * t * jx;
+      const double x2 = cx[2] + t * jx;
+      const double y0 = cy[0] + t * cy[1] + 0.5 * t * t * cy[2] + t * t * t * jy / 6.0;
+      const double y1 = cy[1] + t * cy[2] + 0.5 * t * t * jy;
+      const double y2 = cy[2] + t * jy;
+      if (out) {
+        out->com_x[lk][0] = x0; out->com_x[lk][1] = x1; out->com_x[lk][2] = x2;
+        out->com_y[lk][0] = y0; out->com_y[lk][1] = y1; out->com_y[lk][2] = y2;
+        out->zmp_x[lk] = 1.0 * x0 + 0.0 * x1 + c02 * x2;
+        out->zmp_y[lk] = 1.0 * y0 + 0.0 * y1 + c02 * y2;
+      }
+      if (lk == 11) {
+        s->front_com_x[0] = x0; s->front_com_x[1] = x1; s->front_com_x[2] = x2;
+        s->front_com_y[0] = y0; s->front_com_y[1] = y1; s->front_com_y[2] = y2;
+      }
+    }
+    if (lane == 0) {                                      // OneIteration :230-264
+      const double A01 = T, A02 = T * T / 2.0, A12 = T;
+      const double B0 = T * T * T / 6.0, B1 = T * T / 2.0, B2 = T;
+      double nx[3], ny[3];
+      nx[0] = 0.0 + 1.0 * cx[0] + A01 * cx[1] + A02 * cx[2];
+      nx[1] = 0.0 + 0.0 * cx[0] + 1.0 * cx[1] + A12 * cx[2];
+      nx[2] = 0.0 + 0.0 * cx[0] + 0.0 * cx[1] + 1.0 * cx[2];
+      ny[0] = 0.0 + 1.0 * cy[0] + A01 * cy[1] + A02 * cy[2];
+      ny[1] = 0.0 + 0.0 * cy[0] + 1.0 * cy[1] + A12 * cy[2];
+      ny[2] = 0.0 + 0.0 * cy[0] + 0.0 * cy[1] + 1.0 * cy[2];
+      s->com_x[0] = nx[0] + jx * B0; s->com_x[1] = nx[1] + jx * B1; s->com_x[2] = nx[2] + jx * B2;
+      s->com_y[0] = ny[0] + jy * B0; s->com_y[1] = ny[1] + jy * B1; s->com_y[2] = ny[2] + jy * B2;
+      if (out) {
+        out->jerk_x = jx; out->jerk_y = jy; out->ifail = qr.ifail; out->n_iter = qr.n_iter; out->nact = qr.nact;
+        out->n = n; out->m = mq; out->nb_prw_steps = ns;
+      }
+    }
+  }
+  WG_WSYNC();
+
+  // ---- lane 0: trunk and feet (sequential in k) ----
+  if (lane == 0) {
+    const Sup cs = L.sup[0];
+    const double dt = m.Tctrl;
+    // interpolate_trunk_orientation, OrientationsPreview.cpp:368-418
+    if (cs.phase == WG_SS && time + 3.0 / 2.0 * T < cs.time_limit) {
+      const double a = s->trunk_yaw[1];
+      const double c = 3.0 * (s->trunkT_yaw[1] - s->trunk_yaw[1]) / (T * T);
+      const double d = -2.0 * c / (3.0 * T);
+      const double theta = s->trunk_yaw[0];
+      for (int k = 0; k < K; k++) {
+        const double tT = (double)(k + 1) * dt;
+        // the test uses the yaw rate as updated by the previous sample, like the reference (:390)
+        if (fabs(s->trunkT_yaw[1] - s->trunk_yaw[1]) - 0.000001 > 0) {
+          s->trunk_yaw[0] = (((1.0 / 4.0 * d * tT + 1.0 / 3.0 * c) * tT) * tT + a) * tT + theta;
+          s->trunk_yaw[1] = ((d * tT + c) * tT) * tT + a;
+          s->trunk_yaw[2] = (3.0 * d * tT + 2.0 * c) * tT;
+        } else s->trunk_yaw[0] += dt * s->trunkT_yaw[1];
+        if (out) { out->com_yaw[k][0] = s->trunk_yaw[0]; out->com_yaw[k][1] = s->trunk_yaw[1]; }
+      }
+    } else if (cs.phase == WG_DS || time + 3.0 / 2.0 * T > cs.time_limit) {
+      for (int k = 0; k < K; k++)
+        if (out) { out->com_yaw[k][0] = s->trunk_yaw[0]; out->com_yaw[k][1] = s->trunk_yaw[1]; }
+    } else {
+      for (int k = 0; k < K; k++)
+        if (out) { out->com_yaw[k][0] = 0.0; out->com_yaw[k][1] = 0.0; }
+    }
+
+    // interpolate_feet_positions, OnLineFootTrajectoryGeneration.cpp:235-346
+    double FPx = 0.0, FPy = 0.0;
+    if (cs.phase != WG_DS) {                               // interpret_solution :202-232
+      const double sign = (cs.foot == WG_LEFT) ? 1.0 : -1.0;
+      if (cs.nb_steps_left > 0 && ns > 0) { FPx = q.x[2 * N]; FPy = q.x[2 * N + ns]; }
+      else {
+        FPx = cs.x + sign * wg_sin(cs.yaw) * m.feet_distance;
+        FPy = cs.y - sign * wg_cos(cs.yaw) * m.feet_distance;
+      }
+    }
+    const double local_t = time - (cs.time_limit - (m.t_double + m.t_single));
+    if (out) { out->lf_back = s->lf[2]; out->rf_back = s->rf[2]; }
+    wg_foot_sample_t f11l, f11r, f18l, f18r, f19l, f19r;
+    const wg_foot_sample_t zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    f11l = f18l = f19l = zero; f11r = f18r = f19r = zero;
+    if (cs.phase == WG_SS && time + 3.0 / 2.0 * T < cs.time_limit) {
+      const bool left_support = (cs.foot == WG_LEFT);
+      const double unlocked = m.t_single * 0.9;
+      const double end_lift = (m.t_single - unlocked) * 0.5;
+      double swing_passed = 0.0;
+      if (local_t > end_lift) swing_passed = local_t - end_lift;
+      const wg_foot_sample_t last = left_support ? s->rf[2] : s->lf[2];      // swing foot, queue back
+      const wg_foot_sample_t sw_prev = left_support ? s->rf[1] : s->lf[1];   // swing foot, [StartIndex-1]
+      const wg_foot_sample_t st_prev = left_support ? s->lf[1] : s->rf[1];   // stance foot, [StartIndex-1]
+      const double ti = unlocked - swing_passed;
+      double px5[6], py5[6], pth[4], pom[4], pom2[4];
+      poly5_set(px5, ti, FPx, last.x, last.dx, last.ddx);
+      poly5_set(py5, ti, FPy, last.y, last.dy, last.ddy);
+      if (cs.state_changed) poly4_set(s->poly_z, m.t_single, m.step_height);
+      poly3_set(pth, ti, L.sup_angles[0] * 180.0 / kPi, last.theta, last.dtheta);
+      poly3_set(pom, ti, 0.0 * 180.0 / kPi, last.omega, last.domega);
+      poly3_set(pom2, ti, 2 * 0.0 * 180.0 / kPi, last.omega2, last.domega2);
+      const double start_landing = end_lift + unlocked;
+      const double omega_cmd = 0.0;
+      wg_foot_sample_t p = last;
+      for (int k = 1; k <= K; k++) {                       // UpdateFootPosition :50-199
+        const double it = (double)k * dt;
+        wg_foot_sample_t c = zero;
+        if (local_t + it <= end_lift || local_t + it >= start_landing) {
+          c.x = p.x; c.y = p.y; c.theta = p.theta;
+        } else {
+          const double tt = (local_t < end_lift && local_t + it > end_lift) ? local_t + it - end_lift : it;
+          c.x = poly_eval(px5, 5, tt); c.dx = poly_d1(px5, 5, tt); c.ddx = poly_d2(px5, 5, tt);
+          c.y = poly_eval(py5, 5, tt); c.dy = poly_d1(py5, 5, tt); c.ddy = poly_d2(py5, 5, tt);
+          c.theta = poly_eval(pth, 3, tt); c.dtheta = poly_d1(pth, 3, tt);
+        }
+        c.z = poly_eval(s->poly_z, 4, local_t + it);
+        c.dz = poly_d1(s->poly_z, 4, local_t + it);
+        if (local_t + it < end_lift) {
+          c.omega = poly_eval(pom, 3, it); c.domega = poly_d1(pom, 3, it);
+        } else if (local_t + it < start_landing) {
+          c.omega = omega_cmd - poly_eval(pom2, 3, local_t + it - end_lift) - sw_prev.omega2;
+        } else {
+          c.omega = poly_eval(pom, 3, local_t + it - start_landing) + sw_prev.omega - omega_cmd;
+        }
+        {
+          // :150-198 keeps the sole above the floor while it pitches; omega == 0 on this path
+          // (":omega 0.0"), which makes every term exactly 0 for any ankle geometry
+          const double lOmega = c.omega * kPi / 180.0, lTheta = c.theta * kPi / 180.0;
+          const double cth = wg_cos(lTheta), sth = wg_sin(lTheta);
+          const double Bf = 0.0, Hf = 0.105, Ff = 0.105;
+          double dX, dFZ;
+          if (lOmega < 0) { dX = -(Bf - Bf * wg_cos(-lOmega) + Hf * wg_sin(-lOmega)); dFZ = Hf * wg_cos(-lOmega) + Bf * wg_sin(-lOmega) - Hf; }
+          else { dX = (Ff - Ff * wg_cos(lOmega) + Hf * wg_sin(lOmega)); dFZ = Hf * wg_cos(lOmega) + Ff * wg_sin(lOmega) - Hf; }
+          c.x += cth * dX; c.y += sth * dX; c.z += dFZ;
+        }
+        if (out) { if (left_support) { out->rf[k - 1] = c; out->lf[k - 1] = st_prev; } else { out->lf[k - 1] = c; out->rf[k - 1] = st_prev; } }
+        if (k == 12) { if (left_support) f11r = c; else f11l = c; }
+        if (k == 19) { if (left_support) f18r = c; else f18l = c; }
+        if (k == 20) { if (left_support) f19r = c; else f19l = c; }
+        p = c;
+      }
+      if (left_support) { f11l = f18l = f19l = st_prev; } else { f11r = f18r = f19r = st_prev; }
+    } else if (cs.phase == WG_DS || time + 3.0 / 2.0 * T > cs.time_limit) {
+      f11l = f18l = f19l = s->lf[1];                       // k = 0 rewrites the queue back (:333-336)
+      f11r = f18r = f19r = s->rf[1];
+      if (out) { for (int k = 0; k < K; k++) { out->lf[k] = f19l; out->rf[k] = f19r; } out->lf_back = f19l; out->rf_back = f19r; }
+    } else {
+      if (out) for (int k = 0; k < K; k++) { out->lf[k] = zero; out->rf[k] = zero; }
+    }
+    s->lf[0] = f11l; s->lf[1] = f18l; s->lf[2] = f19l;
+    s->rf[0] = f11r; s->rf[1] = f18r; s->rf[2] = f19r;
+
+    if (!s->ending_phase) s->time_to_stop = s->upper_time_limit + T * N;     // :446-450
+    s->upper_time_limit = s->upper_time_limit + T;
+    s->tick_count++;
+  }
+  WG_WSYNC();
+
+  // ---- state: LDS -> HBM ----
+  {
+    double *dst = reinterpret_cast<double *>(gstate);
+    const double *src = reinterpret_cast<const double *>(s);
+    for (int i = lane; i < (int)(sizeof(wg_gait_state_t) / 8); i += 64) dst[i] = src[i];
+  }
+  TickDiag dg;
+  dg.ifail = qr.ifail; dg.n_iter = qr.n_iter; dg.nact = qr.nact; dg.n = n; dg.m = mq; dg.ns = ns;
+  return dg;
+}
+
+}  // namespace wg

@@ -7,6 +7,51 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libwg_mpc.so")
 
+SAMPLES = 20   # WG_SAMPLES_PER_TICK
+
+
+class FootSample(C.Structure):          # wg_foot_sample_t
+    _fields_ = [(k, C.c_double) for k in
+                ("x", "y", "z", "theta", "omega", "omega2", "dx", "dy", "dz", "dtheta", "domega", "domega2",
+                 "ddx", "ddy", "ddz", "ddtheta", "ddomega", "ddomega2")]
+
+
+class Model(C.Structure):               # wg_model_t
+    _fields_ = [("N", C.c_int), ("flags", C.c_int)] + [(k, C.c_double) for k in
+                ("T", "Tctrl", "com_height_qp", "alpha", "beta", "gamma", "sole_w", "sole_h", "margin_x", "margin_y",
+                 "ds_feet_distance", "hip_l_lo", "hip_l_hi", "hip_r_lo", "hip_r_hi", "hip_vmax", "hip_amax",
+                 "feet_cross_max", "step_period", "ds_period", "dsss_period", "t_single", "t_double", "step_height",
+                 "feet_distance")]
+
+
+class GaitState(C.Structure):           # wg_gait_state_t
+    _fields_ = [("clock", C.c_double), ("upper_time_limit", C.c_double), ("time_to_stop", C.c_double),
+                ("tick_count", C.c_int), ("running", C.c_int), ("ending_phase", C.c_int), ("online", C.c_int),
+                ("vref", C.c_double * 3),
+                ("com_x", C.c_double * 3), ("com_y", C.c_double * 3), ("com_z", C.c_double),
+                ("phase", C.c_int), ("foot", C.c_int), ("nb_steps_left", C.c_int), ("step_number", C.c_int),
+                ("state_changed", C.c_int), ("pad0_", C.c_int),
+                ("time_limit", C.c_double), ("start_time", C.c_double), ("sup_x", C.c_double), ("sup_y", C.c_double),
+                ("sup_yaw", C.c_double),
+                ("in_translation", C.c_int), ("in_rotation", C.c_int), ("nb_steps_after_rotation", C.c_int),
+                ("rot_support_foot", C.c_int), ("post_rotation_phase", C.c_int), ("nb_steps_ssds", C.c_int),
+                ("trunk_yaw", C.c_double * 3), ("trunkT_yaw", C.c_double * 3),
+                ("lf", FootSample * 3), ("rf", FootSample * 3),
+                ("front_com_x", C.c_double * 3), ("front_com_y", C.c_double * 3),
+                ("poly_z", C.c_double * 5)]
+
+
+class TickOut(C.Structure):             # wg_tick_out_t
+    _fields_ = [("jerk_x", C.c_double), ("jerk_y", C.c_double),
+                ("ifail", C.c_int), ("n_iter", C.c_int), ("nact", C.c_int), ("n", C.c_int), ("m", C.c_int),
+                ("nb_prw_steps", C.c_int),
+                ("com_x", (C.c_double * 3) * SAMPLES), ("com_y", (C.c_double * 3) * SAMPLES),
+                ("com_yaw", (C.c_double * 2) * SAMPLES),
+                ("zmp_x", C.c_double * SAMPLES), ("zmp_y", C.c_double * SAMPLES),
+                ("lf", FootSample * SAMPLES), ("rf", FootSample * SAMPLES),
+                ("lf_back", FootSample), ("rf_back", FootSample)]
+
+
 _dp = C.POINTER(C.c_double)
 _ip = C.POINTER(C.c_int)
 _lib = None
@@ -28,6 +73,11 @@ def lib():
         qp_args = [C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 9 + [C.c_double] + [C.c_void_p] * 7 + [C.c_int, C.c_void_p]
         _lib.wg_qp_solve_batch.argtypes = qp_args
         _lib.wg_qp_solve_batch_dev.argtypes = qp_args + [C.c_void_p]
+        _lib.wg_mpc_tick_lds_bytes.restype = C.c_size_t
+        _lib.wg_mpc_tick_batch.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int,
+                                           C.c_void_p]
+        _lib.wg_mpc_tick_batch_dev.argtypes = _lib.wg_mpc_tick_batch.argtypes + [C.c_void_p]
+        _lib.wg_mpc_set_velref_dev.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
     return _lib
 
 
@@ -94,3 +144,53 @@ def qp_solve_batch_dev(B, nmax, mmax, n, m, me, Cd, d, A, b, xl, xu, eps, x, u, 
                                      p(x), p(u), p(ifail), p(n_iter), p(iact), p(nact), p(hist), hist_cap,
                                      p(hist_len), C.c_void_p(stream) if stream else None)
     _check(rc)
+
+
+# ---------------------------------------------------------------------------
+# Herdt-2010 tick
+# ---------------------------------------------------------------------------
+def model_defaults():
+    m = Model()
+    lib().wg_model_defaults(C.byref(m))
+    return m
+
+
+def gait_init(model, com0, left_xyt, right_xyt):
+    s = GaitState()
+    a3 = lambda v: (C.c_double * 3)(*v)
+    lib().wg_gait_init(C.byref(model), C.byref(s), a3(com0), a3(left_xyt), a3(right_xyt))
+    return s
+
+
+def mpc_configure(model):
+    _check(lib().wg_mpc_configure(C.byref(model)))
+
+
+def mpc_tick_lds_bytes():
+    return int(lib().wg_mpc_tick_lds_bytes())
+
+
+def mpc_tick_batch(states, want_out=True, advance_calls=0, hist_cap=0):
+    """Host-pointer entry point.  `states` is a ctypes array (GaitState * B), updated in place."""
+    B = len(states)
+    outs = (TickOut * B)() if want_out else None
+    diag = np.zeros((B, 6), dtype=np.int32)
+    hist = np.zeros((B, hist_cap), dtype=np.int32) if hist_cap else None
+    hlen = np.zeros(B, dtype=np.int32) if hist_cap else None
+    rc = lib().wg_mpc_tick_batch(B, C.addressof(states), C.addressof(outs) if outs is not None else None, _hp(diag),
+                                 advance_calls, _hp(hist), hist_cap, _hp(hlen))
+    _check(rc)
+    return outs, diag, hist, hlen
+
+
+def mpc_tick_batch_dev(B, states_ptr, outs_ptr=None, diag_ptr=None, advance_calls=0, hist_ptr=None, hist_cap=0,
+                       hist_len_ptr=None, stream=None):
+    """Device-pointer entry point; pointers are plain ints (e.g. torch tensor.data_ptr())."""
+    v = lambda p: C.c_void_p(p) if p else None
+    _check(lib().wg_mpc_tick_batch_dev(B, v(states_ptr), v(outs_ptr), v(diag_ptr), advance_calls, v(hist_ptr), hist_cap,
+                                       v(hist_len_ptr), v(stream)))
+
+
+def mpc_set_velref_dev(B, states_ptr, vref_ptr, stream=None):
+    v = lambda p: C.c_void_p(p) if p else None
+    _check(lib().wg_mpc_set_velref_dev(B, v(states_ptr), v(vref_ptr), v(stream)))

@@ -31,6 +31,17 @@
 #include "../include/wg_mpc.h"
 #include "wg_oracle.h"
 
+/* Trigonometry: libm by default (what the reference calls).  -DWGO_PORTABLE_TRIG builds the
+ * variant that shares include/wg_trig.h with the HIP kernels so GPU parity can be bit-exact. */
+#ifdef WGO_PORTABLE_TRIG
+#include "../include/wg_trig.h"
+#define WSIN(x) wg_sin(x)
+#define WCOS(x) wg_cos(x)
+#else
+#define WSIN(x) sin(x)
+#define WCOS(x) cos(x)
+#endif
+
 #define NMAXH 32                     /* largest horizon supported            */
 #define SMAX 6                       /* largest number of previewed steps    */
 #define NV (2 * NMAXH + 2 * SMAX)
@@ -207,8 +218,8 @@ static void hull_set_vertices(const wg_model_t *m, hull_t *H, const sup_t *S, in
   /* convex_hull_t::rotate, privatepgtypes.cpp:157-185 */
   for (int j = 0; j < H->nv; j++) {
     double xo = H->X[j], yo = H->Y[j];
-    H->X[j] = (xo * cos(S->yaw) - yo * sin(S->yaw));
-    H->Y[j] = (xo * sin(S->yaw) + yo * cos(S->yaw));
+    H->X[j] = (xo * WCOS(S->yaw) - yo * WSIN(S->yaw));
+    H->Y[j] = (xo * WSIN(S->yaw) + yo * WCOS(S->yaw));
   }
 }
 
@@ -492,8 +503,8 @@ int wgo_mpc_tick(const wg_model_t *m, wg_gait_state_t *s, wg_tick_out_t *out, wg
   double refx[NMAXH], refy[NMAXH];
   for (int i = 0; i < N; i++) {
     double yt = trunk[i];
-    refx[i] = ref[0] * cos(yt) - ref[1] * sin(yt);
-    refy[i] = ref[1] * cos(yt) + ref[0] * sin(yt);
+    refx[i] = ref[0] * WCOS(yt) - ref[1] * WSIN(yt);
+    refy[i] = ref[1] * WCOS(yt) + ref[0] * WSIN(yt);
   }
 
   /* --- QP storage ------------------------------------------------------------- */
@@ -699,8 +710,8 @@ int wgo_mpc_tick(const wg_model_t *m, wg_gait_state_t *s, wg_tick_out_t *out, wg
       double sign = (cs->foot == WG_LEFT) ? 1.0 : -1.0;
       if (cs->nb_steps_left > 0 && ns > 0) { FPx = x[2 * N]; FPy = x[2 * N + ns]; }
       else {
-        FPx = cs->x + sign * sin(cs->yaw) * m->feet_distance;
-        FPy = cs->y - sign * cos(cs->yaw) * m->feet_distance;
+        FPx = cs->x + sign * WSIN(cs->yaw) * m->feet_distance;
+        FPy = cs->y - sign * WCOS(cs->yaw) * m->feet_distance;
       }
     }
     const double dt = m->Tctrl;
@@ -755,15 +766,15 @@ int wgo_mpc_tick(const wg_model_t *m, wg_gait_state_t *s, wg_tick_out_t *out, wg
           c->omega = poly_eval(pom, 3, local_t + it - start_landing) + sw_prev->omega - omega_cmd;
         }
         /* :150-198 floor-penetration shift: with omega == 0 every term is exactly 0,
-         * but keep the arithmetic (dX = F - F*cos(0) + H*sin(0)) shape-free: */
+         * but keep the arithmetic (dX = F - F*WCOS(0) + H*WSIN(0)) shape-free: */
         {
           double lOmega = c->omega * M_PI / 180.0, lTheta = c->theta * M_PI / 180.0;
-          double cth = cos(lTheta), sth = sin(lTheta);
+          double cth = WCOS(lTheta), sth = WSIN(lTheta);
           /* B, H, F are ankle-geometry constants; they only multiply (1-cos) and sin of
            * lOmega, which is 0 on this path (":omega 0.0"), so any finite value gives 0 */
           double Bf = 0.0, Hf = 0.105, Ff = 0.105, dX, dFZ;
-          if (lOmega < 0) { dX = -(Bf - Bf * cos(-lOmega) + Hf * sin(-lOmega)); dFZ = Hf * cos(-lOmega) + Bf * sin(-lOmega) - Hf; }
-          else { dX = (Ff - Ff * cos(lOmega) + Hf * sin(lOmega)); dFZ = Hf * cos(lOmega) + Ff * sin(lOmega) - Hf; }
+          if (lOmega < 0) { dX = -(Bf - Bf * WCOS(-lOmega) + Hf * WSIN(-lOmega)); dFZ = Hf * WCOS(-lOmega) + Bf * WSIN(-lOmega) - Hf; }
+          else { dX = (Ff - Ff * WCOS(lOmega) + Hf * WSIN(lOmega)); dFZ = Hf * WCOS(lOmega) + Ff * WSIN(lOmega) - Hf; }
           c->x += cth * dX; c->y += sth * dX; c->z += dFZ;
         }
       }
@@ -773,7 +784,7 @@ int wgo_mpc_tick(const wg_model_t *m, wg_gait_state_t *s, wg_tick_out_t *out, wg
     } else {
       for (int k = 1; k <= K; k++) { memset(&L[k], 0, sizeof L[k]); memset(&R[k], 0, sizeof R[k]); }
     }
-    if (out) for (int k = 0; k < K; k++) { out->lf[k] = L[k + 1]; out->rf[k] = R[k + 1]; }
+    if (out) { for (int k = 0; k < K; k++) { out->lf[k] = L[k + 1]; out->rf[k] = R[k + 1]; } out->lf_back = L[0]; out->rf_back = R[0]; }
     /* the back sample itself may have been rewritten (DS branch): it is still in
      * the queue and will be consumed later, so callers replaying the queue need it */
     if (dump) { dump->lf_back_rewritten = L[0]; dump->rf_back_rewritten = R[0]; }

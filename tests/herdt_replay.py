@@ -19,45 +19,10 @@ import oraclelib as ol
 SAMPLES = 20
 
 
-class FootSample(C.Structure):
-    _fields_ = [(k, C.c_double) for k in
-                ("x", "y", "z", "theta", "omega", "omega2", "dx", "dy", "dz", "dtheta", "domega", "domega2",
-                 "ddx", "ddy", "ddz", "ddtheta", "ddomega", "ddomega2")]
+import importlib as _il
 
-
-class Model(C.Structure):
-    _fields_ = [("N", C.c_int), ("flags", C.c_int)] + [(k, C.c_double) for k in
-                ("T", "Tctrl", "com_height_qp", "alpha", "beta", "gamma", "sole_w", "sole_h", "margin_x", "margin_y",
-                 "ds_feet_distance", "hip_l_lo", "hip_l_hi", "hip_r_lo", "hip_r_hi", "hip_vmax", "hip_amax",
-                 "feet_cross_max", "step_period", "ds_period", "dsss_period", "t_single", "t_double", "step_height",
-                 "feet_distance")]
-
-
-class GaitState(C.Structure):
-    _fields_ = [("clock", C.c_double), ("upper_time_limit", C.c_double), ("time_to_stop", C.c_double),
-                ("tick_count", C.c_int), ("running", C.c_int), ("ending_phase", C.c_int), ("online", C.c_int),
-                ("vref", C.c_double * 3),
-                ("com_x", C.c_double * 3), ("com_y", C.c_double * 3), ("com_z", C.c_double),
-                ("phase", C.c_int), ("foot", C.c_int), ("nb_steps_left", C.c_int), ("step_number", C.c_int),
-                ("state_changed", C.c_int), ("pad0_", C.c_int),
-                ("time_limit", C.c_double), ("start_time", C.c_double), ("sup_x", C.c_double), ("sup_y", C.c_double),
-                ("sup_yaw", C.c_double),
-                ("in_translation", C.c_int), ("in_rotation", C.c_int), ("nb_steps_after_rotation", C.c_int),
-                ("rot_support_foot", C.c_int), ("post_rotation_phase", C.c_int), ("nb_steps_ssds", C.c_int),
-                ("trunk_yaw", C.c_double * 3), ("trunkT_yaw", C.c_double * 3),
-                ("lf", FootSample * 3), ("rf", FootSample * 3),
-                ("front_com_x", C.c_double * 3), ("front_com_y", C.c_double * 3),
-                ("poly_z", C.c_double * 5)]
-
-
-class TickOut(C.Structure):
-    _fields_ = [("jerk_x", C.c_double), ("jerk_y", C.c_double),
-                ("ifail", C.c_int), ("n_iter", C.c_int), ("nact", C.c_int), ("n", C.c_int), ("m", C.c_int),
-                ("nb_prw_steps", C.c_int),
-                ("com_x", (C.c_double * 3) * SAMPLES), ("com_y", (C.c_double * 3) * SAMPLES),
-                ("com_yaw", (C.c_double * 2) * SAMPLES),
-                ("zmp_x", C.c_double * SAMPLES), ("zmp_y", C.c_double * SAMPLES),
-                ("lf", FootSample * SAMPLES), ("rf", FootSample * SAMPLES)]
+_wg = _il.import_module("jrl-walkgen_amd")       # POD layouts only (no library load, no GPU needed)
+FootSample, Model, GaitState, TickOut = _wg.FootSample, _wg.Model, _wg.GaitState, _wg.TickOut
 
 
 HIST_CAP = 512
@@ -128,9 +93,8 @@ def replay(model, state, events, max_calls, tick=oracle_tick, zmp0=(0.0, 0.0), o
             out, dump = res
             if on_tick:
                 on_tick(it, clock, state, out, dump)
-            if dump is not None:
-                lf_q[-1] = _copy_foot(dump.lf_back_rewritten)
-                rf_q[-1] = _copy_foot(dump.rf_back_rewritten)
+            lf_q[-1] = _copy_foot(out.lf_back)
+            rf_q[-1] = _copy_foot(out.rf_back)
             for k in range(SAMPLES):
                 com_q.append(dict(x=list(out.com_x[k]), y=list(out.com_y[k]), z=state.com_z, yaw=out.com_yaw[k][0]))
                 zmp_q.append((out.zmp_x[k], out.zmp_y[k]))
