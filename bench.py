@@ -1,0 +1,200 @@
+#!/usr/bin/env python3
+"""bench.py -- MPC ticks/s of the MI355X-native Herdt-2010 hot path.
+
+Metric (BASELINE.json): QP-MPC ticks/sec at batch = 4096 gaits per GPU, horizon N = 16, fp64.
+One *step* = one MPC tick for every gait of the batch = one launch of the fused tick kernel
+(support-state preview, orientation preview, QP assembly, QL dual active-set solve, LIPM update, feet).
+Workload (SURVEY.md section 8d, config[2]): B independent gaits, common start state, per-gait piecewise-constant
+velocity references vx~U[-0.1,0.3], vy~U[-0.1,0.1], w~U[-0.2,0.2] redrawn every 5 s (50 ticks) from
+MT19937-64 seeded 20100 + global gait index.  All inputs are resident in HBM before the timed region.
+
+    python bench.py                       # 1 GPU, K = 200 steps, W = 20 warm-up steps
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+           bench.py --gpus N --steps K --warmup W      # weak scaling: 4096 gaits per GPU, one RCCL broadcast
+"""
+import argparse
+import ctypes as C
+import importlib
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+wg = importlib.import_module("jrl-walkgen_amd")
+shard = importlib.import_module("jrl-walkgen_amd.shard")
+
+BATCH_PER_GPU = 4096
+REDRAW_TICKS = 50            # 5 s of walking
+HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+
+
+def velocity_table(lo, hi, n_seg):
+    """[n_seg, B, 3] references; gait g uses MT19937-64 seeded 20100 + g (global index)."""
+    tab = np.empty((n_seg, hi - lo, 3))
+    for k, g in enumerate(range(lo, hi)):
+        r = np.random.Generator(np.random.MT19937(20100 + g))
+        tab[:, k, 0] = r.uniform(-0.1, 0.3, n_seg)
+        tab[:, k, 1] = r.uniform(-0.1, 0.1, n_seg)
+        tab[:, k, 2] = r.uniform(-0.2, 0.2, n_seg)
+    return tab
+
+
+def start_states(model, B):
+    s0 = wg.gait_init(model, [0.0316055, 0.0, 0.7116911], [0.0, 0.09, 0.0], [0.0, -0.09, 0.0])
+    s0.nb_steps_left = 2                                    # ":numberstepsbeforestop 2"
+    one = bytes(memoryview(s0).cast("B"))
+    return torch.frombuffer(bytearray(one * B), dtype=torch.uint8)
+
+
+def algorithmic_bytes(n, m):
+    """Bytes the reference moves per tick at its own solver boundary (ql0001_ arguments):
+    read 8*(n^2 + n + mmax*n + mmax + 2n), written 8*(n + m + 2n), with mmax = m + 1."""
+    mmax = m + 1
+    return 8.0 * (n * n + n + mmax * n + mmax + 2 * n) + 8.0 * (n + m + 2 * n)
+
+
+def cpu_baseline(model, n_gaits, n_ticks):
+    """The CPU restatement (oracle/, libm trigonometry) on the first `n_gaits` gaits of the same workload,
+    one core.  Checker code timed as a baseline -- never part of the measured GPU path."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oraclelib as ol
+    lib = ol.oracle()
+    tab = velocity_table(0, n_gaits, (n_ticks + REDRAW_TICKS - 1) // REDRAW_TICKS)
+    states = (wg.GaitState * n_gaits)()
+    s0 = wg.gait_init(model, [0.0316055, 0.0, 0.7116911], [0.0, 0.09, 0.0], [0.0, -0.09, 0.0])
+    s0.nb_steps_left = 2
+    for g in range(n_gaits):
+        C.memmove(C.byref(states[g]), C.byref(s0), C.sizeof(wg.GaitState))
+    mref = C.byref(model)
+    t0 = time.perf_counter()
+    for tick in range(n_ticks):
+        adv = 1 if tick == 0 else (19 if tick == 1 else 20)
+        seg = tick // REDRAW_TICKS
+        for g in range(n_gaits):
+            st = states[g]
+            if tick % REDRAW_TICKS == 0:
+                st.vref[0], st.vref[1], st.vref[2] = tab[seg, g]
+            c = st.clock
+            for _ in range(adv):
+                c += model.Tctrl
+            st.clock = c
+            lib.wgo_mpc_tick(mref, C.byref(st), None, None)
+    dt = time.perf_counter() - t0
+    return n_gaits * n_ticks / dt, dt
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--batch", type=int, default=BATCH_PER_GPU, help="gaits per GPU")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank, local_rank, world = shard.init_process_group("nccl")
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the product has no CPU path")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    wg.init(local_rank)
+
+    # ---- the one collective: constant model block from rank 0 (RCCL broadcast over xGMI) ----
+    model = wg.model_defaults() if rank == 0 else wg.Model()
+    shard.broadcast_struct(model, dev, src=0)
+    wg.mpc_configure(model)
+
+    B = args.batch
+    lo, hi = rank * B, (rank + 1) * B                         # weak scaling: B gaits per GPU
+    K, W = args.steps, args.warmup
+    n_seg = (K + W + REDRAW_TICKS - 1) // REDRAW_TICKS
+    vtab = torch.from_numpy(velocity_table(lo, hi, n_seg)).to(dev)
+    states = start_states(model, B).to(dev)
+    diag = torch.zeros(K + W, B, 6, dtype=torch.int32, device=dev)
+    stream = torch.cuda.Stream(device=dev)
+    sh = stream.cuda_stream
+    sp, dp = states.data_ptr(), diag.data_ptr()
+    dstride = B * 6 * 4
+
+    def step(t):
+        if t % REDRAW_TICKS == 0:
+            wg.mpc_set_velref_dev(B, sp, vtab[t // REDRAW_TICKS].data_ptr(), sh)
+        adv = 1 if t == 0 else (19 if t == 1 else 20)
+        wg.mpc_tick_batch_dev(B, sp, None, dp + t * dstride, adv, stream=sh)
+
+    with torch.cuda.stream(stream):
+        for t in range(W):
+            step(t)
+    torch.cuda.synchronize(dev)
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(K)]
+
+    shard.barrier()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    with torch.cuda.stream(stream):
+        for k in range(K):
+            t = W + k
+            if t % REDRAW_TICKS == 0:
+                wg.mpc_set_velref_dev(B, sp, vtab[t // REDRAW_TICKS].data_ptr(), sh)
+            ev[k][0].record(stream)
+            wg.mpc_tick_batch_dev(B, sp, None, dp + t * dstride, 1 if t == 0 else (19 if t == 1 else 20), stream=sh)
+            ev[k][1].record(stream)
+    torch.cuda.synchronize(dev)
+    shard.barrier()
+    elapsed = time.perf_counter() - t0
+    elapsed = shard.max_over_ranks(elapsed, dev)
+
+    kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+    d = diag[W:].cpu().numpy().reshape(-1, 6)
+    n_fail = int((d[:, 0] != 0).sum())
+    alg_bytes_per_launch = float(algorithmic_bytes(d[:, 3].astype(np.float64), d[:, 4].astype(np.float64)).sum() / K)
+    ticks_total = shard.sum_over_ranks(B * K, dev)
+    value = ticks_total / elapsed
+
+    if rank == 0:
+        achieved = alg_bytes_per_launch / (kern_ms * 1e-3) / 1e9
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "round1_pmc_summary.json")
+        if os.path.exists(pmc):
+            try:
+                traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        line = {
+            "metric": "QP-MPC ticks/sec (batch=4096, N=16)",
+            "value": value, "unit": "ticks/s", "n_gpus": world, "steps": K, "warmup": W,
+            "ms_per_step": 1e3 * elapsed / K, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "Herdt2010 N=16 fp64, batch=4096 independent gaits per GPU "
+                                   "(fused tick: preview + QP assembly + QL solve + LIPM + feet)",
+                       "batch_per_gpu": B, "horizon_N": int(model.N), "qp_T": model.T,
+                       "velocity_refs": "U[-0.1,0.3] x U[-0.1,0.1] x U[-0.2,0.2], redrawn every 50 ticks, "
+                                        "MT19937-64 seed 20100+gait",
+                       "sharding": "gaits by contiguous index range, one RCCL broadcast of the model block"},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "kernel": "wg_mpc_tick_kernel", "kernel_ms": kern_ms,
+                         "algorithmic_bytes_per_launch": alg_bytes_per_launch},
+            "solver": {"mean_iterations": float(d[:, 1].mean()), "max_iterations": int(d[:, 1].max()),
+                       "mean_active": float(d[:, 2].mean()), "failed_qps": n_fail,
+                       "n_hist": {str(int(k)): int(v) for k, v in zip(*np.unique(d[:, 3], return_counts=True))}},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            ng, nt = 1024, 200
+            v, secs = cpu_baseline(model, ng, nt)
+            line["cpu_baseline"] = {"value": v, "unit": "ticks/s", "cores": 1, "kind": "port",
+                                    "sample": f"first {ng} gaits x {nt} ticks of the same workload "
+                                              f"({ng * nt} ticks, {secs:.1f} s), oracle/ C restatement, 1 core of "
+                                              f"{os.cpu_count()} host cores"}
+        print(json.dumps(line), flush=True)
+
+
+if __name__ == "__main__":
+    main()

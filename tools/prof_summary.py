@@ -1,0 +1,39 @@
+"""Condenses a tools/prof.sh output directory into a short text + JSON summary (per-kernel averages)."""
+import collections, csv, glob, json, os, sys
+out = sys.argv[1]
+res = {"kernels": {}, "counters": {}}
+for f in glob.glob(os.path.join(out, "trace", "**", "*_kernel_stats.csv"), recursive=True):
+    for r in csv.DictReader(open(f)):
+        name = r["Name"].split("(")[0]
+        if name.startswith("wg_"):
+            res["kernels"][name] = {"calls": int(r["Calls"]), "avg_ns": float(r["AverageNs"]), "min_ns": float(r["MinNs"]),
+                                    "max_ns": float(r["MaxNs"]), "total_ns": float(r["TotalDurationNs"])}
+for f in glob.glob(os.path.join(out, "trace", "**", "*_kernel_trace.csv"), recursive=True):
+    for r in csv.DictReader(open(f)):
+        name = r["Kernel_Name"].split("(")[0]
+        if name.startswith("wg_") and "launch" not in res["kernels"].get(name, {}):
+            res["kernels"].setdefault(name, {})["launch"] = {k: r[k] for k in ("LDS_Block_Size", "Scratch_Size", "VGPR_Count", "Accum_VGPR_Count", "SGPR_Count", "Workgroup_Size_X", "Grid_Size_X")}
+for d in ("pmc1", "pmc2", "pmc3", "pmc4"):
+    for f in glob.glob(os.path.join(out, d, "**", "*_counter_collection.csv"), recursive=True):
+        acc = collections.defaultdict(list)
+        for r in csv.DictReader(open(f)):
+            name = r["Kernel_Name"].split("(")[0]
+            if name.startswith("wg_mpc_tick") or name.startswith("wg_ql_dense"):
+                acc[(name, r["Counter_Name"])].append(float(r["Counter_Value"]))
+        for (name, c), v in acc.items():
+            res["counters"].setdefault(name, {})[c] = {"mean_per_launch": sum(v) / len(v), "launches": len(v)}
+for name, cs in res["counters"].items():
+    # MI355X_MICROARCH.md (HBM): FETCH_SIZE / WRITE_SIZE are in KiB-units of 1024 B; on gfx950 FETCH_SIZE reports half of
+    # the bytes of wide coalesced reads -> doubled here as the guide prescribes.
+    if "FETCH_SIZE" in cs and "WRITE_SIZE" in cs:
+        rd = cs["FETCH_SIZE"]["mean_per_launch"] * 1024 * 2
+        wr = cs["WRITE_SIZE"]["mean_per_launch"] * 1024
+        res.setdefault("hbm", {})[name] = {"read_bytes_per_launch_corrected": rd, "write_bytes_per_launch": wr, "hbm_bytes_per_launch": rd + wr}
+json.dump(res, open(os.path.join(out, "summary.json"), "w"), indent=1)
+for k, v in res["kernels"].items():
+    print("kernel", k, v)
+for name, cs in res["counters"].items():
+    print("counters", name)
+    for c, v in sorted(cs.items()):
+        print("   %-28s %.6g" % (c, v["mean_per_launch"]))
+print("hbm", json.dumps(res.get("hbm", {})))
