@@ -356,6 +356,9 @@ __device__ inline TickDiag mpc_tick(const wg_model_t &m, const TickTables *__res
   TickLds L;
   L.carve(lds_tick, N);
   wg_gait_state_t *s = L.st;
+#ifdef WG_PROFILE
+  unsigned long long tk0 = clock64(), tk1 = 0, tk2 = 0, tk3 = 0;
+#endif
 
   // ---- state: HBM -> LDS (coalesced 8-byte lanes) ----
   {
@@ -458,6 +461,9 @@ __device__ inline TickDiag mpc_tick(const wg_model_t &m, const TickTables *__res
   }
   WG_WSYNC();
 
+#ifdef WG_PROFILE
+  tk1 = clock64();
+#endif
   const int ns = (int)L.misc[0];
   const int n = 2 * N + 2 * ns;
   const int mq = 1 + 4 * N + 5 * ns;     // rows incl. the dummy row 0 (qp-problem.cpp:248)
@@ -578,7 +584,13 @@ __device__ inline TickDiag mpc_tick(const wg_model_t &m, const TickTables *__res
   WG_WSYNC();
 
   // ---- QPProblem::solve -> ql0001_ (eps = 1e-8, qp-problem.cpp:260) ----
+#ifdef WG_PROFILE
+  tk2 = clock64();
+#endif
   QlResult qr = ql_solve(q, 1e-8, hist, hist_cap);
+#ifdef WG_PROFILE
+  tk3 = clock64();
+#endif
   if (hist_len && lane == 0) *hist_len = qr.hist_len;
 
   // ---- CoM: jerk, 20 interpolated samples, state step (ZMPVelocityReferencedQP.cpp:405-428) ----
@@ -765,6 +777,13 @@ __device__ inline TickDiag mpc_tick(const wg_model_t &m, const TickTables *__res
     const double *src = reinterpret_cast<const double *>(s);
     for (int i = lane; i < (int)(sizeof(wg_gait_state_t) / 8); i += 64) dst[i] = src[i];
   }
+#ifdef WG_PROFILE
+  if (lane == 0) {
+    atomicAdd(&g_prof[21], tk1 - tk0);                 // state load + lane-0 scalar part
+    atomicAdd(&g_prof[22], tk2 - tk1);                 // QP assembly
+    atomicAdd(&g_prof[23], clock64() - tk3);           // post-processing + state store
+  }
+#endif
   TickDiag dg;
   dg.ifail = qr.ifail; dg.n_iter = qr.n_iter; dg.nact = qr.nact; dg.n = n; dg.m = mq; dg.ns = ns;
   return dg;

@@ -5,7 +5,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libwg_mpc.so")
+LIB_PATH = os.environ.get("WG_LIB_PATH", os.path.join(_HERE, "lib", "libwg_mpc.so"))
 
 SAMPLES = 20   # WG_SAMPLES_PER_TICK
 

@@ -1,0 +1,33 @@
+"""Diagnostic: per-phase shader cycles of the tick kernel on the bench workload (libwg_mpc_prof.so)."""
+import ctypes as C, importlib, os, sys, numpy as np, torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+os.environ["WG_LIB_PATH"] = os.path.join(ROOT, "jrl-walkgen_amd", "lib", "libwg_mpc_prof.so")
+wg = importlib.import_module("jrl-walkgen_amd"); wg.init(0)
+B = int(os.environ.get("PB", "1024")); WARM = 60; MEAS = 20
+model = wg.model_defaults(); wg.mpc_configure(model)
+rng = np.random.default_rng(20100)
+states = (wg.GaitState * B)()
+s0 = wg.gait_init(model, [0.0316055, 0.0, 0.7116911], [0.0, 0.09, 0.0], [0.0, -0.09, 0.0]); s0.nb_steps_left = 2
+for g in range(B): C.memmove(C.byref(states[g]), C.byref(s0), C.sizeof(wg.GaitState))
+dev = torch.frombuffer(bytearray(bytes(memoryview(states).cast("B"))), dtype=torch.uint8).cuda()
+diag = torch.zeros(B, 6, dtype=torch.int32, device="cuda")
+buf = (C.c_ulonglong * 24)()
+its = 0
+for tick in range(WARM + MEAS):
+    if tick % 50 == 0:
+        v = torch.from_numpy(np.stack([rng.uniform(-0.1, 0.3, B), rng.uniform(-0.1, 0.1, B), rng.uniform(-0.2, 0.2, B)], 1)).cuda()
+        wg.mpc_set_velref_dev(B, dev.data_ptr(), v.data_ptr())
+    if tick == WARM:
+        torch.cuda.synchronize(); wg.lib().wg_prof_read(buf)
+    wg.mpc_tick_batch_dev(B, dev.data_ptr(), None, diag.data_ptr(), 1 if tick == 0 else (19 if tick == 1 else 20))
+    if tick >= WARM:
+        torch.cuda.synchronize(); its += int(diag[:, 1].sum().item())
+torch.cuda.synchronize(); wg.lib().wg_prof_read(buf)
+v = np.array(list(buf), dtype=np.float64); n = B * MEAS
+names = ["norms", "diagchk", "chol", "inverse", "resid/reset+shift", "ZT*ww(resid)", "x-shift", "backsub+lam(resid)", "xmag(resid)",
+         "scan", "fdiff/wx", "newnormal ZTa", "sweep", "route sums", "step-pre", "backsub(step)", "pickdrop", "step/upd/drop", "add",
+         "xmag(add)", "tail", "TICK pre (lane0)", "TICK assembly", "TICK post"]
+print(f"gait-ticks={n} mean QL iters={its/n:.1f} cycles/tick={v.sum()/n:.0f}")
+for k, nme in enumerate(names):
+    print(f"{k:2d} {nme:22s} {v[k]/n:12.0f} cyc/tick  {100*v[k]/v.sum():5.1f}%")
