@@ -84,9 +84,9 @@ __global__ __launch_bounds__(64) void wg_ql_dense_kernel(
     const double *Cg = C + (size_t)qp * nmax * nmax;
     const double *Ag = A + (size_t)qp * mmax * nmax;
     for (int j = 0; j < n; ++j)
-      for (int i = lane; i < n; i += 64) Gm(i, j) = Cg[i + (size_t)j * nmax];
+      for (int i = lane; i < n; i += 64) q.G[i + j * q.ldg] = Cg[i + (size_t)j * nmax];
     for (int i = 0; i < n; ++i)
-      for (int k = lane; k < m; k += 64) Am(k, i) = Ag[k + (size_t)i * mmax];
+      for (int k = lane; k < m; k += 64) q.A[k + i * q.lda] = Ag[k + (size_t)i * mmax];
     for (int i = lane; i < n; i += 64) {
       q.d[i] = dvec[(size_t)qp * nmax + i];
       q.xl[i] = xl[(size_t)qp * nmax + i];
@@ -95,11 +95,12 @@ __global__ __launch_bounds__(64) void wg_ql_dense_kernel(
     for (int k = lane; k < m; k += 64) q.b[k] = -bvec[(size_t)qp * mmax + k];   // qld.cpp:469-475
     WG_WSYNC();
     // qld.cpp:442-444: c(nmax,nmax) == 0 -> eps (inside the n x n block only if nmax == n)
-    if (nmax == n && lane == 0 && fabs(Gm(n - 1, n - 1)) == 0.0) Gm(n - 1, n - 1) = eps;
+    if (nmax == n && lane == 0 && fabs(q.G[(n - 1) + (n - 1) * q.ldg]) == 0.0) q.G[(n - 1) + (n - 1) * q.ldg] = eps;
     WG_WSYNC();
 
     int *hq = hist ? hist + (size_t)qp * hist_cap : nullptr;
-    wg::QlResult r = wg::ql_solve(q, eps, hq, hist_cap);
+    wg::DenseProb prob;
+    wg::QlResult r = wg::ql_solve(q, prob, eps, hq, hist_cap);
 
     // ---- results ----
     for (int i = lane; i < n; i += 64) x[(size_t)qp * nmax + i] = q.x[i];
@@ -260,13 +261,19 @@ DevBuf g_tick_state, g_tick_out, g_tick_aux;
 
 inline int tick_max_n(const wg_model_t &m) { return 2 * m.N + 2 * wg::kSMax; }
 inline int tick_max_m(const wg_model_t &m) { return 1 + 4 * m.N + 5 * wg::kSMax; }
+// compact problem view (no G / A matrices in LDS) exists for N == 16; WG_TICK_DENSE=1 forces the generic one
+inline bool tick_compact(const wg_model_t &m) {
+  const char *e = getenv("WG_TICK_DENSE");
+  return m.N == 16 && !(e && atoi(e) != 0);
+}
 inline size_t tick_ql_bytes(const wg_model_t &m) {
-  size_t b = wg::QlDims(tick_max_n(m), tick_max_m(m), tick_max_m(m)).bytes();
+  size_t b = wg::QlDims(tick_max_n(m), tick_max_m(m), tick_max_m(m), !tick_compact(m)).bytes();
   return (b + 15) & ~(size_t)15;
 }
 }  // namespace
 
-__global__ __launch_bounds__(64) void wg_mpc_tick_kernel(int B, wg_model_t model, const wg::TickTables *__restrict__ tb,
+template <int NH>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void wg_mpc_tick_kernel(int B, wg_model_t model, const wg::TickTables *__restrict__ tb,
                                                          wg_gait_state_t *__restrict__ states,
                                                          wg_tick_out_t *__restrict__ outs, int *__restrict__ diag,
                                                          int advance_calls, int *__restrict__ hist, int hist_cap,
@@ -283,7 +290,7 @@ __global__ __launch_bounds__(64) void wg_mpc_tick_kernel(int B, wg_model_t model
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
       WG_WSYNC();
     }
-    wg::TickDiag dg = wg::mpc_tick(model, tb, states + g, outs ? outs + g : nullptr, wg_lds,
+    wg::TickDiag dg = wg::mpc_tick<NH>(model, tb, states + g, outs ? outs + g : nullptr, wg_lds,
                                    reinterpret_cast<char *>(wg_lds) + ql_bytes, hist ? hist + (size_t)g * hist_cap : nullptr,
                                    hist_cap, hist_len ? hist_len + g : nullptr);
     if (diag && lane == 0) {
@@ -365,8 +372,10 @@ int wg_mpc_tick_batch_dev(int B, wg_gait_state_t *states, wg_tick_out_t *outs, i
   if (B == 0) return WG_OK;
   const size_t qlb = tick_ql_bytes(g_model);
   const size_t lds = qlb + wg::TickLds::bytes(g_model.N);
+  const bool compact = tick_compact(g_model);
   if (lds > 64 * 1024)
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(wg_mpc_tick_kernel),
+    HIP_TRY(hipFuncSetAttribute(compact ? reinterpret_cast<const void *>(wg_mpc_tick_kernel<16>)
+                                        : reinterpret_cast<const void *>(wg_mpc_tick_kernel<0>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   int per_cu = (int)((160 * 1024) / lds);
   if (per_cu < 1) per_cu = 1;
@@ -375,8 +384,12 @@ int wg_mpc_tick_batch_dev(int B, wg_gait_state_t *states, wg_tick_out_t *outs, i
   int grid = g_num_cu * per_cu;
   if (grid > B) grid = B;
   hipStream_t st = reinterpret_cast<hipStream_t>(hip_stream);
-  hipLaunchKernelGGL(wg_mpc_tick_kernel, dim3(grid), dim3(64), lds, st, B, g_model, g_tables_dev, states, outs, diag,
-                     advance_calls, hist, hist_cap, hist_len, (unsigned)qlb);
+  if (compact)
+    hipLaunchKernelGGL(wg_mpc_tick_kernel<16>, dim3(grid), dim3(64), lds, st, B, g_model, g_tables_dev, states, outs, diag,
+                       advance_calls, hist, hist_cap, hist_len, (unsigned)qlb);
+  else
+    hipLaunchKernelGGL(wg_mpc_tick_kernel<0>, dim3(grid), dim3(64), lds, st, B, g_model, g_tables_dev, states, outs, diag,
+                       advance_calls, hist, hist_cap, hist_len, (unsigned)qlb);
   HIP_TRY(hipGetLastError());
   return WG_OK;
 }

@@ -48,6 +48,25 @@ __device__ __forceinline__ double uni(double v) {
   hi = __builtin_amdgcn_readfirstlane(hi);
   return __hiloint2double(hi, lo);
 }
+// value of `v` in lane `src` (src must be wave-uniform): two v_readlane_b32, no LDS round trip
+__device__ __forceinline__ double rl(double v, int src) {
+  int lo = __builtin_amdgcn_readlane(__double2loint(v), src);
+  int hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
+  return __hiloint2double(hi, lo);
+}
+// sum_{j=lo}^{hi-1} v[lane j] in index order, starting from 0.0.  `v` must be 0.0 in every lane that is not in
+// [lo, hi): adding +0.0 never changes a running sum, so the loop can run in chunks of four without a remainder
+// loop (v_readlane is convergent and the compiler will not unroll it itself).  Needs hi <= 61.
+__device__ __forceinline__ double lane_sum_ordered(double v, int lo, int hi) {
+  double sum = 0.0;
+  for (int j = lo; j < hi; j += 4) {
+    sum += rl(v, j);
+    sum += rl(v, j + 1);
+    sum += rl(v, j + 2);
+    sum += rl(v, j + 3);
+  }
+  return sum;
+}
 // f2c.h max/min (qld.cpp:269-270)
 __device__ __forceinline__ double maxd(double a, double b) { return a >= b ? a : b; }
 __device__ __forceinline__ double mind(double a, double b) { return a <= b ? a : b; }
@@ -56,11 +75,12 @@ __device__ __forceinline__ double mind(double a, double b) { return a <= b ? a :
 struct QlDims {
   int n, m, mmax;
   int ldg, ldz, lda;
-  __host__ __device__ QlDims(int n_, int m_, int mmax_)
-      : n(n_), m(m_), mmax(mmax_), ldg(n_ | 1), ldz(n_ | 1), lda(mmax_ | 1) {}
+  bool dense;   // G and A held as LDS matrices (false: the problem view regenerates them)
+  __host__ __device__ QlDims(int n_, int m_, int mmax_, bool dense_ = true)
+      : n(n_), m(m_), mmax(mmax_), ldg(n_ | 1), ldz(n_ | 1), lda(mmax_ | 1), dense(dense_) {}
   __host__ __device__ int r_len() const { return n * (n + 1) / 2 + n; }
   __host__ __device__ int n_doubles() const {
-    return n * ldg + n * ldz + r_len() + n * lda   // G, Z, R, A
+    return (dense ? n * ldg + n * lda : 0) + n * ldz + r_len()   // [G, A,] Z, R
            + 8 * n                                  // x d ww wd wx lam xl xu
            + (m + n) + m                            // wa, b (inner)
            + 4 * n + 8;                             // scratch + scalar slots
@@ -79,10 +99,11 @@ struct QlView {
   __device__ void carve(double *base, const QlDims &D, int me_) {
     n = D.n; m = D.m; me = me_; mn = D.m + D.n; ldg = D.ldg; ldz = D.ldz; lda = D.lda;
     double *p = base;
-    G = p; p += n * ldg;
+    G = nullptr; A = nullptr;
+    if (D.dense) { G = p; p += n * ldg; }
     Z = p; p += n * ldz;
     R = p; p += D.r_len();
-    A = p; p += n * lda;
+    if (D.dense) { A = p; p += n * lda; }
     x = p; p += n;  d = p; p += n;  ww = p; p += n;  wd = p; p += n;
     wx = p; p += n; lam = p; p += n; xl = p; p += n; xu = p; p += n;
     wa = p; p += m + n;
@@ -93,9 +114,19 @@ struct QlView {
   }
 };
 
-#define Gm(i, j) q.G[(i) + (j) * q.ldg]
 #define Zm(i, j) q.Z[(i) + (j) * q.ldz]
-#define Am(k, i) q.A[(k) + (i) * q.lda]
+// G and A go through the problem view `prob` (DenseProb: LDS matrices; HerdtProb: regenerated on the fly)
+#define Gm(i, j) prob.G(q, (i), (j))
+#define Am(k, i) prob.A(q, (k), (i))
+
+struct QlView;
+struct DenseProb {
+  static constexpr bool kCompact = false;
+  __device__ __forceinline__ double G(const QlView &q, int i, int j) const;
+  __device__ __forceinline__ double A(const QlView &q, int k, int i) const;
+  __device__ __forceinline__ double Gd(const QlView &q, int i) const;
+  __device__ __forceinline__ void setGd(const QlView &q, int i, double v) const;
+};
 #define Rp(i, j) q.R[(j) * ((j) + 1) / 2 + (i)]
 
 // ---- optional in-kernel phase timers (diagnostic build only: -DWG_PROFILE) ----
@@ -113,6 +144,11 @@ __device__ unsigned long long g_prof[24];
 struct QlResult {
   int ifail, n_iter, nact, hist_len;
 };
+
+__device__ __forceinline__ double DenseProb::G(const QlView &q, int i, int j) const { return q.G[i + j * q.ldg]; }
+__device__ __forceinline__ double DenseProb::A(const QlView &q, int k, int i) const { return q.A[k + i * q.lda]; }
+__device__ __forceinline__ double DenseProb::Gd(const QlView &q, int i) const { return q.G[i + i * q.ldg]; }
+__device__ __forceinline__ void DenseProb::setGd(const QlView &q, int i, double v) const { q.G[i + i * q.ldg] = v; }
 
 // arg-max over the wave: larger v wins, equal v -> smaller idx.  idx < 0 = no candidate.
 __device__ __forceinline__ void wave_argmax_first(double &v, int &idx) {
@@ -170,9 +206,30 @@ __device__ __forceinline__ void zt_times_ww(const QlView &q, double *s, int lane
   WG_WSYNC();
 }
 
-// ww[0..nact) = R^-1 s[0..nact)   (qld.cpp:1824-1851).  Sequential chain,
-// executed redundantly by every lane on broadcast operands.
+// ww[0..nact) = R^-1 s[0..nact)   (qld.cpp:1824-1851): rows from the bottom up, inner sums ascending in j.
+// nact <= 64: lane j keeps ww[j] in a register; row i's products R(i,j)*ww[j] are formed lane-parallel and
+// summed in index order through v_readlane (no LDS round trip on the dependent chain).
 __device__ __forceinline__ void backsub(const QlView &q, const double *s, int nact, int lane) {
+  if (nact <= 60) {
+    const bool mine = lane < nact;
+    const double sreg = mine ? s[lane] : 0.0;
+    const double dreg = mine ? Rp(lane, lane) : 1.0;
+    double w = 0.0;
+    double rrow = (nact >= 2 && lane == nact - 1) ? Rp(nact - 2, lane) : 0.0;   // R(i, lane) of the next row to do
+    for (int i = nact - 1; i >= 0; --i) {
+      double sum = 0.0;
+      if (i < nact - 1) {
+        const double p = (lane > i && mine) ? rrow * w : 0.0;
+        sum = lane_sum_ordered(p, i + 1, nact);
+      }
+      const double v = (rl(sreg, i) - sum) / rl(dreg, i);
+      if (lane == i) w = v;
+      if (i >= 1) rrow = (lane > i - 1 && mine) ? Rp(i - 1, lane) : 0.0;          // prefetch row i-1
+    }
+    if (mine) q.ww[lane] = w;
+    WG_WSYNC();
+    return;
+  }
   for (int i = nact - 1; i >= 0; --i) {
     double sum = 0.0;
     WG_UNROLL
@@ -206,11 +263,17 @@ __device__ __forceinline__ int pick_drop(const QlView &q, int nact, double res, 
 }
 
 // qld.cpp:2039-2058 (lql): per-lane terms, then the sum in index order.
-__device__ __forceinline__ double xmag_sum(const QlView &q, double vfact, int lane) {
+template <class P>
+__device__ __forceinline__ double xmag_sum(const QlView &q, const P &prob, double vfact, int lane) {
   const int n = q.n;
+  if (n <= 60) {
+    double term = 0.0;
+    if (lane < n) { const double xi = q.x[lane]; term = fabs(xi) * vfact * (fabs(q.d[lane]) + fabs(prob.Gd(q, lane) * xi)); }
+    return lane_sum_ordered(term, 0, n);
+  }
   for (int i = lane; i < n; i += 64) {
     double xi = q.x[i];
-    q.sc3[i] = fabs(xi) * vfact * (fabs(q.d[i]) + fabs(Gm(i, i) * xi));
+    q.sc3[i] = fabs(xi) * vfact * (fabs(q.d[i]) + fabs(prob.Gd(q, i) * xi));
   }
   WG_WSYNC();
   double sum = 0.0;
@@ -219,16 +282,57 @@ __device__ __forceinline__ double xmag_sum(const QlView &q, double vfact, int la
   return sum;
 }
 
-// qld.cpp:1992-2030.  Three phases: (1) the chain of rotation norms, all lanes
-// redundantly; (2) ga/gb of every rotation, one lane each; (3) every lane
-// carries its own row of Z through the whole rotation sequence.
+// qld.cpp:1992-2030.  Three phases: (1) the chain of rotation norms; (2) ga/gb of every rotation, one lane
+// each; (3) every lane carries its own row of Z through the whole rotation sequence.
+// n <= 64: s[] and the rotation coefficients live in registers (lane c <-> column c) and are handed
+// around with v_readlane, so the dependent chain of phase 1 contains no LDS access at all.
 __device__ __forceinline__ void sweep(const QlView &q, double *s, int nu, int nact, int lane) {
   const int n = q.n;
   if (nu - 1 <= nact) return;
+  if (n <= 64) {
+    const double sreg = (lane < nu) ? s[lane] : 0.0;
+    double myP = 0.0, myQ = 0.0, myN = 0.0;
+    {
+      double cur = rl(sreg, nu - 1);
+      for (int c = nu - 1; c > nact; --c) {
+        const double p = rl(sreg, c - 1);
+        double nrm;
+        if (cur == 0.0) { nrm = 0.0; cur = p; }
+        else { nrm = givens_norm(p, cur); if (lane == c) { myP = p; myQ = cur; } cur = nrm; }
+        if (lane == c) myN = nrm;
+      }
+    }
+    double ga = 1.0, gb = 0.0;
+    if (lane > nact && lane < nu && myN != 0.0) {
+      ga = myP / myN;
+      gb = myQ / myN;
+      s[lane - 1] = myN;
+    }
+    {
+      const int i = lane;
+      const bool act = i < n;
+      double carry = act ? Zm(i, nu - 1) : 0.0;
+      double zl = act ? Zm(i, nu - 2) : 0.0;            // nu - 2 >= nact >= 0 here
+      for (int c = nu - 1; c > nact; --c) {
+        const double zn = (act && c - 2 >= nact) ? Zm(i, c - 2) : 0.0;   // prefetch for the next rotation
+        const double nc = rl(myN, c);
+        if (nc == 0.0) { if (act) Zm(i, c) = carry; carry = zl; }
+        else {
+          const double gac = rl(ga, c), gbc = rl(gb, c);
+          const double t = gac * zl + gbc * carry;
+          if (act) Zm(i, c) = gac * carry - gbc * zl;
+          carry = t;
+        }
+        zl = zn;
+      }
+      if (act) Zm(i, nact) = carry;
+    }
+    WG_WSYNC();
+    return;
+  }
   // phase 1: sc0[c] = p (s[c-1] before), sc1[c] = q (s[c] current), sc2[c] = norm; sc2[c] = 0 marks "skipped"
   {
     double cur = s[nu - 1];
-    WG_UNROLL
     for (int c = nu - 1; c > nact; --c) {
       double p = s[c - 1];
       double nrm;
@@ -238,7 +342,6 @@ __device__ __forceinline__ void sweep(const QlView &q, double *s, int nu, int na
     }
     WG_WSYNC();
   }
-  // phase 2: rotation coefficients
   for (int c = nact + 1 + lane; c < nu; c += 64) {
     double nrm = q.sc2[c];
     if (nrm != 0.0) {
@@ -249,10 +352,8 @@ __device__ __forceinline__ void sweep(const QlView &q, double *s, int nu, int na
     }
   }
   WG_WSYNC();
-  // phase 3: rows of Z
   for (int i = lane; i < n; i += 64) {
     double carry = Zm(i, nu - 1);
-    WG_UNROLL
     for (int c = nu - 1; c > nact; --c) {
       if (q.sc2[c] == 0.0) { Zm(i, c) = carry; carry = Zm(i, c - 1); continue; }
       double ga = q.sc0[c], gb = q.sc1[c];
@@ -308,7 +409,8 @@ __device__ __forceinline__ int drop_constraint(const QlView &q, int kdrop, int n
 }
 
 // qld.cpp:1547-1658
-__device__ __forceinline__ bool independent_coordinate(const QlView &q, int knext, int nact, double vsmall, int lane) {
+template <class P>
+__device__ __forceinline__ bool independent_coordinate(const QlView &q, const P &prob, int knext, int nact, double vsmall, int lane) {
   const int n = q.n, m = q.m;
   int k1 = 0;
   if (knext > m) { k1 = knext - m; if (k1 > n) k1 -= n; }
@@ -341,7 +443,8 @@ __device__ __forceinline__ bool independent_coordinate(const QlView &q, int knex
 // The solver.  Problem data must already be in LDS: G (copy of C, patched per
 // qld.cpp:442-444), A, d, b (INNER sign: b = -b_user, qld.cpp:469-475), xl, xu.
 // hist: optional global add(+code)/drop(-code) log written by lane 0.
-__device__ inline QlResult ql_solve(const QlView &q, double vsmall, int *hist, int hist_cap) {
+template <class P>
+__device__ inline QlResult ql_solve(const QlView &q, P &prob, double vsmall, int *hist, int hist_cap) {
   const int lane = threadIdx.x & 63;
   const int n = q.n, m = q.m, me = q.me, mn = q.mn;
   QlResult out;
@@ -367,14 +470,18 @@ __device__ inline QlResult ql_solve(const QlView &q, double vsmall, int *hist, i
   // ---- reciprocal lengths of the constraint normals, :769-807 ----
   {
     int fatal = 0x7fffffff;
-    for (int k = lane; k < m; k += 64) {
-      double sum = 0.0;
-      WG_UNROLL
-      for (int i = 0; i < n; ++i) { double a = Am(k, i); sum += a * a; }
-      if (sum > 0.0) sum = 1.0 / sqrt(sum);
-      else if (q.b[k] == 0.0) {}
-      else if (k + 1 <= me || q.b[k] > 0.0) fatal = k + 1 < fatal ? k + 1 : fatal;
-      q.wa[k] = sum;
+    if constexpr (P::kCompact) {
+      fatal = prob.norms(q, lane);
+    } else {
+      for (int k = lane; k < m; k += 64) {
+        double sum = 0.0;
+        WG_UNROLL
+        for (int i = 0; i < n; ++i) { double a = Am(k, i); sum += a * a; }
+        if (sum > 0.0) sum = 1.0 / sqrt(sum);
+        else if (q.b[k] == 0.0) {}
+        else if (k + 1 <= me || q.b[k] > 0.0) fatal = k + 1 < fatal ? k + 1 : fatal;
+        q.wa[k] = sum;
+      }
     }
     for (int k = lane; k < n; k += 64) q.wa[m + k] = 1.0;
     fatal = wave_min_int(fatal);
@@ -384,9 +491,11 @@ __device__ inline QlResult ql_solve(const QlView &q, double vsmall, int *hist, i
 
   if (!early_exit) {
     // ---- make the Hessian numerically positive definite, :814-854 ----
-    for (int i = lane; i < n; i += 64) q.wd[i] = Gm(i, i);
+    for (int i = lane; i < n; i += 64) q.wd[i] = prob.Gd(q, i);
     WG_WSYNC();
-    {
+    if constexpr (P::kCompact) {
+      diag = prob.diag_check(q, vsmall, lane);
+    } else {
       double dl = 0.0;
       for (int i = lane; i < n; i += 64) {
         double wdi = q.wd[i];
@@ -404,10 +513,15 @@ __device__ inline QlResult ql_solve(const QlView &q, double vsmall, int *hist, i
     }
     bool need_shift = diag > 0.0;
     PT(1);
+    bool factored = false;
+    if constexpr (P::kCompact) {
+      if (!need_shift && prob.blocks_ok) factored = prob.factor(q, vsmall, lane);
+    }
+    if (!factored) {
     for (;;) {
       if (need_shift) {
         diag = diagr * diag;
-        for (int i = lane; i < n; i += 64) Gm(i, i) = diag + q.wd[i];
+        for (int i = lane; i < n; i += 64) prob.setGd(q, i, diag + q.wd[i]);
         WG_WSYNC();
       }
       // ---- Cholesky, row by row (same sums as the column order of :859-890) ----
@@ -480,6 +594,7 @@ __device__ inline QlResult ql_solve(const QlView &q, double vsmall, int *hist, i
       }
     }
     WG_WSYNC();
+    }   // !factored
   }
 
   PT(3);
@@ -507,8 +622,11 @@ __device__ inline QlResult ql_solve(const QlView &q, double vsmall, int *hist, i
         iflag = 2;
         for (int i = lane; i < n; i += 64) {
           double acc = q.d[i];
-          WG_UNROLL
-          for (int j = 0; j < n; ++j) acc += Gm(i, j) * q.x[j];
+          if constexpr (P::kCompact) acc = prob.gdot_acc(q, i, q.x, acc);
+          else {
+            WG_UNROLL
+            for (int j = 0; j < n; ++j) acc += Gm(i, j) * q.x[j];
+          }
           WG_UNROLL
           for (int k = 0; k < nact; ++k) {
             int kk = q.iact[k];
@@ -555,8 +673,11 @@ __device__ inline QlResult ql_solve(const QlView &q, double vsmall, int *hist, i
         WG_WSYNC();
         for (int j = lane; j < n; j += 64) {
           double acc = q.ww[j];
-          WG_UNROLL
-          for (int i = 0; i < n; ++i) acc += q.sc0[i] * Gm(i, j);
+          if constexpr (P::kCompact) acc = prob.gdot_acc(q, j, q.sc0, acc);
+          else {
+            WG_UNROLL
+            for (int i = 0; i < n; ++i) acc += q.sc0[i] * Gm(i, j);
+          }
           q.ww[j] = acc;
         }
         WG_WSYNC();
@@ -581,7 +702,7 @@ __device__ inline QlResult ql_solve(const QlView &q, double vsmall, int *hist, i
         WG_WSYNC();
       }
       PT(7);
-      { double sm = xmag_sum(q, vfact, lane); xmag = maxd(xmag, sm); }
+      { double sm = xmag_sum(q, prob, vfact, lane); xmag = maxd(xmag, sm); }
       PT(8);
       if (iflag == itref) { st = ST_RESID; continue; }      // :1226
       // first inequality with a negative multiplier, :1233-1249
@@ -602,6 +723,41 @@ __device__ inline QlResult ql_solve(const QlView &q, double vsmall, int *hist, i
       // ---- most violated normalised constraint, :1255-1331 ----
       double bestv = 0.0, bestres = 0.0;
       int bidx = -1;
+      if constexpr (P::kCompact) {
+        constexpr int NH = sizeof(prob.ax) / sizeof(double);
+        double xs[2 * NH];
+#pragma unroll
+        for (int c = 0; c < 2 * NH; ++c) xs[c] = q.x[c];
+        {
+          const int k = lane + 1;                     // the lane's CoP row
+          const double wak = q.wa[k], bk = q.b[k];
+          double sum = -bk, asum = fabs(bk);
+          prob.cop_row_dot(xs, sum, asum);
+          if (prob.fj >= 0) {
+            double t = q.x[2 * NH + prob.fj] * prob.fa; sum += t; asum += fabs(t);
+            t = q.x[2 * NH + prob.ns + prob.fj] * prob.fb; sum += t; asum += fabs(t);
+          }
+          const double sumx = -sum * wak;
+          if (wak > 0.0 && !(sumx <= 0.0)) {
+            const double tempa = asum + fabs(sum);
+            const double temp2 = asum + onha * fabs(sum);
+            if (!(tempa <= asum) && !(temp2 <= tempa)) { bestv = sumx; bestres = sum; bidx = k + 1; }
+          }
+        }
+        if (lane < 5 * prob.ns) {
+          const int k = 1 + 4 * NH + lane;            // the lane's foot-placement row
+          const double wak = q.wa[k], bk = q.b[k];
+          double sum = -bk, asum = fabs(bk);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { const double t = q.x[prob.f2c[e]] * prob.f2v[e]; sum += t; asum += fabs(t); }
+          const double sumx = -sum * wak;
+          if (wak > 0.0 && !(sumx <= 0.0) && !(bidx >= 0 && sumx <= bestv)) {
+            const double tempa = asum + fabs(sum);
+            const double temp2 = asum + onha * fabs(sum);
+            if (!(tempa <= asum) && !(temp2 <= tempa)) { bestv = sumx; bestres = sum; bidx = k + 1; }
+          }
+        }
+      } else {
       for (int k = lane; k < m; k += 64) {
         double wak = q.wa[k];
         if (wak <= 0.0) continue;
@@ -621,6 +777,7 @@ __device__ inline QlResult ql_solve(const QlView &q, double vsmall, int *hist, i
         temp += onha * fabs(sum);
         if (temp <= tempa) continue;
         bestv = sumx; bestres = sum; bidx = k + 1;
+      }
       }
       for (int k = lane; k < n; k += 64) {
         if (q.wa[m + k] <= 0.0) continue;
@@ -698,7 +855,8 @@ __device__ inline QlResult ql_solve(const QlView &q, double vsmall, int *hist, i
       if (knext <= m) {
         for (int i = lane; i < n; i += 64) q.ww[i] = Am(knext - 1, i);
         WG_WSYNC();
-        zt_times_ww(q, s, lane);
+        if constexpr (P::kCompact) prob.zt_row(q, s, knext - 1, lane);
+        else zt_times_ww(q, s, lane);
       } else {
         int k1 = knext - m;
         double sg = 1.0;
@@ -721,12 +879,23 @@ __device__ inline QlResult ql_solve(const QlView &q, double vsmall, int *hist, i
         if (nact == 0) route = 0;                           // :1488
         else {                                              // :1491-1532
           double suma = 0.0, sumb = 0.0, sumc = 0.0;
-          WG_UNROLL
-          for (int i = 0; i < n; ++i) {
-            double zi = Zm(i, nact), wi = q.ww[i];
-            suma += wi * zi;
-            sumb += fabs(wi * zi);
-            sumc += zi * zi;
+          if (n <= 60) {
+            double ta = 0.0, tb = 0.0, tc = 0.0;
+            if (lane < n) { const double zi = Zm(lane, nact), wi = q.ww[lane]; ta = wi * zi; tb = fabs(wi * zi); tc = zi * zi; }
+            for (int i = 0; i < n; i += 4) {
+              suma += rl(ta, i); sumb += rl(tb, i); sumc += rl(tc, i);
+              suma += rl(ta, i + 1); sumb += rl(tb, i + 1); sumc += rl(tc, i + 1);
+              suma += rl(ta, i + 2); sumb += rl(tb, i + 2); sumc += rl(tc, i + 2);
+              suma += rl(ta, i + 3); sumb += rl(tb, i + 3); sumc += rl(tc, i + 3);
+            }
+          } else {
+            WG_UNROLL
+            for (int i = 0; i < n; ++i) {
+              double zi = Zm(i, nact), wi = q.ww[i];
+              suma += wi * zi;
+              sumb += fabs(wi * zi);
+              sumc += zi * zi;
+            }
           }
           if (!significant(sumb, fabs(suma)) || !(sumb > vsmall)) route = 1;
           else {
@@ -735,7 +904,7 @@ __device__ inline QlResult ql_solve(const QlView &q, double vsmall, int *hist, i
             if (significant(sumc, fabs(suma))) route = 0;
             else {                                          // :1538-1540
               backsub(q, s, nact, lane);
-              route = independent_coordinate(q, knext, nact, vsmall, lane) ? 0 : 2;
+              route = independent_coordinate(q, prob, knext, nact, vsmall, lane) ? 0 : 2;
             }
           }
         }
@@ -816,7 +985,7 @@ __device__ inline QlResult ql_solve(const QlView &q, double vsmall, int *hist, i
       LOG_EVENT(knext);
       WG_WSYNC();
       PT(18);
-      double sm = xmag_sum(q, vfact, lane);                 // :1776-1786
+      double sm = xmag_sum(q, prob, vfact, lane);                 // :1776-1786
       xmag = maxd(xmag, sm);
       PT(19);
       if (sm < xmagr * xmag) st = ST_RESET;

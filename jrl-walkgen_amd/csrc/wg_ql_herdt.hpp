@@ -1,0 +1,270 @@
+// wg_ql_herdt.hpp -- problem view of the Herdt-2010 QP for the in-wave QL solver: nothing of the
+// Hessian or of the constraint matrix is stored as a matrix.
+//
+// Structure used (all from the reference's assembly, generator-vel-ref.cpp:393-474, 587-674):
+//   * C = blockdiag(Qb, Qb) + a 2ns-column border; Qb (N x N) is a constant of the model.
+//   * general rows 1..4N ("CoP rows", 4 per previewed instant r) are
+//         [ -(a*Uz[r,:]) | -(b*Uz[r,:]) | a*e_step | b*e_step ],   Uz[r,c] = u[r-c] (Toeplitz, c <= r)
+//     i.e. three doubles (a, b, r) + the 16-entry vector u describe a row; rows 4N+1.. (foot placement)
+//     have at most four non-zeros.
+//   * 4N = 64 rows = one row per lane (N = 16): each lane keeps the 2N products of ITS row in registers, so
+//     the per-iteration violation scan is pure register arithmetic on LDS-broadcast x.
+//   * the leading 2N x 2N block of the Cholesky factor and of its inverse does not depend on the gait; it is
+//     computed once per model (same recurrences, same order => same bits) and copied in; only the last 2ns
+//     columns are factorised per tick.
+// Skipped terms are structural zeros only: x*(+-0) added to a running sum never changes it, so every value
+// that the reference's dense loops produce is reproduced bit for bit.
+#pragma once
+#include "wg_ql_device.hpp"
+
+namespace wg {
+
+constexpr int kSMaxQ = 4;   // == kSMax of the tick
+
+template <int NH>
+struct HerdtProb {
+  static constexpr bool kCompact = true;
+  static_assert(4 * NH == 64, "one CoP row per lane needs 4N == 64");
+  // ---- LDS / global tables (wave-uniform pointers) ----
+  const double *Qb;       // LDS, NH x (NH+1)
+  const double *u;        // LDS, NH
+  double *Gv;             // LDS, n x (2*kSMaxQ): G(i, 2N + c)
+  double *gd;             // LDS, n: current Hessian diagonal (shifted when needed)
+  const double *rowA, *rowB;
+  const int *rowK, *stepidx;
+  const double *V_f;
+  const double *R2, *Z2;  // global: constant 2N x 2N factor blocks (packed R, dense Z, ld 2N)
+  double diag_b;          // the constant block's contribution to ql0002's diagonal test
+  int blocks_ok;
+  int ns;
+  // ---- per-lane registers: the lane's own constraint rows ----
+  double ax[NH], ay[NH];  // CoP row (lane+1): x- and y-jerk parts
+  double fa, fb; int fj;  // its two foot-variable entries (columns 2N+fj, 2N+ns+fj), fj < 0: none
+  double f2v[4]; int f2c[4]; int f2n;   // foot-placement row (1+4N+lane), entries in column order
+
+  // ------------------------------------------------------------------ element access (rare paths)
+  __device__ __forceinline__ double G(const QlView &q, int i, int j) const {
+    if (i == j) return gd[i];
+    if (j < i) { const int t = i; i = j; j = t; }
+    if (j < 2 * NH) {
+      if (i < NH && j < NH) return Qb[i * (NH + 1) + j];
+      if (i >= NH && j >= NH) return Qb[(i - NH) * (NH + 1) + (j - NH)];
+      return 0.0;
+    }
+    return Gv[i * (2 * kSMaxQ) + (j - 2 * NH)];
+  }
+  __device__ __forceinline__ double Gd(const QlView &, int i) const { return gd[i]; }
+  __device__ __forceinline__ void setGd(const QlView &, int i, double v) const { gd[i] = v; }
+
+  __device__ __forceinline__ double A(const QlView &, int k, int i) const {
+    if (k == 0) return 0.0;
+    const double a = rowA[k], b = rowB[k];
+    const int kk = rowK[k];
+    if (k <= 4 * NH) {
+      const int r = kk;
+      if (i < NH) return (i <= r) ? 0.0 + (0.0 + a * u[r - i]) * -1.0 : 0.0;
+      if (i < 2 * NH) { const int c = i - NH; return (c <= r) ? 0.0 + (0.0 + b * u[r - c]) * -1.0 : 0.0; }
+      int j = i - 2 * NH;
+      if (j < ns) { const double v = (stepidx[r] == j + 1) ? 1.0 : 0.0; return 0.0 + (0.0 + a * v) * 1.0; }
+      j -= ns;
+      { const double v = (stepidx[r] == j + 1) ? 1.0 : 0.0; return 0.0 + (0.0 + b * v) * 1.0; }
+    }
+    if (kk < 0 || i < 2 * NH) return 0.0;
+    int j = i - 2 * NH;
+    if (j < ns) return 0.0 + (0.0 + a * V_f[kk * kSMaxQ + j]) * -1.0;
+    j -= ns;
+    return 0.0 + (0.0 + b * V_f[kk * kSMaxQ + j]) * -1.0;
+  }
+
+  // ------------------------------------------------------------------ per-lane rows into registers
+  __device__ __forceinline__ void load_rows(int lane) {
+    {
+      const int k = lane + 1;
+      const double a = rowA[k], b = rowB[k];
+      const int r = rowK[k];
+#pragma unroll
+      for (int c = 0; c < NH; ++c) {
+        const double uu = (c <= r) ? u[r - c] : 0.0;
+        ax[c] = (c <= r) ? 0.0 + (0.0 + a * uu) * -1.0 : 0.0;
+        ay[c] = (c <= r) ? 0.0 + (0.0 + b * uu) * -1.0 : 0.0;
+      }
+      fj = stepidx[r] - 1;
+      fa = 0.0 + (0.0 + a * 1.0) * 1.0;
+      fb = 0.0 + (0.0 + b * 1.0) * 1.0;
+      if (fj >= ns) fj = -1;
+    }
+    f2n = 0;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { f2v[e] = 0.0; f2c[e] = 2 * NH; }   // unused entries: value 0 on a valid column
+    if (lane < 5 * ns) {
+      const int k = 1 + 4 * NH + lane;
+      const int kk = rowK[k];
+      if (kk >= 0) {
+        const double a = rowA[k], b = rowB[k];
+        // column order: [2N+kk-1] 2N+kk [2N+ns+kk-1] 2N+ns+kk ; without a predecessor the two "-1" entries are zeros
+        const bool pred = kk > 0;
+        f2c[0] = pred ? 2 * NH + kk - 1 : 2 * NH + kk;  f2v[0] = pred ? 0.0 + (0.0 + a * -1.0) * -1.0 : 0.0;
+        f2c[1] = 2 * NH + kk;                            f2v[1] = 0.0 + (0.0 + a * 1.0) * -1.0;
+        f2c[2] = pred ? 2 * NH + ns + kk - 1 : 2 * NH + ns + kk;  f2v[2] = pred ? 0.0 + (0.0 + b * -1.0) * -1.0 : 0.0;
+        f2c[3] = 2 * NH + ns + kk;                       f2v[3] = 0.0 + (0.0 + b * 1.0) * -1.0;
+        const int e = 4;
+        f2n = e;
+      }
+    }
+  }
+
+  // ------------------------------------------------------------------ qld.cpp:769-800
+  __device__ __forceinline__ int norms(const QlView &q, int lane) const {
+    int fatal = 0x7fffffff;
+    {
+      double sum = 0.0;
+#pragma unroll
+      for (int c = 0; c < NH; ++c) sum += ax[c] * ax[c];
+#pragma unroll
+      for (int c = 0; c < NH; ++c) sum += ay[c] * ay[c];
+      if (fj >= 0) { sum += fa * fa; sum += fb * fb; }
+      const int k = lane + 1;
+      if (sum > 0.0) sum = 1.0 / sqrt(sum);
+      else if (q.b[k] == 0.0) {}
+      else if (q.b[k] > 0.0) fatal = k + 1;
+      q.wa[k] = sum;
+    }
+    if (lane < 5 * ns) {
+      double sum = 0.0;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) sum += f2v[e] * f2v[e];
+      const int k = 1 + 4 * NH + lane;
+      if (sum > 0.0) sum = 1.0 / sqrt(sum);
+      else if (q.b[k] == 0.0) {}
+      else if (q.b[k] > 0.0) fatal = (k + 1 < fatal) ? k + 1 : fatal;
+      q.wa[k] = sum;
+    }
+    if (lane == 0) q.wa[0] = 0.0;     // the dummy row: zero normal, zero rhs (qp-problem.cpp:428-440)
+    return fatal;
+  }
+
+  // ------------------------------------------------------------------ row . x for the lane's rows
+  // sum = init + sum_c x[c]*A(row,c),  asum = ainit + sum_c |x[c]*A(row,c)|   (column order)
+  __device__ __forceinline__ void cop_row_dot(const double *xs, double &sum, double &asum) const {
+#pragma unroll
+    for (int c = 0; c < NH; ++c) { const double t = xs[c] * ax[c]; sum += t; asum += fabs(t); }
+#pragma unroll
+    for (int c = 0; c < NH; ++c) { const double t = xs[NH + c] * ay[c]; sum += t; asum += fabs(t); }
+  }
+
+  // ------------------------------------------------------------------ sum_k G(row,k)*v[k] on top of acc
+  __device__ __forceinline__ double gdot_acc(const QlView &q, int row, const double *v, double acc) const {
+    const int n = q.n;
+    if (row < 2 * NH) {
+      const int blk = (row < NH) ? 0 : NH;
+      const double *qr = Qb + (row - blk) * (NH + 1);
+#pragma unroll
+      for (int k = 0; k < NH; ++k) {
+        const double g = (blk + k == row) ? gd[row] : qr[k];
+        acc += g * v[blk + k];
+      }
+      for (int c = 0; c < n - 2 * NH; ++c) acc += Gv[row * (2 * kSMaxQ) + c] * v[2 * NH + c];
+      return acc;
+    }
+    const int cc = row - 2 * NH;
+    for (int k = 0; k < 2 * NH; ++k) acc += Gv[k * (2 * kSMaxQ) + cc] * v[k];
+    for (int c = 0; c < n - 2 * NH; ++c) {
+      const double g = (c == cc) ? gd[row] : Gv[row * (2 * kSMaxQ) + c];
+      acc += g * v[2 * NH + c];
+    }
+    return acc;
+  }
+
+  // ------------------------------------------------------------------ ql0002's diagonal test, :814-843
+  __device__ __forceinline__ double diag_check(const QlView &q, double vsmall, int lane) const {
+    const int n = q.n;
+    double dl = diag_b;
+    for (int i = lane; i < n; i += 64) {
+      const double wdi = q.wd[i];
+      if (i >= 2 * NH) dl = maxd(dl, vsmall - wdi);
+      const int j0 = (i + 1 > 2 * NH) ? i + 1 : 2 * NH;
+      for (int j = j0; j < n; ++j) {
+        const double gjj = q.wd[j], gij = G(q, i, j);
+        double ga = -mind(wdi, gjj);
+        const double gb = fabs(wdi - gjj) + fabs(gij);
+        if (gb > 0.0) ga += gij * gij / gb;
+        dl = maxd(dl, ga);
+      }
+    }
+    return wave_max(dl);
+  }
+
+  // ------------------------------------------------------------------ R and Z = R^-1 (:859-975)
+  // Leading 2N columns: copied.  Remaining columns: the reference recurrences, restricted to them.
+  // Returns false (nothing usable written) if a pivot fails -> caller falls back to the generic path.
+  __device__ __forceinline__ bool factor(const QlView &q, double vsmall, int lane) const {
+    const int n = q.n;
+    constexpr int M2 = 2 * NH;
+    for (int e = lane; e < M2 * (M2 + 1) / 2; e += 64) q.R[e] = R2[e];
+    for (int e = lane; e < M2 * M2; e += 64) { const int i = e % M2, j = e / M2; Zm(i, j) = Z2[e]; }
+    for (int e = lane; e < (n - M2) * M2; e += 64) { const int i = M2 + e % (n - M2), j = e / (n - M2); Zm(i, j) = 0.0; }
+    WG_WSYNC();
+    // rows of R, columns >= 2N only (lane <-> column)
+    const int j = M2 + lane;
+    const bool col = j < n;
+    bool ok = true;
+    for (int i = 0; i < n; ++i) {
+      double temp = 0.0;
+      if (col && j >= i) {
+        temp = G(q, i, j);
+        // R(k,i) == 0 for k in the other diagonal block: those products are exact zeros
+        const int k0 = (i >= NH && i < M2) ? NH : 0;
+        WG_UNROLL
+        for (int k = k0; k < i; ++k) temp -= Rp(k, j) * Rp(k, i);
+      }
+      if (i >= M2) {
+        if (col && j == i) {
+          if (temp < vsmall) q.slot[0] = 1.0; else { q.slot[0] = 0.0; Rp(i, i) = sqrt(temp); }
+        }
+        WG_WSYNC();
+        if (q.slot[0] != 0.0) { ok = false; break; }
+      }
+      const double rii = Rp(i, i);
+      if (col && j > i) Rp(i, j) = temp / rii;
+      WG_WSYNC();
+    }
+    if (!ok) return false;
+    // columns >= 2N of Z: lane <-> row
+    for (int c = M2; c < n; ++c) {
+      const int i = lane;
+      double sum = 0.0;
+      if (i < c) {
+        // Z(i,k) == -+0 for k in the other block (i < N <= k < 2N): exact zeros again
+        WG_UNROLL
+        for (int k = i; k < c; ++k) sum += Zm(i, k) * Rp(k, c);
+      }
+      const double rcc = Rp(c, c);
+      if (i < c) Zm(i, c) = -sum / rcc;
+      else if (i == c) Zm(i, c) = 1.0 / rcc;
+      else if (i < n) Zm(i, c) = 0.0;
+    }
+    WG_WSYNC();
+    return true;
+  }
+
+  // ------------------------------------------------------------------ s = Z' * (row rk of A), :2071-2085
+  __device__ __forceinline__ void zt_row(const QlView &q, double *s, int rk, int lane) const {
+    const int n = q.n;
+    if (lane < n) {
+      const int i = lane;
+      const double *zc = q.Z + i * q.ldz;            // column i of Z is contiguous
+      double acc = 0.0;
+      if (rk >= 1 && rk <= 4 * NH) {
+        // entries of the row beyond its instant are exact zeros: their products leave acc unchanged, so the
+        // loops can run the full static length (loads pipeline, no remainder handling)
+#pragma unroll
+        for (int j = 0; j < 2 * NH; ++j) acc += zc[j] * q.ww[j];
+      }
+      for (int j = 2 * NH; j < n; ++j) acc += zc[j] * q.ww[j];
+      s[i] = acc;
+    }
+    WG_WSYNC();
+  }
+};
+
+}  // namespace wg

@@ -23,8 +23,12 @@
 #define WG_TRIG_FN __host__ __device__ static inline
 #include "../../include/wg_trig.h"
 #include "wg_ql_device.hpp"
+#include "wg_ql_herdt.hpp"
 
 namespace wg {
+
+#define GmL(i, j) q.G[(i) + (j) * q.ldg]
+#define AmL(k, i) q.A[(k) + (i) * q.lda]
 
 constexpr int kNMaxH = 32;   // largest horizon
 constexpr int kSMax = 4;     // largest number of previewed steps
@@ -37,6 +41,11 @@ struct TickTables {
   double Sv[kNMaxH][3], Sz[kNMaxH][3];
   double Uv[kNMaxH][kNMaxH], Uz[kNMaxH][kNMaxH];
   double Qb[kNMaxH][kNMaxH];
+  // gait-independent part of ql0002's set-up for C = blockdiag(Qb, Qb) + border (wg_ql_herdt.hpp):
+  double R2[2 * kNMaxH * (2 * kNMaxH + 1) / 2];   // packed Cholesky factor of blockdiag(Qb, Qb), qld.cpp:859-890
+  double Z2[4 * kNMaxH * kNMaxH];                 // its inverse, column-major ld 2N, qld.cpp:937-975
+  double diag_b;                                  // diagonal test over the constant block, qld.cpp:814-843
+  int blocks_ok, pad_;
 };
 
 inline void build_tables(const wg_model_t &m, TickTables &t) {
@@ -67,6 +76,53 @@ inline void build_tables(const wg_model_t &m, TickTables &t) {
       q += pz * m.gamma;
       t.Qb[i][j] = q;
     }
+  // ---- constant factor blocks: exactly ql0002's recurrences on blockdiag(Qb, Qb), eps = 1e-8 ----
+  {
+    const int M = 2 * N;
+    const double vsmall = 1e-8;
+    auto g2 = [&](int i, int j) -> double {
+      if (i < N && j < N) return t.Qb[i][j];
+      if (i >= N && j >= N) return t.Qb[i - N][j - N];
+      return 0.0;
+    };
+    double diag = 0.0;
+    for (int i = 0; i < M; ++i) {
+      const double wdi = g2(i, i);
+      diag = (diag >= vsmall - wdi) ? diag : vsmall - wdi;
+      for (int j = i + 1; j < M; ++j) {
+        const double gjj = g2(j, j), gij = g2(i, j);
+        double ga = -((wdi <= gjj) ? wdi : gjj);
+        const double gb = fabs(wdi - gjj) + fabs(gij);
+        if (gb > 0.0) ga += gij * gij / gb;
+        diag = (diag >= ga) ? diag : ga;
+      }
+    }
+    t.diag_b = diag;
+    t.blocks_ok = (diag <= 0.0) ? 1 : 0;
+    t.pad_ = 0;
+    auto R = [&](int i, int j) -> double & { return t.R2[(size_t)j * (j + 1) / 2 + i]; };
+    for (int j = 0; j < M && t.blocks_ok; ++j) {
+      double temp = 0.0;
+      for (int i = 0; i <= j; ++i) {
+        temp = g2(i, j);
+        for (int k = 0; k < i; ++k) temp -= R(k, j) * R(k, i);
+        if (i < j) R(i, j) = temp / R(i, i);
+      }
+      if (temp < vsmall) { t.blocks_ok = 0; break; }
+      R(j, j) = sqrt(temp);
+    }
+    auto Z = [&](int i, int j) -> double & { return t.Z2[(size_t)i + (size_t)j * M]; };
+    if (t.blocks_ok)
+      for (int i = 0; i < M; ++i) {
+        for (int j = 0; j < i; ++j) Z(i, j) = 0.0;
+        Z(i, i) = 1.0 / R(i, i);
+        for (int j = i; j < M - 1; ++j) {
+          double sum = 0.0;
+          for (int k = i; k <= j; ++k) sum += Z(i, k) * R(k, j + 1);
+          Z(i, j + 1) = -sum / R(j + 1, j + 1);
+        }
+      }
+  }
 }
 
 struct Sup {
@@ -88,10 +144,13 @@ struct TickLds {
   double *rowA, *rowB, *rowD;     // [m]  polygon edge per constraint row
   int *rowK;                      // [m]  instant (CoP rows) or step (foot rows)
   double *misc;                   // [16] scalars handed from lane 0 to the wave
+  double *Qb, *uvec, *Gv, *gd;    // compact problem view (wg_ql_herdt.hpp): N x (N+1), N, nmax x 8, nmax
   wg_gait_state_t *st;            // working copy of the state
   __host__ __device__ static size_t bytes(int N) {
     const int m = 1 + 4 * N + 5 * kSMax;
-    size_t b = sizeof(Sup) * (N + 1) + 8 * (size_t)(2 * N + 2 * kSMax + kSMax * kSMax + 8 + (N + 1) + 6 * N + 3 * m + 16) +
+    const int nmax = 2 * N + 2 * kSMax;
+    size_t b = sizeof(Sup) * (N + 1) + 8 * (size_t)(2 * N + 2 * kSMax + kSMax * kSMax + 8 + (N + 1) + 6 * N + 3 * m + 16 +
+                                                    N * (N + 1) + N + nmax * 2 * kSMax + nmax) +
                4 * (size_t)(((N + 1) & ~1) + ((m + 1) & ~1)) + ((sizeof(wg_gait_state_t) + 15) & ~(size_t)15);
     return (b + 15) & ~(size_t)15;
   }
@@ -105,6 +164,7 @@ struct TickLds {
     sup_angles = d; d += 8; trunk = d; d += N + 1; refx = d; d += N; refy = d; d += N;
     svx = d; d += N; svy = d; d += N; szx = d; d += N; szy = d; d += N;
     rowA = d; d += m; rowB = d; d += m; rowD = d; d += m; misc = d; d += 16;
+    { const int nmax = 2 * N + 2 * kSMax; Qb = d; d += N * (N + 1); uvec = d; d += N; Gv = d; d += nmax * 2 * kSMax; gd = d; d += nmax; }
     int *ip = reinterpret_cast<int *>(d);
     stepidx = ip; ip += (N + 1) & ~1; rowK = ip;
   }
@@ -346,6 +406,7 @@ __device__ inline void poly3_set(double *c, double FT, double FP, double p0, dou
 // ---------------------------------------------------------------------------
 struct TickDiag { int ifail, n_iter, nact, n, m, ns; };
 
+template <int NH>   // NH == 16: compact problem view (no G / A matrices in LDS); NH == 0: generic dense view
 __device__ inline TickDiag mpc_tick(const wg_model_t &m, const TickTables *__restrict__ tb, wg_gait_state_t *gstate,
                                     wg_tick_out_t *out, double *lds_ql, char *lds_tick, int *hist, int hist_cap,
                                     int *hist_len) {
@@ -467,7 +528,8 @@ __device__ inline TickDiag mpc_tick(const wg_model_t &m, const TickTables *__res
   const int ns = (int)L.misc[0];
   const int n = 2 * N + 2 * ns;
   const int mq = 1 + 4 * N + 5 * ns;     // rows incl. the dummy row 0 (qp-problem.cpp:248)
-  QlDims D(n, mq, mq);
+  constexpr bool kCompactView = (NH == 16);
+  QlDims D(n, mq, mq, !kCompactView);
   QlView q;
   q.carve(lds_ql, D, 0);
 
@@ -509,36 +571,66 @@ __device__ inline TickDiag mpc_tick(const wg_model_t &m, const TickTables *__res
   }
   for (int i = lane; i < n; i += 64) { q.xl[i] = -1e8; q.xu[i] = 1e8; }   // qp-problem.cpp:118-121
 
-  // ---- Hessian: invariant blocks + variant columns ----
-  for (int e = lane; e < n * n; e += 64) {
-    const int i = e % n, j = e / n;
-    double v = 0.0;
-    if (i < N && j < N) v = tb->Qb[i][j];
-    else if (i >= N && i < 2 * N && j >= N && j < 2 * N) v = tb->Qb[i - N][j - N];
-    Gm(i, j) = v;
-  }
-  WG_WSYNC();
-  for (int e = lane; e < N * ns; e += 64) {
-    const int i = e % N, j = e / N;
-    double p = 0.0, pt = 0.0;
-    for (int k = 0; k < N; k++) {
-      const double v = (L.stepidx[k] == j + 1) ? 1.0 : 0.0;
-      p += tb->Uz[k][i] * v;
-      pt += v * tb->Uz[k][i];
+  // ---- Hessian ----
+  if constexpr (kCompactView) {
+    // compact view: Qb and u as small LDS tables, the 2ns border columns (symmetric) and the diagonal
+    for (int e = lane; e < N * N; e += 64) { const int i = e / N, j = e % N; L.Qb[i * (N + 1) + j] = tb->Qb[i][j]; }
+    for (int d = lane; d < N; d += 64) L.uvec[d] = tb->Uz[d][0];                 // Uz[r][c] = u[r-c]
+    for (int e = lane; e < n * 2 * kSMax; e += 64) L.Gv[e] = 0.0;
+    for (int i = lane; i < 2 * N; i += 64) L.gd[i] = tb->Qb[i % N][i % N];
+    WG_WSYNC();
+    for (int e = lane; e < N * ns; e += 64) {
+      const int i = e % N, j = e / N;
+      double p = 0.0;
+      for (int k = 0; k < N; k++) { const double v = (L.stepidx[k] == j + 1) ? 1.0 : 0.0; p += tb->Uz[k][i] * v; }
+      p *= -m.gamma;
+      L.Gv[i * (2 * kSMax) + j] = 0.0 + p;                                        // x block  x  x-foot column
+      L.Gv[(N + i) * (2 * kSMax) + ns + j] = 0.0 + p;                             // y block  x  y-foot column
     }
-    p *= -m.gamma; pt *= -m.gamma;
-    Gm(i, 2 * N + j) += p; Gm(N + i, 2 * N + ns + j) += p;
-    Gm(2 * N + j, i) += pt; Gm(2 * N + ns + j, N + i) += pt;
-  }
-  for (int e = lane; e < ns * ns; e += 64) {
-    const int i = e % ns, j = e / ns;
-    double p = 0.0;
-    for (int k = 0; k < N; k++) {
-      const double vi = (L.stepidx[k] == i + 1) ? 1.0 : 0.0, vj = (L.stepidx[k] == j + 1) ? 1.0 : 0.0;
-      p += vi * vj;
+    for (int e = lane; e < ns * ns; e += 64) {
+      const int i = e % ns, j = e / ns;
+      double p = 0.0;
+      for (int k = 0; k < N; k++) {
+        const double vi = (L.stepidx[k] == i + 1) ? 1.0 : 0.0, vj = (L.stepidx[k] == j + 1) ? 1.0 : 0.0;
+        p += vi * vj;
+      }
+      p *= m.gamma;
+      if (i == j) { L.gd[2 * N + i] = 0.0 + p; L.gd[2 * N + ns + i] = 0.0 + p; }
+      else { L.Gv[(2 * N + i) * (2 * kSMax) + j] = 0.0 + p; L.Gv[(2 * N + ns + i) * (2 * kSMax) + ns + j] = 0.0 + p; }
     }
-    p *= m.gamma;
-    Gm(2 * N + i, 2 * N + j) += p; Gm(2 * N + ns + i, 2 * N + ns + j) += p;
+    // the border rows' Gv entries toward the border columns mirror the lower-left block (symmetry is exact:
+    // (VT Uz)(j,i) and (UzT V)(i,j) are the same products in the same order)
+  } else {
+    for (int e = lane; e < n * n; e += 64) {
+      const int i = e % n, j = e / n;
+      double v = 0.0;
+      if (i < N && j < N) v = tb->Qb[i][j];
+      else if (i >= N && i < 2 * N && j >= N && j < 2 * N) v = tb->Qb[i - N][j - N];
+      GmL(i, j) = v;
+    }
+    WG_WSYNC();
+    for (int e = lane; e < N * ns; e += 64) {
+      const int i = e % N, j = e / N;
+      double p = 0.0, pt = 0.0;
+      for (int k = 0; k < N; k++) {
+        const double v = (L.stepidx[k] == j + 1) ? 1.0 : 0.0;
+        p += tb->Uz[k][i] * v;
+        pt += v * tb->Uz[k][i];
+      }
+      p *= -m.gamma; pt *= -m.gamma;
+      GmL(i, 2 * N + j) += p; GmL(N + i, 2 * N + ns + j) += p;
+      GmL(2 * N + j, i) += pt; GmL(2 * N + ns + j, N + i) += pt;
+    }
+    for (int e = lane; e < ns * ns; e += 64) {
+      const int i = e % ns, j = e / ns;
+      double p = 0.0;
+      for (int k = 0; k < N; k++) {
+        const double vi = (L.stepidx[k] == i + 1) ? 1.0 : 0.0, vj = (L.stepidx[k] == j + 1) ? 1.0 : 0.0;
+        p += vi * vj;
+      }
+      p *= m.gamma;
+      GmL(2 * N + i, 2 * N + j) += p; GmL(2 * N + ns + i, 2 * N + ns + j) += p;
+    }
   }
 
   // ---- constraints, build_constraints_cop :393-448, build_constraints_feet :451-474 ----
@@ -548,15 +640,17 @@ __device__ inline TickDiag mpc_tick(const wg_model_t &m, const TickTables *__res
     double bacc = 0.0;
     if (r >= 1 && r <= 4 * N) {
       const int i = kk;
-      for (int c = 0; c < N; c++) {
-        const double u = tb->Uz[i][c];
-        const double px = 0.0 + a * u, py = 0.0 + bb * u;
-        Am(r, c) = 0.0 + px * -1.0; Am(r, N + c) = 0.0 + py * -1.0;
-      }
-      for (int j = 0; j < ns; j++) {
-        const double v = (L.stepidx[i] == j + 1) ? 1.0 : 0.0;
-        const double px = 0.0 + a * v, py = 0.0 + bb * v;
-        Am(r, 2 * N + j) = 0.0 + px * 1.0; Am(r, 2 * N + ns + j) = 0.0 + py * 1.0;
+      if constexpr (!kCompactView) {
+        for (int c = 0; c < N; c++) {
+          const double u = tb->Uz[i][c];
+          const double px = 0.0 + a * u, py = 0.0 + bb * u;
+          AmL(r, c) = 0.0 + px * -1.0; AmL(r, N + c) = 0.0 + py * -1.0;
+        }
+        for (int j = 0; j < ns; j++) {
+          const double v = (L.stepidx[i] == j + 1) ? 1.0 : 0.0;
+          const double px = 0.0 + a * v, py = 0.0 + bb * v;
+          AmL(r, 2 * N + j) = 0.0 + px * 1.0; AmL(r, 2 * N + ns + j) = 0.0 + py * 1.0;
+        }
       }
       bacc += L.rowD[r];
       bacc += (0.0 + a * L.szx[i]) * -1.0;
@@ -564,13 +658,15 @@ __device__ inline TickDiag mpc_tick(const wg_model_t &m, const TickTables *__res
       bacc += (0.0 + a * L.VcX[i]) * 1.0;
       bacc += (0.0 + bb * L.VcY[i]) * 1.0;
     } else {
-      for (int c = 0; c < n; c++) Am(r, c) = 0.0;
+      if constexpr (!kCompactView) for (int c = 0; c < n; c++) AmL(r, c) = 0.0;
       if (r > 4 * N && kk >= 0) {
         const int k = kk;
-        for (int j = 0; j < ns; j++) {
-          const double vf = L.V_f[k * kSMax + j];
-          const double px = 0.0 + a * vf, py = 0.0 + bb * vf;
-          Am(r, 2 * N + j) = 0.0 + px * -1.0; Am(r, 2 * N + ns + j) = 0.0 + py * -1.0;
+        if constexpr (!kCompactView) {
+          for (int j = 0; j < ns; j++) {
+            const double vf = L.V_f[k * kSMax + j];
+            const double px = 0.0 + a * vf, py = 0.0 + bb * vf;
+            AmL(r, 2 * N + j) = 0.0 + px * -1.0; AmL(r, 2 * N + ns + j) = 0.0 + py * -1.0;
+          }
         }
         bacc += L.rowD[r];
         bacc += (0.0 + a * L.Vc_fX[k]) * 1.0;
@@ -580,14 +676,27 @@ __device__ inline TickDiag mpc_tick(const wg_model_t &m, const TickTables *__res
     q.b[r] = -bacc;                 // inner sign, qld.cpp:469-475
   }
   WG_WSYNC();
-  if (lane == 0 && fabs(Gm(n - 1, n - 1)) == 0.0) Gm(n - 1, n - 1) = 1e-8;   // qld.cpp:442-444 (nmax == n)
-  WG_WSYNC();
 
   // ---- QPProblem::solve -> ql0001_ (eps = 1e-8, qp-problem.cpp:260) ----
 #ifdef WG_PROFILE
   tk2 = clock64();
 #endif
-  QlResult qr = ql_solve(q, 1e-8, hist, hist_cap);
+  QlResult qr;
+  if constexpr (kCompactView) {
+    if (lane == 0 && fabs(L.gd[n - 1]) == 0.0) L.gd[n - 1] = 1e-8;               // qld.cpp:442-444 (nmax == n)
+    WG_WSYNC();
+    HerdtProb<16> prob;
+    prob.Qb = L.Qb; prob.u = L.uvec; prob.Gv = L.Gv; prob.gd = L.gd;
+    prob.rowA = L.rowA; prob.rowB = L.rowB; prob.rowK = L.rowK; prob.stepidx = L.stepidx; prob.V_f = L.V_f;
+    prob.R2 = tb->R2; prob.Z2 = tb->Z2; prob.diag_b = tb->diag_b; prob.blocks_ok = tb->blocks_ok; prob.ns = ns;
+    prob.load_rows(lane);
+    qr = ql_solve(q, prob, 1e-8, hist, hist_cap);
+  } else {
+    if (lane == 0 && fabs(GmL(n - 1, n - 1)) == 0.0) GmL(n - 1, n - 1) = 1e-8;   // qld.cpp:442-444 (nmax == n)
+    WG_WSYNC();
+    DenseProb prob;
+    qr = ql_solve(q, prob, 1e-8, hist, hist_cap);
+  }
 #ifdef WG_PROFILE
   tk3 = clock64();
 #endif
