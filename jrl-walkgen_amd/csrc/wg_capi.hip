@@ -157,9 +157,9 @@ void wg_shutdown(void) {
 
 #ifdef WG_PROFILE
 // diagnostic build only: read-and-reset the in-kernel phase timers (shader cycles)
-int wg_prof_read(unsigned long long *out24) {
-  if (hipMemcpyFromSymbol(out24, HIP_SYMBOL(wg::g_prof), 24 * sizeof(unsigned long long)) != hipSuccess) return -1;
-  unsigned long long z[24] = {0};
+int wg_prof_read(unsigned long long *out32) {
+  if (hipMemcpyFromSymbol(out32, HIP_SYMBOL(wg::g_prof), 32 * sizeof(unsigned long long)) != hipSuccess) return -1;
+  unsigned long long z[32] = {0};
   if (hipMemcpyToSymbol(HIP_SYMBOL(wg::g_prof), z, sizeof z) != hipSuccess) return -1;
   return 0;
 }

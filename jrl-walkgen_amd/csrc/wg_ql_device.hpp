@@ -54,6 +54,17 @@ __device__ __forceinline__ double rl(double v, int src) {
   int hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
   return __hiloint2double(hi, lo);
 }
+// value of `v` in the neighbouring lane (gfx9 DPP wave shifts: one VALU move per 32-bit half, no LDS, no SGPR hop)
+__device__ __forceinline__ double from_lane_below(double v) {   // lane L gets lane L-1 (wave_shr:1); lane 0 keeps its own
+  int lo = __builtin_amdgcn_update_dpp(__double2loint(v), __double2loint(v), 0x138, 0xf, 0xf, false);
+  int hi = __builtin_amdgcn_update_dpp(__double2hiint(v), __double2hiint(v), 0x138, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double from_lane_above(double v) {   // lane L gets lane L+1 (wave_shl:1); lane 63 keeps its own
+  int lo = __builtin_amdgcn_update_dpp(__double2loint(v), __double2loint(v), 0x130, 0xf, 0xf, false);
+  int hi = __builtin_amdgcn_update_dpp(__double2hiint(v), __double2hiint(v), 0x130, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
 // sum_{j=lo}^{hi-1} v[lane j] in index order, starting from 0.0.  `v` must be 0.0 in every lane that is not in
 // [lo, hi): adding +0.0 never changes a running sum, so the loop can run in chunks of four without a remainder
 // loop (v_readlane is convergent and the compiler will not unroll it itself).  Needs hi <= 61.
@@ -122,6 +133,7 @@ struct QlView {
 struct QlView;
 struct DenseProb {
   static constexpr bool kCompact = false;
+  static constexpr int kNM = 0;        // no compile-time bound on n
   __device__ __forceinline__ double G(const QlView &q, int i, int j) const;
   __device__ __forceinline__ double A(const QlView &q, int k, int i) const;
   __device__ __forceinline__ double Gd(const QlView &q, int i) const;
@@ -131,7 +143,7 @@ struct DenseProb {
 
 // ---- optional in-kernel phase timers (diagnostic build only: -DWG_PROFILE) ----
 #ifdef WG_PROFILE
-__device__ unsigned long long g_prof[24];
+__device__ unsigned long long g_prof[32];
 #define PT_DECL unsigned long long pt_acc[24] = {0}; unsigned long long pt_last = clock64();
 #define PT(k) do { unsigned long long t_ = clock64(); pt_acc[k] += t_ - pt_last; pt_last = t_; } while (0)
 #define PT_FLUSH do { if ((threadIdx.x & 63) == 0) for (int k_ = 0; k_ < 24; ++k_) atomicAdd(&g_prof[k_], pt_acc[k_]); } while (0)
@@ -240,6 +252,137 @@ __device__ __forceinline__ void backsub(const QlView &q, const double *s, int na
   }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Compile-time-bounded versions for n <= NM (the Herdt QP: NM = 36).  Measured on MI355X (tools/micro/lat.hip):
+// a dependent fp64 add/mul costs ~8 cycles, an add fed by v_readlane ~40, a divide 71, sqrt ~100.  With static
+// trip counts every LDS address is an immediate offset, so the compiler issues all loads ahead of the dependent
+// chain and the ordered sums run at the 8-cycle floor.
+// ---------------------------------------------------------------------------------------------------
+
+// sum of term[0..cnt) in index order (term lives one-per-lane); scratch: NM doubles of LDS, 16-byte aligned.
+template <int NM>
+__device__ __forceinline__ double ordered_sum_lds(double term, double *scratch, int cnt, int lane) {
+  if (lane < NM) scratch[lane] = (lane < cnt) ? term : 0.0;
+  WG_WSYNC();
+  double t[NM];
+#pragma unroll
+  for (int i = 0; i < NM; ++i) t[i] = scratch[i];
+  double sum = 0.0;
+#pragma unroll
+  for (int i = 0; i < NM; ++i) sum += t[i];      // entries >= cnt are +0.0: they leave the sum unchanged
+  WG_WSYNC();
+  return sum;
+}
+
+// back substitution (qld.cpp:1824-1851), every lane redundantly on LDS-broadcast operands.  The freshest
+// multiplier (needed first by the next row, sums ascend in j) stays in a register; the other terms are loaded
+// four at a time, one group ahead of the dependent add chain.
+__device__ __forceinline__ void backsub_pipe(const QlView &q, const double *s, int nact, int lane) {
+  double wprev = 0.0;
+  for (int i = nact - 1; i >= 0; --i) {
+    const double si = s[i], rii = Rp(i, i);
+    double sum = 0.0;
+    int j = i + 1;
+    if (j < nact) {
+      sum += Rp(i, j) * wprev;
+      ++j;
+      const int last = nact - 1;
+      double r0, r1, r2, r3, w0, w1, w2, w3;
+      if (j < nact) {
+        { const int a = j, b = j + 1 < last ? j + 1 : last, c = j + 2 < last ? j + 2 : last, d = j + 3 < last ? j + 3 : last;
+          r0 = Rp(i, a); r1 = Rp(i, b); r2 = Rp(i, c); r3 = Rp(i, d);
+          w0 = q.ww[a]; w1 = q.ww[b]; w2 = q.ww[c]; w3 = q.ww[d]; }
+        for (;;) {
+          const int jn = j + 4;
+          const bool more = jn < nact;
+          double nr0 = 0, nr1 = 0, nr2 = 0, nr3 = 0, nw0 = 0, nw1 = 0, nw2 = 0, nw3 = 0;
+          if (more) {
+            const int a = jn, b = jn + 1 < last ? jn + 1 : last, c = jn + 2 < last ? jn + 2 : last, d = jn + 3 < last ? jn + 3 : last;
+            nr0 = Rp(i, a); nr1 = Rp(i, b); nr2 = Rp(i, c); nr3 = Rp(i, d);
+            nw0 = q.ww[a]; nw1 = q.ww[b]; nw2 = q.ww[c]; nw3 = q.ww[d];
+          }
+          sum += r0 * w0;
+          if (j + 1 < nact) sum += r1 * w1;
+          if (j + 2 < nact) sum += r2 * w2;
+          if (j + 3 < nact) sum += r3 * w3;
+          if (!more) break;
+          r0 = nr0; r1 = nr1; r2 = nr2; r3 = nr3; w0 = nw0; w1 = nw1; w2 = nw2; w3 = nw3;
+          j = jn;
+        }
+      }
+    }
+    const double v = (si - sum) / rii;
+    if (lane == 0) q.ww[i] = v;
+    wprev = v;
+  }
+  WG_WSYNC();
+}
+
+// Givens sweep (qld.cpp:1992-2030) for n <= 64, written without data-dependent control flow: on a single
+// resident wave every taken branch costs tens of cycles, so predicates become selects, inactive lanes shadow
+// lane n-1 (same addresses, same values), and LDS operands are fetched one or two steps ahead of the
+// dependent chain.
+//   phase 1  chain of rotation norms (all lanes redundantly; s[c-1] prefetched); lane c records its rotation;
+//   phase 2  lane c turns (p, q, norm) into (ga, gb) and publishes the pair in LDS;
+//   phase 3  lane i carries row i of Z through the rotations.
+__device__ __forceinline__ void sweep_flat(const QlView &q, double *s, int nu, int nact, int lane) {
+  const int n = q.n;
+  if (nu - 1 <= nact) return;
+  double myP = 0.0, myQ = 0.0, myN = 0.0;
+  {
+    double cur = s[nu - 1];
+    double p = s[nu - 2];
+    for (int c = nu - 1; c > nact; --c) {
+      const int nx = (c - 2 >= 0) ? c - 2 : 0;
+      const double p_next = s[nx];                          // operand of the next rotation, off the chain
+      const bool z = (cur == 0.0);
+      const double nrmc = givens_norm(p, z ? 1.0 : cur);
+      const double nrm = z ? 0.0 : nrmc;
+      const bool me = (lane == c);
+      myP = me ? p : myP; myQ = me ? cur : myQ; myN = me ? nrm : myN;
+      cur = z ? p : nrmc;
+      p = p_next;
+    }
+  }
+  double *gab = q.sc0;                                      // pairs {ga, gb}; sc0 and sc1 are adjacent (2n doubles)
+  {
+    const bool mine = lane > nact && lane < nu;
+    const bool rot = mine && myN != 0.0;
+    const double den = rot ? myN : 1.0;
+    const double ga = rot ? myP / den : 1.0;
+    const double gb = rot ? myQ / den : 0.0;                // gb == 0 marks a skipped rotation (q was 0)
+    const int cl = mine ? lane : nu - 1;                    // lanes without a rotation shadow lane nu-1 ... with ITS values
+    const double ga_w = mine ? ga : rl(ga, nu - 1), gb_w = mine ? gb : rl(gb, nu - 1);
+    gab[2 * cl] = ga_w; gab[2 * cl + 1] = gb_w;
+    if (rot) s[lane - 1] = myN;
+  }
+  WG_WSYNC();
+  {
+    const int i = lane < n ? lane : n - 1;                  // surplus lanes shadow row n-1
+    const int ldz = q.ldz;
+    double *zp = q.Z + i + (nu - 1) * ldz;                  // Z(i, c)
+    double carry = zp[0];
+    double zl = zp[-ldz];
+    double ga = gab[2 * (nu - 1)], gb = gab[2 * (nu - 1) + 1];
+    int c1 = nu - 2 > nact ? nu - 2 : nact + 1;             // rotation after the current one (clamped)
+    double zl1 = q.Z[i + (c1 - 1) * ldz], ga1 = gab[2 * c1], gb1 = gab[2 * c1 + 1];
+    for (int c = nu - 1; c > nact; --c) {
+      const int c2 = c - 2 > nact ? c - 2 : nact + 1;       // two rotations ahead (clamped: value unused past the end)
+      const double zl2 = q.Z[i + (c2 - 1) * ldz], ga2 = gab[2 * c2], gb2 = gab[2 * c2 + 1];
+      const bool skip = (gb == 0.0);
+      const double t_r = ga * zl + gb * carry;
+      const double z_r = ga * carry - gb * zl;
+      zp[0] = skip ? carry : z_r;
+      carry = skip ? zl : t_r;
+      zp -= ldz;
+      zl = zl1; ga = ga1; gb = gb1;
+      zl1 = zl2; ga1 = ga2; gb1 = gb2;
+    }
+    zp[0] = carry;                                           // Z(i, nact)
+  }
+  WG_WSYNC();
+}
+
 // qld.cpp:1861-1889.  Returns kdrop (0-based) or -1; ratio updated when found.
 __device__ __forceinline__ int pick_drop(const QlView &q, int nact, double res, double &ratio, int lane) {
   double best = 0.0, bestt = 0.0;
@@ -266,6 +409,11 @@ __device__ __forceinline__ int pick_drop(const QlView &q, int nact, double res, 
 template <class P>
 __device__ __forceinline__ double xmag_sum(const QlView &q, const P &prob, double vfact, int lane) {
   const int n = q.n;
+  if constexpr (P::kNM > 0) {
+    double term = 0.0;
+    if (lane < n) { const double xi = q.x[lane]; term = fabs(xi) * vfact * (fabs(q.d[lane]) + fabs(prob.Gd(q, lane) * xi)); }
+    return ordered_sum_lds<P::kNM>(term, q.sc3, n, lane);
+  }
   if (n <= 60) {
     double term = 0.0;
     if (lane < n) { const double xi = q.x[lane]; term = fabs(xi) * vfact * (fabs(q.d[lane]) + fabs(prob.Gd(q, lane) * xi)); }
@@ -443,6 +591,10 @@ __device__ __forceinline__ bool independent_coordinate(const QlView &q, const P 
 // The solver.  Problem data must already be in LDS: G (copy of C, patched per
 // qld.cpp:442-444), A, d, b (INNER sign: b = -b_user, qld.cpp:469-475), xl, xu.
 // hist: optional global add(+code)/drop(-code) log written by lane 0.
+#define WG_BACKSUB(q, s, nact, lane) backsub(q, s, nact, lane)
+#define WG_SWEEP(q, s, nu, nact, lane) \
+  do { if constexpr (P::kNM > 0) sweep_flat(q, s, nu, nact, lane); else sweep(q, s, nu, nact, lane); } while (0)
+
 template <class P>
 __device__ inline QlResult ql_solve(const QlView &q, P &prob, double vsmall, int *hist, int hist_cap) {
   const int lane = threadIdx.x & 63;
@@ -697,7 +849,7 @@ __device__ inline QlResult ql_solve(const QlView &q, P &prob, double vsmall, int
       }
       PT(6);
       if (nact != 0) {                                      // :1208-1217
-        backsub(q, s, nact, lane);
+        WG_BACKSUB(q, s, nact, lane);
         for (int k = lane; k < nact; k += 64) q.lam[k] += q.ww[k];
         WG_WSYNC();
       }
@@ -874,12 +1026,26 @@ __device__ inline QlResult ql_solve(const QlView &q, P &prob, double vsmall, int
       int route;   // 0 step, 1 dependent (multipliers needed), 2 dependent (multipliers in ww)
       if (nact == n) route = 1;                             // :1477
       else {
-        sweep(q, s, n, nact, lane);                         // :1480-1482
+        WG_SWEEP(q, s, n, nact, lane);                         // :1480-1482
         PT(12);
         if (nact == 0) route = 0;                           // :1488
         else {                                              // :1491-1532
           double suma = 0.0, sumb = 0.0, sumc = 0.0;
-          if (n <= 60) {
+          if constexpr (P::kNM > 0) {
+            constexpr int NM = P::kNM;
+            if (lane < NM) {
+              const bool in = lane < n;
+              const double zi = in ? Zm(lane, nact) : 0.0, wi = in ? q.ww[lane] : 0.0;
+              q.sc0[lane] = wi * zi; q.sc1[lane] = fabs(wi * zi); q.sc2[lane] = zi * zi;
+            }
+            WG_WSYNC();
+            double ta[NM], tb[NM], tc[NM];
+#pragma unroll
+            for (int i = 0; i < NM; ++i) { ta[i] = q.sc0[i]; tb[i] = q.sc1[i]; tc[i] = q.sc2[i]; }
+#pragma unroll
+            for (int i = 0; i < NM; ++i) { suma += ta[i]; sumb += tb[i]; sumc += tc[i]; }
+            WG_WSYNC();
+          } else if (n <= 60) {
             double ta = 0.0, tb = 0.0, tc = 0.0;
             if (lane < n) { const double zi = Zm(lane, nact), wi = q.ww[lane]; ta = wi * zi; tb = fabs(wi * zi); tc = zi * zi; }
             for (int i = 0; i < n; i += 4) {
@@ -903,7 +1069,7 @@ __device__ inline QlResult ql_solve(const QlView &q, P &prob, double vsmall, int
             if (knext <= m) sumc /= q.wa[knext - 1];
             if (significant(sumc, fabs(suma))) route = 0;
             else {                                          // :1538-1540
-              backsub(q, s, nact, lane);
+              WG_BACKSUB(q, s, nact, lane);
               route = independent_coordinate(q, prob, knext, nact, vsmall, lane) ? 0 : 2;
             }
           }
@@ -912,7 +1078,7 @@ __device__ inline QlResult ql_solve(const QlView &q, P &prob, double vsmall, int
       route = uni(route);
       PT(13);
       if (route != 0) {
-        if (route == 1) backsub(q, s, nact, lane);
+        if (route == 1) WG_BACKSUB(q, s, nact, lane);
         kdrop = pick_drop(q, nact, res, ratio, lane);
         info = -knext;                                      // :1663
         if (kdrop < 0) { st = ST_CONVERGED; continue; }
@@ -930,7 +1096,7 @@ __device__ inline QlResult ql_solve(const QlView &q, P &prob, double vsmall, int
           kdrop = -1;
           if (nact > 0) {
             PT(14);
-            backsub(q, s, nact, lane);
+            WG_BACKSUB(q, s, nact, lane);
             PT(15);
             kdrop = pick_drop(q, nact, res, ratio, lane);
             PT(16);
@@ -968,7 +1134,7 @@ __device__ inline QlResult ql_solve(const QlView &q, P &prob, double vsmall, int
             WG_WSYNC();
           }
           s = snew;
-          sweep(q, s, nu, nact, lane);
+          WG_SWEEP(q, s, nu, nact, lane);
         }
       }
 

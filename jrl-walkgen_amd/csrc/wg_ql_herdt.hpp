@@ -24,6 +24,7 @@ constexpr int kSMaxQ = 4;   // == kSMax of the tick
 template <int NH>
 struct HerdtProb {
   static constexpr bool kCompact = true;
+  static constexpr int kNM = 2 * NH + 2 * 2;   // n <= 2N + 2*2: at most two previewed steps (checked by wg_mpc_configure)
   static_assert(4 * NH == 64, "one CoP row per lane needs 4N == 64");
   // ---- LDS / global tables (wave-uniform pointers) ----
   const double *Qb;       // LDS, NH x (NH+1)

@@ -12,7 +12,7 @@ s0 = wg.gait_init(model, [0.0316055, 0.0, 0.7116911], [0.0, 0.09, 0.0], [0.0, -0
 for g in range(B): C.memmove(C.byref(states[g]), C.byref(s0), C.sizeof(wg.GaitState))
 dev = torch.frombuffer(bytearray(bytes(memoryview(states).cast("B"))), dtype=torch.uint8).cuda()
 diag = torch.zeros(B, 6, dtype=torch.int32, device="cuda")
-buf = (C.c_ulonglong * 24)()
+buf = (C.c_ulonglong * 32)()
 its = 0
 for tick in range(WARM + MEAS):
     if tick % 50 == 0:
@@ -27,7 +27,8 @@ torch.cuda.synchronize(); wg.lib().wg_prof_read(buf)
 v = np.array(list(buf), dtype=np.float64); n = B * MEAS
 names = ["norms", "diagchk", "chol", "inverse", "resid/reset+shift", "ZT*ww(resid)", "x-shift", "backsub+lam(resid)", "xmag(resid)",
          "scan", "fdiff/wx", "newnormal ZTa", "sweep", "route sums", "step-pre", "backsub(step)", "pickdrop", "step/upd/drop", "add",
-         "xmag(add)", "tail", "TICK pre (lane0)", "TICK assembly", "TICK post"]
-print(f"gait-ticks={n} mean QL iters={its/n:.1f} cycles/tick={v.sum()/n:.0f}")
+         "xmag(add)", "tail", "TICK pre (lane0)", "TICK assembly", "TICK post", "(sweep ph1)", "(sweep ph2)", "(sweep ph3)"]
+tot = v[:24].sum()
+print(f"gait-ticks={n} mean QL iters={its/n:.1f} cycles/tick={tot/n:.0f}  sweeps/tick={v[28]/n:.1f} rotations/sweep={v[27]/max(v[28],1):.1f}")
 for k, nme in enumerate(names):
-    print(f"{k:2d} {nme:22s} {v[k]/n:12.0f} cyc/tick  {100*v[k]/v.sum():5.1f}%")
+    print(f"{k:2d} {nme:22s} {v[k]/n:12.0f} cyc/tick  {100*v[k]/tot:5.1f}%")
