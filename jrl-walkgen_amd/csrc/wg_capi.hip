@@ -259,12 +259,16 @@ bool g_model_set = false;
 wg::TickTables *g_tables_dev = nullptr;
 DevBuf g_tick_state, g_tick_out, g_tick_aux;
 
-inline int tick_max_n(const wg_model_t &m) { return 2 * m.N + 2 * wg::kSMax; }
-inline int tick_max_m(const wg_model_t &m) { return 1 + 4 * m.N + 5 * wg::kSMax; }
+inline bool tick_compact(const wg_model_t &m);
+// at most two step changes fit in the preview window when N*T <= 2*step_period (each change is one step period
+// after the previous one and the first previewed change is at pi >= 1): the compact kernel is sized for that
+inline int tick_smax(const wg_model_t &m) { return tick_compact(m) ? 2 : wg::kSMax; }
+inline int tick_max_n(const wg_model_t &m) { return 2 * m.N + 2 * tick_smax(m); }
+inline int tick_max_m(const wg_model_t &m) { return 1 + 4 * m.N + 5 * tick_smax(m); }
 // compact problem view (no G / A matrices in LDS) exists for N == 16; WG_TICK_DENSE=1 forces the generic one
 inline bool tick_compact(const wg_model_t &m) {
   const char *e = getenv("WG_TICK_DENSE");
-  return m.N == 16 && !(e && atoi(e) != 0);
+  return m.N == 16 && m.N * m.T <= 2.0 * m.step_period + 1e-12 && !(e && atoi(e) != 0);
 }
 inline size_t tick_ql_bytes(const wg_model_t &m) {
   size_t b = wg::QlDims(tick_max_n(m), tick_max_m(m), tick_max_m(m), !tick_compact(m)).bytes();
@@ -346,7 +350,7 @@ int wg_mpc_configure(const wg_model_t *model) {
   if (model->N < 2 || model->N > wg::kNMaxH) return fail(WG_ERR_BAD_ARG, "N=%d outside [2,%d]", model->N, wg::kNMaxH);
   if ((int)(model->T / model->Tctrl) != WG_SAMPLES_PER_TICK)
     return fail(WG_ERR_BAD_ARG, "T/Tctrl must be %d", WG_SAMPLES_PER_TICK);
-  size_t lds = tick_ql_bytes(*model) + wg::TickLds::bytes(model->N);
+  size_t lds = tick_ql_bytes(*model) + wg::TickLds::bytes(model->N, tick_smax(*model));
   if (lds > 160 * 1024) return fail(WG_ERR_TOO_LARGE, "tick needs %zu B of LDS > 160 KiB", lds);
   std::lock_guard<std::mutex> lk(g_mu);
   static wg::TickTables host_tables;
@@ -360,7 +364,7 @@ int wg_mpc_configure(const wg_model_t *model) {
 
 size_t wg_mpc_tick_lds_bytes(void) {
   if (!g_model_set) return 0;
-  return tick_ql_bytes(g_model) + wg::TickLds::bytes(g_model.N);
+  return tick_ql_bytes(g_model) + wg::TickLds::bytes(g_model.N, tick_smax(g_model));
 }
 
 int wg_mpc_tick_batch_dev(int B, wg_gait_state_t *states, wg_tick_out_t *outs, int *diag, int advance_calls, int *hist,
@@ -371,7 +375,7 @@ int wg_mpc_tick_batch_dev(int B, wg_gait_state_t *states, wg_tick_out_t *outs, i
   if (hist && (!hist_len || hist_cap <= 0)) return fail(WG_ERR_BAD_ARG, "hist needs hist_len and hist_cap > 0");
   if (B == 0) return WG_OK;
   const size_t qlb = tick_ql_bytes(g_model);
-  const size_t lds = qlb + wg::TickLds::bytes(g_model.N);
+  const size_t lds = qlb + wg::TickLds::bytes(g_model.N, tick_smax(g_model));
   const bool compact = tick_compact(g_model);
   if (lds > 64 * 1024)
     HIP_TRY(hipFuncSetAttribute(compact ? reinterpret_cast<const void *>(wg_mpc_tick_kernel<16>)

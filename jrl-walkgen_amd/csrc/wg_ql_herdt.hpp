@@ -20,6 +20,7 @@
 namespace wg {
 
 constexpr int kSMaxQ = 4;   // == kSMax of the tick
+constexpr int kQbLd = 32;   // row stride of TickTables::Qb (== kNMaxH)
 
 template <int NH>
 struct HerdtProb {
@@ -27,7 +28,7 @@ struct HerdtProb {
   static constexpr int kNM = 2 * NH + 2 * 2;   // n <= 2N + 2*2: at most two previewed steps (checked by wg_mpc_configure)
   static_assert(4 * NH == 64, "one CoP row per lane needs 4N == 64");
   // ---- LDS / global tables (wave-uniform pointers) ----
-  const double *Qb;       // LDS, NH x (NH+1)
+  const double *Qb;       // global (L1/L2-resident constant of the model), NH x kQbLd
   const double *u;        // LDS, NH
   double *Gv;             // LDS, n x (2*kSMaxQ): G(i, 2N + c)
   double *gd;             // LDS, n: current Hessian diagonal (shifted when needed)
@@ -48,8 +49,8 @@ struct HerdtProb {
     if (i == j) return gd[i];
     if (j < i) { const int t = i; i = j; j = t; }
     if (j < 2 * NH) {
-      if (i < NH && j < NH) return Qb[i * (NH + 1) + j];
-      if (i >= NH && j >= NH) return Qb[(i - NH) * (NH + 1) + (j - NH)];
+      if (i < NH && j < NH) return Qb[i * kQbLd + j];
+      if (i >= NH && j >= NH) return Qb[(i - NH) * kQbLd + (j - NH)];
       return 0.0;
     }
     return Gv[i * (2 * kSMaxQ) + (j - 2 * NH)];
@@ -158,7 +159,7 @@ struct HerdtProb {
     const int n = q.n;
     if (row < 2 * NH) {
       const int blk = (row < NH) ? 0 : NH;
-      const double *qr = Qb + (row - blk) * (NH + 1);
+      const double *qr = Qb + (row - blk) * kQbLd;
 #pragma unroll
       for (int k = 0; k < NH; ++k) {
         const double g = (blk + k == row) ? gd[row] : qr[k];

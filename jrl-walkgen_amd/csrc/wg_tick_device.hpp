@@ -146,16 +146,16 @@ struct TickLds {
   double *misc;                   // [16] scalars handed from lane 0 to the wave
   double *Qb, *uvec, *Gv, *gd;    // compact problem view (wg_ql_herdt.hpp): N x (N+1), N, nmax x 8, nmax
   wg_gait_state_t *st;            // working copy of the state
-  __host__ __device__ static size_t bytes(int N) {
-    const int m = 1 + 4 * N + 5 * kSMax;
-    const int nmax = 2 * N + 2 * kSMax;
+  __host__ __device__ static size_t bytes(int N, int smax = kSMax) {
+    const int m = 1 + 4 * N + 5 * smax;
+    const int nmax = 2 * N + 2 * smax;
     size_t b = sizeof(Sup) * (N + 1) + 8 * (size_t)(2 * N + 2 * kSMax + kSMax * kSMax + 8 + (N + 1) + 6 * N + 3 * m + 16 +
-                                                    N * (N + 1) + N + nmax * 2 * kSMax + nmax) +
+                                                    N + nmax * 2 * kSMax + nmax) +
                4 * (size_t)(((N + 1) & ~1) + ((m + 1) & ~1)) + ((sizeof(wg_gait_state_t) + 15) & ~(size_t)15);
     return (b + 15) & ~(size_t)15;
   }
-  __device__ void carve(char *base, int N) {
-    const int m = 1 + 4 * N + 5 * kSMax;
+  __device__ void carve(char *base, int N, int smax = kSMax) {
+    const int m = 1 + 4 * N + 5 * smax;
     char *p = base;
     st = reinterpret_cast<wg_gait_state_t *>(p); p += (sizeof(wg_gait_state_t) + 15) & ~(size_t)15;
     sup = reinterpret_cast<Sup *>(p); p += sizeof(Sup) * (N + 1);
@@ -164,7 +164,7 @@ struct TickLds {
     sup_angles = d; d += 8; trunk = d; d += N + 1; refx = d; d += N; refy = d; d += N;
     svx = d; d += N; svy = d; d += N; szx = d; d += N; szy = d; d += N;
     rowA = d; d += m; rowB = d; d += m; rowD = d; d += m; misc = d; d += 16;
-    { const int nmax = 2 * N + 2 * kSMax; Qb = d; d += N * (N + 1); uvec = d; d += N; Gv = d; d += nmax * 2 * kSMax; gd = d; d += nmax; }
+    { const int nmax = 2 * N + 2 * smax; Qb = nullptr; uvec = d; d += N; Gv = d; d += nmax * 2 * kSMax; gd = d; d += nmax; }
     int *ip = reinterpret_cast<int *>(d);
     stepidx = ip; ip += (N + 1) & ~1; rowK = ip;
   }
@@ -224,43 +224,45 @@ __device__ inline void fsm_set_support_state(const wg_model_t &m, int nb_steps_s
 
 struct Hull { int nv; double X[5], Y[5], A[5], B[5], D[5]; };
 
-// RelativeFeetInequalities::set_vertices (:185-234) on the hulls of init_convex_hulls (:88-149)
-__device__ inline void hull_set_vertices(const wg_model_t &m, Hull &H, int foot, int phase, double yaw, bool feet) {
-  if (!feet) {
+// RelativeFeetInequalities::set_vertices (:185-234) on the hulls of init_convex_hulls (:88-149) followed by
+// compute_linear_system (:264-319).  NV is a compile-time constant so the vertex arrays stay in registers.
+template <int NV>
+__device__ __forceinline__ void hull_edges(const wg_model_t &m, int hull_foot, int hull_phase, double yaw, int sign_foot,
+                                           double *A, double *B, double *D) {
+  double X[NV], Y[NV];
+  if (NV == 4) {
     const double lx[4] = {1.0, 1.0, -1.0, -1.0};
     const double lyr[4] = {-1.0, 1.0, 1.0, -1.0}, lyl[4] = {1.0, -1.0, -1.0, 1.0};
     double hw = 0.5 * m.sole_w; hw -= m.margin_x;      // FootHalfSize.cpp:62-70
     double hh = 0.5 * m.sole_h; hh -= m.margin_y;
     const double hhds = hh + m.ds_feet_distance / 2.0;
-    H.nv = 4;
+#pragma unroll
     for (int j = 0; j < 4; j++) {
-      H.X[j] = lx[j] * hw;
-      if (foot == WG_LEFT) H.Y[j] = (phase == WG_DS) ? lyl[j] * hhds - m.ds_feet_distance / 2.0 : lyl[j] * hh;
-      else H.Y[j] = (phase == WG_DS) ? lyr[j] * hhds + m.ds_feet_distance / 2.0 : lyr[j] * hh;
+      X[j] = lx[j] * hw;
+      if (hull_foot == WG_LEFT) Y[j] = (hull_phase == WG_DS) ? lyl[j] * hhds - m.ds_feet_distance / 2.0 : lyl[j] * hh;
+      else Y[j] = (hull_phase == WG_DS) ? lyr[j] * hhds + m.ds_feet_distance / 2.0 : lyr[j] * hh;
     }
   } else {
     const double px[5] = {-0.28, -0.2, 0.0, 0.2, 0.28};
     const double py[5] = {-0.2, -0.3, -0.4, -0.3, -0.2};
-    H.nv = 5;
-    for (int j = 0; j < 5; j++) { H.X[j] = px[j]; H.Y[j] = (foot == WG_LEFT) ? py[j] : -py[j]; }
+#pragma unroll
+    for (int j = 0; j < NV; j++) { X[j] = px[j]; Y[j] = (hull_foot == WG_LEFT) ? py[j] : -py[j]; }
   }
   const double c = wg_cos(yaw), s = wg_sin(yaw);        // convex_hull_t::rotate, privatepgtypes.cpp:157-185
-  for (int j = 0; j < H.nv; j++) {
-    const double xo = H.X[j], yo = H.Y[j];
-    H.X[j] = (xo * c - yo * s);
-    H.Y[j] = (xo * s + yo * c);
+#pragma unroll
+  for (int j = 0; j < NV; j++) {
+    const double xo = X[j], yo = Y[j];
+    X[j] = (xo * c - yo * s);
+    Y[j] = (xo * s + yo * c);
   }
-}
-
-// compute_linear_system :264-319
-__device__ inline void hull_linear_system(Hull &H, int foot) {
-  const double sign = (foot == WG_LEFT) ? 1.0 : -1.0;
-  for (int i = 0; i < H.nv; i++) {
-    const int i2 = (i + 1 == H.nv) ? 0 : i + 1;
-    const double y1 = H.Y[i], y2 = H.Y[i2], x1 = H.X[i], x2 = H.X[i2];
+  const double sign = (sign_foot == WG_LEFT) ? 1.0 : -1.0;
+#pragma unroll
+  for (int i = 0; i < NV; i++) {
+    const int i2 = (i + 1 == NV) ? 0 : i + 1;
+    const double y1 = Y[i], y2 = Y[i2], x1 = X[i], x2 = X[i2];
     const double dx = y1 - y2, dy = x2 - x1;
     const double dc = dx * x1 + dy * y1;
-    H.A[i] = sign * dx; H.B[i] = sign * dy; H.D[i] = sign * dc;
+    A[i] = sign * dx; B[i] = sign * dy; D[i] = sign * dc;
   }
 }
 
@@ -415,7 +417,7 @@ __device__ inline TickDiag mpc_tick(const wg_model_t &m, const TickTables *__res
   const double T = m.T;
   const int K = WG_SAMPLES_PER_TICK;
   TickLds L;
-  L.carve(lds_tick, N);
+  L.carve(lds_tick, N, (NH == 16) ? 2 : kSMax);
   wg_gait_state_t *s = L.st;
 #ifdef WG_PROFILE
   unsigned long long tk0 = clock64(), tk1 = 0, tk2 = 0, tk3 = 0;
@@ -464,7 +466,8 @@ __device__ inline TickDiag mpc_tick(const wg_model_t &m, const TickTables *__res
       }
     }
     int ns = L.sup[N].step_number;
-    if (ns > kSMax) ns = kSMax;        // cannot happen for N*T <= kSMax*step_period; keeps indices in range
+    constexpr int kSCap = (NH == 16) ? 2 : kSMax;   // compact kernel: N*T <= 2*step_period is checked at configure time
+    if (ns > kSCap) ns = kSCap;                     // cannot happen; keeps every index in range
     // generate_selection_matrices :137-208
     for (int k = 0; k < kSMax; k++) { L.Vc_fX[k] = 0.0; L.Vc_fY[k] = 0.0; }
     for (int k = 0; k < kSMax * kSMax; k++) L.V_f[k] = 0.0;
@@ -484,36 +487,46 @@ __device__ inline TickDiag mpc_tick(const wg_model_t &m, const TickTables *__res
     }
     op_preview(m, s, time, ref, L.sup, L.sup_angles, L.trunk);
     // compute_global_reference :211-229 (only 3 distinct yaw values occur)
-    for (int i = 0; i < N; i++) {
-      const double yt = L.trunk[i];
-      const double c = wg_cos(yt), sn = wg_sin(yt);
-      L.refx[i] = ref[0] * c - ref[1] * sn;
-      L.refy[i] = ref[1] * c + ref[0] * sn;
+    {
+      // trunk[2..N] all hold the same angle (OrientationsPreview.cpp:229-233): three sin/cos pairs suffice
+      double cs3[3], sn3[3];
+      for (int e = 0; e < 3; e++) { const double yt = L.trunk[e < N ? e : N - 1]; cs3[e] = wg_cos(yt); sn3[e] = wg_sin(yt); }
+      for (int i = 0; i < N; i++) {
+        const int e = i < 2 ? i : 2;
+        L.refx[i] = ref[0] * cs3[e] - ref[1] * sn3[e];
+        L.refy[i] = ref[1] * cs3[e] + ref[0] * sn3[e];
+      }
     }
     // polygon edges per constraint row: build_inequalities_cop :284-314, build_inequalities_feet :317-354
     const int mq = 1 + 4 * N + 5 * ns;
     L.rowA[0] = 0.0; L.rowB[0] = 0.0; L.rowD[0] = 0.0; L.rowK[0] = -1;
-    Hull H;
-    hull_set_vertices(m, H, L.sup[0].foot, L.sup[0].phase, L.sup[0].yaw, false);
-    for (int i = 0; i < N; i++) {
-      const Sup &S = L.sup[i + 1];
-      if (S.state_changed) hull_set_vertices(m, H, S.foot, S.phase, S.yaw, false);
-      hull_linear_system(H, S.foot);
-      for (int e = 0; e < 4; e++) {
-        const int r = 1 + 4 * i + e;
-        L.rowA[r] = H.A[e]; L.rowB[r] = H.B[e]; L.rowD[r] = H.D[e]; L.rowK[r] = i;
+    {
+      // the CoP hull changes only where the support state changes; its edges are re-signed by each instant's foot
+      int hf = L.sup[0].foot, hp = L.sup[0].phase; double hy = L.sup[0].yaw;
+      double eA[4], eB[4], eD[4];
+      int last_sign = -1; bool fresh = true;
+      for (int i = 0; i < N; i++) {
+        const Sup &S = L.sup[i + 1];
+        if (S.state_changed) { hf = S.foot; hp = S.phase; hy = S.yaw; fresh = true; }
+        if (fresh || S.foot != last_sign) { hull_edges<4>(m, hf, hp, hy, S.foot, eA, eB, eD); fresh = false; last_sign = S.foot; }
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+          const int r = 1 + 4 * i + e;
+          L.rowA[r] = eA[e]; L.rowB[r] = eB[e]; L.rowD[r] = eD[e]; L.rowK[r] = i;
+        }
       }
     }
     for (int r = 1 + 4 * N; r < mq; r++) { L.rowA[r] = 0.0; L.rowB[r] = 0.0; L.rowD[r] = 0.0; L.rowK[r] = -1; }
     for (int i = 0; i < N; i++) {
       const Sup &S = L.sup[i + 1];
       if (S.state_changed && S.step_number > 0 && S.step_number <= ns && S.phase != WG_DS) {
-        hull_set_vertices(m, H, L.sup[i].foot, L.sup[i].phase, L.sup[i].yaw, true);
-        hull_linear_system(H, S.foot);
+        double eA[5], eB[5], eD[5];
+        hull_edges<5>(m, L.sup[i].foot, L.sup[i].phase, L.sup[i].yaw, S.foot, eA, eB, eD);
         const int k = S.step_number - 1;
+#pragma unroll
         for (int e = 0; e < 5; e++) {
           const int r = 1 + 4 * N + 5 * k + e;
-          L.rowA[r] = H.A[e]; L.rowB[r] = H.B[e]; L.rowD[r] = H.D[e]; L.rowK[r] = k;
+          L.rowA[r] = eA[e]; L.rowB[r] = eB[e]; L.rowD[r] = eD[e]; L.rowK[r] = k;
         }
       }
     }
@@ -574,7 +587,6 @@ __device__ inline TickDiag mpc_tick(const wg_model_t &m, const TickTables *__res
   // ---- Hessian ----
   if constexpr (kCompactView) {
     // compact view: Qb and u as small LDS tables, the 2ns border columns (symmetric) and the diagonal
-    for (int e = lane; e < N * N; e += 64) { const int i = e / N, j = e % N; L.Qb[i * (N + 1) + j] = tb->Qb[i][j]; }
     for (int d = lane; d < N; d += 64) L.uvec[d] = tb->Uz[d][0];                 // Uz[r][c] = u[r-c]
     for (int e = lane; e < n * 2 * kSMax; e += 64) L.Gv[e] = 0.0;
     for (int i = lane; i < 2 * N; i += 64) L.gd[i] = tb->Qb[i % N][i % N];
@@ -686,7 +698,7 @@ __device__ inline TickDiag mpc_tick(const wg_model_t &m, const TickTables *__res
     if (lane == 0 && fabs(L.gd[n - 1]) == 0.0) L.gd[n - 1] = 1e-8;               // qld.cpp:442-444 (nmax == n)
     WG_WSYNC();
     HerdtProb<16> prob;
-    prob.Qb = L.Qb; prob.u = L.uvec; prob.Gv = L.Gv; prob.gd = L.gd;
+    prob.Qb = &tb->Qb[0][0]; prob.u = L.uvec; prob.Gv = L.Gv; prob.gd = L.gd;
     prob.rowA = L.rowA; prob.rowB = L.rowB; prob.rowK = L.rowK; prob.stepidx = L.stepidx; prob.V_f = L.V_f;
     prob.R2 = tb->R2; prob.Z2 = tb->Z2; prob.diag_b = tb->diag_b; prob.blocks_ok = tb->blocks_ok; prob.ns = ns;
     prob.load_rows(lane);
@@ -791,22 +803,29 @@ __device__ inline TickDiag mpc_tick(const wg_model_t &m, const TickTables *__res
         if (out) { out->com_yaw[k][0] = 0.0; out->com_yaw[k][1] = 0.0; }
     }
 
-    // interpolate_feet_positions, OnLineFootTrajectoryGeneration.cpp:235-346
-    double FPx = 0.0, FPy = 0.0;
-    if (cs.phase != WG_DS) {                               // interpret_solution :202-232
-      const double sign = (cs.foot == WG_LEFT) ? 1.0 : -1.0;
-      if (cs.nb_steps_left > 0 && ns > 0) { FPx = q.x[2 * N]; FPy = q.x[2 * N + ns]; }
-      else {
-        FPx = cs.x + sign * wg_sin(cs.yaw) * m.feet_distance;
-        FPy = cs.y - sign * wg_cos(cs.yaw) * m.feet_distance;
-      }
-    }
-    const double local_t = time - (cs.time_limit - (m.t_double + m.t_single));
-    if (out) { out->lf_back = s->lf[2]; out->rf_back = s->rf[2]; }
-    wg_foot_sample_t f11l, f11r, f18l, f18r, f19l, f19r;
+  }
+  WG_WSYNC();
+
+  // ---- feet: one lane per 5 ms sample (interpolate_feet_positions, OnLineFootTrajectoryGeneration.cpp:235-346) ----
+  {
+    const Sup cs = L.sup[0];
+    const double dt = m.Tctrl;
     const wg_foot_sample_t zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    f11l = f18l = f19l = zero; f11r = f18r = f19r = zero;
+    const int k = lane + 1;                                // sample index 1..20
+    const bool mine = lane < K;
+    wg_foot_sample_t outl = zero, outr = zero;             // this lane's pair of samples
+    wg_foot_sample_t backl = s->lf[2], backr = s->rf[2];   // the queue's newest sample (rewritten in DS)
     if (cs.phase == WG_SS && time + 3.0 / 2.0 * T < cs.time_limit) {
+      double FPx, FPy;                                     // interpret_solution :202-232
+      {
+        const double sign = (cs.foot == WG_LEFT) ? 1.0 : -1.0;
+        if (cs.nb_steps_left > 0 && ns > 0) { FPx = q.x[2 * N]; FPy = q.x[2 * N + ns]; }
+        else {
+          FPx = cs.x + sign * wg_sin(cs.yaw) * m.feet_distance;
+          FPy = cs.y - sign * wg_cos(cs.yaw) * m.feet_distance;
+        }
+      }
+      const double local_t = time - (cs.time_limit - (m.t_double + m.t_single));
       const bool left_support = (cs.foot == WG_LEFT);
       const double unlocked = m.t_single * 0.9;
       const double end_lift = (m.t_single - unlocked) * 0.5;
@@ -816,67 +835,74 @@ __device__ inline TickDiag mpc_tick(const wg_model_t &m, const TickTables *__res
       const wg_foot_sample_t sw_prev = left_support ? s->rf[1] : s->lf[1];   // swing foot, [StartIndex-1]
       const wg_foot_sample_t st_prev = left_support ? s->lf[1] : s->rf[1];   // stance foot, [StartIndex-1]
       const double ti = unlocked - swing_passed;
-      double px5[6], py5[6], pth[4], pom[4], pom2[4];
+      double px5[6], py5[6], pth[4], pom[4], pom2[4], pz[5];
       poly5_set(px5, ti, FPx, last.x, last.dx, last.ddx);
       poly5_set(py5, ti, FPy, last.y, last.dy, last.ddy);
-      if (cs.state_changed) poly4_set(s->poly_z, m.t_single, m.step_height);
+      if (cs.state_changed) poly4_set(pz, m.t_single, m.step_height);
+      else { for (int e = 0; e < 5; ++e) pz[e] = s->poly_z[e]; }
       poly3_set(pth, ti, L.sup_angles[0] * 180.0 / kPi, last.theta, last.dtheta);
       poly3_set(pom, ti, 0.0 * 180.0 / kPi, last.omega, last.domega);
       poly3_set(pom2, ti, 2 * 0.0 * 180.0 / kPi, last.omega2, last.domega2);
       const double start_landing = end_lift + unlocked;
       const double omega_cmd = 0.0;
-      wg_foot_sample_t p = last;
-      for (int k = 1; k <= K; k++) {                       // UpdateFootPosition :50-199
-        const double it = (double)k * dt;
-        wg_foot_sample_t c = zero;
-        if (local_t + it <= end_lift || local_t + it >= start_landing) {
-          c.x = p.x; c.y = p.y; c.theta = p.theta;
-        } else {
-          const double tt = (local_t < end_lift && local_t + it > end_lift) ? local_t + it - end_lift : it;
-          c.x = poly_eval(px5, 5, tt); c.dx = poly_d1(px5, 5, tt); c.ddx = poly_d2(px5, 5, tt);
-          c.y = poly_eval(py5, 5, tt); c.dy = poly_d1(py5, 5, tt); c.ddy = poly_d2(py5, 5, tt);
-          c.theta = poly_eval(pth, 3, tt); c.dtheta = poly_d1(pth, 3, tt);
-        }
-        c.z = poly_eval(s->poly_z, 4, local_t + it);
-        c.dz = poly_d1(s->poly_z, 4, local_t + it);
-        if (local_t + it < end_lift) {
-          c.omega = poly_eval(pom, 3, it); c.domega = poly_d1(pom, 3, it);
-        } else if (local_t + it < start_landing) {
-          c.omega = omega_cmd - poly_eval(pom2, 3, local_t + it - end_lift) - sw_prev.omega2;
-        } else {
-          c.omega = poly_eval(pom, 3, local_t + it - start_landing) + sw_prev.omega - omega_cmd;
-        }
-        {
-          // :150-198 keeps the sole above the floor while it pitches; omega == 0 on this path
-          // (":omega 0.0"), which makes every term exactly 0 for any ankle geometry
-          const double lOmega = c.omega * kPi / 180.0, lTheta = c.theta * kPi / 180.0;
-          const double cth = wg_cos(lTheta), sth = wg_sin(lTheta);
-          const double Bf = 0.0, Hf = 0.105, Ff = 0.105;
-          double dX, dFZ;
-          if (lOmega < 0) { dX = -(Bf - Bf * wg_cos(-lOmega) + Hf * wg_sin(-lOmega)); dFZ = Hf * wg_cos(-lOmega) + Bf * wg_sin(-lOmega) - Hf; }
-          else { dX = (Ff - Ff * wg_cos(lOmega) + Hf * wg_sin(lOmega)); dFZ = Hf * wg_cos(lOmega) + Ff * wg_sin(lOmega) - Hf; }
-          c.x += cth * dX; c.y += sth * dX; c.z += dFZ;
-        }
-        if (out) { if (left_support) { out->rf[k - 1] = c; out->lf[k - 1] = st_prev; } else { out->lf[k - 1] = c; out->rf[k - 1] = st_prev; } }
-        if (k == 12) { if (left_support) f11r = c; else f11l = c; }
-        if (k == 19) { if (left_support) f18r = c; else f18l = c; }
-        if (k == 20) { if (left_support) f19r = c; else f19l = c; }
-        p = c;
+      // UpdateFootPosition :50-199.  x, y, theta are frozen before lift-off and after landing ("= previous
+      // sample"): samples before the moving window repeat the queue back, samples after it repeat the last
+      // moving sample -- so the samples are independent and each lane evaluates its own.
+      const double it = (double)k * dt;
+      const bool frozen = (local_t + it <= end_lift) || (local_t + it >= start_landing);
+      wg_foot_sample_t c = zero;
+      {
+        const double tt = (local_t < end_lift && local_t + it > end_lift) ? local_t + it - end_lift : it;
+        c.x = poly_eval(px5, 5, tt); c.dx = poly_d1(px5, 5, tt); c.ddx = poly_d2(px5, 5, tt);
+        c.y = poly_eval(py5, 5, tt); c.dy = poly_d1(py5, 5, tt); c.ddy = poly_d2(py5, 5, tt);
+        c.theta = poly_eval(pth, 3, tt); c.dtheta = poly_d1(pth, 3, tt);
       }
-      if (left_support) { f11l = f18l = f19l = st_prev; } else { f11r = f18r = f19r = st_prev; }
+      // last moving sample at or before this one (lanes are in time order)
+      const unsigned long long moving = __ballot(mine && !frozen);
+      const unsigned long long below = moving & ((2ull << lane) - 1ull);          // lanes <= mine
+      const int src = below ? 63 - __builtin_clzll(below) : -1;
+      const double hx = __shfl(c.x, src < 0 ? 0 : src), hy = __shfl(c.y, src < 0 ? 0 : src), hth = __shfl(c.theta, src < 0 ? 0 : src);
+      if (frozen) {
+        c = zero;
+        c.x = (src < 0) ? last.x : hx; c.y = (src < 0) ? last.y : hy; c.theta = (src < 0) ? last.theta : hth;
+      }
+      c.z = poly_eval(pz, 4, local_t + it);
+      c.dz = poly_d1(pz, 4, local_t + it);
+      if (local_t + it < end_lift) {
+        c.omega = poly_eval(pom, 3, it); c.domega = poly_d1(pom, 3, it);
+      } else if (local_t + it < start_landing) {
+        c.omega = omega_cmd - poly_eval(pom2, 3, local_t + it - end_lift) - sw_prev.omega2;
+      } else {
+        c.omega = poly_eval(pom, 3, local_t + it - start_landing) + sw_prev.omega - omega_cmd;
+      }
+      {
+        // :150-198 keeps the sole above the floor while it pitches; omega == 0 on this path
+        // (":omega 0.0"), which makes every term exactly 0 for any ankle geometry
+        const double lOmega = c.omega * kPi / 180.0, lTheta = c.theta * kPi / 180.0;
+        const double cth = wg_cos(lTheta), sth = wg_sin(lTheta);
+        const double Bf = 0.0, Hf = 0.105, Ff = 0.105;
+        double dX, dFZ;
+        if (lOmega < 0) { dX = -(Bf - Bf * wg_cos(-lOmega) + Hf * wg_sin(-lOmega)); dFZ = Hf * wg_cos(-lOmega) + Bf * wg_sin(-lOmega) - Hf; }
+        else { dX = (Ff - Ff * wg_cos(lOmega) + Hf * wg_sin(lOmega)); dFZ = Hf * wg_cos(lOmega) + Ff * wg_sin(lOmega) - Hf; }
+        c.x += cth * dX; c.y += sth * dX; c.z += dFZ;
+      }
+      if (left_support) { outr = c; outl = st_prev; } else { outl = c; outr = st_prev; }
+      if (lane == 0 && cs.state_changed) for (int e = 0; e < 5; ++e) s->poly_z[e] = pz[e];
     } else if (cs.phase == WG_DS || time + 3.0 / 2.0 * T > cs.time_limit) {
-      f11l = f18l = f19l = s->lf[1];                       // k = 0 rewrites the queue back (:333-336)
-      f11r = f18r = f19r = s->rf[1];
-      if (out) { for (int k = 0; k < K; k++) { out->lf[k] = f19l; out->rf[k] = f19r; } out->lf_back = f19l; out->rf_back = f19r; }
-    } else {
-      if (out) for (int k = 0; k < K; k++) { out->lf[k] = zero; out->rf[k] = zero; }
+      outl = s->lf[1]; outr = s->rf[1];                    // k = 0 rewrites the queue back (:333-336)
+      backl = outl; backr = outr;
     }
-    s->lf[0] = f11l; s->lf[1] = f18l; s->lf[2] = f19l;
-    s->rf[0] = f11r; s->rf[1] = f18r; s->rf[2] = f19r;
-
-    if (!s->ending_phase) s->time_to_stop = s->upper_time_limit + T * N;     // :446-450
-    s->upper_time_limit = s->upper_time_limit + T;
-    s->tick_count++;
+    WG_WSYNC();
+    if (mine && out) { out->lf[lane] = outl; out->rf[lane] = outr; }
+    if (lane == 0 && out) { out->lf_back = backl; out->rf_back = backr; }
+    if (lane == 11) { s->lf[0] = outl; s->rf[0] = outr; }
+    if (lane == 18) { s->lf[1] = outl; s->rf[1] = outr; }
+    if (lane == 19) { s->lf[2] = outl; s->rf[2] = outr; }
+    if (lane == 0) {
+      if (!s->ending_phase) s->time_to_stop = s->upper_time_limit + T * N;     // :446-450
+      s->upper_time_limit = s->upper_time_limit + T;
+      s->tick_count++;
+    }
   }
   WG_WSYNC();
 
