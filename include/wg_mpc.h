@@ -234,6 +234,27 @@ int wg_mpc_set_velref_dev(int B, wg_gait_state_t *states, const double *vref, vo
 /* LDS bytes one gait occupies in the tick kernel for the configured model. */
 size_t wg_mpc_tick_lds_bytes(void);
 
+/* Kajita preview-control gains (host, no device work) -----------------------
+ *
+ * wg_riccati_solve replaces
+ *     OptimalControllerSolver(A, b, c, Q, R, Nl) + ComputeWeights(mode) + GetK/GetF
+ *     src/PreviewControl/OptimalControllerSolver.hh:143-144, OptimalControllerSolver.cpp:97-126, 200-352
+ * for a single-input single-output system x+ = A x + b u, p = c x of order n <= 8 (A row-major n x n):
+ * P = stabilising solution of the discrete Riccati equation with weights Q (output) and R (input),
+ *     K[n]  = (R + b'Pb)^-1 b'PA,
+ *     F[Nl] = (R + b'Pb)^-1 b' ((A - bK)')^k  (c'Q            mode WG_RICCATI_WITH_INITIALPOS
+ *                                              P c'Q          mode WG_RICCATI_WITHOUT_INITIALPOS).
+ * wg_riccati_gains replaces PreviewControl::ComputeOptimalWeights (src/PreviewControl/PreviewControl.cpp:198-322):
+ * it builds the cart-table system for sampling period T and CoM height zc (g = 9.81) -- 3 states for
+ * WITH_INITIALPOS, the 4-state error system for WITHOUT_INITIALPOS -- and returns
+ *     WITHOUT_INITIALPOS: K = {Ks, Kx[0], Kx[1], Kx[2]};  WITH_INITIALPOS: K = {Kx[0] (= Ks), Kx[1], Kx[2], 0}.
+ * The reference passes Q = 1, R = 1e-6 (WITHOUT) or 1e-5 (WITH), Nl = (int)(preview time / T). */
+#define WG_RICCATI_WITH_INITIALPOS 0
+#define WG_RICCATI_WITHOUT_INITIALPOS 1
+int wg_riccati_solve(int n, const double *A, const double *b, const double *c, double Q, double R, int Nl, int mode,
+                     double *K, double *F);
+int wg_riccati_gains(double T, double zc, double Q, double R, int Nl, int mode, double *K, double *F);
+
 #ifdef __cplusplus
 }
 #endif

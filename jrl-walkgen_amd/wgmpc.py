@@ -78,6 +78,9 @@ def lib():
                                            C.c_void_p]
         _lib.wg_mpc_tick_batch_dev.argtypes = _lib.wg_mpc_tick_batch.argtypes + [C.c_void_p]
         _lib.wg_mpc_set_velref_dev.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        _lib.wg_riccati_solve.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_double, C.c_int,
+                                          C.c_int, C.c_void_p, C.c_void_p]
+        _lib.wg_riccati_gains.argtypes = [C.c_double] * 4 + [C.c_int, C.c_int, C.c_void_p, C.c_void_p]
     return _lib
 
 
@@ -194,3 +197,31 @@ def mpc_tick_batch_dev(B, states_ptr, outs_ptr=None, diag_ptr=None, advance_call
 def mpc_set_velref_dev(B, states_ptr, vref_ptr, stream=None):
     v = lambda p: C.c_void_p(p) if p else None
     _check(lib().wg_mpc_set_velref_dev(B, v(states_ptr), v(vref_ptr), v(stream)))
+
+
+RICCATI_WITH_INITIALPOS = 0
+RICCATI_WITHOUT_INITIALPOS = 1
+
+
+def riccati_solve(A, b, c, Q, R, Nl, mode):
+    """OptimalControllerSolver(A,b,c,Q,R,Nl).ComputeWeights(mode) -> (K[n], F[Nl]); host-side entry point."""
+    A = np.ascontiguousarray(A, dtype=np.float64)
+    n = A.shape[0]
+    b = np.ascontiguousarray(b, dtype=np.float64).reshape(n)
+    c = np.ascontiguousarray(c, dtype=np.float64).reshape(n)
+    K = np.zeros(n)
+    F = np.zeros(max(int(Nl), 1))
+    rc = lib().wg_riccati_solve(n, _hp(A), _hp(b), _hp(c), float(Q), float(R), int(Nl), int(mode), _hp(K), _hp(F))
+    if rc != 0:
+        raise WgError(f"wg_riccati_solve failed ({rc})")
+    return K, F[:int(Nl)]
+
+
+def riccati_gains(T, zc, Q, R, Nl, mode):
+    """PreviewControl::ComputeOptimalWeights -> (K[4], F[Nl]); see include/wg_mpc.h for the layout of K."""
+    K = np.zeros(4)
+    F = np.zeros(max(int(Nl), 1))
+    rc = lib().wg_riccati_gains(float(T), float(zc), float(Q), float(R), int(Nl), int(mode), _hp(K), _hp(F))
+    if rc != 0:
+        raise WgError(f"wg_riccati_gains failed ({rc})")
+    return K, F[:int(Nl)]

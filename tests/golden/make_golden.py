@@ -6,6 +6,8 @@
   ql_golden.npz : QPs (inputs) + the COMPILED REFERENCE qld.cpp's outputs (x, u, ifail, final active set)
         - 24 QPs per family of tests/qpgen.py (branch coverage of ql0002), and
         - the 225 QPs the Herdt oracle assembles while replaying the EmergencyStop scenario.
+  preview_control_parameters.npz : the reference's precomputed Kajita gains
+        /root/reference/src/data/PreviewControlParameters.ini  (Zc, T, preview time, Kx[3], Ks, F[320]), as data.
 """
 import os
 import sys
@@ -21,7 +23,16 @@ import qpgen  # noqa: E402
 REF = "/root/reference/tests/TestHerdt2010EmergencyStopTestFGPI.datref.cmake"
 
 
+def preview_ini():
+    v = np.array(open("/root/reference/src/data/PreviewControlParameters.ini").read().split(), dtype=float)
+    nl = int(v[2] / v[1])
+    assert v.size == 7 + nl
+    np.savez_compressed(os.path.join(HERE, "preview_control_parameters.npz"), zc=v[0], T=v[1], preview_time=v[2],
+                        Kx=v[3:6], Ks=v[6], F=v[7:7 + nl])
+
+
 def main():
+    preview_ini()
     datref = np.loadtxt(REF)
     np.savez_compressed(os.path.join(HERE, "herdt_emergency_stop_datref.npz"), datref=datref)
 
