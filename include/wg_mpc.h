@@ -255,6 +255,66 @@ int wg_riccati_solve(int n, const double *A, const double *b, const double *c, d
                      double *K, double *F);
 int wg_riccati_gains(double T, double zc, double Q, double R, int Nl, int mode, double *K, double *F);
 
+/* PLDP: primal active-set solver in LQ-preconditioned coordinates (Dimitrov 2008) with OptCholesky updates ----------
+ *
+ * wg_pldp_configure replaces the constructor
+ *     PLDPSolver(CardU, iPu, Px, Pu, iLQ)            src/Mathematics/PLDPSolver.cpp:40-96 (+ PrecomputeiPuPx :208-285)
+ * and wg_pldp_solve_batch replaces, batched over B independent problems, each with its own hot-start state,
+ *     PLDPSolver::SolveProblem(CstPartOfTheCostFunction, NbOfConstraints, LinearPartOfConstraints,
+ *                              CstPartOfConstraints, ZMPRef, XkYk, X, SimilarConstraint,
+ *                              NumberOfRemovedConstraints, StartingSequence)      PLDPSolver.cpp:654-1007
+ * including the row-append Cholesky of E E' it drives,
+ *     OptCholesky::AddActiveConstraint / UpdateCholeskyMatrixFortran              OptCholesky.cpp:92-104, 171-223
+ * called from ZMPConstrainedQPFastFormulation::BuildZMPTrajectoryFromFootTrajectory
+ *     src/ZMPRefTrajectoryGeneration/ZMPConstrainedQPFastFormulation.cpp:1318-1327.
+ *
+ *     minimise 1/2 |v|^2 + D'v   s.t.  A v + b >= 0,      v in R^(2N)  (x block, then y block)
+ *
+ *   N        preview length (CardU), 1 <= N <= WG_PLDP_N;  iPu, Pu: N x N row-major, Px: N x 3 row-major
+ *   mcap     slot size of the per-problem arrays, m[b] <= mcap <= WG_PLDP_MMAX
+ *   m        B          number of constraint rows of problem b
+ *   D        B x 2N     linear part of the cost
+ *   A        B slots of (mcap+1)*2N doubles; problem b is COLUMN-major with LEADING DIMENSION m[b]+1, exactly as
+ *                       BuildConstraintMatrices writes DPu (ZMPConstrainedQPFastFormulation.cpp:773-775, 893-905)
+ *   b        B x mcap   constant part (DPx)
+ *   zmpref   B x 2N,  xkyk B x 6 (x, dx, ddx, y, dy, ddy)
+ *   similar  B x mcap   SimilarConstraint: 0, or the (negative) offset to an earlier row with A_i = -A_j
+ *                       (FootConstraintsAsLinearSystem.cpp:55-93); positive offsets are rejected
+ *   n_removed, starting   B each: NumberOfRemovedConstraints, StartingSequence
+ *   max_iter  the reference stops on a 1.3 ms wall-clock budget (PLDPSolver.cpp:51-52, 889-900), which cannot be
+ *             reproduced; max_iter <= 0 runs to completion (the reference when the budget is not hit), otherwise the
+ *             loop ends after max_iter iterations, like a budget that expires during that iteration
+ *   states   B          hot-start state, read and updated (m_PreviouslyActivatedConstraints, m_PreviousZMPSolution)
+ *   X        B x 2N     solution;   ret B: 0, WG_PLDP_NAN (reference returns -1), WG_PLDP_NEG_ALPHA (reference calls
+ *                       exit(0)), WG_PLDP_CAPACITY (more than WG_PLDP_ACTIVE_CAP active rows; E E' is singular long
+ *                       before that)
+ *   n_iter   B          m_ItNb;  active B x mcap / n_active B: m_ActivatedConstraints in activation order (or NULL) */
+#define WG_PLDP_N 16
+#define WG_PLDP_MMAX (8 * WG_PLDP_N)
+#define WG_PLDP_ACTIVE_CAP 64
+#define WG_PLDP_NAN (-1)
+#define WG_PLDP_NEG_ALPHA (-2)
+#define WG_PLDP_CAPACITY (-3)
+typedef struct wg_pldp_state {
+  int n_prev;
+  int prev_active[WG_PLDP_MMAX];
+  int pad_;
+  double prev_zmp[2 * WG_PLDP_N];
+  double internal_time;
+} wg_pldp_state_t;
+int wg_pldp_configure(int N, const double *iPu, const double *Px, const double *Pu);
+int wg_pldp_solve_batch(int B, int mcap, const int *m, const double *D, const double *A, const double *b,
+                        const double *zmpref, const double *xkyk, const int *similar, const int *n_removed,
+                        const int *starting, int max_iter, wg_pldp_state_t *states, double *X, int *ret, int *n_iter,
+                        int *active, int *n_active);
+/* same, DEVICE pointers, asynchronous on hip_stream */
+int wg_pldp_solve_batch_dev(int B, int mcap, const int *m, const double *D, const double *A, const double *b,
+                            const double *zmpref, const double *xkyk, const int *similar, const int *n_removed,
+                            const int *starting, int max_iter, wg_pldp_state_t *states, double *X, int *ret,
+                            int *n_iter, int *active, int *n_active, void *hip_stream);
+/* LDS bytes one problem occupies in the PLDP kernel. */
+size_t wg_pldp_lds_bytes(void);
+
 #ifdef __cplusplus
 }
 #endif

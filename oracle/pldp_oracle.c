@@ -1,0 +1,283 @@
+/*
+ * pldp_oracle.c -- TEST INFRASTRUCTURE ONLY (see wg_oracle.h).
+ *
+ * CPU restatement of the reference's Dimitrov-2008 back-end:
+ *   OptCholesky   /root/reference/src/Mathematics/OptCholesky.cpp
+ *   PLDPSolver    /root/reference/src/Mathematics/PLDPSolver.cpp
+ * Same operations in the same order (every inner sum ascending like the reference's loops), so results are meant to
+ * be bit-identical to a build of those files.
+ *
+ * PARITY UNPINNED against a compiled reference: both translation units include <jrl/mal/matrixabstractlayer.hh>
+ * (jrl-mal >= 1.9.0, CMakeLists.txt:45), which is not in this image, so they are unbuildable here.  The pins that exist
+ * are the reference's own self-checking test tests/TestOptCholesky.cpp (srand(0), 12 x 15, |A A' - L L'|_F <= 1e-6),
+ * replayed in tests/test_pldp_oracle.py, and the optimality (KKT) conditions of the QP the solver claims to solve.
+ *
+ * Deliberate deviations, all at places where the reference is not reproducible:
+ *   - the 1.3 ms gettimeofday budget (PLDPSolver.cpp:51-52, 889-900) is an iteration cap (max_iter);
+ *   - alpha < 0 makes the reference call exit(0) (:833-838); here the solve returns WG_PLDP_NEG_ALPHA;
+ *   - m_ConstraintsValueComputed is uninitialised heap memory in the reference (:139); the flags are only ever read
+ *     for rows below the current one when SimilarConstraint offsets are negative (what FindSimilarConstraints emits),
+ *     so positive offsets are rejected instead of reading stale data;
+ *   - diagnostic printing and file dumps are dropped.
+ */
+#include <math.h>
+#include <string.h>
+
+#include "wg_oracle.h"
+
+/* ---- OptCholesky ---------------------------------------------------------------------------------------------- */
+
+/* OptCholesky::UpdateCholeskyMatrixNormal, OptCholesky.cpp:123-169: the newest entry of set[] is row i of L.
+ * A row-major, card_u doubles per row; L row-major with leading dimension ldl. */
+void wgo_optchol_update_normal(const double *A, int card_u, const int *set, int nset, double *L, int ldl) {
+  const int i = nset > 0 ? nset - 1 : 0;
+  const double *arow_i = A + (size_t)card_u * set[i];
+  for (int lj = 0; lj < nset; lj++) {
+    const double *arow_j = A + (size_t)card_u * set[lj];
+    double mij = 0.0;
+    for (int lk = 0; lk < card_u; lk++) mij += arow_i[lk] * arow_j[lk];
+    double r = mij;
+    for (int lk = 0; lk < lj; lk++) r = r - L[i * ldl + lk] * L[lj * ldl + lk];
+    if (lj != nset - 1) L[i * ldl + lj] = r / L[lj * ldl + lj];
+    else L[i * ldl + lj] = sqrt(r);
+  }
+}
+
+/* OptCholesky::UpdateCholeskyMatrixFortran, OptCholesky.cpp:171-223: A column-major, leading dimension m+1. */
+void wgo_optchol_update_fortran(const double *A, int m, int card_u, const int *set, int nset, double *L, int ldl) {
+  const int i = nset > 0 ? nset - 1 : 0;
+  const int lda = m + 1;
+  for (int lj = 0; lj < nset; lj++) {
+    const double *pi = A + set[i], *pj = A + set[lj];
+    double mij = 0.0;
+    for (int lk = 0; lk < card_u; lk++) { mij += (*pi) * (*pj); pi += lda; pj += lda; }
+    double r = mij;
+    for (int lk = 0; lk < lj; lk++) r = r - L[i * ldl + lk] * L[lj * ldl + lk];
+    if (lj != nset - 1) L[i * ldl + lj] = r / L[lj * ldl + lj];
+    else L[i * ldl + lj] = sqrt(r);
+  }
+}
+
+/* OptCholesky::ComputeNormalCholeskyOnANormal, OptCholesky.cpp:225-259 (A is n x n, row-major; only the lower
+ * triangle of L is written) */
+void wgo_chol_normal(const double *A, int n, double *L) {
+  for (int li = 0; li < n; li++)
+    for (int lj = 0; lj <= li; lj++) {
+      double r = A[li * n + lj];
+      for (int lk = 0; lk < lj; lk++) r = r - L[li * n + lk] * L[lj * n + lk];
+      if (lj != li) L[li * n + lj] = r / L[lj * n + lj];
+      else L[li * n + lj] = sqrt(r);
+    }
+}
+
+/* OptCholesky::ComputeInverseCholeskyNormal, OptCholesky.cpp:261-302, over the leading `size` rows */
+void wgo_chol_inverse(const double *L, int n, int size, double *iL) {
+  for (int lj = size - 1; lj >= 0; lj--) {
+    const double d = 1 / L[lj * n + lj];
+    iL[lj * n + lj] = d;
+    for (int li = lj + 1; li < size; li++) {
+      double r = 0.0;
+      for (int lk = lj + 1; lk < size; lk++) r = r + iL[li * n + lk] * L[lk * n + lj];
+      iL[li * n + lj] = -d * r;
+    }
+  }
+}
+
+/* ---- PLDPSolver ----------------------------------------------------------------------------------------------- */
+
+/* constructor + PrecomputeiPuPx, PLDPSolver.cpp:40-96, 208-285 */
+int wgo_pldp_setup(wgo_pldp_model_t *M, int N, const double *iPu, const double *Px, const double *Pu) {
+  if (N < 1 || N > WG_PLDP_N) return -1;
+  memset(M, 0, sizeof(*M));
+  M->N = N;
+  memcpy(M->iPu, iPu, sizeof(double) * N * N);
+  memcpy(M->Pu, Pu, sizeof(double) * N * N);
+  memcpy(M->Px, Px, sizeof(double) * N * 3);
+  for (int i = 0; i < N; i++)
+    for (int j = 0; j < 3; j++) {
+      M->iPuPx[i * 6 + j] = 0.0;
+      M->iPuPx[i * 6 + j + 3] = 0.0;
+      M->iPuPx[(i + N) * 6 + j] = 0.0;
+      M->iPuPx[(i + N) * 6 + j + 3] = 0.0;
+      for (int k = 0; k < N; k++) {
+        const double tmp = iPu[k * N + i] * Px[k * 3 + j];
+        M->iPuPx[i * 6 + j] += tmp;
+        M->iPuPx[(i + N) * 6 + j + 3] += tmp;
+      }
+    }
+  return 0;
+}
+
+typedef struct {
+  const wgo_pldp_model_t *M;
+  int m, lda, nact;
+  const double *A, *b, *D;
+  int act[WG_PLDP_MMAX];
+  double Vk[2 * WG_PLDP_N], c[2 * WG_PLDP_N], d[2 * WG_PLDP_N];
+  double v1[WG_PLDP_MMAX], v2[WG_PLDP_MMAX], y[WG_PLDP_MMAX], tmp1[WG_PLDP_MMAX], tmp2[WG_PLDP_MMAX];
+  unsigned char computed[2 * WG_PLDP_MMAX];
+  double L[WG_PLDP_MMAX * WG_PLDP_MMAX];
+} pldp_work_t;
+
+/* ComputeInitialSolution, PLDPSolver.cpp:287-340 (m_HotStart is always true, :46) */
+static void initial_solution(pldp_work_t *w, const wg_pldp_state_t *st, const double *zmpref, const double *xkyk,
+                             int starting) {
+  const wgo_pldp_model_t *M = w->M;
+  const int N = M->N;
+  for (int i = 0; i < N; i++) {
+    w->Vk[i] = 0.0;
+    w->Vk[i + N] = 0.0;
+    for (int j = 0; j < 3; j++) w->Vk[i] -= M->iPuPx[i * 6 + j] * xkyk[j];
+    for (int j = 3; j < 6; j++) w->Vk[i + N] -= M->iPuPx[(i + N) * 6 + j] * xkyk[j];
+    if (!starting) {
+      for (int j = 0; j < N - 1; j++) w->Vk[i] += M->iPu[j * N + i] * st->prev_zmp[j + 1];
+      w->Vk[i] += M->iPu[(N - 1) * N + i] * zmpref[N - 1];
+      for (int j = 0; j < N - 1; j++) w->Vk[i + N] += M->iPu[j * N + i] * st->prev_zmp[j + N + 1];
+      w->Vk[i + N] += M->iPu[(N - 1) * N + i] * zmpref[N - 1 + N];
+    } else {
+      for (int j = 0; j < N; j++) w->Vk[i] += M->iPu[j * N + i] * zmpref[j];
+      for (int j = 0; j < N; j++) w->Vk[i + N] += M->iPu[j * N + i] * zmpref[j + N];
+    }
+  }
+}
+
+/* ComputeProjectedDescentDirection with Forward/BackwardSubstitution, PLDPSolver.cpp:342-532 */
+static void projected_direction(pldp_work_t *w) {
+  const int n = 2 * w->M->N, S = w->nact, ld = WG_PLDP_MMAX;
+  for (int li = 0; li < S; li++) {
+    w->v1[li] = 0.0;
+    const int row = w->act[li];
+    for (int lj = 0; lj < n; lj++) w->v1[li] += w->A[row + lj * w->lda] * w->c[lj];
+  }
+  for (int i = 0; i < S; i++) {
+    w->y[i] = w->v1[i];
+    for (int k = 0; k < i; k++) w->y[i] += -w->L[i * ld + k] * w->y[k];
+    if (w->L[i * ld + i] != 0.0) w->y[i] /= w->L[i * ld + i];
+  }
+  for (int i = S - 1; i >= 0; i--) {
+    w->v2[i] = w->y[i];
+    for (int k = i + 1; k < S; k++) w->v2[i] -= w->L[k * ld + i] * w->v2[k];
+    w->v2[i] = w->v2[i] / w->L[i * ld + i];
+  }
+  for (int li = 0; li < n; li++) {
+    w->d[li] = w->c[li];
+    for (int lj = 0; lj < S; lj++) w->d[li] -= w->A[w->act[lj] + li * w->lda] * w->v2[lj];
+  }
+}
+
+/* ComputeAlpha, PLDPSolver.cpp:534-653.  *add receives the row to activate or -1. */
+static double compute_alpha(pldp_work_t *w, const int *similar, int *add) {
+  const int n = 2 * w->M->N, m = w->m;
+  const double tol = 1e-8;                                  /* m_tol, :49 */
+  double alpha = 10000000.0;
+  int to_add = 0, which = 0;
+  for (int li = 0; li < m; li++) {
+    int found = 0;
+    w->computed[li] = 0;
+    w->computed[li + m] = 0;
+    for (int ci = 0; ci < w->nact; ci++)
+      if (w->act[ci] == li) { found = 1; break; }
+    if (found) continue;
+    const double *pa = w->A + li;
+    w->tmp1[li] = 0.0;
+    {
+      int compute = 1;
+      if (similar[li] != 0) {
+        const int lindex = li + similar[li];
+        if (w->computed[lindex]) { w->tmp1[li] = -w->tmp1[lindex]; compute = 0; }
+      }
+      if (compute)
+        for (int lj = 0; lj < n; lj++) { w->tmp1[li] += *pa * w->d[lj]; pa += w->lda; }
+    }
+    w->computed[li] = 1;
+    if (w->tmp1[li] < 0.0) {
+      const double *pa2 = w->A + li;
+      w->tmp2[li] = -w->b[li];
+      {
+        int compute = 1;
+        if (similar[li] != 0) {
+          const int lindex = li + similar[li];
+          if (w->computed[lindex + m]) { w->tmp2[li] += -w->tmp2[lindex] - w->b[lindex]; compute = 0; }
+        }
+        if (compute)
+          for (int lj = 0; lj < n; lj++) { w->tmp2[li] -= *pa2 * w->Vk[lj]; pa2 += w->lda; }
+      }
+      if (w->tmp2[li] > tol) { /* the reference only prints "PB ON constraint" here */ }
+      else if (w->tmp2[li] > 0.0) w->tmp2[li] = -tol;
+      const double lalpha = w->tmp2[li] / w->tmp1[li];
+      if (alpha > lalpha) {
+        alpha = lalpha;
+        if (alpha < 1) { to_add = 1; which = li; }
+      }
+    }
+  }
+  *add = to_add ? which : -1;
+  return alpha;
+}
+
+static void add_active(pldp_work_t *w, int row) {
+  w->v2[w->nact] = 0.0;       /* reference: whatever m_v2 held; only read if max_iter ends the loop right after an add */
+  w->act[w->nact++] = row;
+  wgo_optchol_update_fortran(w->A, w->m, 2 * w->M->N, w->act, w->nact, w->L, WG_PLDP_MMAX);
+}
+
+/* SolveProblem, PLDPSolver.cpp:654-1007 */
+int wgo_pldp_solve(const wgo_pldp_model_t *M, wg_pldp_state_t *st, const double *D, int m, const double *A,
+                   const double *b, const double *zmpref, const double *xkyk, const int *similar, int n_removed,
+                   int starting, int max_iter, double *X, int *n_iter, int *active, int *n_active) {
+  static pldp_work_t work;                                   /* test infrastructure: single-threaded */
+  pldp_work_t *w = &work;
+  const int N = M->N, n = 2 * N;
+  if (m < 0 || m > WG_PLDP_MMAX) return -100;
+  for (int i = 0; i < m; i++)
+    if (similar[i] > 0 || i + similar[i] < 0) return -100;
+  w->M = M; w->m = m; w->lda = m + 1; w->A = A; w->b = b; w->D = D; w->nact = 0;
+  if (starting) st->internal_time = 0.0;
+  initial_solution(w, st, zmpref, xkyk, starting);
+  for (int i = 0; i < st->n_prev; i++) {                     /* hot start :777-791 */
+    const int lindex = st->prev_active[i] - n_removed;
+    if (lindex >= 0) w->act[w->nact++] = lindex;
+  }
+  {
+    const int total = w->nact;
+    w->nact = 0;
+    for (int i = 0; i < total; i++) add_active(w, w->act[i]);
+  }
+  st->n_prev = 0;
+  int it = 0, go = 1, rc = 0;
+  while (go) {
+    for (int i = 0; i < n; i++) w->c[i] = -D[i] - w->Vk[i];
+    projected_direction(w);
+    int add = -1;
+    double alpha = compute_alpha(w, similar, &add);
+    if (alpha >= 1.0) { alpha = 1.0; go = 0; }
+    if (alpha < 0.0) { rc = WG_PLDP_NEG_ALPHA; break; }
+    for (int i = 0; i < n; i++) w->Vk[i] = w->Vk[i] + alpha * w->d[i];
+    if (go && add >= 0) add_active(w, add);
+    if (max_iter > 0 && it + 1 >= max_iter) go = 0;
+    it++;
+  }
+  for (int i = 0; i < n; i++) X[i] = w->Vk[i];
+  if (rc == 0) {
+    for (int i = 0; i < w->nact; i++)                        /* :959-968; v2 of the last projection */
+      if (w->v2[i] < 0.0) st->prev_active[st->n_prev++] = w->act[i];
+    for (int i = 0; i < N; i++) {                            /* StoreCurrentZMPSolution :1010-1036 */
+      st->prev_zmp[i] = 0.0;
+      st->prev_zmp[i + N] = 0.0;
+      for (int j = 0; j < N; j++) {
+        st->prev_zmp[i] += M->Pu[j * N + i] * w->Vk[j];
+        st->prev_zmp[i + N] += M->Pu[j * N + i] * w->Vk[j + N];
+      }
+      for (int j = 0; j < 3; j++) {
+        st->prev_zmp[i] += M->Px[i * 3 + j] * xkyk[j];
+        st->prev_zmp[i + N] += M->Px[i * 3 + j] * xkyk[j + 3];
+      }
+    }
+    if (isnan(X[0]) || isnan(X[N]) || isinf(X[0]) || isinf(X[N])) rc = WG_PLDP_NAN;
+    else st->internal_time += 0.02;
+  }
+  if (n_iter) *n_iter = it;
+  if (n_active) *n_active = w->nact;
+  if (active) for (int i = 0; i < w->nact; i++) active[i] = w->act[i];
+  return rc;
+}

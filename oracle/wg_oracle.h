@@ -50,6 +50,22 @@ void wgo_gait_init(const wg_model_t *model, wg_gait_state_t *state, const double
  * out and dump may be NULL.  Returns 0, or <0 if the sizes are unsupported. */
 int wgo_mpc_tick(const wg_model_t *model, wg_gait_state_t *state, wg_tick_out_t *out, wgo_qp_dump_t *dump);
 
+/* ---- Dimitrov back-end: OptCholesky + PLDPSolver restatement (pldp_oracle.c) -------------------------------------- */
+typedef struct wgo_pldp_model {
+  int N, pad_;
+  double iPu[WG_PLDP_N * WG_PLDP_N], Px[WG_PLDP_N * 3], Pu[WG_PLDP_N * WG_PLDP_N], iPuPx[2 * WG_PLDP_N * 6];
+} wgo_pldp_model_t;
+
+void wgo_optchol_update_normal(const double *A, int card_u, const int *set, int nset, double *L, int ldl);
+void wgo_optchol_update_fortran(const double *A, int m, int card_u, const int *set, int nset, double *L, int ldl);
+void wgo_chol_normal(const double *A, int n, double *L);
+void wgo_chol_inverse(const double *L, int n, int size, double *iL);
+int wgo_pldp_setup(wgo_pldp_model_t *M, int N, const double *iPu, const double *Px, const double *Pu);
+/* arguments as wg_pldp_solve_batch (include/wg_mpc.h) for one problem; returns its `ret` (or -100 on bad input) */
+int wgo_pldp_solve(const wgo_pldp_model_t *M, wg_pldp_state_t *st, const double *D, int m, const double *A,
+                   const double *b, const double *zmpref, const double *xkyk, const int *similar, int n_removed,
+                   int starting, int max_iter, double *X, int *n_iter, int *active, int *n_active);
+
 #ifdef __cplusplus
 }
 #endif

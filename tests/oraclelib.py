@@ -111,3 +111,79 @@ def same_bits(a, b):
     a = np.ascontiguousarray(a, dtype=np.float64)
     b = np.ascontiguousarray(b, dtype=np.float64)
     return a.shape == b.shape and np.array_equal(a.view(np.uint64), b.view(np.uint64))
+
+
+# ---- Dimitrov back-end (oracle/pldp_oracle.c) ------------------------------------------------------------------
+
+PLDP_N = 16
+PLDP_MMAX = 8 * PLDP_N
+
+
+class PldpState(C.Structure):            # wg_pldp_state_t (include/wg_mpc.h)
+    _fields_ = [("n_prev", C.c_int), ("prev_active", C.c_int * PLDP_MMAX), ("pad_", C.c_int),
+                ("prev_zmp", C.c_double * (2 * PLDP_N)), ("internal_time", C.c_double)]
+
+
+class PldpModel(C.Structure):            # wgo_pldp_model_t (oracle/wg_oracle.h)
+    _fields_ = [("N", C.c_int), ("pad_", C.c_int), ("iPu", C.c_double * (PLDP_N * PLDP_N)),
+                ("Px", C.c_double * (PLDP_N * 3)), ("Pu", C.c_double * (PLDP_N * PLDP_N)),
+                ("iPuPx", C.c_double * (2 * PLDP_N * 6))]
+
+
+def chol_normal(A):
+    """OptCholesky::ComputeNormalCholeskyOnANormal -> L (lower, row-major)"""
+    A = np.ascontiguousarray(A, dtype=np.float64); n = A.shape[0]
+    L = np.zeros((n, n))
+    oracle().wgo_chol_normal(_d(A), C.c_int(n), _d(L))
+    return L
+
+
+def chol_inverse(L):
+    L = np.ascontiguousarray(L, dtype=np.float64); n = L.shape[0]
+    iL = np.zeros((n, n))
+    oracle().wgo_chol_inverse(_d(L), C.c_int(n), C.c_int(n), _d(iL))
+    return iL
+
+
+def optchol_rows_normal(A, order):
+    """OptCholesky in MODE_NORMAL: AddActiveConstraint(order[0]), ... -> L (len(order) x len(order))"""
+    A = np.ascontiguousarray(A, dtype=np.float64)
+    k = len(order)
+    L = np.zeros((k, k))
+    st = np.asarray(order, dtype=np.int32)
+    for i in range(1, k + 1):
+        oracle().wgo_optchol_update_normal(_d(A), C.c_int(A.shape[1]), _i(st), C.c_int(i), _d(L), C.c_int(k))
+    return L
+
+
+def optchol_rows_fortran(A_colmajor_ld, m, card_u, order):
+    """OptCholesky in MODE_FORTRAN on a column-major array with leading dimension m+1"""
+    k = len(order)
+    L = np.zeros((k, k))
+    st = np.asarray(order, dtype=np.int32)
+    for i in range(1, k + 1):
+        oracle().wgo_optchol_update_fortran(_d(A_colmajor_ld), C.c_int(m), C.c_int(card_u), _i(st), C.c_int(i), _d(L),
+                                            C.c_int(k))
+    return L
+
+
+def pldp_setup(N, iPu, Px, Pu):
+    M = PldpModel()
+    rc = oracle().wgo_pldp_setup(C.byref(M), C.c_int(N), _d(np.ascontiguousarray(iPu, dtype=np.float64)),
+                                 _d(np.ascontiguousarray(Px, dtype=np.float64)),
+                                 _d(np.ascontiguousarray(Pu, dtype=np.float64)))
+    assert rc == 0
+    return M
+
+
+def pldp_solve(M, st, D, m, A, b, zmpref, xkyk, similar, n_removed, starting, max_iter=0):
+    """one PLDPSolver::SolveProblem on the oracle; A is the flat column-major (m+1) x 2N array"""
+    n = 2 * M.N
+    X = np.zeros(n)
+    act = np.zeros(PLDP_MMAX, dtype=np.int32)
+    nit = C.c_int(0); nact = C.c_int(0)
+    sim = np.ascontiguousarray(similar, dtype=np.int32)
+    rc = oracle().wgo_pldp_solve(C.byref(M), C.byref(st), _d(D), C.c_int(m), _d(A), _d(b), _d(zmpref), _d(xkyk), _i(sim),
+                                 C.c_int(n_removed), C.c_int(1 if starting else 0), C.c_int(max_iter), _d(X),
+                                 C.byref(nit), _i(act), C.byref(nact))
+    return dict(ret=rc, X=X, n_iter=nit.value, active=act[:nact.value].copy())
