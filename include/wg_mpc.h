@@ -287,7 +287,7 @@ int wg_riccati_gains(double T, double zc, double Q, double R, int Nl, int mode, 
  *   states   B          hot-start state, read and updated (m_PreviouslyActivatedConstraints, m_PreviousZMPSolution)
  *   X        B x 2N     solution;   ret B: 0, WG_PLDP_NAN (reference returns -1), WG_PLDP_NEG_ALPHA (reference calls
  *                       exit(0)), WG_PLDP_CAPACITY (more than WG_PLDP_ACTIVE_CAP active rows; E E' is singular long
- *                       before that)
+ *                       before that), WG_PLDP_BAD_INPUT (a positive or out-of-range SimilarConstraint offset)
  *   n_iter   B          m_ItNb;  active B x mcap / n_active B: m_ActivatedConstraints in activation order (or NULL) */
 #define WG_PLDP_N 16
 #define WG_PLDP_MMAX (8 * WG_PLDP_N)
@@ -295,6 +295,7 @@ int wg_riccati_gains(double T, double zc, double Q, double R, int Nl, int mode, 
 #define WG_PLDP_NAN (-1)
 #define WG_PLDP_NEG_ALPHA (-2)
 #define WG_PLDP_CAPACITY (-3)
+#define WG_PLDP_BAD_INPUT (-4)
 typedef struct wg_pldp_state {
   int n_prev;
   int prev_active[WG_PLDP_MMAX];

@@ -56,6 +56,7 @@ struct DevBuf {
   void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
 };
 DevBuf g_in, g_out;
+std::vector<void (*)()> g_release_hooks;   // device buffers owned by the later sections of this file
 
 }  // namespace
 
@@ -150,6 +151,7 @@ int wg_init(int device_ordinal) {
 
 void wg_shutdown(void) {
   std::lock_guard<std::mutex> lk(g_mu);
+  for (auto h : g_release_hooks) h();
   g_in.release();
   g_out.release();
   g_device = -1;
@@ -437,6 +439,148 @@ int wg_mpc_set_velref_dev(int B, wg_gait_state_t *states, const double *vref, vo
   hipLaunchKernelGGL(wg_set_velref_kernel, dim3((B + 255) / 256), dim3(256), 0, reinterpret_cast<hipStream_t>(hip_stream),
                      B, states, vref);
   HIP_TRY(hipGetLastError());
+  return WG_OK;
+}
+
+}  // extern "C"
+
+// ---- PLDP / OptCholesky back-end -----------------------------------------------------------------------------------
+#include "wg_pldp_device.hpp"
+
+__global__ void __launch_bounds__(64)
+wg_pldp_kernel(int B, int mcap, const wg::PldpModel *__restrict__ model, const int *__restrict__ m,
+               const double *__restrict__ D, const double *__restrict__ A, const double *__restrict__ b,
+               const double *__restrict__ zmpref, const double *__restrict__ xkyk, const int *__restrict__ similar,
+               const int *__restrict__ n_removed, const int *__restrict__ starting, int max_iter,
+               wg_pldp_state_t *states, double *X, int *ret, int *n_iter, int *active, int *n_active) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char pldp_lds[];
+  const wg::PldpModel &M = *model;
+  const int n = 2 * M.N;
+  const size_t aslot = (size_t)(mcap + 1) * n;
+  for (int p = blockIdx.x; p < B; p += gridDim.x) {
+    int mp = m[p];
+    if (mp < 0 || mp > mcap) {                      // refuse rather than index out of the slot
+      if (threadIdx.x == 0) { ret[p] = WG_PLDP_BAD_INPUT; if (n_iter) n_iter[p] = 0; if (n_active) n_active[p] = 0; }
+      continue;
+    }
+    wg::pldp_problem(M, pldp_lds, mcap, mp, D + (size_t)p * n, A + p * aslot, b + (size_t)p * mcap,
+                     zmpref + (size_t)p * n, xkyk + (size_t)p * 6, similar + (size_t)p * mcap, n_removed[p], starting[p],
+                     max_iter, states + p, X + (size_t)p * n, ret + p, n_iter ? n_iter + p : nullptr,
+                     active ? active + (size_t)p * mcap : nullptr, n_active ? n_active + p : nullptr);
+  }
+}
+
+namespace {
+wg::PldpModel *g_pldp_dev = nullptr;
+int g_pldp_N = 0;
+DevBuf g_pldp_buf;
+}  // namespace
+
+extern "C" {
+
+size_t wg_pldp_lds_bytes(void) { return wg::PldpLds::bytes(WG_PLDP_MMAX); }
+
+int wg_pldp_configure(int N, const double *iPu, const double *Px, const double *Pu) {
+  if (int rc = ensure_device()) return rc;
+  if (N < 1 || N > WG_PLDP_N || !iPu || !Px || !Pu) return fail(WG_ERR_BAD_ARG, "wg_pldp_configure: 1 <= N <= %d", WG_PLDP_N);
+  static wg::PldpModel host;
+  std::lock_guard<std::mutex> lk(g_mu);
+  memset(&host, 0, sizeof host);
+  host.N = N;
+  memcpy(host.iPu, iPu, sizeof(double) * N * N);
+  memcpy(host.Pu, Pu, sizeof(double) * N * N);
+  memcpy(host.Px, Px, sizeof(double) * N * 3);
+  // PLDPSolver::PrecomputeiPuPx, PLDPSolver.cpp:263-283 (block diagonal, k ascending)
+  for (int i = 0; i < N; i++)
+    for (int j = 0; j < 3; j++) {
+      double s = 0.0;
+      for (int k = 0; k < N; k++) s += iPu[k * N + i] * Px[k * 3 + j];
+      host.iPuPx[i * 6 + j] = s;
+      host.iPuPx[(i + N) * 6 + j + 3] = s;
+    }
+  if (!g_pldp_dev) {
+    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&g_pldp_dev), sizeof(wg::PldpModel)));
+    g_release_hooks.push_back([] {
+      if (g_pldp_dev) (void)hipFree(g_pldp_dev);
+      g_pldp_dev = nullptr; g_pldp_N = 0;
+      g_pldp_buf.release();
+    });
+  }
+  HIP_TRY(hipMemcpy(g_pldp_dev, &host, sizeof host, hipMemcpyHostToDevice));
+  g_pldp_N = N;
+  return WG_OK;
+}
+
+int wg_pldp_solve_batch_dev(int B, int mcap, const int *m, const double *D, const double *A, const double *b,
+                            const double *zmpref, const double *xkyk, const int *similar, const int *n_removed,
+                            const int *starting, int max_iter, wg_pldp_state_t *states, double *X, int *ret, int *n_iter,
+                            int *active, int *n_active, void *hip_stream) {
+  if (int rc = ensure_device()) return rc;
+  if (!g_pldp_N) return fail(WG_ERR_BAD_ARG, "wg_pldp_configure() has not been called");
+  if (B < 0 || mcap < 1 || mcap > WG_PLDP_MMAX) return fail(WG_ERR_BAD_ARG, "need 1 <= mcap <= %d", WG_PLDP_MMAX);
+  if (!m || !D || !A || !b || !zmpref || !xkyk || !similar || !n_removed || !starting || !states || !X || !ret)
+    return fail(WG_ERR_BAD_ARG, "null argument");
+  if (B == 0) return WG_OK;
+  const size_t lds = wg::PldpLds::bytes(mcap);
+  if (lds > 64 * 1024)
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(wg_pldp_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)lds));
+  int per_cu = (int)((160 * 1024) / lds);
+  if (per_cu < 1) per_cu = 1;
+  if (per_cu > 8) per_cu = 8;
+  int grid = g_num_cu * per_cu * 2;
+  if (grid > B) grid = B;
+  hipLaunchKernelGGL(wg_pldp_kernel, dim3(grid), dim3(64), lds, reinterpret_cast<hipStream_t>(hip_stream), B, mcap,
+                     g_pldp_dev, m, D, A, b, zmpref, xkyk, similar, n_removed, starting, max_iter, states, X, ret, n_iter,
+                     active, n_active);
+  HIP_TRY(hipGetLastError());
+  return WG_OK;
+}
+
+int wg_pldp_solve_batch(int B, int mcap, const int *m, const double *D, const double *A, const double *b,
+                        const double *zmpref, const double *xkyk, const int *similar, const int *n_removed,
+                        const int *starting, int max_iter, wg_pldp_state_t *states, double *X, int *ret, int *n_iter,
+                        int *active, int *n_active) {
+  if (int rc = ensure_device()) return rc;
+  if (!g_pldp_N) return fail(WG_ERR_BAD_ARG, "wg_pldp_configure() has not been called");
+  if (B < 0 || mcap < 1 || mcap > WG_PLDP_MMAX) return fail(WG_ERR_BAD_ARG, "need 1 <= mcap <= %d", WG_PLDP_MMAX);
+  if (!m || !D || !A || !b || !zmpref || !xkyk || !similar || !n_removed || !starting || !states || !X || !ret)
+    return fail(WG_ERR_BAD_ARG, "null argument");
+  if (B == 0) return WG_OK;
+  std::lock_guard<std::mutex> lk(g_mu);
+  const size_t sB = (size_t)B, n = 2 * (size_t)g_pldp_N;
+  const size_t aslot = (size_t)(mcap + 1) * n;
+  // one arena: doubles first, then the state structs (8-byte aligned), then ints
+  const size_t nd = sB * (n /*D*/ + aslot + mcap /*b*/ + n /*zmpref*/ + 6 + n /*X*/);
+  const size_t ni = sB * (1 /*m*/ + mcap /*similar*/ + 1 + 1 /*n_removed starting*/ + 1 + 1 /*ret n_iter*/ + mcap + 1 /*active n_active*/);
+  const size_t bytes = nd * 8 + sB * sizeof(wg_pldp_state_t) + ni * 4;
+  if (int rc = g_pldp_buf.reserve(bytes)) return rc;
+  double *dD = static_cast<double *>(g_pldp_buf.p), *dA = dD + sB * n, *db = dA + sB * aslot, *dz = db + sB * mcap,
+         *dx = dz + sB * n, *dX = dx + sB * 6;
+  wg_pldp_state_t *dst = reinterpret_cast<wg_pldp_state_t *>(dX + sB * n);
+  int *dm = reinterpret_cast<int *>(dst + sB), *dsim = dm + sB, *dnr = dsim + sB * mcap, *dstart = dnr + sB,
+      *dret = dstart + sB, *dit = dret + sB, *dact = dit + sB, *dnact = dact + sB * mcap;
+  HIP_TRY(hipMemcpy(dD, D, sB * n * 8, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(dA, A, sB * aslot * 8, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(db, b, sB * mcap * 8, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(dz, zmpref, sB * n * 8, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(dx, xkyk, sB * 6 * 8, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(dst, states, sB * sizeof(wg_pldp_state_t), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(dm, m, sB * 4, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(dsim, similar, sB * mcap * 4, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(dnr, n_removed, sB * 4, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(dstart, starting, sB * 4, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemset(dret, 0, sB * (3 + mcap) * 4));
+  int rc = wg_pldp_solve_batch_dev(B, mcap, dm, dD, dA, db, dz, dx, dsim, dnr, dstart, max_iter, dst, dX, dret, dit, dact,
+                                   dnact, nullptr);
+  if (rc) return rc;
+  HIP_TRY(hipDeviceSynchronize());
+  HIP_TRY(hipMemcpy(states, dst, sB * sizeof(wg_pldp_state_t), hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(X, dX, sB * n * 8, hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(ret, dret, sB * 4, hipMemcpyDeviceToHost));
+  if (n_iter) HIP_TRY(hipMemcpy(n_iter, dit, sB * 4, hipMemcpyDeviceToHost));
+  if (active) HIP_TRY(hipMemcpy(active, dact, sB * mcap * 4, hipMemcpyDeviceToHost));
+  if (n_active) HIP_TRY(hipMemcpy(n_active, dnact, sB * 4, hipMemcpyDeviceToHost));
   return WG_OK;
 }
 

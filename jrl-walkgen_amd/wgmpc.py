@@ -78,6 +78,10 @@ def lib():
                                            C.c_void_p]
         _lib.wg_mpc_tick_batch_dev.argtypes = _lib.wg_mpc_tick_batch.argtypes + [C.c_void_p]
         _lib.wg_mpc_set_velref_dev.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        _lib.wg_pldp_lds_bytes.restype = C.c_size_t
+        _lib.wg_pldp_configure.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        _lib.wg_pldp_solve_batch.argtypes = [C.c_int, C.c_int] + [C.c_void_p] * 9 + [C.c_int] + [C.c_void_p] * 6
+        _lib.wg_pldp_solve_batch_dev.argtypes = _lib.wg_pldp_solve_batch.argtypes + [C.c_void_p]
         _lib.wg_riccati_solve.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_double, C.c_int,
                                           C.c_int, C.c_void_p, C.c_void_p]
         _lib.wg_riccati_gains.argtypes = [C.c_double] * 4 + [C.c_int, C.c_int, C.c_void_p, C.c_void_p]
@@ -225,3 +229,41 @@ def riccati_gains(T, zc, Q, R, Nl, mode):
     if rc != 0:
         raise WgError(f"wg_riccati_gains failed ({rc})")
     return K, F[:int(Nl)]
+
+
+PLDP_N = 16
+PLDP_MMAX = 8 * PLDP_N
+
+
+class PldpState(C.Structure):           # wg_pldp_state_t
+    _fields_ = [("n_prev", C.c_int), ("prev_active", C.c_int * PLDP_MMAX), ("pad_", C.c_int),
+                ("prev_zmp", C.c_double * (2 * PLDP_N)), ("internal_time", C.c_double)]
+
+
+def pldp_configure(N, iPu, Px, Pu):
+    iPu = np.ascontiguousarray(iPu, dtype=np.float64); Px = np.ascontiguousarray(Px, dtype=np.float64)
+    Pu = np.ascontiguousarray(Pu, dtype=np.float64)
+    _check(lib().wg_pldp_configure(int(N), _hp(iPu), _hp(Px), _hp(Pu)))
+
+
+def pldp_lds_bytes():
+    return int(lib().wg_pldp_lds_bytes())
+
+
+def pldp_solve_batch(N, mcap, m, D, A, b, zmpref, xkyk, similar, n_removed, starting, states, max_iter=0):
+    """Host-pointer batch solve.  Arrays follow include/wg_mpc.h (A: B x (mcap+1)*2N flat slots, leading dimension
+    m[b]+1 inside a slot); `states` is a ctypes array of PldpState, updated in place."""
+    B = len(m)
+    n = 2 * N
+    m = np.ascontiguousarray(m, dtype=np.int32); D = np.ascontiguousarray(D, dtype=np.float64)
+    A = np.ascontiguousarray(A, dtype=np.float64); b = np.ascontiguousarray(b, dtype=np.float64)
+    zmpref = np.ascontiguousarray(zmpref, dtype=np.float64); xkyk = np.ascontiguousarray(xkyk, dtype=np.float64)
+    similar = np.ascontiguousarray(similar, dtype=np.int32)
+    n_removed = np.ascontiguousarray(n_removed, dtype=np.int32); starting = np.ascontiguousarray(starting, dtype=np.int32)
+    assert A.size == B * (mcap + 1) * n and b.size == B * mcap and similar.size == B * mcap
+    X = np.zeros((B, n)); ret = np.zeros(B, dtype=np.int32); nit = np.zeros(B, dtype=np.int32)
+    act = np.zeros((B, mcap), dtype=np.int32); nact = np.zeros(B, dtype=np.int32)
+    _check(lib().wg_pldp_solve_batch(B, int(mcap), _hp(m), _hp(D), _hp(A), _hp(b), _hp(zmpref), _hp(xkyk), _hp(similar),
+                                     _hp(n_removed), _hp(starting), int(max_iter), C.addressof(states), _hp(X), _hp(ret),
+                                     _hp(nit), _hp(act), _hp(nact)))
+    return dict(X=X, ret=ret, n_iter=nit, active=[act[i, :nact[i]].copy() for i in range(B)])
