@@ -1,0 +1,238 @@
+// wg_walkgen.hh -- host C++ facade over the C ABI (include/wg_mpc.h): the reference's PatternGeneratorInterface /
+// SimplePlugin API for the Herdt-2010 path, same class names, method names, argument meaning and error behaviour, so a
+// caller of jrl-walkgen can switch library for THIS path.  Built as lib/libwg_walkgen.so (links libwg_mpc.so).
+//
+//   reference interface                                                        here
+//   include/jrl/walkgen/pgtypes.hh:51-154                                      COMPosition, COMState, ZMPPosition, FootAbsolutePosition,
+//                                                                              RelativeFootPosition
+//   src/SimplePlugin.hh:46-72, src/SimplePluginManager.hh:46-93                SimplePlugin, SimplePluginManager
+//   src/ZMPRefTrajectoryGeneration/ZMPRefTrajectoryGeneration.hh               ZMPRefTrajectoryGeneration (on-line part)
+//   src/ZMPRefTrajectoryGeneration/ZMPVelocityReferencedQP.hh:59-131           ZMPVelocityReferencedQP
+//   include/jrl/walkgen/patterngeneratorinterface.hh:72-306                    PatternGeneratorInterface (+ factory), the methods
+//                                                                              live on this path; the others of the reference belong
+//                                                                              to generators that are out of scope and are not declared
+//
+// Differences forced by the image (documented, not hidden):
+//   * CjrlHumanoidDynamicRobot (abstract-robot-dynamics) is absent.  The path reads ~14 numbers from it
+//     (SURVEY.md 8(b)); they are the plain struct HumanoidModel.  EvaluateStartingState needs forward kinematics of the
+//     full robot, so the starting CoM / feet are fields of HumanoidModel the caller supplies.
+//   * MAL_VECTOR (jrl-mal) arguments are std::vector<double>.
+//   * There is no CPU fall-back: construction throws std::runtime_error when the HIP device or library is unusable.
+#ifndef WG_WALKGEN_HH
+#define WG_WALKGEN_HH
+
+#include <cstring>
+#include <deque>
+#include <map>
+#include <sstream>
+#include <string>
+#include <vector>
+
+#include "wg_mpc.h"
+
+namespace PatternGeneratorJRL {
+
+// ---- pgtypes.hh ---------------------------------------------------------------------------------------------------
+struct COMState_s;
+struct COMPosition_s {
+  double x[3], y[3];
+  double z[3];
+  double yaw, pitch, roll;
+  COMPosition_s &operator=(const COMState_s &aCS);
+};
+typedef COMPosition_s COMPosition;
+struct COMState_s {
+  double x[3], y[3], z[3];
+  double yaw[3], pitch[3], roll[3];
+  COMState_s &operator=(const COMPosition_s &aCS);
+  void reset();
+  COMState_s();
+};
+typedef COMState_s COMState;
+struct RelativeFootPosition_s {
+  double sx, sy, theta;
+  double SStime, DStime;
+  int stepType;
+  double DeviationHipHeight;
+};
+typedef RelativeFootPosition_s RelativeFootPosition;
+struct ZMPPosition_s {
+  double px, py, pz;
+  double theta;
+  double time;
+  int stepType;
+};
+typedef ZMPPosition_s ZMPPosition;
+struct FootAbsolutePosition_t {
+  double x, y, z, theta, omega, omega2;
+  double dx, dy, dz, dtheta, domega, domega2;
+  double ddx, ddy, ddz, ddtheta, ddomega, ddomega2;
+  double time;
+  int stepType;
+};
+typedef FootAbsolutePosition_t FootAbsolutePosition;
+
+// ---- what the path reads from the robot model -----------------------------------------------------------------------
+struct HumanoidModel {
+  double mass;                         // mass()                         ZMPVelocityReferencedQP.cpp:68, 97
+  double soleWidth, soleHeight;        // leftFoot()->getSoleSize(w,h)   relative-feet-inequalities.cpp:158-172
+  double anklePosition[3];             // getAnklePositionInLocalFrame   rigid-body-system.cpp:38, 176 (kept, unused by the tick)
+  bool hasHipYawLimits;                // jointsBetween(waist, ankle)[1] bounds, OrientationsPreview.cpp:42-68
+  double leftHipYawLower, leftHipYawUpper, rightHipYawLower, rightHipYawUpper, hipYawVelocityMax;
+  // EvaluateStartingState outputs (PatternGeneratorInterfacePrivate.cpp:588-617) -- supplied, no kinematics here
+  double startCoM[3];
+  double startZMP[3];
+  double startLeftFoot[3], startRightFoot[3];   // x, y, theta (degrees)
+  // jrl-dynamics' sample robot in TestHerdt2010's starting posture (constants identified from the reference's golden
+  // file)
+  static HumanoidModel sampleRobot();
+};
+
+// ---- SimplePlugin / SimplePluginManager -------------------------------------------------------------------------------
+class SimplePlugin;
+class SimplePluginManager {
+ public:
+  struct ltstr {
+    bool operator()(const std::string s1, const std::string s2) const { return strcmp(s1.c_str(), s2.c_str()) < 0; }
+  };
+
+ protected:
+  std::multimap<std::string, SimplePlugin *, ltstr> m_SimplePlugins;
+
+ public:
+  inline SimplePluginManager() {}
+  virtual ~SimplePluginManager();
+  const std::multimap<std::string, SimplePlugin *, ltstr> &getSimplePlugins() const { return m_SimplePlugins; }
+  bool RegisterMethod(std::string &MethodName, SimplePlugin *aSP);
+  void UnregisterPlugin(SimplePlugin *aSP);
+  bool CallMethod(std::string &MethodName, std::istringstream &istrm);
+  void Print();
+};
+
+class SimplePlugin {
+ private:
+  SimplePluginManager *m_SimplePluginManager;
+  friend class SimplePluginManager;
+
+ public:
+  inline SimplePlugin(SimplePluginManager *lSPM) : m_SimplePluginManager(lSPM) {}
+  virtual ~SimplePlugin();
+  bool RegisterMethod(std::string &MethodName);
+  virtual void CallMethod(std::string &Method, std::istringstream &astrm) = 0;
+  SimplePluginManager *getSimplePluginManager() const { return m_SimplePluginManager; }
+};
+
+// ---- ZMPRefTrajectoryGeneration (on-line part) --------------------------------------------------------------------------
+class ZMPRefTrajectoryGeneration : public SimplePlugin {
+ protected:
+  double m_Tsingle, m_Tdble, m_SamplingPeriod, m_ModulationSupportCoefficient, m_Omega, m_PreviewControlTime,
+      m_StepHeight, m_CurrentTime, m_ComHeight;
+  bool m_OnLineMode;
+
+ public:
+  ZMPRefTrajectoryGeneration(SimplePluginManager *lSPM);
+  virtual ~ZMPRefTrajectoryGeneration() {}
+  void SetTSingleSupport(double v) { m_Tsingle = v; }
+  double GetTSingleSupport() const { return m_Tsingle; }
+  void SetTDoubleSupport(double v) { m_Tdble = v; }
+  double GetTDoubleSupport() const { return m_Tdble; }
+  void SetSamplingPeriod(double v) { m_SamplingPeriod = v; }
+  double GetSamplingPeriod() const { return m_SamplingPeriod; }
+  void SetCurrentTime(double v) { m_CurrentTime = v; }
+  double GetCurrentTime() const { return m_CurrentTime; }
+  bool GetOnLineMode();
+  virtual int InitOnLine(std::deque<ZMPPosition> &FinalZMPPositions, std::deque<COMState> &COMStates,
+                         std::deque<FootAbsolutePosition> &FinalLeftFootAbsolutePositions,
+                         std::deque<FootAbsolutePosition> &FinalRightFootAbsolutePositions,
+                         FootAbsolutePosition &InitLeftFootAbsolutePosition,
+                         FootAbsolutePosition &InitRightFootAbsolutePosition,
+                         std::deque<RelativeFootPosition> &RelativeFootPositions, COMState &lStartingCOMState,
+                         double lStartingZMPPosition[3]) = 0;
+  virtual void OnLine(double time, std::deque<ZMPPosition> &FinalZMPPositions, std::deque<COMState> &COMStates,
+                      std::deque<FootAbsolutePosition> &FinalLeftFootAbsolutePositions,
+                      std::deque<FootAbsolutePosition> &FinalRightFootAbsolutePositions) = 0;
+  virtual void CallMethod(std::string &Method, std::istringstream &strm);
+};
+
+// ---- ZMPVelocityReferencedQP ----------------------------------------------------------------------------------------------
+// solution_t (privatepgtypes.hh:330-377), the fields a caller of Solution() can still read
+struct solution_t {
+  int NbVariables, NbConstraints;   // n, m of the last QP
+  int Fail;                          // QL ifail
+  int NbIterations, NbActiveConstraints;
+  double JerkX, JerkY;               // Solution_vec[0], Solution_vec[N]
+  void reset();
+};
+
+class ZMPVelocityReferencedQP : public ZMPRefTrajectoryGeneration {
+ public:
+  ZMPVelocityReferencedQP(SimplePluginManager *SPM, std::string DataFile, const HumanoidModel *aHS = 0);
+  ~ZMPVelocityReferencedQP();
+  void CallMethod(std::string &Method, std::istringstream &strm);
+  int InitOnLine(std::deque<ZMPPosition> &FinalZMPPositions, std::deque<COMState> &CoMStates,
+                 std::deque<FootAbsolutePosition> &FinalLeftFootTraj_deq,
+                 std::deque<FootAbsolutePosition> &FinalRightFootTraj_deq,
+                 FootAbsolutePosition &InitLeftFootAbsolutePosition, FootAbsolutePosition &InitRightFootAbsolutePosition,
+                 std::deque<RelativeFootPosition> &RelativeFootPositions, COMState &lStartingCOMState,
+                 double lStartingZMPPosition[3]);
+  void OnLine(double time, std::deque<ZMPPosition> &FinalZMPPositions, std::deque<COMState> &CoMStates,
+              std::deque<FootAbsolutePosition> &FinalLeftFootTraj_deq,
+              std::deque<FootAbsolutePosition> &FinalRightFootTraj_deq);
+  void Reference(std::istringstream &strm) { strm >> State_.vref[0]; strm >> State_.vref[1]; strm >> State_.vref[2]; }
+  inline void Reference(double dx, double dy, double dyaw) { State_.vref[0] = dx; State_.vref[1] = dy; State_.vref[2] = dyaw; }
+  inline bool Running() { return Running_; }
+  inline void EndingPhase(bool EndingPhase) { State_.ending_phase = EndingPhase ? 1 : 0; }
+  void setCoMPerturbationForce(double x, double y);
+  void setCoMPerturbationForce(std::istringstream &strm);
+  solution_t &Solution() { return Solution_; }
+  inline const int &QP_N(void) const { return Model_.N; }
+  // the flat state / model behind the facade (fleet callers hand these to wg_mpc_tick_batch_dev themselves)
+  const wg_model_t &Model() const { return Model_; }
+  wg_gait_state_t &State() { return State_; }
+  // Replays the revision that recorded TestHerdt2010EmergencyStopTestFGPI.datref: initial support
+  // Y = 0.1, no stop-centring branch, Running() stays true until the queues drain.  Call before InitOnLine.
+  void LegacyGoldenReplay(bool on);
+  bool LegacyGoldenReplay() const { return Legacy_; }
+
+ private:
+  wg_model_t Model_;
+  wg_gait_state_t State_;
+  solution_t Solution_;
+  bool Running_, Legacy_;
+  int NbStepsSSDS_;
+  double RobotMass_, PerturbationAcceleration_[6];
+  bool PerturbationOccured_;
+};
+
+// ---- PatternGeneratorInterface ---------------------------------------------------------------------------------------------
+class PatternGeneratorInterface {
+ public:
+  PatternGeneratorInterface(const HumanoidModel *) {}
+  virtual ~PatternGeneratorInterface() {}
+  // patterngeneratorinterface.hh:115-176
+  virtual bool RunOneStepOfTheControlLoop(std::vector<double> &CurrentConfiguration, std::vector<double> &CurrentVelocity,
+                                          std::vector<double> &CurrentAcceleration, std::vector<double> &ZMPTarget) = 0;
+  virtual bool RunOneStepOfTheControlLoop(std::vector<double> &CurrentConfiguration, std::vector<double> &CurrentVelocity,
+                                          std::vector<double> &CurrentAcceleration, std::vector<double> &ZMPTarget,
+                                          COMPosition &COMPosition, FootAbsolutePosition &LeftFootPosition,
+                                          FootAbsolutePosition &RightFootPosition) = 0;
+  virtual bool RunOneStepOfTheControlLoop(std::vector<double> &CurrentConfiguration, std::vector<double> &CurrentVelocity,
+                                          std::vector<double> &CurrentAcceleration, std::vector<double> &ZMPTarget,
+                                          COMState &COMState, FootAbsolutePosition &LeftFootPosition,
+                                          FootAbsolutePosition &RightFootPosition) = 0;
+  virtual bool RunOneStepOfTheControlLoop(FootAbsolutePosition &LeftFootPosition, FootAbsolutePosition &RightFootPosition,
+                                          ZMPPosition &ZMPRefPos, COMPosition &COMRefPos) = 0;
+  virtual void SetCurrentJointValues(std::vector<double> &lCurrentJointValues) = 0;   // :184
+  virtual int ParseCmd(std::istringstream &strm) = 0;                                  // :270
+  virtual void EvaluateStartingState(COMState &lStartingCOMState, double lStartingZMPPosition[3],
+                                     std::vector<double> &lStartingWaistPose, FootAbsolutePosition &InitLeftFootAbsPos,
+                                     FootAbsolutePosition &InitRightFootAbsPos) = 0;   // :279-283
+  virtual void setVelocityReference(double x, double y, double yaw) = 0;               // :294
+  virtual void setCoMPerturbationForce(double x, double y) = 0;                        // :301
+};
+
+// patterngeneratorinterface.hh:306; the caller owns the model and the returned object
+PatternGeneratorInterface *patternGeneratorInterfaceFactory(const HumanoidModel *);
+
+}  // namespace PatternGeneratorJRL
+#endif

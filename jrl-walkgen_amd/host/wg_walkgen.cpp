@@ -1,0 +1,421 @@
+// wg_walkgen.cpp -- host C++ facade (include/wg_walkgen.hh) over the C ABI.  No numerics here: every tick goes through
+// wg_mpc_tick_batch (HIP); this file only carries the reference's plumbing (command dispatch, the four queues, the 5 ms
+// clock) so that the reference's own test programs read the same against this library.
+#include "../../include/wg_walkgen.hh"
+
+#include <cassert>
+#include <cmath>
+#include <cstdio>
+#include <iostream>
+#include <stdexcept>
+
+using namespace std;
+
+namespace PatternGeneratorJRL {
+
+// ---- pgtypes (src/pgtypes.cpp:27-70) ----------------------------------------------------------------------------------
+COMPosition_s &COMPosition_s::operator=(const COMState_s &aCS) {
+  for (unsigned int i = 0; i < 3; i++) { x[i] = aCS.x[i]; y[i] = aCS.y[i]; z[i] = aCS.z[i]; }
+  yaw = aCS.yaw[0]; pitch = aCS.pitch[0]; roll = aCS.roll[0];
+  return *this;
+}
+COMState_s &COMState_s::operator=(const COMPosition_s &aCS) {
+  for (unsigned int i = 0; i < 3; i++) { x[i] = aCS.x[i]; y[i] = aCS.y[i]; z[i] = aCS.z[i]; }
+  yaw[0] = aCS.yaw; yaw[1] = yaw[2] = 0.0;
+  pitch[0] = aCS.pitch; pitch[1] = pitch[2] = 0.0;
+  roll[0] = aCS.roll; roll[1] = roll[2] = 0.0;
+  return *this;
+}
+void COMState_s::reset() {
+  for (unsigned int i = 0; i < 3; i++) { x[i] = 0.0; y[i] = 0.0; yaw[i] = 0.0; pitch[i] = 0.0; roll[i] = 0.0; }
+}
+COMState_s::COMState_s() { reset(); }
+
+HumanoidModel HumanoidModel::sampleRobot() {
+  HumanoidModel h;
+  memset(&h, 0, sizeof h);
+  h.mass = 56.0;                               // only scales setCoMPerturbationForce, which the tick never reads
+  h.soleWidth = 0.25; h.soleHeight = 0.14;
+  h.hasHipYawLimits = false;
+  h.startCoM[0] = 0.0316055; h.startCoM[1] = 0.0; h.startCoM[2] = 0.7116911;
+  h.startLeftFoot[1] = 0.09; h.startRightFoot[1] = -0.09;
+  return h;
+}
+
+// ---- SimplePluginManager / SimplePlugin (src/SimplePluginManager.cpp:40-163, src/SimplePlugin.cpp:35-50) -------------------
+SimplePluginManager::~SimplePluginManager() {
+  for (auto it = m_SimplePlugins.begin(); it != m_SimplePlugins.end(); ++it) it->second->m_SimplePluginManager = 0;
+}
+void SimplePluginManager::UnregisterPlugin(SimplePlugin *aSimplePlugin) {
+  auto it = m_SimplePlugins.begin();
+  while (it != m_SimplePlugins.end()) {
+    if (it->second == aSimplePlugin) it = m_SimplePlugins.erase(it);
+    else ++it;
+  }
+}
+void SimplePluginManager::Print() {
+  for (auto it = m_SimplePlugins.begin(); it != m_SimplePlugins.end(); ++it) cout << it->first << endl;
+}
+bool SimplePluginManager::RegisterMethod(string &MethodName, SimplePlugin *aSP) {
+  m_SimplePlugins.insert(pair<string, SimplePlugin *>(MethodName, aSP));
+  return true;
+}
+bool SimplePluginManager::CallMethod(string &MethodName, istringstream &istrm) {
+  auto range = m_SimplePlugins.equal_range(MethodName);
+  // every plugin registered for the method gets its own stream over the remaining arguments
+  string rest;
+  {
+    streambuf *pbuf = istrm.rdbuf();
+    streamsize size = pbuf->in_avail();
+    for (streamsize i = 0; i < size; i++) rest.push_back((char)pbuf->sbumpc());
+  }
+  bool FoundAPlugin = false;
+  for (auto it = range.first; it != range.second; ++it) {
+    istringstream iss(rest);
+    SimplePlugin *aSP = it->second;
+    if (aSP != 0) { aSP->CallMethod(MethodName, iss); FoundAPlugin = true; }
+    else cout << "SimplePlugin empty " << endl;
+  }
+  return FoundAPlugin;
+}
+bool SimplePlugin::RegisterMethod(string &MethodName) {
+  bool r = false;
+  if (m_SimplePluginManager != 0) r = m_SimplePluginManager->RegisterMethod(MethodName, this);
+  return r;
+}
+SimplePlugin::~SimplePlugin() {
+  if (m_SimplePluginManager != 0) m_SimplePluginManager->UnregisterPlugin(this);
+}
+
+// ---- ZMPRefTrajectoryGeneration (ZMPRefTrajectoryGeneration.cpp:34-110) -------------------------------------------------
+ZMPRefTrajectoryGeneration::ZMPRefTrajectoryGeneration(SimplePluginManager *lSPM)
+    : SimplePlugin(lSPM), m_Tsingle(0.), m_Tdble(0.), m_SamplingPeriod(0.), m_ModulationSupportCoefficient(0.), m_Omega(0.),
+      m_PreviewControlTime(0.), m_StepHeight(0.), m_CurrentTime(0.), m_ComHeight(0.), m_OnLineMode(false) {
+  string aMethodName[6] = {":omega", ":stepheight", ":singlesupporttime", ":doublesupporttime", ":comheight", ":samplingperiod"};
+  for (int i = 0; i < 6; i++)
+    if (!RegisterMethod(aMethodName[i])) cerr << "Unable to register " << aMethodName[i] << endl;
+}
+void ZMPRefTrajectoryGeneration::CallMethod(string &Method, istringstream &strm) {
+  if (Method == ":omega") strm >> m_Omega;
+  else if (Method == ":stepheight") strm >> m_StepHeight;
+  else if (Method == ":singlesupporttime") strm >> m_Tsingle;
+  else if (Method == ":doublesupporttime") strm >> m_Tdble;
+  else if (Method == ":comheight") strm >> m_ComHeight;
+  else if (Method == ":samplingperiod") strm >> m_SamplingPeriod;
+}
+bool ZMPRefTrajectoryGeneration::GetOnLineMode() { return m_OnLineMode; }
+
+// ---- ZMPVelocityReferencedQP ------------------------------------------------------------------------------------------------
+void solution_t::reset() { NbVariables = NbConstraints = Fail = NbIterations = NbActiveConstraints = 0; JerkX = JerkY = 0.0; }
+
+static void wg_throw(const char *what) { throw runtime_error(string(what) + ": " + wg_last_error()); }
+
+// ZMPVelocityReferencedQP.cpp:56-135
+ZMPVelocityReferencedQP::ZMPVelocityReferencedQP(SimplePluginManager *SPM, string, const HumanoidModel *aHS)
+    : ZMPRefTrajectoryGeneration(SPM) {
+  if (aHS == 0) throw runtime_error("ZMPVelocityReferencedQP: a HumanoidModel is required");
+  Running_ = false;
+  Legacy_ = false;
+  NbStepsSSDS_ = 2;                           // :79
+  m_SamplingPeriod = 0.005;
+  PerturbationOccured_ = false;
+  for (int i = 0; i < 6; i++) PerturbationAcceleration_[i] = 0.0;
+  RobotMass_ = aHS->mass;
+  Solution_.reset();
+  wg_model_defaults(&Model_);                 // QP_T_ 0.1, QP_N_ 16, 0.814, weights, FSM periods, OFTG constants
+  Model_.sole_w = aHS->soleWidth;             // RelativeFeetInequalities::set_feet_dimensions
+  Model_.sole_h = aHS->soleHeight;
+  if (aHS->hasHipYawLimits) {                 // OrientationsPreview.cpp:42-68
+    Model_.hip_l_lo = aHS->leftHipYawLower; Model_.hip_l_hi = aHS->leftHipYawUpper;
+    Model_.hip_r_lo = aHS->rightHipYawLower; Model_.hip_r_hi = aHS->rightHipYawUpper;
+    Model_.hip_vmax = fabs(aHS->hipYawVelocityMax);
+  }
+  memset(&State_, 0, sizeof State_);
+  if (wg_mpc_configure(&Model_) != WG_OK) wg_throw("wg_mpc_configure");
+  const unsigned int NbMethods = 3;
+  string aMethodName[NbMethods] = {":previewcontroltime", ":numberstepsbeforestop", ":stoppg"};
+  for (unsigned int i = 0; i < NbMethods; i++)
+    if (!RegisterMethod(aMethodName[i])) cerr << "Unable to register " << aMethodName[i] << endl;
+}
+ZMPVelocityReferencedQP::~ZMPVelocityReferencedQP() {}
+
+void ZMPVelocityReferencedQP::setCoMPerturbationForce(istringstream &strm) {   // :162-173 (stored; no reader on the path)
+  strm >> PerturbationAcceleration_[2];
+  strm >> PerturbationAcceleration_[5];
+  PerturbationAcceleration_[2] = PerturbationAcceleration_[2] / RobotMass_;
+  PerturbationAcceleration_[5] = PerturbationAcceleration_[5] / RobotMass_;
+  PerturbationOccured_ = true;
+}
+void ZMPVelocityReferencedQP::setCoMPerturbationForce(double x, double y) {     // :175-184
+  PerturbationAcceleration_[2] = x / RobotMass_;
+  PerturbationAcceleration_[5] = y / RobotMass_;
+  PerturbationOccured_ = true;
+}
+
+void ZMPVelocityReferencedQP::CallMethod(string &Method, istringstream &strm) {   // :191-209
+  if (Method == ":previewcontroltime") strm >> m_PreviewControlTime;
+  if (Method == ":numberstepsbeforestop") {
+    strm >> State_.nb_steps_left;                  // CurrentSupport.NbStepsLeft
+    NbStepsSSDS_ = State_.nb_steps_left;           // SupportFSM_->NbStepsSSDS()
+    State_.nb_steps_ssds = NbStepsSSDS_;
+  }
+  if (Method == ":stoppg") State_.ending_phase = 1;
+  ZMPRefTrajectoryGeneration::CallMethod(Method, strm);
+  Model_.Tctrl = m_SamplingPeriod;
+}
+
+void ZMPVelocityReferencedQP::LegacyGoldenReplay(bool on) {
+  Legacy_ = on;
+  if (on) Model_.flags |= WG_FLAG_NO_STOP_CENTERING;
+  else Model_.flags &= ~WG_FLAG_NO_STOP_CENTERING;
+  if (wg_mpc_configure(&Model_) != WG_OK) wg_throw("wg_mpc_configure");
+}
+
+static FootAbsolutePosition toFAP(const wg_foot_sample_t &s, double time, int stepType) {
+  FootAbsolutePosition f;
+  memcpy(&f, &s, sizeof s);           // same 18 leading doubles, pgtypes.hh:137-154
+  f.time = time; f.stepType = stepType;
+  return f;
+}
+
+// :212-319
+int ZMPVelocityReferencedQP::InitOnLine(deque<ZMPPosition> &FinalZMPTraj_deq, deque<COMState> &FinalCoMPositions_deq,
+                                        deque<FootAbsolutePosition> &FinalLeftFootTraj_deq,
+                                        deque<FootAbsolutePosition> &FinalRightFootTraj_deq,
+                                        FootAbsolutePosition &InitLeftFootAbsolutePosition,
+                                        FootAbsolutePosition &InitRightFootAbsolutePosition, deque<RelativeFootPosition> &,
+                                        COMState &lStartingCOMState, double lStartingZMPPosition[3]) {
+  int AddArraySize;
+  {
+    assert(m_SamplingPeriod > 0);
+    double ldAddArraySize = 0.04 / m_SamplingPeriod;        // TimeBuffer_ :62
+    AddArraySize = (int)ldAddArraySize;
+  }
+  FinalZMPTraj_deq.resize(AddArraySize);
+  FinalCoMPositions_deq.resize(AddArraySize);
+  FinalLeftFootTraj_deq.resize(AddArraySize);
+  FinalRightFootTraj_deq.resize(AddArraySize);
+  m_CurrentTime = 0;
+  for (unsigned int i = 0; i < FinalZMPTraj_deq.size(); i++) {
+    FinalZMPTraj_deq[i].px = lStartingZMPPosition[0];
+    FinalZMPTraj_deq[i].py = lStartingZMPPosition[1];
+    FinalZMPTraj_deq[i].pz = lStartingZMPPosition[2];
+    FinalZMPTraj_deq[i].theta = 0.0;
+    FinalZMPTraj_deq[i].time = m_CurrentTime;
+    FinalZMPTraj_deq[i].stepType = 0;
+    FinalCoMPositions_deq[i] = lStartingCOMState;
+    FinalLeftFootTraj_deq[i] = InitLeftFootAbsolutePosition;
+    FinalRightFootTraj_deq[i] = InitRightFootAbsolutePosition;
+    FinalLeftFootTraj_deq[i].time = FinalRightFootTraj_deq[i].time = m_CurrentTime;
+    FinalLeftFootTraj_deq[i].stepType = FinalRightFootTraj_deq[i].stepType = 10;
+    m_CurrentTime += m_SamplingPeriod;
+  }
+  const double com0[3] = {lStartingCOMState.x[0], lStartingCOMState.y[0], lStartingCOMState.z[0]};
+  const double l[3] = {InitLeftFootAbsolutePosition.x, InitLeftFootAbsolutePosition.y, InitLeftFootAbsolutePosition.theta};
+  const double r[3] = {InitRightFootAbsolutePosition.x, InitRightFootAbsolutePosition.y, InitRightFootAbsolutePosition.theta};
+  const double vref[3] = {State_.vref[0], State_.vref[1], State_.vref[2]};
+  wg_gait_init(&Model_, &State_, com0, l, r);           // support state, LIPM, trunk state, scheduling (:228-305)
+  State_.com_x[1] = lStartingCOMState.x[1]; State_.com_x[2] = lStartingCOMState.x[2];
+  State_.com_y[1] = lStartingCOMState.y[1]; State_.com_y[2] = lStartingCOMState.y[2];
+  State_.vref[0] = vref[0]; State_.vref[1] = vref[1]; State_.vref[2] = vref[2];   // NewVelRef_ survives InitOnLine
+  State_.nb_steps_ssds = NbStepsSSDS_;                                            // SupportFSM_ survives too
+  if (Legacy_) State_.sup_y = 0.1;
+  m_OnLineMode = true;
+  Running_ = false;
+  return 0;
+}
+
+// :323-458
+void ZMPVelocityReferencedQP::OnLine(double time, deque<ZMPPosition> &FinalZMPTraj_deq, deque<COMState> &FinalCOMTraj_deq,
+                                     deque<FootAbsolutePosition> &FinalLeftFootTraj_deq,
+                                     deque<FootAbsolutePosition> &FinalRightFootTraj_deq) {
+  if (!m_OnLineMode) return;
+  if (State_.ending_phase && time >= State_.time_to_stop) { m_OnLineMode = false; State_.online = 0; }
+  if (time + 0.00001 > State_.upper_time_limit) {
+    State_.clock = time;
+    wg_tick_out_t out;
+    if (wg_mpc_tick_batch(1, &State_, &out, 0, 0, 0, 0, 0) != WG_OK) wg_throw("wg_mpc_tick_batch");
+    Solution_.NbVariables = out.n; Solution_.NbConstraints = out.m; Solution_.Fail = out.ifail;
+    Solution_.NbIterations = out.n_iter; Solution_.NbActiveConstraints = out.nact;
+    Solution_.JerkX = out.jerk_x; Solution_.JerkY = out.jerk_y;
+    if (!FinalLeftFootTraj_deq.empty()) {       // the DS branch rewrites the newest queued sample, OFTG.cpp:333-336
+      FinalLeftFootTraj_deq.back() = toFAP(out.lf_back, FinalLeftFootTraj_deq.back().time, FinalLeftFootTraj_deq.back().stepType);
+      FinalRightFootTraj_deq.back() = toFAP(out.rf_back, FinalRightFootTraj_deq.back().time, FinalRightFootTraj_deq.back().stepType);
+    }
+    for (int k = 0; k < WG_SAMPLES_PER_TICK; ++k) {
+      COMState c;
+      for (int d = 0; d < 3; d++) { c.x[d] = out.com_x[k][d]; c.y[d] = out.com_y[k][d]; }
+      c.z[0] = State_.com_z; c.z[1] = 0.0; c.z[2] = 0.0;
+      c.yaw[0] = out.com_yaw[k][0]; c.yaw[1] = out.com_yaw[k][1];
+      FinalCOMTraj_deq.push_back(c);
+      ZMPPosition z;
+      z.px = out.zmp_x[k]; z.py = out.zmp_y[k]; z.pz = 0.0; z.theta = 0.0;
+      z.time = time + k * m_SamplingPeriod; z.stepType = 0;
+      FinalZMPTraj_deq.push_back(z);
+      FinalLeftFootTraj_deq.push_back(toFAP(out.lf[k], z.time, 0));
+      FinalRightFootTraj_deq.push_back(toFAP(out.rf[k], z.time, 0));
+    }
+    Running_ = State_.running != 0;
+  }
+}
+
+// ---- PatternGeneratorInterfacePrivate (Herdt branch) ------------------------------------------------------------------------
+namespace {
+
+class PatternGeneratorInterfacePrivate : public virtual PatternGeneratorInterface, SimplePluginManager, SimplePlugin {
+ public:
+  PatternGeneratorInterfacePrivate(const HumanoidModel *aHDR)
+      : PatternGeneratorInterface(aHDR), SimplePlugin(this), m_Model(*aHDR) {
+    // PatternGeneratorInterfacePrivate.cpp:181-215: the commands this object handles itself
+    string aMethodName[6] = {":samplingperiod", ":setVelReference", ":HerdtOnline", ":setCoMPerturbationForce",
+                             ":SetAlgoForZmpTrajectory", ":wg_legacy_golden"};
+    for (int i = 0; i < 6; i++)
+      if (!SimplePlugin::RegisterMethod(aMethodName[i])) cerr << "Unable to register " << aMethodName[i] << endl;
+    m_ZMPVRQP = new ZMPVelocityReferencedQP(this, "", &m_Model);
+    m_SamplingPeriod = 0.005;
+    m_InternalClock = 0.0;
+    m_ShouldBeRunning = false;
+    m_Running = false;
+    m_Herdt = false;
+    m_NbOfHitBottom = 0;
+  }
+  ~PatternGeneratorInterfacePrivate() { delete m_ZMPVRQP; }
+
+  int ParseCmd(istringstream &strm) {                     // :1029-1039
+    string aCmd;
+    strm >> aCmd;
+    if (SimplePluginManager::CallMethod(aCmd, strm)) {}
+    return 0;
+  }
+
+  void CallMethod(string &aCmd, istringstream &strm) {    // :1055-1133 (the commands that exist on this path)
+    if (aCmd == ":samplingperiod") {
+      double sp;
+      strm >> sp;
+      m_SamplingPeriod = sp;
+    } else if (aCmd == ":setVelReference") {
+      m_ZMPVRQP->Reference(strm);
+    } else if (aCmd == ":HerdtOnline") {
+      m_InternalClock = 0.0;
+      initOnlineHerdt();
+      printf("Online \n");
+    } else if (aCmd == ":setCoMPerturbationForce") {
+      m_ZMPVRQP->setCoMPerturbationForce(strm);
+    } else if (aCmd == ":SetAlgoForZmpTrajectory") {
+      string ZMPTrajAlgo;
+      strm >> ZMPTrajAlgo;
+      if (ZMPTrajAlgo == "Herdt") { m_Herdt = true; cout << "Herdt" << endl; }
+      else { m_Herdt = false; cerr << "wg: only the Herdt generator is built (asked for " << ZMPTrajAlgo << ")" << endl; }
+    } else if (aCmd == ":wg_legacy_golden") {
+      int on = 0;
+      strm >> on;
+      m_ZMPVRQP->LegacyGoldenReplay(on != 0);
+    }
+  }
+
+  void EvaluateStartingState(COMState &lStartingCOMState, double lStartingZMPPosition[3], vector<double> &lStartingWaistPose,
+                             FootAbsolutePosition &InitLeftFootAbsPos, FootAbsolutePosition &InitRightFootAbsPos) {
+    lStartingCOMState.reset();
+    lStartingCOMState.x[0] = m_Model.startCoM[0]; lStartingCOMState.y[0] = m_Model.startCoM[1];
+    lStartingCOMState.z[0] = m_Model.startCoM[2]; lStartingCOMState.z[1] = lStartingCOMState.z[2] = 0.0;
+    for (int i = 0; i < 3; i++) lStartingZMPPosition[i] = m_Model.startZMP[i];
+    lStartingWaistPose.assign(6, 0.0);
+    memset(&InitLeftFootAbsPos, 0, sizeof InitLeftFootAbsPos);
+    memset(&InitRightFootAbsPos, 0, sizeof InitRightFootAbsPos);
+    InitLeftFootAbsPos.x = m_Model.startLeftFoot[0]; InitLeftFootAbsPos.y = m_Model.startLeftFoot[1];
+    InitLeftFootAbsPos.theta = m_Model.startLeftFoot[2];
+    InitRightFootAbsPos.x = m_Model.startRightFoot[0]; InitRightFootAbsPos.y = m_Model.startRightFoot[1];
+    InitRightFootAbsPos.theta = m_Model.startRightFoot[2];
+  }
+
+  void initOnlineHerdt() {                                // :517-560
+    COMState lStartingCOMState;
+    double lStartingZMPPosition[3];
+    vector<double> lStartingWaistPose;
+    FootAbsolutePosition InitLeftFootAbsPos, InitRightFootAbsPos;
+    EvaluateStartingState(lStartingCOMState, lStartingZMPPosition, lStartingWaistPose, InitLeftFootAbsPos, InitRightFootAbsPos);
+    deque<RelativeFootPosition> RelativeFootPositions;
+    m_ZMPVRQP->SetCurrentTime(m_InternalClock);
+    m_ZMPVRQP->InitOnLine(m_ZMPPositions, m_COMBuffer, m_LeftFootPositions, m_RightFootPositions, InitLeftFootAbsPos,
+                          InitRightFootAbsPos, RelativeFootPositions, lStartingCOMState, lStartingZMPPosition);
+    m_NbOfHitBottom = 0;
+    m_ShouldBeRunning = true;
+  }
+
+  // CoMAndFootOnlyStrategy::EndOfMotion with m_BufferSizeLimit = 0, CoMAndFootOnlyStrategy.cpp:157-188
+  int EndOfMotion() {
+    if (m_LeftFootPositions.size() > 0) { m_NbOfHitBottom = 0; return 1; }
+    if (m_NbOfHitBottom == 0) { m_NbOfHitBottom++; return 0; }
+    return -1;
+  }
+
+  // :1246-1514 (Herdt branch) + CoMAndFootOnlyStrategy::OneGlobalStepOfControl
+  bool RunOneStepOfTheControlLoop(vector<double> &, vector<double> &, vector<double> &, vector<double> &ZMPTarget,
+                                  COMState &finalCOMState, FootAbsolutePosition &LeftFootPosition,
+                                  FootAbsolutePosition &RightFootPosition) {
+    m_InternalClock += m_SamplingPeriod;
+    if ((!m_ShouldBeRunning) || (EndOfMotion() < 0)) {
+      m_Running = false;
+      return m_Running;
+    }
+    m_Running = true;
+    if (m_Herdt) {
+      m_ZMPVRQP->OnLine(m_InternalClock, m_ZMPPositions, m_COMBuffer, m_LeftFootPositions, m_RightFootPositions);
+      m_Running = m_ZMPVRQP->Running() || m_ZMPVRQP->LegacyGoldenReplay();
+    }
+    if (m_LeftFootPositions.size() > 0) { LeftFootPosition = m_LeftFootPositions[0]; m_LeftFootPositions.pop_front(); }
+    else return m_Running = false;
+    if (m_RightFootPositions.size() > 0) { RightFootPosition = m_RightFootPositions[0]; m_RightFootPositions.pop_front(); }
+    if (m_COMBuffer.size() > 0) { finalCOMState = m_COMBuffer[0]; m_COMBuffer.pop_front(); }
+    if (m_ZMPPositions.size() > 0) {
+      ZMPTarget.assign(3, 0.0);
+      ZMPTarget[0] = m_ZMPPositions[0].px; ZMPTarget[1] = m_ZMPPositions[0].py; ZMPTarget[2] = 0;
+      m_ZMPPositions.pop_front();
+    }
+    return m_Running;
+  }
+  bool RunOneStepOfTheControlLoop(vector<double> &q, vector<double> &dq, vector<double> &ddq, vector<double> &ZMPTarget,
+                                  COMPosition &finalCOMPosition, FootAbsolutePosition &L, FootAbsolutePosition &R) {
+    COMState aCOMState;
+    m_Running = RunOneStepOfTheControlLoop(q, dq, ddq, ZMPTarget, aCOMState, L, R);
+    finalCOMPosition = aCOMState;
+    return m_Running;
+  }
+  bool RunOneStepOfTheControlLoop(vector<double> &q, vector<double> &dq, vector<double> &ddq, vector<double> &ZMPTarget) {
+    FootAbsolutePosition L, R;
+    COMState c;
+    return RunOneStepOfTheControlLoop(q, dq, ddq, ZMPTarget, c, L, R);
+  }
+  bool RunOneStepOfTheControlLoop(FootAbsolutePosition &L, FootAbsolutePosition &R, ZMPPosition &ZMPRefPos,
+                                  COMPosition &COMRefPos) {    // :1198-1229
+    vector<double> q, dq, ddq, ZMPTarget;
+    COMState c;
+    bool r = RunOneStepOfTheControlLoop(q, dq, ddq, ZMPTarget, c, L, R);
+    if (ZMPTarget.size() >= 3) { ZMPRefPos.px = ZMPTarget[0]; ZMPRefPos.py = ZMPTarget[1]; ZMPRefPos.pz = ZMPTarget[2]; }
+    COMRefPos = c;
+    return r;
+  }
+  void SetCurrentJointValues(vector<double> &v) { m_CurrentJointValues = v; }
+  void setVelocityReference(double x, double y, double yaw) { m_ZMPVRQP->Reference(x, y, yaw); }
+  void setCoMPerturbationForce(double x, double y) { m_ZMPVRQP->setCoMPerturbationForce(x, y); }
+
+ private:
+  HumanoidModel m_Model;
+  ZMPVelocityReferencedQP *m_ZMPVRQP;
+  deque<ZMPPosition> m_ZMPPositions;
+  deque<COMState> m_COMBuffer;
+  deque<FootAbsolutePosition> m_LeftFootPositions, m_RightFootPositions;
+  vector<double> m_CurrentJointValues;
+  double m_SamplingPeriod, m_InternalClock;
+  bool m_ShouldBeRunning, m_Running, m_Herdt;
+  int m_NbOfHitBottom;
+};
+
+}  // namespace
+
+PatternGeneratorInterface *patternGeneratorInterfaceFactory(const HumanoidModel *aHDR) {
+  if (aHDR == 0) throw runtime_error("patternGeneratorInterfaceFactory: a HumanoidModel is required");
+  return new PatternGeneratorInterfacePrivate(aHDR);
+}
+
+}  // namespace PatternGeneratorJRL

@@ -40,3 +40,24 @@ def test_fails_loudly_without_gpu():
     rc = lib.wg_init(0)
     assert rc != 0
     assert b"no CPU path" in lib.wg_last_error() or b"HIP" in lib.wg_last_error()
+
+
+def test_cpp_facade_builds_and_fails_loudly_without_gpu(tmp_path):
+    """libwg_walkgen.so (PatternGeneratorInterface / SimplePlugin API) exports the factory; without a HIP device the
+    TestHerdt2010 driver stops with an error instead of producing a trace from some fall-back."""
+    import subprocess
+    import torch
+    lib = os.path.join(ROOT, "jrl-walkgen_amd", "lib", "libwg_walkgen.so")
+    exe = os.path.join(ROOT, "jrl-walkgen_amd", "bin", "test_herdt2010")
+    assert os.path.exists(lib) and os.path.exists(exe), "run __graft_entry__.build()"
+    syms = subprocess.run(["nm", "-DC", lib], capture_output=True, text=True).stdout
+    for s in ("PatternGeneratorJRL::patternGeneratorInterfaceFactory", "PatternGeneratorJRL::SimplePluginManager::CallMethod",
+              "PatternGeneratorJRL::SimplePlugin::RegisterMethod", "PatternGeneratorJRL::ZMPVelocityReferencedQP::OnLine",
+              "PatternGeneratorJRL::ZMPVelocityReferencedQP::InitOnLine"):
+        assert s in syms, s
+    if torch.cuda.is_available():
+        return
+    out = tmp_path / "t.dat"
+    r = subprocess.run([exe, str(out)], capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0 and "FAILED" in r.stderr
+    assert (not out.exists()) or out.stat().st_size == 0
