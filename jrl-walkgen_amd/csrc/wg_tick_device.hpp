@@ -353,6 +353,16 @@ __device__ inline void op_preview(const wg_model_t &m, wg_gait_state_t *s, doubl
   }
 }
 
+// dst = cond ? a : b, field by field (keeps the samples in registers)
+__device__ __forceinline__ void foot_select(wg_foot_sample_t &dst, bool cond, const wg_foot_sample_t &a,
+                                            const wg_foot_sample_t &b) {
+#define WG_FSEL(f) dst.f = cond ? a.f : b.f
+  WG_FSEL(x); WG_FSEL(y); WG_FSEL(z); WG_FSEL(theta); WG_FSEL(omega); WG_FSEL(omega2);
+  WG_FSEL(dx); WG_FSEL(dy); WG_FSEL(dz); WG_FSEL(dtheta); WG_FSEL(domega); WG_FSEL(domega2);
+  WG_FSEL(ddx); WG_FSEL(ddy); WG_FSEL(ddz); WG_FSEL(ddtheta); WG_FSEL(ddomega); WG_FSEL(ddomega2);
+#undef WG_FSEL
+}
+
 // polynomial helpers, Polynome.cpp:44-76, PolynomeFoot.cpp:59-79, 100-120, 226-240
 __device__ inline double poly_eval(const double *c, int deg, double t) {
   double r = 0.0, pt = 1.0;
@@ -785,16 +795,21 @@ __device__ inline TickDiag mpc_tick(const wg_model_t &m, const TickTables *__res
       const double c = 3.0 * (s->trunkT_yaw[1] - s->trunk_yaw[1]) / (T * T);
       const double d = -2.0 * c / (3.0 * T);
       const double theta = s->trunk_yaw[0];
+      const double yT1 = s->trunkT_yaw[1];
+      double y0 = theta, y1 = a, y2 = s->trunk_yaw[2];
+      // kept rolled: unrolling makes the compiler hoist all 20 sample times to the top of the kernel and spill them
+#pragma unroll 1
       for (int k = 0; k < K; k++) {
         const double tT = (double)(k + 1) * dt;
         // the test uses the yaw rate as updated by the previous sample, like the reference (:390)
-        if (fabs(s->trunkT_yaw[1] - s->trunk_yaw[1]) - 0.000001 > 0) {
-          s->trunk_yaw[0] = (((1.0 / 4.0 * d * tT + 1.0 / 3.0 * c) * tT) * tT + a) * tT + theta;
-          s->trunk_yaw[1] = ((d * tT + c) * tT) * tT + a;
-          s->trunk_yaw[2] = (3.0 * d * tT + 2.0 * c) * tT;
-        } else s->trunk_yaw[0] += dt * s->trunkT_yaw[1];
-        if (out) { out->com_yaw[k][0] = s->trunk_yaw[0]; out->com_yaw[k][1] = s->trunk_yaw[1]; }
+        if (fabs(yT1 - y1) - 0.000001 > 0) {
+          y0 = (((1.0 / 4.0 * d * tT + 1.0 / 3.0 * c) * tT) * tT + a) * tT + theta;
+          y1 = ((d * tT + c) * tT) * tT + a;
+          y2 = (3.0 * d * tT + 2.0 * c) * tT;
+        } else y0 += dt * yT1;
+        if (out) { out->com_yaw[k][0] = y0; out->com_yaw[k][1] = y1; }
       }
+      s->trunk_yaw[0] = y0; s->trunk_yaw[1] = y1; s->trunk_yaw[2] = y2;
     } else if (cs.phase == WG_DS || time + 3.0 / 2.0 * T > cs.time_limit) {
       for (int k = 0; k < K; k++)
         if (out) { out->com_yaw[k][0] = s->trunk_yaw[0]; out->com_yaw[k][1] = s->trunk_yaw[1]; }
@@ -831,9 +846,10 @@ __device__ inline TickDiag mpc_tick(const wg_model_t &m, const TickTables *__res
       const double end_lift = (m.t_single - unlocked) * 0.5;
       double swing_passed = 0.0;
       if (local_t > end_lift) swing_passed = local_t - end_lift;
-      const wg_foot_sample_t last = left_support ? s->rf[2] : s->lf[2];      // swing foot, queue back
-      const wg_foot_sample_t sw_prev = left_support ? s->rf[1] : s->lf[1];   // swing foot, [StartIndex-1]
-      const wg_foot_sample_t st_prev = left_support ? s->lf[1] : s->rf[1];   // stance foot, [StartIndex-1]
+      // pointers, not struct copies: a selected struct value becomes a 144-byte stack object (scratch)
+      const wg_foot_sample_t &last = left_support ? s->rf[2] : s->lf[2];      // swing foot, queue back
+      const wg_foot_sample_t &sw_prev = left_support ? s->rf[1] : s->lf[1];   // swing foot, [StartIndex-1]
+      const wg_foot_sample_t &st_prev = left_support ? s->lf[1] : s->rf[1];   // stance foot, [StartIndex-1]
       const double ti = unlocked - swing_passed;
       double px5[6], py5[6], pth[4], pom[4], pom2[4], pz[5];
       poly5_set(px5, ti, FPx, last.x, last.dx, last.ddx);
@@ -886,7 +902,11 @@ __device__ inline TickDiag mpc_tick(const wg_model_t &m, const TickTables *__res
         else { dX = (Ff - Ff * wg_cos(lOmega) + Hf * wg_sin(lOmega)); dFZ = Hf * wg_cos(lOmega) + Ff * wg_sin(lOmega) - Hf; }
         c.x += cth * dX; c.y += sth * dX; c.z += dFZ;
       }
-      if (left_support) { outr = c; outl = st_prev; } else { outl = c; outr = st_prev; }
+      {
+        const wg_foot_sample_t stance = st_prev;
+        foot_select(outl, left_support, stance, c);
+        foot_select(outr, left_support, c, stance);
+      }
       if (lane == 0 && cs.state_changed) for (int e = 0; e < 5; ++e) s->poly_z[e] = pz[e];
     } else if (cs.phase == WG_DS || time + 3.0 / 2.0 * T > cs.time_limit) {
       outl = s->lf[1]; outr = s->rf[1];                    // k = 0 rewrites the queue back (:333-336)
