@@ -58,34 +58,52 @@ def algorithmic_bytes(n, m):
     return 8.0 * (n * n + n + mmax * n + mmax + 2 * n) + 8.0 * (n + m + 2 * n)
 
 
-def cpu_baseline(model, n_gaits, n_ticks):
-    """The CPU restatement (oracle/, libm trigonometry) on the first `n_gaits` gaits of the same workload,
-    one core.  Checker code timed as a baseline -- never part of the measured GPU path."""
+def _cpu_run(args):
+    """one process = one core: gaits [g0, g0+ng) of the benchmark workload through the CPU checker, loop in C"""
+    g0, ng, n_ticks, use_ref = args
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oraclelib as ol
     lib = ol.oracle()
-    tab = velocity_table(0, n_gaits, (n_ticks + REDRAW_TICKS - 1) // REDRAW_TICKS)
-    states = (wg.GaitState * n_gaits)()
+    kind = "port"
+    lib.wgo_set_reference_ql(None)
+    if use_ref and ol.have_ref():
+        lib.wgo_set_reference_ql(C.cast(getattr(ol.ref(), ol.REF_SYM), C.c_void_p))
+        kind = "reference"
+    model = wg.Model()
+    lib.wgo_model_defaults(C.byref(model))
+    tab = np.ascontiguousarray(velocity_table(g0, g0 + ng, (n_ticks + REDRAW_TICKS - 1) // REDRAW_TICKS))
+    states = (wg.GaitState * ng)()
     s0 = wg.gait_init(model, [0.0316055, 0.0, 0.7116911], [0.0, 0.09, 0.0], [0.0, -0.09, 0.0])
     s0.nb_steps_left = 2
-    for g in range(n_gaits):
+    for g in range(ng):
         C.memmove(C.byref(states[g]), C.byref(s0), C.sizeof(wg.GaitState))
-    mref = C.byref(model)
     t0 = time.perf_counter()
-    for tick in range(n_ticks):
-        adv = 1 if tick == 0 else (19 if tick == 1 else 20)
-        seg = tick // REDRAW_TICKS
-        for g in range(n_gaits):
-            st = states[g]
-            if tick % REDRAW_TICKS == 0:
-                st.vref[0], st.vref[1], st.vref[2] = tab[seg, g]
-            c = st.clock
-            for _ in range(adv):
-                c += model.Tctrl
-            st.clock = c
-            lib.wgo_mpc_tick(mref, C.byref(st), None, None)
+    rc = lib.wgo_mpc_run(C.byref(model), states, ng, n_ticks, tab.ctypes.data_as(C.c_void_p), REDRAW_TICKS)
     dt = time.perf_counter() - t0
-    return n_gaits * n_ticks / dt, dt
+    assert rc == 0
+    return ng * n_ticks, dt, kind
+
+
+def cpu_baseline(n_gaits, n_ticks):
+    """The CPU checker on the first `n_gaits` gaits of the same workload: tick assembly = oracle/ C restatement,
+    QP solve = the reference's own qld.cpp compiled -O3 -DNDEBUG (oracle/_ref, ~all of the CPU time) when it was built,
+    else the restated solver.  Timed on one core, then on every host core (one process per core, QLD keeps statics).
+    Checker code timed as a baseline -- never part of the measured GPU path."""
+    import multiprocessing as mp
+    ticks, dt, kind = _cpu_run((0, n_gaits, n_ticks, True))
+    one = dict(value=ticks / dt, seconds=dt, kind=kind)
+    cores = os.cpu_count() or 1
+    per = max(8, n_gaits // 16)
+    try:
+        with mp.get_context("fork").Pool(cores) as pool:
+            t0 = time.perf_counter()
+            res = pool.map(_cpu_run, [(w * per, per, n_ticks, True) for w in range(cores)])
+            wall = time.perf_counter() - t0
+        allc = dict(value=sum(r[0] for r in res) / max(r[1] for r in res), cores=cores, wall_seconds=wall,
+                    sample="%d gaits x %d ticks per core" % (per, n_ticks))
+    except Exception as e:                                        # noqa: BLE001 -- a baseline, never fatal
+        allc = dict(value=None, cores=cores, error=str(e))
+    return one, allc
 
 
 def main():
@@ -96,6 +114,19 @@ def main():
     ap.add_argument("--batch", type=int, default=BATCH_PER_GPU, help="gaits per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
+
+    # CPU baseline first: it forks one worker per host core, which must happen before this process touches the GPU
+    cpu_line = None
+    if int(os.environ.get("WORLD_SIZE", "1")) == 1 and not args.no_cpu_baseline:
+        ng, nt = 256, 200
+        one, allc = cpu_baseline(ng, nt)
+        solver = ("QP solve by the reference's qld.cpp compiled -O3 -DNDEBUG (oracle/_ref)" if one["kind"] == "reference"
+                  else "QP solve by the restated QL (oracle/ql_oracle.c)")
+        cpu_line = {"value": one["value"], "unit": "ticks/s", "cores": 1, "kind": one["kind"],
+                    "sample": f"first {ng} gaits x {nt} ticks of the same workload ({ng * nt} ticks, "
+                              f"{one['seconds']:.1f} s); tick assembly by the oracle/ C restatement, {solver}; "
+                              f"1 core of {os.cpu_count()} host cores",
+                    "all_cores": allc}
 
     rank, local_rank, world = shard.init_process_group("nccl")
     if world != args.gpus and world > 1:
@@ -186,13 +217,8 @@ def main():
                        "mean_active": float(d[:, 2].mean()), "failed_qps": n_fail,
                        "n_hist": {str(int(k)): int(v) for k, v in zip(*np.unique(d[:, 3], return_counts=True))}},
         }
-        if world == 1 and not args.no_cpu_baseline:
-            ng, nt = 1024, 200
-            v, secs = cpu_baseline(model, ng, nt)
-            line["cpu_baseline"] = {"value": v, "unit": "ticks/s", "cores": 1, "kind": "port",
-                                    "sample": f"first {ng} gaits x {nt} ticks of the same workload "
-                                              f"({ng * nt} ticks, {secs:.1f} s), oracle/ C restatement, 1 core of "
-                                              f"{os.cpu_count()} host cores"}
+        if cpu_line is not None:
+            line["cpu_baseline"] = cpu_line
         print(json.dumps(line), flush=True)
 
 

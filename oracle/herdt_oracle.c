@@ -424,6 +424,13 @@ typedef struct {
   double *C, *d, *A, *b, *xl, *xu;     /* column-major, ld n / mmax */
 } qp_t;
 
+typedef int (*wgo_ql0001_fn)(int *m, int *me, int *mmax, int *n, int *nmax, int *mnn, double *c, double *d, double *a,
+                             double *b, double *xl, double *xu, double *x, double *u, int *iout, int *ifail, int *iprint,
+                             double *war, int *lwar, int *iwar, int *liwar, double *eps1);
+static wgo_ql0001_fn g_ref_ql = 0;
+/* route the tick's QP through the reference's own compiled solver (NULL = this directory's restatement) */
+void wgo_set_reference_ql(void *ql0001_entry) { g_ref_ql = (wgo_ql0001_fn)ql0001_entry; }
+
 int wgo_mpc_tick(const wg_model_t *m, wg_gait_state_t *s, wg_tick_out_t *out, wgo_qp_dump_t *dump) {
   const int N = m->N;
   const double T = m->T;
@@ -630,6 +637,19 @@ int wgo_mpc_tick(const wg_model_t *m, wg_gait_state_t *s, wg_tick_out_t *out, wg
   /* --- QPProblem::solve, qp-problem.cpp:245-294 ------------------------------- */
   int ifail = 0, nact = 0, nit = 0, hlen = 0;
   int *iact = (int *)calloc((size_t)n + 1, sizeof(int));
+  if (g_ref_ql) {
+    /* the REFERENCE's compiled ql0001_ (oracle/_ref/libqld_ref.so) does the solve, called exactly like
+     * QPProblem::solve does (qp-problem.cpp:256-279): iwar[0] = 1, lwar = 3 nmax^2/2 + 10 nmax + 2 mmax + 20000 */
+    int m_ = mq, me_ = 0, mmax_ = mmax, n_ = n, nmax_ = n, mnn_ = mq + 2 * n, iout_ = 0, iprint_ = 1, liwar_ = n;
+    int lwar_ = 3 * n * n / 2 + 10 * n + 2 * mmax + 20000;
+    double eps_ = 1e-8;
+    double *war = (double *)calloc((size_t)lwar_, sizeof(double));
+    iact[0] = 1;
+    g_ref_ql(&m_, &me_, &mmax_, &n_, &nmax_, &mnn_, C, d, A, b, xl, xu, x, u, &iout_, &ifail, &iprint_, war, &lwar_, iact,
+             &liwar_, &eps_);
+    free(war);
+    for (int i = 0; i < mq + 2 * n; i++) nact += (u[i] != 0.0);
+  } else
   wgo_ql_solve(mq, 0, mmax, n, n, C, d, A, b, xl, xu, 1e-8, x, u, &ifail, iact, &nact, &nit,
                dump ? dump->hist : NULL, dump ? WGO_HIST_CAP : 0, &hlen);
   if (dump) {
@@ -799,4 +819,26 @@ int wgo_mpc_tick(const wg_model_t *m, wg_gait_state_t *s, wg_tick_out_t *out, wg
 
   free(iact); free(C); free(d); free(A); free(b); free(xl); free(xu); free(x); free(u); free(tb);
   return rc;
+}
+
+/* bench.py's cpu_baseline leg: the benchmark workload (velocity table vel[seg][gait][3], redrawn every `redraw`
+ * ticks; the 5 ms clock advanced like RunOneStepOfTheControlLoop does) for gaits [0, n_gaits), entirely in C. */
+int wgo_mpc_run(const wg_model_t *model, wg_gait_state_t *states, int n_gaits, int n_ticks, const double *vel, int redraw) {
+  for (int tick = 0; tick < n_ticks; tick++) {
+    const int adv = tick == 0 ? 1 : (tick == 1 ? 19 : 20);
+    const int seg = tick / redraw;
+    for (int g = 0; g < n_gaits; g++) {
+      wg_gait_state_t *st = &states[g];
+      if (tick % redraw == 0) {
+        const double *v = vel + ((size_t)seg * n_gaits + g) * 3;
+        st->vref[0] = v[0]; st->vref[1] = v[1]; st->vref[2] = v[2];
+      }
+      double c = st->clock;
+      for (int k = 0; k < adv; k++) c += model->Tctrl;
+      st->clock = c;
+      int rc = wgo_mpc_tick(model, st, 0, 0);
+      if (rc) return rc;
+    }
+  }
+  return 0;
 }

@@ -49,6 +49,11 @@ void wgo_gait_init(const wg_model_t *model, wg_gait_state_t *state, const double
 /* one tick at time state->clock (the caller advances the clock, see tests/herdt_replay.py);
  * out and dump may be NULL.  Returns 0, or <0 if the sizes are unsupported. */
 int wgo_mpc_tick(const wg_model_t *model, wg_gait_state_t *state, wg_tick_out_t *out, wgo_qp_dump_t *dump);
+/* NULL (default): the tick solves with wgo_ql_solve; otherwise with the given ql0001_ entry point (the reference's own
+ * compiled qld.cpp from oracle/_ref/libqld_ref.so) */
+void wgo_set_reference_ql(void *ql0001_entry);
+/* the benchmark workload on the CPU, loop in C (see herdt_oracle.c) */
+int wgo_mpc_run(const wg_model_t *model, wg_gait_state_t *states, int n_gaits, int n_ticks, const double *vel, int redraw);
 
 /* ---- Dimitrov back-end: OptCholesky + PLDPSolver restatement (pldp_oracle.c) -------------------------------------- */
 typedef struct wgo_pldp_model {
