@@ -70,14 +70,14 @@ __global__ __launch_bounds__(64) void wg_ql_dense_kernel(
     const double *__restrict__ A, const double *__restrict__ bvec, const double *__restrict__ xl,
     const double *__restrict__ xu, double eps, double *__restrict__ x, double *__restrict__ u,
     int *__restrict__ ifail, int *__restrict__ n_iter, int *__restrict__ iact, int *__restrict__ nact,
-    int *__restrict__ hist, int hist_cap, int *__restrict__ hist_len) {
+    int *__restrict__ hist, int hist_cap, int *__restrict__ hist_len, int a_in_lds) {
   extern __shared__ __attribute__((aligned(16))) double wg_lds[];
   const int lane = threadIdx.x & 63;
   for (int qp = blockIdx.x; qp < B; qp += gridDim.x) {
     const int n = n_arr ? n_arr[qp] : nmax;
     const int m = m_arr ? m_arr[qp] : mmax - 1;
     const int me = me_arr ? me_arr[qp] : 0;
-    wg::QlDims D(n, m, m);
+    wg::QlDims D(n, m, m, true, a_in_lds != 0);
     wg::QlView q;
     q.carve(wg_lds, D, me);
 
@@ -86,8 +86,13 @@ __global__ __launch_bounds__(64) void wg_ql_dense_kernel(
     const double *Ag = A + (size_t)qp * mmax * nmax;
     for (int j = 0; j < n; ++j)
       for (int i = lane; i < n; i += 64) q.G[i + j * q.ldg] = Cg[i + (size_t)j * nmax];
-    for (int i = 0; i < n; ++i)
-      for (int k = lane; k < m; k += 64) q.A[k + i * q.lda] = Ag[k + (size_t)i * mmax];
+    if (a_in_lds) {
+      for (int i = 0; i < n; ++i)
+        for (int k = lane; k < m; k += 64) q.A[k + i * q.lda] = Ag[k + (size_t)i * mmax];
+    } else {                                   // too large for LDS next to G, Z, R: the solver only reads A -> in place (L2)
+      q.A = const_cast<double *>(Ag);
+      q.lda = mmax;
+    }
     for (int i = lane; i < n; i += 64) {
       q.d[i] = dvec[(size_t)qp * nmax + i];
       q.xl[i] = xl[(size_t)qp * nmax + i];
@@ -181,6 +186,8 @@ int wg_qp_solve_batch_dev(int B, int nmax, int mmax, const int *n, const int *m,
   if (B == 0) return WG_OK;
   const int m_cap = m ? mmax : mmax - 1;
   size_t lds = wg::QlDims(nmax, m_cap, m_cap).bytes();
+  int a_in_lds = 1;
+  if (lds > 160 * 1024) { a_in_lds = 0; lds = wg::QlDims(nmax, m_cap, m_cap, true, false).bytes(); }
   if (lds > 160 * 1024) return fail(WG_ERR_TOO_LARGE, "QP (n=%d, m=%d) needs %zu B of LDS > 160 KiB", nmax, m_cap, lds);
   if (lds > 64 * 1024)
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(wg_ql_dense_kernel),
@@ -193,7 +200,7 @@ int wg_qp_solve_batch_dev(int B, int nmax, int mmax, const int *n, const int *m,
   if (grid > B) grid = B;
   hipStream_t st = reinterpret_cast<hipStream_t>(hip_stream);
   hipLaunchKernelGGL(wg_ql_dense_kernel, dim3(grid), dim3(64), lds, st, B, nmax, mmax, n, m, me, C, d, A, b,
-                     xl, xu, eps, x, u, ifail, n_iter, iact, nact, hist, hist_cap, hist_len);
+                     xl, xu, eps, x, u, ifail, n_iter, iact, nact, hist, hist_cap, hist_len, a_in_lds);
   HIP_TRY(hipGetLastError());
   return WG_OK;
 }

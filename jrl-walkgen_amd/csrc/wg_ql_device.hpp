@@ -87,14 +87,17 @@ struct QlDims {
   int n, m, mmax;
   int ldg, ldz, lda;
   bool dense;   // G and A held as LDS matrices (false: the problem view regenerates them)
-  __host__ __device__ QlDims(int n_, int m_, int mmax_, bool dense_ = true)
-      : n(n_), m(m_), mmax(mmax_), ldg(n_ | 1), ldz(n_ | 1), lda(mmax_ | 1), dense(dense_) {}
+  bool a_lds;   // dense only: A staged in LDS (false: read in place from global memory -- large QPs)
+  int nsc;      // length of each of the four scratch vectors: n, or the static length of the compact view's ordered sums
+  __host__ __device__ QlDims(int n_, int m_, int mmax_, bool dense_ = true, bool a_lds_ = true, int nsc_ = 0)
+      : n(n_), m(m_), mmax(mmax_), ldg(n_ | 1), ldz(n_ | 1), lda(mmax_ | 1), dense(dense_), a_lds(a_lds_),
+        nsc(nsc_ > n_ ? nsc_ : n_) {}
   __host__ __device__ int r_len() const { return n * (n + 1) / 2 + n; }
   __host__ __device__ int n_doubles() const {
-    return (dense ? n * ldg + n * lda : 0) + n * ldz + r_len()   // [G, A,] Z, R
+    return (dense ? n * ldg + (a_lds ? n * lda : 0) : 0) + n * ldz + r_len()   // [G, A,] Z, R
            + 8 * n                                  // x d ww wd wx lam xl xu
            + (m + n) + m                            // wa, b (inner)
-           + 4 * n + 8;                             // scratch + scalar slots
+           + 4 * nsc + 8;                           // scratch + scalar slots
   }
   __host__ __device__ size_t bytes() const {
     return (size_t)n_doubles() * 8 + (size_t)((n + 1) & ~1) * 4;
@@ -114,12 +117,12 @@ struct QlView {
     if (D.dense) { G = p; p += n * ldg; }
     Z = p; p += n * ldz;
     R = p; p += D.r_len();
-    if (D.dense) { A = p; p += n * lda; }
+    if (D.dense && D.a_lds) { A = p; p += n * lda; }
     x = p; p += n;  d = p; p += n;  ww = p; p += n;  wd = p; p += n;
     wx = p; p += n; lam = p; p += n; xl = p; p += n; xu = p; p += n;
     wa = p; p += m + n;
     b = p; p += m;
-    sc0 = p; p += n; sc1 = p; p += n; sc2 = p; p += n; sc3 = p; p += n;
+    sc0 = p; p += D.nsc; sc1 = p; p += D.nsc; sc2 = p; p += D.nsc; sc3 = p; p += D.nsc;
     slot = p; p += 8;
     iact = reinterpret_cast<int *>(p);
   }
@@ -1063,6 +1066,10 @@ __device__ inline QlResult ql_solve(const QlView &q, P &prob, double vsmall, int
               sumc += zi * zi;
             }
           }
+#ifdef WG_DEBUG_ROUTE
+          if (lane == 0 && blockIdx.x == 2 && iterc == 3) { for (int i = 0; i < n; i++) printf("GPUW %d %.17g %.17g\n", i, q.ww[i], Zm(i, nact)); }
+          if (lane == 0) printf("GPU blk %d it %d knext %d nact %d suma %.17g sumb %.17g sumc %.17g wa %.17g\n", (int)blockIdx.x, iterc, knext, nact, suma, sumb, sumc, knext <= m ? q.wa[knext - 1] : 0.0);
+#endif
           if (!significant(sumb, fabs(suma)) || !(sumb > vsmall)) route = 1;
           else {
             sumc = sqrt(sumc);

@@ -552,7 +552,7 @@ __device__ inline TickDiag mpc_tick(const wg_model_t &m, const TickTables *__res
   const int n = 2 * N + 2 * ns;
   const int mq = 1 + 4 * N + 5 * ns;     // rows incl. the dummy row 0 (qp-problem.cpp:248)
   constexpr bool kCompactView = (NH == 16);
-  QlDims D(n, mq, mq, !kCompactView);
+  QlDims D(n, mq, mq, !kCompactView, true, kCompactView ? 2 * NH + 4 : 0);   // ordered sums run the static length
   QlView q;
   q.carve(lds_ql, D, 0);
 

@@ -536,6 +536,10 @@ int wgo_ql_solve(int m, int me, int mmax, int n, int nmax,
             sumb += fabs(q->ww[i] * zi);
             sumc += zi * zi;
           }
+#ifdef WGO_DEBUG_ROUTE
+          if (iterc == 3) for (int i = 0; i < n; i++) fprintf(stderr, "ORCW %d %.17g %.17g\n", i, q->ww[i], Z(i, q->nact));
+          fprintf(stderr, "ORC it %d knext %d nact %d suma %.17g sumb %.17g sumc %.17g wa %.17g\n", iterc, knext, q->nact, suma, sumb, sumc, knext <= m ? q->wa[knext - 1] : 0.0);
+#endif
           if (!significant(sumb, fabs(suma)) || !(sumb > q->vsmall)) route = 1;
           else {
             sumc = sqrt(sumc);

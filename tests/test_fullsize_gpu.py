@@ -1,0 +1,175 @@
+"""Full-size and edge-size checks of the HIP path (through the C ABI).
+
+At BASELINE.json's size (4096 gaits x 200 ticks) the oracle cannot follow every gait in test time, so the run is
+checked through size-independent properties -- determinism, batch-composition invariance (a gait's trajectory does not
+depend on its neighbours or its slot), shard consistency, physical sanity -- plus a seeded sample of gaits followed
+bit-for-bit by the oracle over the whole 200 ticks.  Edge sizes: n = 1, config-5-sized dense QPs (n = 72, m = 149),
+ragged batches, other horizons N through the dense tick policy, and a horizon that cannot fit LDS."""
+import ctypes as C
+import importlib
+import os
+import sys
+
+import numpy as np
+import pytest
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import oraclelib as ol  # noqa: E402
+import qpgen  # noqa: E402
+
+wg = importlib.import_module("jrl-walkgen_amd")
+pytestmark = pytest.mark.gpu
+REDRAW = 50
+
+
+def _vel(g, n_seg):
+    r = np.random.Generator(np.random.MT19937(20100 + g))          # bench.py's table
+    return np.stack([r.uniform(-0.1, 0.3, n_seg), r.uniform(-0.1, 0.1, n_seg), r.uniform(-0.2, 0.2, n_seg)], 1)
+
+
+def _start(model, B):
+    s0 = wg.gait_init(model, [0.0316055, 0.0, 0.7116911], [0.0, 0.09, 0.0], [0.0, -0.09, 0.0])
+    s0.nb_steps_left = 2
+    st = (wg.GaitState * B)()
+    for g in range(B):
+        C.memmove(C.byref(st[g]), C.byref(s0), C.sizeof(wg.GaitState))
+    return st
+
+
+def _run(model, gaits, n_ticks):
+    """advance the listed global gait indices n_ticks; returns the final state bytes per gait + per-tick diag"""
+    B = len(gaits)
+    st = _start(model, B)
+    vt = [_vel(g, (n_ticks + REDRAW - 1) // REDRAW) for g in gaits]
+    fails = 0; iters = []
+    for t in range(n_ticks):
+        if t % REDRAW == 0:
+            for k in range(B):
+                st[k].vref[0], st[k].vref[1], st[k].vref[2] = vt[k][t // REDRAW]
+        adv = 1 if t == 0 else (19 if t == 1 else 20)
+        _, diag, _, _ = wg.mpc_tick_batch(st, want_out=False, advance_calls=adv)
+        fails += int((diag[:, 0] != 0).sum()); iters.append(diag[:, 1].copy())
+    sz = C.sizeof(wg.GaitState)
+    raw = bytes(memoryview(st).cast("B"))
+    return [raw[k * sz:(k + 1) * sz] for k in range(B)], st, fails, np.array(iters)
+
+
+@pytest.fixture(scope="module")
+def full_run():
+    wg.init(0)
+    model = wg.model_defaults()
+    wg.mpc_configure(model)
+    B, T = 4096, 200
+    fin, st, fails, iters = _run(model, list(range(B)), T)
+    return model, B, T, fin, st, fails, iters
+
+
+def test_full_size_run_is_sane(full_run):
+    model, B, T, fin, st, fails, iters = full_run
+    assert fails == 0                                              # every one of the 819 200 QPs solved (ifail == 0)
+    assert iters.max() < 200 and iters.mean() > 5
+    com = np.array([[s.com_x[0], s.com_y[0], s.com_x[1], s.com_y[1]] for s in st])
+    feet = np.array([[s.lf[2].x, s.lf[2].y, s.rf[2].x, s.rf[2].y] for s in st])
+    assert np.isfinite(com).all() and np.isfinite(feet).all()
+    mid = 0.5 * (feet[:, :2] + feet[:, 2:])
+    assert np.abs(com[:, :2] - mid).max() < 0.35                   # the CoM stays between the feet
+    assert np.abs(com[:, 2:]).max() < 1.0                          # |v| bounded (references are <= 0.3 m/s)
+    assert all(s.tick_count == T and s.running == 1 for s in st)
+    assert len({f for f in fin}) > 4000                            # gaits really are different problems
+
+
+def test_full_size_sample_followed_by_the_oracle(full_run):
+    model, B, T, fin, st, fails, iters = full_run
+    pt = C.CDLL(os.path.join(ol.ORACLE_DIR, "libwg_oracle_ptrig.so"))
+    ol.build_oracle()
+    rng = np.random.default_rng(4096)
+    sample = sorted(rng.choice(B, 48, replace=False).tolist()) + [0, B - 1]
+    for g in sample:
+        s = _start(model, 1)[0]
+        vt = _vel(g, (T + REDRAW - 1) // REDRAW)
+        for t in range(T):
+            if t % REDRAW == 0:
+                s.vref[0], s.vref[1], s.vref[2] = vt[t // REDRAW]
+            c = s.clock
+            for _ in range(1 if t == 0 else (19 if t == 1 else 20)):
+                c += model.Tctrl
+            s.clock = c
+            assert pt.wgo_mpc_tick(C.byref(model), C.byref(s), None, None) == 0
+        assert bytes(memoryview(s).cast("B")) == fin[g], g
+
+
+def test_determinism_and_batch_composition_invariance(full_run):
+    model, B, T, fin, st, fails, iters = full_run
+    # same gaits in another order, other batch size, other neighbours -> identical bytes per gait
+    perm = np.random.default_rng(1).permutation(B)[:600].tolist()
+    fin2, _, _, _ = _run(model, perm, T)
+    for k, g in enumerate(perm):
+        assert fin2[k] == fin[g], g
+    # shard consistency: two "ranks" with contiguous ranges reproduce the single-process run
+    for lo, hi in ((0, 256), (3840, 4096)):
+        fr, _, _, _ = _run(model, list(range(lo, hi)), T)
+        assert fr == fin[lo:hi]
+
+
+def test_dense_qp_edge_sizes_bit_exact():
+    wg.init(0)
+    rng = np.random.default_rng(72)
+    qps = [qpgen.random_pd(rng, 1, 1), qpgen.random_pd(rng, 1, 3), qpgen.random_pd(rng, 2, 1),
+           qpgen.random_pd(rng, 72, 149),                          # config-5-sized (N = 32: n <= 72, m <= 149), fp64
+           qpgen.herdt_like(rng, 32, 4), qpgen.random_pd(rng, 64, 10), qpgen.boxed(rng, 50, 120),
+           qpgen.random_pd(rng, 3, 100)]
+    import test_ql_gpu as tq
+    pk = wg.pack_qps(qps)                                          # one ragged batch: strides = the largest member
+    res = wg.qp_solve_batch(pk, hist_cap=1024)
+    bad = tq._compare(qps, res, "edge", pk)
+    assert not bad, bad[:5]
+    assert int(res["ifail"][3]) == 0
+
+
+@pytest.mark.parametrize("N,T,step", [(8, 0.1, 0.8), (12, 0.1, 0.8), (16, 0.05, 0.8), (20, 0.1, 0.8)])
+def test_other_horizons_run_through_the_dense_policy_bit_exact(N, T, step):
+    """The register-resident problem view is instantiated for N = 16 with <= 2 previewed steps; every other model goes
+    through the generic (dense, LDS) policy of the same solver and must agree with the oracle just the same."""
+    wg.init(0)
+    pt = C.CDLL(os.path.join(ol.ORACLE_DIR, "libwg_oracle_ptrig.so"))
+    model = wg.model_defaults()
+    model.N = N; model.T = T; model.t_double = T; model.step_period = step
+    model.Tctrl = T / 20.0                                         # the ABI fixes 20 control samples per tick
+    wg.mpc_configure(model)
+    try:
+        B = 6
+        st = _start(model, B)
+        ref = _start(model, B)
+        rng = np.random.default_rng(N)
+        per_tick = int(round(T / model.Tctrl))
+        sizes = set()
+        for t in range(40):
+            if t % 15 == 0:
+                for g in range(B):
+                    v = [rng.uniform(-0.1, 0.3), rng.uniform(-0.1, 0.1), rng.uniform(-0.2, 0.2)]
+                    for s in (st[g], ref[g]):
+                        s.vref[0], s.vref[1], s.vref[2] = v
+            adv = 1 if t == 0 else (per_tick - 1 if t == 1 else per_tick)
+            _, diag, _, _ = wg.mpc_tick_batch(st, want_out=False, advance_calls=adv)
+            sizes |= set(int(v) for v in diag[:, 3])
+            for g in range(B):
+                c = ref[g].clock
+                for _ in range(adv):
+                    c += model.Tctrl
+                ref[g].clock = c
+                assert pt.wgo_mpc_tick(C.byref(model), C.byref(ref[g]), None, None) == 0
+            assert bytes(memoryview(st).cast("B")) == bytes(memoryview(ref).cast("B")), t
+        assert max(sizes) > 2 * N                                  # foot-placement variables did appear
+    finally:
+        wg.mpc_configure(wg.model_defaults())
+
+
+def test_horizon_that_cannot_fit_lds_is_refused():
+    wg.init(0)
+    model = wg.model_defaults()
+    model.N = 32                                                   # config 5's horizon: n <= 72, m <= 149, dense tick view
+    rc = wg.lib().wg_mpc_configure(C.byref(model))
+    assert rc == -4 and b"LDS" in wg.lib().wg_last_error()        # WG_ERR_TOO_LARGE, nothing launched
+    model.N = 48
+    assert wg.lib().wg_mpc_configure(C.byref(model)) == -2        # WG_ERR_BAD_ARG: beyond the table size
+    wg.mpc_configure(wg.model_defaults())
