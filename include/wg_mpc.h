@@ -316,6 +316,60 @@ int wg_pldp_solve_batch_dev(int B, int mcap, const int *m, const double *D, cons
 /* LDS bytes one problem occupies in the PLDP kernel. */
 size_t wg_pldp_lds_bytes(void);
 
+/* Dimitrov-2008 receding-horizon tick around PLDP, batched over independent gaits ------------------------------------
+ *
+ * wg_dimitrov_configure replaces ZMPConstrainedQPFastFormulation::InitConstants
+ *     src/ZMPRefTrajectoryGeneration/ZMPConstrainedQPFastFormulation.cpp:692-703  (= InitializeMatrixPbConstants :158-246,
+ *     BuildingConstantPartOfTheObjectiveFunction[QLDANDLQ] :384-560, BuildingConstantPartOfConstraintMatrices :597-690)
+ * in mode PLDP (:55) and hands the resulting iPu, Px, Pu to the PLDP back-end (the PLDPSolver constructor, :104-109).
+ * wg_dimitrov_tick_batch replaces one pass of the loop body of BuildZMPTrajectoryFromFootTrajectory (:1180-1400):
+ *     BuildConstraintMatrices (:759-1022)  from the ZMP polytopes of the N previewed instants
+ *     D = OptB xk - OptC ZMPRef (:1254-1262), PLDPSolver::SolveProblem (:1322-1339), X <- iLQ' X (:1355-1381),
+ *     LinearizedInvertedPendulum2D::Interpolation + OneIteration (:1388-1392).
+ * The polytopes are what FootConstraintsAsLinearSystem::BuildLinearConstraintInequalities produces
+ * (LinearConstraintInequality_t, pgtypes.hh:158-165): rows A_j (2 coefficients), B_j, the centre (the ZMP reference)
+ * and SimilarConstraints; constraint sense A_j . zmp + B_j >= 0.  The caller supplies, per gait, the polytope of each
+ * previewed instant (N entries) -- 2 KB per gait-tick instead of the 33 KB dense DPu. */
+#define WG_POLY_MAX_ROWS 8            /* "8 constraints per support foot", :771-772 */
+typedef struct wg_dimitrov_model {
+  int N, pad_;                        /* m_QP_N = 16                                  :83  */
+  double T;                           /* m_QP_T = 0.1                                 :82  */
+  double Tctrl;                       /* m_SamplingPeriod = 0.005 */
+  double com_height;                  /* m_ComHeight = 0.80                           :87  */
+  double alpha, beta;                 /* 200, 1000                                    :95-96 */
+} wg_dimitrov_model_t;
+typedef struct wg_zmp_polytope {
+  int nrows, pad_;
+  int similar[WG_POLY_MAX_ROWS];
+  double A[WG_POLY_MAX_ROWS][2];
+  double B[WG_POLY_MAX_ROWS];
+  double centre[2];
+} wg_zmp_polytope_t;
+typedef struct wg_dimitrov_state {
+  double xk[6];                       /* LIPM state x, dx, ddx, y, dy, ddy  (m_2DLIPM->GetState) */
+  wg_pldp_state_t pldp;               /* the solver's hot-start members */
+  int n_removed;                      /* NumberOfRemovedConstraints for the next solve (:1340) */
+  int starting;                       /* StartingSequence: 1 before the first tick (:1167, :1339) */
+} wg_dimitrov_state_t;
+typedef struct wg_dimitrov_out {
+  double jerk_x, jerk_y;              /* ptX[0], ptX[N] */
+  int ret, n_iter, n_active, m;       /* PLDP return code (see wg_pldp_solve_batch), m_ItNb, active rows, rows */
+  /* what Interpolation writes for lk = 0..interval (21 samples; the last one is overwritten by the next tick) */
+  double com_x[WG_SAMPLES_PER_TICK + 1][3], com_y[WG_SAMPLES_PER_TICK + 1][3];
+  double zmp_x[WG_SAMPLES_PER_TICK + 1], zmp_y[WG_SAMPLES_PER_TICK + 1];
+} wg_dimitrov_out_t;
+void wg_dimitrov_defaults(wg_dimitrov_model_t *model);
+int wg_dimitrov_configure(const wg_dimitrov_model_t *model);
+/* the constants InitConstants leaves behind, for inspection: iLQ, OptC 2N x 2N, OptB 2N x 6, Pu (= iLQ Pu'), iPu N x N,
+ * Px N x 3, all row-major; any pointer may be NULL */
+int wg_dimitrov_get_constants(double *iLQ, double *OptB, double *OptC, double *Pu, double *iPu, double *Px);
+/* polys: B x N polytopes (instant-major per gait); outs may be NULL.  A gait whose solve returns ret != 0 keeps its
+ * state (xk not advanced), like the reference which stops there (:1343-1347). */
+int wg_dimitrov_tick_batch(int B, const wg_zmp_polytope_t *polys, wg_dimitrov_state_t *states, wg_dimitrov_out_t *outs,
+                           int max_iter);
+int wg_dimitrov_tick_batch_dev(int B, const wg_zmp_polytope_t *polys, wg_dimitrov_state_t *states,
+                               wg_dimitrov_out_t *outs, int max_iter, void *hip_stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -592,3 +592,118 @@ int wg_pldp_solve_batch(int B, int mcap, const int *m, const double *D, const do
 }
 
 }  // extern "C"
+
+// ---- Dimitrov-2008 tick around PLDP ------------------------------------------------------------------------------------
+#include "wg_dimitrov_device.hpp"
+
+__global__ void __launch_bounds__(64)
+wg_dimitrov_tick_kernel(int B, const wg::DimitrovConst *__restrict__ K, const wg_zmp_polytope_t *__restrict__ polys,
+                        wg_dimitrov_state_t *states, wg_dimitrov_out_t *outs, int max_iter) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char dim_lds[];
+  const int N = K->N;
+  for (int g = blockIdx.x; g < B; g += gridDim.x)
+    wg::dimitrov_tick(*K, dim_lds, polys + (size_t)g * N, states + g, outs ? outs + g : nullptr, max_iter);
+}
+
+namespace {
+wg::DimitrovConst *g_dim_dev = nullptr;
+wg::DimitrovConst g_dim_host;
+bool g_dim_set = false;
+DevBuf g_dim_buf;
+inline size_t dimitrov_lds_bytes() {
+  return wg::PldpLds::bytes(WG_PLDP_MMAX) + (4 * 2 * WG_PLDP_N + 8) * 8 + ((WG_PLDP_N + 1) * 4 + 15) / 16 * 16;
+}
+}  // namespace
+
+extern "C" {
+
+void wg_dimitrov_defaults(wg_dimitrov_model_t *m) {      // ZMPConstrainedQPFastFormulation.cpp:81-97
+  if (!m) return;
+  memset(m, 0, sizeof *m);
+  m->N = 16; m->T = 0.1; m->Tctrl = 0.005; m->com_height = 0.80; m->alpha = 200.0; m->beta = 1000.0;
+}
+
+int wg_dimitrov_configure(const wg_dimitrov_model_t *model) {
+  if (int rc = ensure_device()) return rc;
+  if (!model) return fail(WG_ERR_BAD_ARG, "null model");
+  if (model->N < 1 || model->N > WG_PLDP_N) return fail(WG_ERR_BAD_ARG, "N=%d outside [1,%d]", model->N, WG_PLDP_N);
+  if (!(model->T > 0.0) || !(model->Tctrl > 0.0) || (int)(model->T / model->Tctrl) != WG_SAMPLES_PER_TICK)
+    return fail(WG_ERR_BAD_ARG, "T/Tctrl must be %d", WG_SAMPLES_PER_TICK);
+  {
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (!wg::DimitrovHost::build(*model, g_dim_host))
+      return fail(WG_ERR_BAD_ARG, "the LQ factor or the inverse of Pu does not exist for this model");
+    if (!g_dim_dev) {
+      HIP_TRY(hipMalloc(reinterpret_cast<void **>(&g_dim_dev), sizeof(wg::DimitrovConst)));
+      g_release_hooks.push_back([] {
+        if (g_dim_dev) (void)hipFree(g_dim_dev);
+        g_dim_dev = nullptr; g_dim_set = false;
+        g_dim_buf.release();
+      });
+    }
+    HIP_TRY(hipMemcpy(g_dim_dev, &g_dim_host, sizeof g_dim_host, hipMemcpyHostToDevice));
+    g_dim_set = true;
+  }
+  // the PLDPSolver constructor of the reference (:104-109): same iPu, Px, Pu
+  return wg_pldp_configure(model->N, g_dim_host.pldp.iPu, g_dim_host.pldp.Px, g_dim_host.pldp.Pu);
+}
+
+int wg_dimitrov_get_constants(double *iLQ, double *OptB, double *OptC, double *Pu, double *iPu, double *Px) {
+  if (!g_dim_set) return fail(WG_ERR_BAD_ARG, "wg_dimitrov_configure() has not been called");
+  const size_t N = (size_t)g_dim_host.N, n = 2 * N;
+  if (iLQ) memcpy(iLQ, g_dim_host.iLQ, 8 * n * n);
+  if (OptB) memcpy(OptB, g_dim_host.OptB, 8 * n * 6);
+  if (OptC) memcpy(OptC, g_dim_host.OptC, 8 * n * n);
+  if (Pu) memcpy(Pu, g_dim_host.pldp.Pu, 8 * N * N);
+  if (iPu) memcpy(iPu, g_dim_host.pldp.iPu, 8 * N * N);
+  if (Px) memcpy(Px, g_dim_host.pldp.Px, 8 * N * 3);
+  return WG_OK;
+}
+
+int wg_dimitrov_tick_batch_dev(int B, const wg_zmp_polytope_t *polys, wg_dimitrov_state_t *states,
+                               wg_dimitrov_out_t *outs, int max_iter, void *hip_stream) {
+  if (int rc = ensure_device()) return rc;
+  if (!g_dim_set) return fail(WG_ERR_BAD_ARG, "wg_dimitrov_configure() has not been called");
+  if (B < 0 || !polys || !states) return fail(WG_ERR_BAD_ARG, "bad arguments");
+  if (B == 0) return WG_OK;
+  const size_t lds = dimitrov_lds_bytes();
+  if (lds > 64 * 1024)
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(wg_dimitrov_tick_kernel),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  int per_cu = (int)((160 * 1024) / lds);
+  if (per_cu < 1) per_cu = 1;
+  int grid = g_num_cu * per_cu * 2;
+  if (grid > B) grid = B;
+  hipLaunchKernelGGL(wg_dimitrov_tick_kernel, dim3(grid), dim3(64), lds, reinterpret_cast<hipStream_t>(hip_stream), B,
+                     g_dim_dev, polys, states, outs, max_iter);
+  HIP_TRY(hipGetLastError());
+  return WG_OK;
+}
+
+int wg_dimitrov_tick_batch(int B, const wg_zmp_polytope_t *polys, wg_dimitrov_state_t *states, wg_dimitrov_out_t *outs,
+                           int max_iter) {
+  if (int rc = ensure_device()) return rc;
+  if (!g_dim_set) return fail(WG_ERR_BAD_ARG, "wg_dimitrov_configure() has not been called");
+  if (B < 0 || !polys || !states) return fail(WG_ERR_BAD_ARG, "bad arguments");
+  if (B == 0) return WG_OK;
+  std::lock_guard<std::mutex> lk(g_mu);
+  const size_t sB = (size_t)B, N = (size_t)g_dim_host.N;
+  const size_t pb = sB * N * sizeof(wg_zmp_polytope_t), sb = sB * sizeof(wg_dimitrov_state_t),
+               ob = outs ? sB * sizeof(wg_dimitrov_out_t) : 0;
+  if (int rc = g_dim_buf.reserve(pb + sb + ob)) return rc;
+  unsigned char *base = static_cast<unsigned char *>(g_dim_buf.p);
+  wg_zmp_polytope_t *dp = reinterpret_cast<wg_zmp_polytope_t *>(base);
+  wg_dimitrov_state_t *ds = reinterpret_cast<wg_dimitrov_state_t *>(base + pb);
+  wg_dimitrov_out_t *dout = outs ? reinterpret_cast<wg_dimitrov_out_t *>(base + pb + sb) : nullptr;
+  HIP_TRY(hipMemcpy(dp, polys, pb, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(ds, states, sb, hipMemcpyHostToDevice));
+  if (dout) HIP_TRY(hipMemset(dout, 0, ob));
+  int rc = wg_dimitrov_tick_batch_dev(B, dp, ds, dout, max_iter, nullptr);
+  if (rc) return rc;
+  HIP_TRY(hipDeviceSynchronize());
+  HIP_TRY(hipMemcpy(states, ds, sb, hipMemcpyDeviceToHost));
+  if (dout) HIP_TRY(hipMemcpy(outs, dout, ob, hipMemcpyDeviceToHost));
+  return WG_OK;
+}
+
+}  // extern "C"

@@ -82,6 +82,9 @@ def lib():
         _lib.wg_pldp_configure.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
         _lib.wg_pldp_solve_batch.argtypes = [C.c_int, C.c_int] + [C.c_void_p] * 9 + [C.c_int] + [C.c_void_p] * 6
         _lib.wg_pldp_solve_batch_dev.argtypes = _lib.wg_pldp_solve_batch.argtypes + [C.c_void_p]
+        _lib.wg_dimitrov_tick_batch.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+        _lib.wg_dimitrov_tick_batch_dev.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+        _lib.wg_dimitrov_get_constants.argtypes = [C.c_void_p] * 6
         _lib.wg_riccati_solve.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_double, C.c_int,
                                           C.c_int, C.c_void_p, C.c_void_p]
         _lib.wg_riccati_gains.argtypes = [C.c_double] * 4 + [C.c_int, C.c_int, C.c_void_p, C.c_void_p]
@@ -267,3 +270,54 @@ def pldp_solve_batch(N, mcap, m, D, A, b, zmpref, xkyk, similar, n_removed, star
                                      _hp(n_removed), _hp(starting), int(max_iter), C.addressof(states), _hp(X), _hp(ret),
                                      _hp(nit), _hp(act), _hp(nact)))
     return dict(X=X, ret=ret, n_iter=nit, active=[act[i, :nact[i]].copy() for i in range(B)])
+
+
+POLY_MAX_ROWS = 8
+
+
+class DimitrovModel(C.Structure):       # wg_dimitrov_model_t
+    _fields_ = [("N", C.c_int), ("pad_", C.c_int), ("T", C.c_double), ("Tctrl", C.c_double), ("com_height", C.c_double),
+                ("alpha", C.c_double), ("beta", C.c_double)]
+
+
+class ZmpPolytope(C.Structure):         # wg_zmp_polytope_t
+    _fields_ = [("nrows", C.c_int), ("pad_", C.c_int), ("similar", C.c_int * POLY_MAX_ROWS),
+                ("A", (C.c_double * 2) * POLY_MAX_ROWS), ("B", C.c_double * POLY_MAX_ROWS), ("centre", C.c_double * 2)]
+
+
+class DimitrovState(C.Structure):       # wg_dimitrov_state_t
+    _fields_ = [("xk", C.c_double * 6), ("pldp", PldpState), ("n_removed", C.c_int), ("starting", C.c_int)]
+
+
+class DimitrovOut(C.Structure):         # wg_dimitrov_out_t
+    _fields_ = [("jerk_x", C.c_double), ("jerk_y", C.c_double), ("ret", C.c_int), ("n_iter", C.c_int),
+                ("n_active", C.c_int), ("m", C.c_int),
+                ("com_x", (C.c_double * 3) * 21), ("com_y", (C.c_double * 3) * 21),
+                ("zmp_x", C.c_double * 21), ("zmp_y", C.c_double * 21)]
+
+
+def dimitrov_defaults():
+    m = DimitrovModel()
+    lib().wg_dimitrov_defaults(C.byref(m))
+    return m
+
+
+def dimitrov_configure(model):
+    _check(lib().wg_dimitrov_configure(C.byref(model)))
+
+
+def dimitrov_constants(N):
+    n = 2 * N
+    iLQ = np.zeros((n, n)); OptB = np.zeros((n, 6)); OptC = np.zeros((n, n))
+    Pu = np.zeros((N, N)); iPu = np.zeros((N, N)); Px = np.zeros((N, 3))
+    _check(lib().wg_dimitrov_get_constants(_hp(iLQ), _hp(OptB), _hp(OptC), _hp(Pu), _hp(iPu), _hp(Px)))
+    return dict(iLQ=iLQ, OptB=OptB, OptC=OptC, Pu=Pu, iPu=iPu, Px=Px)
+
+
+def dimitrov_tick_batch(polys, states, want_out=True, max_iter=0):
+    """polys: ctypes array (ZmpPolytope * (B*N)), states: (DimitrovState * B), updated in place."""
+    B = len(states)
+    outs = (DimitrovOut * B)() if want_out else None
+    _check(lib().wg_dimitrov_tick_batch(B, C.addressof(polys), C.addressof(states),
+                                        C.addressof(outs) if outs is not None else None, int(max_iter)))
+    return outs

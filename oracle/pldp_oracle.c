@@ -281,3 +281,85 @@ int wgo_pldp_solve(const wgo_pldp_model_t *M, wg_pldp_state_t *st, const double 
   if (active) for (int i = 0; i < w->nact; i++) active[i] = w->act[i];
   return rc;
 }
+
+/* ---- Dimitrov-2008 tick around PLDP ---------------------------------------------------------------------------------
+ * One pass of the loop body of ZMPConstrainedQPFastFormulation::BuildZMPTrajectoryFromFootTrajectory
+ * (/root/reference/src/ZMPRefTrajectoryGeneration/ZMPConstrainedQPFastFormulation.cpp:1180-1400):
+ * BuildConstraintMatrices :759-1022, D :1254-1262, SolveProblem :1322-1339, X <- iLQ' X :1355-1381,
+ * LinearizedInvertedPendulum2D::Interpolation / OneIteration (LinearizedInvertedPendulum2D.cpp:157-264).
+ * The constants (OptB, OptC, iLQ: row-major 2N x 6 / 2N x 2N / 2N x 2N) are inputs; PARITY UNPINNED like the rest of
+ * this file (the translation unit needs jrl-mal). */
+int wgo_dimitrov_tick(const wgo_pldp_model_t *M, const double *OptB, const double *OptC, const double *iLQ, double T,
+                      double Tctrl, double com_height, const wg_zmp_polytope_t *polys, wg_dimitrov_state_t *st,
+                      wg_dimitrov_out_t *out, int max_iter) {
+  const int N = M->N, n = 2 * N;
+  static double A[(WG_PLDP_MMAX + 1) * 2 * WG_PLDP_N];
+  double b[WG_PLDP_MMAX], zr[2 * WG_PLDP_N], D[2 * WG_PLDP_N], X[2 * WG_PLDP_N], NewX[2 * WG_PLDP_N];
+  int sim[WG_PLDP_MMAX], act[WG_PLDP_MMAX];
+  const double *xk = st->xk;
+  int m = 0;
+  for (int i = 0; i < N; i++) m += polys[i].nrows;
+  if (m > WG_PLDP_MMAX) return -100;
+  memset(A, 0, sizeof(double) * (size_t)(m + 1) * n);
+  int idx = 0;
+  for (int i = 0; i < N; i++) {
+    zr[i] = polys[i].centre[0];
+    zr[i + N] = polys[i].centre[1];
+    for (int j = 0; j < polys[i].nrows; j++) {
+      b[idx] = (xk[0] * M->Px[i * 3 + 0] + xk[1] * M->Px[i * 3 + 1] + xk[2] * M->Px[i * 3 + 2]) * polys[i].A[j][0] +
+               (xk[3] * M->Px[i * 3 + 0] + xk[4] * M->Px[i * 3 + 1] + xk[5] * M->Px[i * 3 + 2]) * polys[i].A[j][1] +
+               polys[i].B[j];
+      sim[idx] = polys[i].similar[j];
+      for (int k = 0; k < N; k++) {
+        A[idx + k * (m + 1)] = polys[i].A[j][0] * M->Pu[k * N + i];
+        A[idx + (k + N) * (m + 1)] = polys[i].A[j][1] * M->Pu[k * N + i];
+      }
+      idx++;
+    }
+  }
+  for (int i = 0; i < n; i++) {
+    double l1 = 0.0, od = 0.0;
+    for (int j = 0; j < n; j++) l1 += OptC[i * n + j] * zr[j];
+    for (int j = 0; j < 6; j++) od += OptB[i * 6 + j] * xk[j];
+    D[i] = od - l1;
+  }
+  int nit = 0, nact = 0;
+  int rc = wgo_pldp_solve(M, &st->pldp, D, m, A, b, zr, xk, sim, st->n_removed, st->starting, max_iter, X, &nit, act, &nact);
+  if (rc == -100) rc = WG_PLDP_BAD_INPUT;
+  for (int i = 0; i < n; i++) {
+    double s = 0.0;
+    for (int j = i; j < n; j++) s += iLQ[j * n + i] * X[j];
+    NewX[i] = s;
+  }
+  const double jx = NewX[0], jy = NewX[N];
+  if (rc == 0) {
+    const double c02 = -com_height / 9.81;
+    if (out)
+      for (int lk = 0; lk <= WG_SAMPLES_PER_TICK; lk++) {
+        const double t = (lk + 1) * Tctrl;
+        const double cx0 = xk[0] + t * xk[1] + 0.5 * t * t * xk[2] + t * t * t * jx / 6.0;
+        const double cx1 = xk[1] + t * xk[2] + 0.5 * t * t * jx;
+        const double cx2 = xk[2] + t * jx;
+        const double cy0 = xk[3] + t * xk[4] + 0.5 * t * t * xk[5] + t * t * t * jy / 6.0;
+        const double cy1 = xk[4] + t * xk[5] + 0.5 * t * t * jy;
+        const double cy2 = xk[5] + t * jy;
+        out->com_x[lk][0] = cx0; out->com_x[lk][1] = cx1; out->com_x[lk][2] = cx2;
+        out->com_y[lk][0] = cy0; out->com_y[lk][1] = cy1; out->com_y[lk][2] = cy2;
+        out->zmp_x[lk] = 1.0 * cx0 + 0.0 * cx1 + c02 * cx2;
+        out->zmp_y[lk] = 1.0 * cy0 + 0.0 * cy1 + c02 * cy2;
+      }
+    const double A01 = T, A02 = T * T / 2.0, A12 = T, B0 = T * T * T / 6.0, B1 = T * T / 2.0, B2 = T;
+    for (int a = 0; a < 2; a++) {
+      const double u = a == 0 ? jx : jy;
+      double *c = st->xk + 3 * a;
+      const double n0 = 0.0 + 1.0 * c[0] + A01 * c[1] + A02 * c[2];
+      const double n1 = 0.0 + 0.0 * c[0] + 1.0 * c[1] + A12 * c[2];
+      const double n2 = 0.0 + 0.0 * c[0] + 0.0 * c[1] + 1.0 * c[2];
+      c[0] = n0 + u * B0; c[1] = n1 + u * B1; c[2] = n2 + u * B2;
+    }
+  }
+  st->starting = 0;
+  st->n_removed = polys[0].nrows;
+  if (out) { out->jerk_x = jx; out->jerk_y = jy; out->ret = rc; out->n_iter = nit; out->n_active = nact; out->m = m; }
+  return rc;
+}

@@ -70,6 +70,10 @@ int wgo_pldp_setup(wgo_pldp_model_t *M, int N, const double *iPu, const double *
 int wgo_pldp_solve(const wgo_pldp_model_t *M, wg_pldp_state_t *st, const double *D, int m, const double *A,
                    const double *b, const double *zmpref, const double *xkyk, const int *similar, int n_removed,
                    int starting, int max_iter, double *X, int *n_iter, int *active, int *n_active);
+/* one Dimitrov-2008 tick (see pldp_oracle.c); constants row-major */
+int wgo_dimitrov_tick(const wgo_pldp_model_t *M, const double *OptB, const double *OptC, const double *iLQ, double T,
+                      double Tctrl, double com_height, const wg_zmp_polytope_t *polys, wg_dimitrov_state_t *st,
+                      wg_dimitrov_out_t *out, int max_iter);
 
 #ifdef __cplusplus
 }

@@ -137,3 +137,47 @@ def test_batch_of_desynchronised_gaits_bit_exact():
         sizes |= set(int(v) for v in diag[:, 3])
         assert (diag[:, 0] == 0).all()
     assert {34, 36} <= sizes <= {32, 34, 36}
+
+
+def test_pushed_gaits_including_infeasible_qps_bit_exact():
+    """Gaits started with large CoM velocities (a shove): many active rows while n = 32/34/36, QPs that QL declares
+    inconsistent (ifail > 10) and their aftermath -- every state byte and every ifail code must still match the oracle."""
+    wg = _wg()
+    pt = _ptrig()
+    model = wg.model_defaults()
+    wg.mpc_configure(model)
+    B = 160
+    rng = np.random.default_rng(77)
+    states = (wg.GaitState * B)()
+    for g in range(B):
+        s = wg.gait_init(model, [0.0316055, 0.0, 0.7116911], [0.0, 0.09, 0.0], [0.0, -0.09, 0.0])
+        s.nb_steps_left = 2
+        amp = 0.05 + 0.45 * g / B
+        s.com_x[1] = rng.uniform(-amp, amp); s.com_y[1] = rng.uniform(-0.6 * amp, 0.6 * amp)
+        s.com_x[2] = rng.uniform(-amp, amp)
+        C.memmove(C.byref(states[g]), C.byref(s), C.sizeof(wg.GaitState))
+    ref_states = (wg.GaitState * B)()
+    C.memmove(ref_states, states, C.sizeof(states))
+    seen_fail = set(); sizes = set(); max_act = 0
+    for tick in range(45):
+        if tick % 12 == 0:
+            for g in range(B):
+                v = [rng.uniform(-0.2, 0.4), rng.uniform(-0.2, 0.2), rng.uniform(-0.3, 0.3)] if g % 3 else [0.0, 0.0, 0.0]
+                for st in (states[g], ref_states[g]):
+                    st.vref[0], st.vref[1], st.vref[2] = v
+        adv = 1 if tick == 0 else (19 if tick == 1 else 20)
+        outs, diag, _, _ = wg.mpc_tick_batch(states, want_out=True, advance_calls=adv)
+        for g in range(B):
+            c = ref_states[g].clock
+            for _ in range(adv):
+                c += model.Tctrl
+            ref_states[g].clock = c
+            o = hr.TickOut()
+            assert pt.wgo_mpc_tick(C.byref(model), C.byref(ref_states[g]), C.byref(o), None) == 0
+            assert o.ifail == diag[g, 0] and o.n_iter == diag[g, 1] and o.nact == diag[g, 2], (tick, g, o.ifail, diag[g])
+            assert bytes(o) == bytes(outs[g]), (tick, g)
+        assert _bytes(states) == _bytes(ref_states), tick
+        seen_fail |= set(int(v) for v in diag[:, 0]); sizes |= set(int(v) for v in diag[:, 3])
+        max_act = max(max_act, int(diag[:, 2].max()))
+    assert sizes == {32, 34, 36} and max_act >= 28
+    assert any(f > 10 for f in seen_fail) and 0 in seen_fail
