@@ -611,7 +611,8 @@ wg::DimitrovConst g_dim_host;
 bool g_dim_set = false;
 DevBuf g_dim_buf;
 inline size_t dimitrov_lds_bytes() {
-  return wg::PldpLds::bytes(WG_PLDP_MMAX) + (4 * 2 * WG_PLDP_N + 8) * 8 + ((WG_PLDP_N + 1) * 4 + 15) / 16 * 16;
+  return wg::PldpLds::bytes(WG_PLDP_MMAX, wg::kDimitrovActiveCap, true) + (4 * 2 * WG_PLDP_N + 8) * 8 +
+         ((WG_PLDP_N + 1) * 4 + 15) / 16 * 16;
 }
 }  // namespace
 

@@ -141,14 +141,16 @@ struct DimitrovHost {
   }
 };
 
-// one gait, one tick.  LDS: the PLDP work area (mcap = 8N) + 4 * 2N doubles (D, zmpref, NewX, X) + 8 (xk).
+constexpr int kDimitrovActiveCap = 40;   // E E' is singular beyond 2N = 32 active rows
+
+// one gait, one tick.  LDS: the structured PLDP work area (mcap = 8N) + 4 * 2N doubles (D, zmpref, NewX, X) + 8 (xk).
 __device__ void dimitrov_tick(const DimitrovConst &K, unsigned char *lds, const wg_zmp_polytope_t *__restrict__ polys,
                               wg_dimitrov_state_t *st, wg_dimitrov_out_t *out, int max_iter) {
   const int lane = threadIdx.x;
   const int N = K.N, n = 2 * N, mcap = WG_POLY_MAX_ROWS * N;
   PldpLds W;
-  W.carve(lds, mcap);
-  double *D = reinterpret_cast<double *>(lds + PldpLds::bytes(mcap));
+  W.carve(lds, mcap, kDimitrovActiveCap, true, N);
+  double *D = reinterpret_cast<double *>(lds + PldpLds::bytes(mcap, kDimitrovActiveCap, true));
   double *zr = D + 2 * WG_PLDP_N, *NewX = zr + 2 * WG_PLDP_N, *X = NewX + 2 * WG_PLDP_N, *xk = X + 2 * WG_PLDP_N;
   int *rowbase = reinterpret_cast<int *>(xk + 8);                 // [N+1] first row of each instant
   if (lane < 6) xk[lane] = st->xk[lane];
@@ -174,15 +176,12 @@ __device__ void dimitrov_tick(const DimitrovConst &K, unsigned char *lds, const 
       W.similar[idx] = sim;
       W.state[idx] = 0;
       if (sim > 0 || idx + sim < 0) bad = true;
-      for (int k = 0; k < N; k++) {
-        const double pu = K.pldp.Pu[k * N + i];
-        W.A[idx + k * W.lda] = a0 * pu;
-        W.A[idx + (k + N) * W.lda] = a1 * pu;
-      }
+      W.c0[idx] = a0; W.c1[idx] = a1; W.slot[idx] = i;          // DPu(idx, k) = a0 Pu[k][i], DPu(idx, k+N) = a1 Pu[k][i]
     }
   }
   if (lane < N) { zr[lane] = polys[lane].centre[0]; zr[lane + N] = polys[lane].centre[1]; }
-  if (lane < WG_PLDP_ACTIVE_CAP) W.v2[lane] = 0.0;
+  for (int e = lane; e < N * N; e += 64) W.PuL[e] = K.pldp.Pu[e];
+  if (lane < W.cap) W.v2[lane] = 0.0;
   WG_WSYNC();
   // ---- D = OptB xk - OptC ZMPRef :1254-1262 ----
   if (lane < n) {
@@ -195,7 +194,7 @@ __device__ void dimitrov_tick(const DimitrovConst &K, unsigned char *lds, const 
   int S = 0, it = 0, rc;
   const int first_rows = rowbase[1] - rowbase[0];                  // NextNumberOfRemovedConstraints :823
   if (__ballot(bad)) rc = WG_PLDP_BAD_INPUT;
-  else rc = pldp_solve(K.pldp, W, m, D, zr, xk, st->n_removed, st->starting, max_iter, &st->pldp, S, it);
+  else rc = pldp_solve<true>(K.pldp, W, m, D, zr, xk, st->n_removed, st->starting, max_iter, &st->pldp, S, it);
   if (lane < n) X[lane] = W.Vk[lane];
   WG_WSYNC();
   // ---- X <- iLQ' X :1355-1381 ----

@@ -37,20 +37,26 @@ struct PldpModel {               // device-resident constants (wg_pldp_configure
 
 struct PldpLds {
   double *A, *L, *b, *c, *d, *Vk, *v2, *tmp1;
+  double *c0, *c1, *PuL;         // structured view: A(row, k) = c0[row] * Pu[k][slot[row]], A(row, k+N) = c1[row] * Pu[k][slot[row]]
   int *similar, *act, *state;    // state[row]: 1 active, 0 not
-  int lda;
+  int *slot;
+  int lda, cap, N;
   __host__ __device__ static int lda_for(int mcap) { return (mcap + 1) | 1; }
-  __host__ __device__ static size_t bytes(int mcap) {
-    const size_t n = 2 * WG_PLDP_N, cap = WG_PLDP_ACTIVE_CAP;
-    size_t dbl = (size_t)lda_for(mcap) * n + cap * (cap + 1) / 2 + mcap /*b*/ + 3 * n /*c d Vk*/ + cap /*v2*/ + mcap /*tmp1*/;
-    size_t ints = (size_t)mcap /*similar*/ + cap /*act*/ + mcap /*state*/;
+  // dense view: A staged with an odd leading dimension; structured view: 2 coefficients + the instant per row
+  __host__ __device__ static size_t bytes(int mcap, int cap = WG_PLDP_ACTIVE_CAP, bool structured = false) {
+    const size_t n = 2 * WG_PLDP_N;
+    size_t dbl = (structured ? (size_t)2 * mcap + WG_PLDP_N * WG_PLDP_N : (size_t)lda_for(mcap) * n) +
+                 (size_t)cap * (cap + 1) / 2 + mcap /*b*/ + 3 * n /*c d Vk*/ + cap /*v2*/ + mcap /*tmp1*/;
+    size_t ints = (size_t)mcap /*similar*/ + cap /*act*/ + mcap /*state*/ + (structured ? mcap : 0) /*slot*/;
     return dbl * 8 + ((ints * 4 + 7) & ~size_t(7));
   }
-  __device__ void carve(unsigned char *base, int mcap) {
-    const int n = 2 * WG_PLDP_N, cap = WG_PLDP_ACTIVE_CAP;
+  __device__ void carve(unsigned char *base, int mcap, int cap_ = WG_PLDP_ACTIVE_CAP, bool structured = false, int N_ = WG_PLDP_N) {
+    const int n = 2 * WG_PLDP_N;
     double *p = reinterpret_cast<double *>(base);
-    lda = lda_for(mcap);
-    A = p; p += lda * n;
+    lda = lda_for(mcap); cap = cap_; N = N_;
+    A = nullptr; c0 = c1 = PuL = nullptr; slot = nullptr;
+    if (structured) { c0 = p; p += mcap; c1 = p; p += mcap; PuL = p; p += WG_PLDP_N * WG_PLDP_N; }
+    else { A = p; p += lda * n; }
     L = p; p += cap * (cap + 1) / 2;
     b = p; p += mcap;
     c = p; p += n;
@@ -61,7 +67,19 @@ struct PldpLds {
     int *q = reinterpret_cast<int *>(p);
     similar = q; q += mcap;
     act = q; q += cap;
-    state = q;
+    state = q; q += mcap;
+    if (structured) slot = q;
+  }
+  // element (row, col) of the constraint matrix; ST selects the structured view at compile time.  The structured
+  // product c * Pu is the very multiplication BuildConstraintMatrices performs (:893-905), so the value is identical.
+  template <bool ST>
+  __device__ __forceinline__ double a(int row, int col) const {
+    if constexpr (ST) {
+      const bool y = col >= N;
+      return (y ? c1[row] : c0[row]) * PuL[(y ? col - N : col) * N + slot[row]];
+    } else {
+      return A[row + col * lda];
+    }
   }
 };
 
@@ -79,6 +97,7 @@ __device__ __forceinline__ void wave_argmin_first(double &v, int &idx) {
 }
 
 // OptCholesky::AddActiveConstraint + UpdateCholeskyMatrixFortran: append `row` as active row S (S < cap checked by caller)
+template <bool ST>
 __device__ __forceinline__ void pldp_add_row(const PldpLds &W, int n, int S, int row, int lane) {
   if (lane == 0) { W.act[S] = row; W.state[row] = 1; W.v2[S] = 0.0; }
   WG_WSYNC();
@@ -86,7 +105,7 @@ __device__ __forceinline__ void pldp_add_row(const PldpLds &W, int n, int S, int
   if (lane <= S) {
     const int rj = W.act[lane];
     double mij = 0.0;
-    for (int k = 0; k < n; k++) mij += W.A[row + k * W.lda] * W.A[rj + k * W.lda];
+    for (int k = 0; k < n; k++) mij += W.a<ST>(row, k) * W.a<ST>(rj, k);
     r = mij;
   }
   for (int lk = 0; lk <= S; lk++) {
@@ -102,6 +121,7 @@ __device__ __forceinline__ void pldp_add_row(const PldpLds &W, int n, int S, int
 }
 
 // one SolveProblem; returns ret (uniform).  Outputs written by the caller from LDS/registers.
+template <bool ST>
 __device__ int pldp_solve(const PldpModel &M, const PldpLds &W, int m, const double *__restrict__ D_g,
                           const double *__restrict__ zmpref, const double *__restrict__ xkyk, int n_removed,
                           int starting, int max_iter, wg_pldp_state_t *st, int &S_out, int &it_out) {
@@ -133,8 +153,8 @@ __device__ int pldp_solve(const PldpModel &M, const PldpLds &W, int m, const dou
   for (int i = 0; i < n_prev; i++) {
     const int lindex = st->prev_active[i] - n_removed;
     if (lindex >= 0) {
-      if (S >= WG_PLDP_ACTIVE_CAP || lindex >= m) { rc = WG_PLDP_CAPACITY; break; }
-      pldp_add_row(W, n, S, lindex, lane);
+      if (S >= W.cap || lindex >= m) { rc = WG_PLDP_CAPACITY; break; }
+      pldp_add_row<ST>(W, n, S, lindex, lane);
       S++;
     }
   }
@@ -153,7 +173,7 @@ __device__ int pldp_solve(const PldpModel &M, const PldpLds &W, int m, const dou
     double acc = 0.0;
     if (lane < S) {
       const int row = W.act[lane];
-      for (int lj = 0; lj < n; lj++) acc += W.A[row + lj * W.lda] * W.c[lj];
+      for (int lj = 0; lj < n; lj++) acc += W.a<ST>(row, lj) * W.c[lj];
     }
     for (int k = 0; k < S; k++) {
       double yk = 0.0;
@@ -178,7 +198,7 @@ __device__ int pldp_solve(const PldpModel &M, const PldpLds &W, int m, const dou
     // d = c - E' v2 :509-519
     if (lane < n) {
       double dd = cl;
-      for (int lj = 0; lj < S; lj++) dd -= W.A[W.act[lj] + lane * W.lda] * W.v2[lj];
+      for (int lj = 0; lj < S; lj++) dd -= W.a<ST>(W.act[lj], lane) * W.v2[lj];
       dl = dd;
       W.d[lane] = dd;
     }
@@ -200,7 +220,7 @@ __device__ int pldp_solve(const PldpModel &M, const PldpLds &W, int m, const dou
           if (sim != 0 && !W.state[li + sim]) pending[h] = true;
           else {
             double s = 0.0;
-            for (int lj = 0; lj < n; lj++) s += W.A[li + lj * W.lda] * W.d[lj];
+            for (int lj = 0; lj < n; lj++) s += W.a<ST>(li, lj) * W.d[lj];
             t1[h] = s;
             W.tmp1[li] = s;
           }
@@ -232,7 +252,7 @@ __device__ int pldp_solve(const PldpModel &M, const PldpLds &W, int m, const dou
         const int li = lane + 64 * h;
         if (cand[h] && t1[h] < 0.0) {
           double t2 = -W.b[li];
-          for (int lj = 0; lj < n; lj++) t2 -= W.A[li + lj * W.lda] * W.Vk[lj];
+          for (int lj = 0; lj < n; lj++) t2 -= W.a<ST>(li, lj) * W.Vk[lj];
           if (t2 > tol) { /* reference prints "PB ON constraint" */ }
           else if (t2 > 0.0) t2 = -tol;
           const double la = t2 / t1[h];
@@ -248,8 +268,8 @@ __device__ int pldp_solve(const PldpModel &M, const PldpLds &W, int m, const dou
     if (alpha < 0.0) { rc = WG_PLDP_NEG_ALPHA; break; }
     vk = vk + alpha * dl;                                      // :841-844
     if (go && add >= 0) {
-      if (S >= WG_PLDP_ACTIVE_CAP) { rc = WG_PLDP_CAPACITY; break; }
-      pldp_add_row(W, n, S, add, lane);
+      if (S >= W.cap) { rc = WG_PLDP_CAPACITY; break; }
+      pldp_add_row<ST>(W, n, S, add, lane);
       S++;
     }
     if (max_iter > 0 && it + 1 >= max_iter) go = false;
@@ -304,11 +324,11 @@ __device__ void pldp_problem(const PldpModel &M, unsigned char *lds, int mcap, i
   const int ldg = m + 1;
   for (int col = 0; col < n; col++)
     for (int row = lane; row < m; row += 64) W.A[row + col * W.lda] = A[row + col * ldg];
-  if (lane < WG_PLDP_ACTIVE_CAP) W.v2[lane] = 0.0;
+  if (lane < W.cap) W.v2[lane] = 0.0;
   WG_WSYNC();
   int S = 0, it = 0, rc;
   if (__ballot(bad)) rc = WG_PLDP_BAD_INPUT;
-  else rc = pldp_solve(M, W, m, D, zmpref, xkyk, n_removed, starting, max_iter, st, S, it);
+  else rc = pldp_solve<false>(M, W, m, D, zmpref, xkyk, n_removed, starting, max_iter, st, S, it);
   if (lane < n) X[lane] = W.Vk[lane];
   if (lane == 0) {
     *ret = rc;
