@@ -285,15 +285,28 @@ inline size_t tick_ql_bytes(const wg_model_t &m) {
 }
 }  // namespace
 
+// Waves per SIMD the tick kernel is compiled for: 2 => at most 256 registers per lane.  With 26.2 KB of LDS per gait six
+// gaits fit a CU (SIMDs hold 2,2,1,1 waves); the second wave of a SIMD hides the first one's dependent fp64 chains
+// (measured: 4 -> 6 resident gaits per CU = 1.78 -> 2.23 M ticks/s).  -DWG_TICK_WPE_MIN=1 -DWG_TICK_WPE_MAX=1 gives the
+// 512-register build (lib/libwg_mpc_w1.so, tools/bench_variants.sh).
+#ifndef WG_TICK_WPE_MIN
+#define WG_TICK_WPE_MIN 2
+#endif
+#ifndef WG_TICK_WPE_MAX
+#define WG_TICK_WPE_MAX 2
+#endif
 template <int NH>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void wg_mpc_tick_kernel(int B, wg_model_t model, const wg::TickTables *__restrict__ tb,
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WG_TICK_WPE_MIN, WG_TICK_WPE_MAX))) void wg_mpc_tick_kernel(int B, wg_model_t model, const wg::TickTables *__restrict__ tb,
                                                          wg_gait_state_t *__restrict__ states,
                                                          wg_tick_out_t *__restrict__ outs, int *__restrict__ diag,
                                                          int advance_calls, int *__restrict__ hist, int hist_cap,
                                                          int *__restrict__ hist_len, unsigned ql_bytes) {
   extern __shared__ __attribute__((aligned(16))) double wg_lds[];
   const int lane = threadIdx.x & 63;
-  for (int g = blockIdx.x; g < B; g += gridDim.x) {
+  // one block = one gait (grid == B): no grid-stride loop, so nothing lane-dependent is hoisted out of it and kept
+  // alive (in registers) across the whole tick
+  const int g = blockIdx.x;
+  if (g < B) {
     if (advance_calls > 0) {
       if (lane == 0) {
         double c = states[g].clock;
@@ -359,7 +372,7 @@ int wg_mpc_configure(const wg_model_t *model) {
   if (model->N < 2 || model->N > wg::kNMaxH) return fail(WG_ERR_BAD_ARG, "N=%d outside [2,%d]", model->N, wg::kNMaxH);
   if ((int)(model->T / model->Tctrl) != WG_SAMPLES_PER_TICK)
     return fail(WG_ERR_BAD_ARG, "T/Tctrl must be %d", WG_SAMPLES_PER_TICK);
-  size_t lds = tick_ql_bytes(*model) + wg::TickLds::bytes(model->N, tick_smax(*model));
+  size_t lds = tick_ql_bytes(*model) + wg::TickLds::bytes(model->N, tick_smax(*model), tick_compact(*model));
   if (lds > 160 * 1024) return fail(WG_ERR_TOO_LARGE, "tick needs %zu B of LDS > 160 KiB", lds);
   std::lock_guard<std::mutex> lk(g_mu);
   static wg::TickTables host_tables;
@@ -373,7 +386,7 @@ int wg_mpc_configure(const wg_model_t *model) {
 
 size_t wg_mpc_tick_lds_bytes(void) {
   if (!g_model_set) return 0;
-  return tick_ql_bytes(g_model) + wg::TickLds::bytes(g_model.N, tick_smax(g_model));
+  return tick_ql_bytes(g_model) + wg::TickLds::bytes(g_model.N, tick_smax(g_model), tick_compact(g_model));
 }
 
 int wg_mpc_tick_batch_dev(int B, wg_gait_state_t *states, wg_tick_out_t *outs, int *diag, int advance_calls, int *hist,
@@ -384,18 +397,14 @@ int wg_mpc_tick_batch_dev(int B, wg_gait_state_t *states, wg_tick_out_t *outs, i
   if (hist && (!hist_len || hist_cap <= 0)) return fail(WG_ERR_BAD_ARG, "hist needs hist_len and hist_cap > 0");
   if (B == 0) return WG_OK;
   const size_t qlb = tick_ql_bytes(g_model);
-  const size_t lds = qlb + wg::TickLds::bytes(g_model.N, tick_smax(g_model));
+  size_t lds = qlb + wg::TickLds::bytes(g_model.N, tick_smax(g_model), tick_compact(g_model));
+  if (const char *pad = getenv("WG_TICK_LDS_PAD")) lds += (size_t)atoi(pad);   // experiments: lower the residency
   const bool compact = tick_compact(g_model);
   if (lds > 64 * 1024)
     HIP_TRY(hipFuncSetAttribute(compact ? reinterpret_cast<const void *>(wg_mpc_tick_kernel<16>)
                                         : reinterpret_cast<const void *>(wg_mpc_tick_kernel<0>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  int per_cu = (int)((160 * 1024) / lds);
-  if (per_cu < 1) per_cu = 1;
-  per_cu *= 2;                                    // a few blocks in flight per slot evens out solver iteration counts
-  if (const char *ov = getenv("WG_WAVES_PER_CU")) { int v = atoi(ov); if (v > 0) per_cu = v; }
-  int grid = g_num_cu * per_cu;
-  if (grid > B) grid = B;
+  const int grid = B;                             // one gait per block; the dispatcher balances uneven iteration counts
   hipStream_t st = reinterpret_cast<hipStream_t>(hip_stream);
   if (compact)
     hipLaunchKernelGGL(wg_mpc_tick_kernel<16>, dim3(grid), dim3(64), lds, st, B, g_model, g_tables_dev, states, outs, diag,

@@ -263,16 +263,24 @@ __device__ __forceinline__ void backsub(const QlView &q, const double *s, int na
 // ---------------------------------------------------------------------------------------------------
 
 // sum of term[0..cnt) in index order (term lives one-per-lane); scratch: NM doubles of LDS, 16-byte aligned.
+#ifndef WG_OS_CHUNK
+#define WG_OS_CHUNK 12
+#endif
+constexpr int kOsChunk = WG_OS_CHUNK;
 template <int NM>
 __device__ __forceinline__ double ordered_sum_lds(double term, double *scratch, int cnt, int lane) {
   if (lane < NM) scratch[lane] = (lane < cnt) ? term : 0.0;
   WG_WSYNC();
-  double t[NM];
-#pragma unroll
-  for (int i = 0; i < NM; ++i) t[i] = scratch[i];
+  // loads in groups of kOsChunk ahead of the add chain: enough to cover the LDS latency, few enough live registers
   double sum = 0.0;
 #pragma unroll
-  for (int i = 0; i < NM; ++i) sum += t[i];      // entries >= cnt are +0.0: they leave the sum unchanged
+  for (int i0 = 0; i0 < NM; i0 += kOsChunk) {
+    double t[kOsChunk];
+#pragma unroll
+    for (int i = 0; i < kOsChunk; ++i) t[i] = (i0 + i < NM) ? scratch[i0 + i] : 0.0;
+#pragma unroll
+    for (int i = 0; i < kOsChunk; ++i) if (i0 + i < NM) sum += t[i];   // entries >= cnt are +0.0: they leave the sum unchanged
+  }
   WG_WSYNC();
   return sum;
 }
@@ -1042,11 +1050,16 @@ __device__ inline QlResult ql_solve(const QlView &q, P &prob, double vsmall, int
               q.sc0[lane] = wi * zi; q.sc1[lane] = fabs(wi * zi); q.sc2[lane] = zi * zi;
             }
             WG_WSYNC();
-            double ta[NM], tb[NM], tc[NM];
 #pragma unroll
-            for (int i = 0; i < NM; ++i) { ta[i] = q.sc0[i]; tb[i] = q.sc1[i]; tc[i] = q.sc2[i]; }
+            for (int i0 = 0; i0 < NM; i0 += kOsChunk) {
+              double ta[kOsChunk], tb[kOsChunk], tc[kOsChunk];
 #pragma unroll
-            for (int i = 0; i < NM; ++i) { suma += ta[i]; sumb += tb[i]; sumc += tc[i]; }
+              for (int i = 0; i < kOsChunk; ++i)
+                if (i0 + i < NM) { ta[i] = q.sc0[i0 + i]; tb[i] = q.sc1[i0 + i]; tc[i] = q.sc2[i0 + i]; }
+#pragma unroll
+              for (int i = 0; i < kOsChunk; ++i)
+                if (i0 + i < NM) { suma += ta[i]; sumb += tb[i]; sumc += tc[i]; }
+            }
             WG_WSYNC();
           } else if (n <= 60) {
             double ta = 0.0, tb = 0.0, tc = 0.0;

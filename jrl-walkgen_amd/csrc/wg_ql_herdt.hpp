@@ -20,6 +20,7 @@
 namespace wg {
 
 constexpr int kSMaxQ = 4;   // == kSMax of the tick
+constexpr int kGvLd = 4;    // row stride of the border block Gv: 2*ns <= 4 columns (at most two previewed steps)
 constexpr int kQbLd = 32;   // row stride of TickTables::Qb (== kNMaxH)
 
 template <int NH>
@@ -30,7 +31,7 @@ struct HerdtProb {
   // ---- LDS / global tables (wave-uniform pointers) ----
   const double *Qb;       // global (L1/L2-resident constant of the model), NH x kQbLd
   const double *u;        // LDS, NH
-  double *Gv;             // LDS, n x (2*kSMaxQ): G(i, 2N + c)
+  double *Gv;             // LDS, n x kGvLd: G(i, 2N + c)
   double *gd;             // LDS, n: current Hessian diagonal (shifted when needed)
   const double *rowA, *rowB;
   const int *rowK, *stepidx;
@@ -53,7 +54,7 @@ struct HerdtProb {
       if (i >= NH && j >= NH) return Qb[(i - NH) * kQbLd + (j - NH)];
       return 0.0;
     }
-    return Gv[i * (2 * kSMaxQ) + (j - 2 * NH)];
+    return Gv[i * kGvLd + (j - 2 * NH)];
   }
   __device__ __forceinline__ double Gd(const QlView &, int i) const { return gd[i]; }
   __device__ __forceinline__ void setGd(const QlView &, int i, double v) const { gd[i] = v; }
@@ -165,13 +166,13 @@ struct HerdtProb {
         const double g = (blk + k == row) ? gd[row] : qr[k];
         acc += g * v[blk + k];
       }
-      for (int c = 0; c < n - 2 * NH; ++c) acc += Gv[row * (2 * kSMaxQ) + c] * v[2 * NH + c];
+      for (int c = 0; c < n - 2 * NH; ++c) acc += Gv[row * kGvLd + c] * v[2 * NH + c];
       return acc;
     }
     const int cc = row - 2 * NH;
-    for (int k = 0; k < 2 * NH; ++k) acc += Gv[k * (2 * kSMaxQ) + cc] * v[k];
+    for (int k = 0; k < 2 * NH; ++k) acc += Gv[k * kGvLd + cc] * v[k];
     for (int c = 0; c < n - 2 * NH; ++c) {
-      const double g = (c == cc) ? gd[row] : Gv[row * (2 * kSMaxQ) + c];
+      const double g = (c == cc) ? gd[row] : Gv[row * kGvLd + c];
       acc += g * v[2 * NH + c];
     }
     return acc;

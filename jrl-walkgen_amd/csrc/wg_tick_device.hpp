@@ -130,43 +130,63 @@ struct Sup {
   double time_limit, start_time, x, y, yaw;
 };
 
-// LDS scratch of the tick (besides the solver's QlView)
+// LDS scratch of the tick (besides the solver's QlView).  Two groups:
+//   * persistent: read by the solver's problem view or by the post-solve interpolation;
+//   * pre-solve only (support preview, selection vectors, reference, S*c products, edge offsets): dead once the QP is
+//     assembled.  In the compact build they are overlaid on the solver's Z matrix, which the solver writes first thing
+//     (factor()) and nobody reads before -- 2.8 KB less LDS per gait.
 struct TickLds {
+  // ---- pre-solve only ----
   Sup *sup;                       // [N+1]
-  int *stepidx;                   // [N]
   double *VcX, *VcY;              // [N]
   double *Vc_fX, *Vc_fY;          // [kSMax]
-  double *V_f;                    // [kSMax*kSMax]
-  double *sup_angles;             // [8]
   double *trunk;                  // [N+1]
   double *refx, *refy;            // [N]
   double *svx, *svy, *szx, *szy;  // [N]
-  double *rowA, *rowB, *rowD;     // [m]  polygon edge per constraint row
+  double *rowD;                   // [m]
+  // ---- persistent ----
+  Sup *sup0;                      // [1] copy of sup[0] for the post-solve phase
+  int *stepidx;                   // [N]
+  double *V_f;                    // [kSMax*kSMax]
+  double *sup_angles;             // [8]
+  double *rowA, *rowB;            // [m]  polygon edge per constraint row
   int *rowK;                      // [m]  instant (CoP rows) or step (foot rows)
   double *misc;                   // [16] scalars handed from lane 0 to the wave
-  double *Qb, *uvec, *Gv, *gd;    // compact problem view (wg_ql_herdt.hpp): N x (N+1), N, nmax x 8, nmax
+  double *uvec, *Gv, *gd;         // compact problem view (wg_ql_herdt.hpp): N, nmax x kGvLd, nmax
   wg_gait_state_t *st;            // working copy of the state
-  __host__ __device__ static size_t bytes(int N, int smax = kSMax) {
+  __host__ __device__ static size_t pre_doubles(int N, int m) { return (size_t)(2 * N + 2 * kSMax + (N + 1) + 6 * N + m); }
+  __host__ __device__ static size_t pre_bytes(int N, int smax) {
+    const int m = 1 + 4 * N + 5 * smax;
+    return sizeof(Sup) * (N + 1) + 8 * pre_doubles(N, m);
+  }
+  // compact: the pre-solve group lives elsewhere (overlay), and the compact view's tables are present
+  __host__ __device__ static size_t bytes(int N, int smax = kSMax, bool compact = false) {
     const int m = 1 + 4 * N + 5 * smax;
     const int nmax = 2 * N + 2 * smax;
-    size_t b = sizeof(Sup) * (N + 1) + 8 * (size_t)(2 * N + 2 * kSMax + kSMax * kSMax + 8 + (N + 1) + 6 * N + 3 * m + 16 +
-                                                    N + nmax * 2 * kSMax + nmax) +
+    size_t b = sizeof(Sup) + 8 * (size_t)(kSMax * kSMax + 8 + 2 * m + 16 + (compact ? N + nmax * kGvLd + nmax : 0)) +
                4 * (size_t)(((N + 1) & ~1) + ((m + 1) & ~1)) + ((sizeof(wg_gait_state_t) + 15) & ~(size_t)15);
+    if (!compact) b += pre_bytes(N, smax);
     return (b + 15) & ~(size_t)15;
   }
-  __device__ void carve(char *base, int N, int smax = kSMax) {
+  __device__ void carve(char *base, int N, int smax, bool compact, char *overlay) {
     const int m = 1 + 4 * N + 5 * smax;
     char *p = base;
     st = reinterpret_cast<wg_gait_state_t *>(p); p += (sizeof(wg_gait_state_t) + 15) & ~(size_t)15;
-    sup = reinterpret_cast<Sup *>(p); p += sizeof(Sup) * (N + 1);
+    sup0 = reinterpret_cast<Sup *>(p); p += sizeof(Sup);
     double *d = reinterpret_cast<double *>(p);
-    VcX = d; d += N; VcY = d; d += N; Vc_fX = d; d += kSMax; Vc_fY = d; d += kSMax; V_f = d; d += kSMax * kSMax;
-    sup_angles = d; d += 8; trunk = d; d += N + 1; refx = d; d += N; refy = d; d += N;
-    svx = d; d += N; svy = d; d += N; szx = d; d += N; szy = d; d += N;
-    rowA = d; d += m; rowB = d; d += m; rowD = d; d += m; misc = d; d += 16;
-    { const int nmax = 2 * N + 2 * smax; Qb = nullptr; uvec = d; d += N; Gv = d; d += nmax * 2 * kSMax; gd = d; d += nmax; }
+    V_f = d; d += kSMax * kSMax; sup_angles = d; d += 8;
+    rowA = d; d += m; rowB = d; d += m; misc = d; d += 16;
+    uvec = Gv = gd = nullptr;
+    if (compact) { const int nmax = 2 * N + 2 * smax; uvec = d; d += N; Gv = d; d += nmax * kGvLd; gd = d; d += nmax; }
     int *ip = reinterpret_cast<int *>(d);
-    stepidx = ip; ip += (N + 1) & ~1; rowK = ip;
+    stepidx = ip; ip += (N + 1) & ~1; rowK = ip; ip += (m + 1) & ~1;
+    char *o = compact ? overlay : reinterpret_cast<char *>(ip);
+    sup = reinterpret_cast<Sup *>(o); o += sizeof(Sup) * (N + 1);
+    double *e = reinterpret_cast<double *>(o);
+    VcX = e; e += N; VcY = e; e += N; Vc_fX = e; e += kSMax; Vc_fY = e; e += kSMax;
+    trunk = e; e += N + 1; refx = e; e += N; refy = e; e += N;
+    svx = e; e += N; svy = e; e += N; szx = e; e += N; szy = e; e += N;
+    rowD = e; e += m;
   }
 };
 
@@ -427,7 +447,9 @@ __device__ inline TickDiag mpc_tick(const wg_model_t &m, const TickTables *__res
   const double T = m.T;
   const int K = WG_SAMPLES_PER_TICK;
   TickLds L;
-  L.carve(lds_tick, N, (NH == 16) ? 2 : kSMax);
+  // compact: the pre-solve group is overlaid on Z, the first array of the solver's area (QlView::carve without G)
+  static_assert(sizeof(Sup) % 8 == 0, "Sup must keep doubles aligned");
+  L.carve(lds_tick, N, (NH == 16) ? 2 : kSMax, NH == 16, reinterpret_cast<char *>(lds_ql));
   wg_gait_state_t *s = L.st;
 #ifdef WG_PROFILE
   unsigned long long tk0 = clock64(), tk1 = 0, tk2 = 0, tk3 = 0;
@@ -540,6 +562,7 @@ __device__ inline TickDiag mpc_tick(const wg_model_t &m, const TickTables *__res
         }
       }
     }
+    *L.sup0 = L.sup[0];
     L.misc[0] = (double)ns;
     L.misc[1] = ref[0]; L.misc[2] = ref[1]; L.misc[3] = ref[2];
   }
@@ -598,7 +621,7 @@ __device__ inline TickDiag mpc_tick(const wg_model_t &m, const TickTables *__res
   if constexpr (kCompactView) {
     // compact view: Qb and u as small LDS tables, the 2ns border columns (symmetric) and the diagonal
     for (int d = lane; d < N; d += 64) L.uvec[d] = tb->Uz[d][0];                 // Uz[r][c] = u[r-c]
-    for (int e = lane; e < n * 2 * kSMax; e += 64) L.Gv[e] = 0.0;
+    for (int e = lane; e < n * kGvLd; e += 64) L.Gv[e] = 0.0;
     for (int i = lane; i < 2 * N; i += 64) L.gd[i] = tb->Qb[i % N][i % N];
     WG_WSYNC();
     for (int e = lane; e < N * ns; e += 64) {
@@ -606,8 +629,8 @@ __device__ inline TickDiag mpc_tick(const wg_model_t &m, const TickTables *__res
       double p = 0.0;
       for (int k = 0; k < N; k++) { const double v = (L.stepidx[k] == j + 1) ? 1.0 : 0.0; p += tb->Uz[k][i] * v; }
       p *= -m.gamma;
-      L.Gv[i * (2 * kSMax) + j] = 0.0 + p;                                        // x block  x  x-foot column
-      L.Gv[(N + i) * (2 * kSMax) + ns + j] = 0.0 + p;                             // y block  x  y-foot column
+      L.Gv[i * kGvLd + j] = 0.0 + p;                                        // x block  x  x-foot column
+      L.Gv[(N + i) * kGvLd + ns + j] = 0.0 + p;                             // y block  x  y-foot column
     }
     for (int e = lane; e < ns * ns; e += 64) {
       const int i = e % ns, j = e / ns;
@@ -618,7 +641,7 @@ __device__ inline TickDiag mpc_tick(const wg_model_t &m, const TickTables *__res
       }
       p *= m.gamma;
       if (i == j) { L.gd[2 * N + i] = 0.0 + p; L.gd[2 * N + ns + i] = 0.0 + p; }
-      else { L.Gv[(2 * N + i) * (2 * kSMax) + j] = 0.0 + p; L.Gv[(2 * N + ns + i) * (2 * kSMax) + ns + j] = 0.0 + p; }
+      else { L.Gv[(2 * N + i) * kGvLd + j] = 0.0 + p; L.Gv[(2 * N + ns + i) * kGvLd + ns + j] = 0.0 + p; }
     }
     // the border rows' Gv entries toward the border columns mirror the lower-left block (symmetry is exact:
     // (VT Uz)(j,i) and (UzT V)(i,j) are the same products in the same order)
@@ -726,7 +749,7 @@ __device__ inline TickDiag mpc_tick(const wg_model_t &m, const TickTables *__res
 
   // ---- CoM: jerk, 20 interpolated samples, state step (ZMPVelocityReferencedQP.cpp:405-428) ----
   double jx, jy;
-  const bool stop_branch = (L.sup[0].nb_steps_left == 0) && !(m.flags & WG_FLAG_NO_STOP_CENTERING);
+  const bool stop_branch = (L.sup0->nb_steps_left == 0) && !(m.flags & WG_FLAG_NO_STOP_CENTERING);
   if (stop_branch) {
     jx = (s->lf[0].x + s->rf[0].x) / 2 - s->front_com_x[0];
     jy = (s->lf[0].y + s->rf[0].y) / 2 - s->front_com_y[0];
@@ -787,7 +810,7 @@ __device__ inline TickDiag mpc_tick(const wg_model_t &m, const TickTables *__res
 
   // ---- lane 0: trunk and feet (sequential in k) ----
   if (lane == 0) {
-    const Sup cs = L.sup[0];
+    const Sup cs = *L.sup0;
     const double dt = m.Tctrl;
     // interpolate_trunk_orientation, OrientationsPreview.cpp:368-418
     if (cs.phase == WG_SS && time + 3.0 / 2.0 * T < cs.time_limit) {
@@ -823,7 +846,7 @@ __device__ inline TickDiag mpc_tick(const wg_model_t &m, const TickTables *__res
 
   // ---- feet: one lane per 5 ms sample (interpolate_feet_positions, OnLineFootTrajectoryGeneration.cpp:235-346) ----
   {
-    const Sup cs = L.sup[0];
+    const Sup cs = *L.sup0;
     const double dt = m.Tctrl;
     const wg_foot_sample_t zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     const int k = lane + 1;                                // sample index 1..20
