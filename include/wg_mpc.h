@@ -370,6 +370,37 @@ int wg_dimitrov_tick_batch(int B, const wg_zmp_polytope_t *polys, wg_dimitrov_st
 int wg_dimitrov_tick_batch_dev(int B, const wg_zmp_polytope_t *polys, wg_dimitrov_state_t *states,
                                wg_dimitrov_out_t *outs, int max_iter, void *hip_stream);
 
+/* Kajita stage-1 preview control, batched over independent gaits ------------------------------------------------------
+ *
+ * wg_preview_configure replaces the members PreviewControl holds once ComputeOptimalWeights
+ * (src/PreviewControl/PreviewControl.cpp:198-322) or ReadPrecomputedFile (:134-194) has run: sampling period T and CoM
+ * height zc (=> m_A, m_B, m_C :203-214), m_Kx, m_Ks and the window gains m_F[nl], nl = (int)(preview time / T).
+ * (wg_riccati_gains computes them; mode WITHOUT_INITIALPOS returns K = {Ks, Kx[0..2]}.)
+ * wg_preview_run_batch replaces, for each of B independent gaits, L consecutive calls
+ *     PreviewControl::OneIterationOfPreview(x, y, sxzmp, syzmp, ZMPPositions, lindex = l, zmpx2, zmpy2, Simulation)
+ *     src/PreviewControl/PreviewControl.cpp:324-374        (OneIterationOfPreview1D :376-420 is one axis of it)
+ * for l = 0..L-1 on a ZMP reference queue of L + nl - 1 samples (the reference throws when fewer than nl samples are
+ * left, :341-344; here the caller sizes the queue).  Same operation order as the reference, bit for bit.
+ *   zmp_x, zmp_y   B x (L + nl - 1)   ZMPPositions[.].px / .py per gait
+ *   state          B x 8              x(0..2,0), y(0..2,0), sxzmp, syzmp -- read, advanced L steps, written back
+ *   com            B x L x 6          x and y after each step (what callers push on the CoM buffer), may be NULL
+ *   zmp2           B x L x 2          zmpx2, zmpy2 of each step, may be NULL
+ *   simulation     the reference's `Simulation` flag: accumulate the ZMP tracking error into sxzmp / syzmp
+ * The _dev variant takes TIME-MAJOR device arrays so that a wave's window reads are contiguous:
+ *   zmp_*_tm [(L + nl - 1)][B],  com_tm [L][6][B],  zmp2_tm [L][2][B];  state stays [B][8]. */
+#define WG_PREVIEW_NL_MAX 4096
+typedef struct wg_preview_gains {
+  double T, zc;                       /* m_SamplingPeriod, m_Zc */
+  double Ks, Kx[3];                   /* m_Ks, m_Kx */
+  int nl, pad_;                       /* m_SizeOfPreviewWindow */
+} wg_preview_gains_t;
+int wg_preview_configure(const wg_preview_gains_t *gains, const double *F);
+int wg_preview_window(void);          /* nl of the configured gains, 0 before wg_preview_configure */
+int wg_preview_run_batch(int B, int L, const double *zmp_x, const double *zmp_y, double *state, double *com, double *zmp2,
+                         int simulation);
+int wg_preview_run_batch_dev(int B, int L, const double *zmp_x_tm, const double *zmp_y_tm, double *state, double *com_tm,
+                             double *zmp2_tm, int simulation, void *hip_stream);
+
 #ifdef __cplusplus
 }
 #endif

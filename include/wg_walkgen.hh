@@ -8,6 +8,7 @@
 //   src/SimplePlugin.hh:46-72, src/SimplePluginManager.hh:46-93                SimplePlugin, SimplePluginManager
 //   src/ZMPRefTrajectoryGeneration/ZMPRefTrajectoryGeneration.hh               ZMPRefTrajectoryGeneration (on-line part)
 //   src/ZMPRefTrajectoryGeneration/ZMPVelocityReferencedQP.hh:59-131           ZMPVelocityReferencedQP
+//   src/PreviewControl/OptimalControllerSolver.hh:137-221, PreviewControl.hh:53-187   OptimalControllerSolver, PreviewControl (Kajita stage 1)
 //   include/jrl/walkgen/patterngeneratorinterface.hh:72-306                    PatternGeneratorInterface (+ factory), the methods
 //                                                                              live on this path; the others of the reference belong
 //                                                                              to generators that are out of scope and are not declared
@@ -202,6 +203,68 @@ class ZMPVelocityReferencedQP : public ZMPRefTrajectoryGeneration {
   int NbStepsSSDS_;
   double RobotMass_, PerturbationAcceleration_[6];
   bool PerturbationOccured_;
+};
+
+// ---- OptimalControllerSolver / PreviewControl (Kajita stage 1) -----------------------------------------------------------
+// src/PreviewControl/OptimalControllerSolver.hh:137-221 over wg_riccati_solve; matrices are row-major std::vector<double>
+class OptimalControllerSolver {
+ public:
+  static const unsigned int MODE_WITHOUT_INITIALPOS = 1;
+  static const unsigned int MODE_WITH_INITIALPOS = 0;
+  OptimalControllerSolver(const std::vector<double> &A, const std::vector<double> &b, const std::vector<double> &c, double Q,
+                          double R, unsigned int Nl);
+  void ComputeWeights(unsigned int Mode);
+  void GetF(std::vector<double> &LF) { LF = m_F; }
+  void GetK(std::vector<double> &LK) { LK = m_K; }
+
+ protected:
+  std::vector<double> m_A, m_b, m_c, m_K, m_F;
+  double m_Q, m_R;
+  unsigned int m_Nl;
+};
+
+// src/PreviewControl/PreviewControl.hh:53-187.  x and y (MAL_MATRIX 3x1 in the reference) are std::vector<double>(3).
+// Every OneIterationOfPreview* call runs on the GPU through wg_preview_run_batch (B = 1, L = 1); callers with many gaits
+// or many steps use RunBatch, which maps to one launch.
+class PreviewControl : public SimplePlugin {
+ public:
+  PreviewControl(SimplePluginManager *lSPM, unsigned int defaultMode = OptimalControllerSolver::MODE_WITH_INITIALPOS,
+                 bool computeWeightsAutomatically = false);
+  ~PreviewControl();
+  void ReadPrecomputedFile(std::string aFileName);
+  int OneIterationOfPreview(std::vector<double> &x, std::vector<double> &y, double &sxzmp, double &syzmp,
+                            std::deque<ZMPPosition> &ZMPPositions, unsigned int lindex, double &zmpx2, double &zmpy2,
+                            bool Simulation);
+  int OneIterationOfPreview1D(std::vector<double> &x, double &sxzmp, std::deque<double> &ZMPPositions, unsigned int lindex,
+                              double &zmpx2, bool Simulation);
+  int OneIterationOfPreview1D(std::vector<double> &x, double &sxzmp, std::vector<double> &ZMPPositions, unsigned int lindex,
+                              double &zmpx2, bool Simulation);
+  // L steps of B gaits in one launch; arguments as wg_preview_run_batch (include/wg_mpc.h)
+  int RunBatch(int B, int L, const double *zmp_x, const double *zmp_y, double *state, double *com, double *zmp2,
+               bool Simulation);
+  double SamplingPeriod() const { return m_SamplingPeriod; }
+  double PreviewControlTime() const { return m_PreviewControlTime; }
+  double GetHeightOfCoM() const { return m_Zc; }
+  void SetSamplingPeriod(double lSamplingPeriod);
+  void SetPreviewControlTime(double lPreviewControlTime);
+  void SetHeightOfCoM(double lZc);
+  bool IsCoherent() { return m_Coherent; }
+  void ComputeOptimalWeights(unsigned int mode);
+  void print();
+  virtual void CallMethod(std::string &Method, std::istringstream &astrm);
+  // gains as held (m_Kx, m_Ks, m_F)
+  const double *Kx() const { return m_Kx; }
+  double Ks() const { return m_Ks; }
+  const std::vector<double> &F() const { return m_F; }
+
+ private:
+  void Upload();   // hands the current gains to the device side (wg_preview_configure) when they changed
+  double m_Kx[3], m_Ks;
+  std::vector<double> m_F;
+  double m_PreviewControlTime, m_SamplingPeriod, m_Zc;
+  unsigned int m_SizeOfPreviewWindow;
+  bool m_Coherent, m_AutoComputeWeights, m_Uploaded;
+  unsigned int m_DefaultWeightComputationMode;
 };
 
 // ---- PatternGeneratorInterface ---------------------------------------------------------------------------------------------

@@ -717,3 +717,101 @@ int wg_dimitrov_tick_batch(int B, const wg_zmp_polytope_t *polys, wg_dimitrov_st
 }
 
 }  // extern "C"
+
+// ---- Kajita stage-1 preview control -------------------------------------------------------------------------------------
+#include "wg_preview_device.hpp"
+
+namespace {
+wg::PreviewConst g_prev;
+double *g_prev_F = nullptr;          // device copy of the window gains
+bool g_prev_set = false;
+DevBuf g_prev_buf;
+}  // namespace
+
+extern "C" {
+
+int wg_preview_configure(const wg_preview_gains_t *gains, const double *F) {
+  if (int rc = ensure_device()) return rc;
+  if (!gains || !F) return fail(WG_ERR_BAD_ARG, "null argument");
+  if (gains->nl < 1 || gains->nl > WG_PREVIEW_NL_MAX) return fail(WG_ERR_BAD_ARG, "need 1 <= nl <= %d", WG_PREVIEW_NL_MAX);
+  if (!(gains->T > 0.0)) return fail(WG_ERR_BAD_ARG, "sampling period must be positive");
+  std::lock_guard<std::mutex> lk(g_mu);
+  if (!g_prev_F) {
+    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&g_prev_F), sizeof(double) * WG_PREVIEW_NL_MAX));
+    g_release_hooks.push_back([] {
+      if (g_prev_F) (void)hipFree(g_prev_F);
+      g_prev_F = nullptr; g_prev_set = false;
+      g_prev_buf.release();
+    });
+  }
+  HIP_TRY(hipMemcpy(g_prev_F, F, sizeof(double) * gains->nl, hipMemcpyHostToDevice));
+  const double T = gains->T;                                   // PreviewControl.cpp:203-214
+  g_prev.A01 = T; g_prev.A02 = T * T / 2.0; g_prev.A12 = T;
+  g_prev.B0 = T * T * T / 6.0; g_prev.B1 = T * T / 2.0; g_prev.B2 = T;
+  g_prev.C2 = -gains->zc / 9.81;
+  g_prev.Kx0 = gains->Kx[0]; g_prev.Kx1 = gains->Kx[1]; g_prev.Kx2 = gains->Kx[2]; g_prev.Ks = gains->Ks;
+  g_prev.nl = gains->nl;
+  g_prev_set = true;
+  return WG_OK;
+}
+
+int wg_preview_window(void) { return g_prev_set ? g_prev.nl : 0; }
+
+int wg_preview_run_batch_dev(int B, int L, const double *zmp_x_tm, const double *zmp_y_tm, double *state, double *com_tm,
+                             double *zmp2_tm, int simulation, void *hip_stream) {
+  if (int rc = ensure_device()) return rc;
+  if (!g_prev_set) return fail(WG_ERR_BAD_ARG, "wg_preview_configure() has not been called");
+  if (B < 0 || L < 0 || !zmp_x_tm || !zmp_y_tm || !state) return fail(WG_ERR_BAD_ARG, "bad arguments");
+  if (B == 0 || L == 0) return WG_OK;
+  const int threads = B >= 4096 ? 256 : 64;                   // small batches: more blocks, one wave each
+  hipLaunchKernelGGL(wg::wg_preview_kernel, dim3((B + threads - 1) / threads, 2), dim3(threads), 0,
+                     reinterpret_cast<hipStream_t>(hip_stream), B, L, g_prev, g_prev_F, zmp_x_tm, zmp_y_tm, state, com_tm,
+                     zmp2_tm, simulation);
+  HIP_TRY(hipGetLastError());
+  return WG_OK;
+}
+
+int wg_preview_run_batch(int B, int L, const double *zmp_x, const double *zmp_y, double *state, double *com, double *zmp2,
+                         int simulation) {
+  if (int rc = ensure_device()) return rc;
+  if (!g_prev_set) return fail(WG_ERR_BAD_ARG, "wg_preview_configure() has not been called");
+  if (B < 0 || L < 0 || !zmp_x || !zmp_y || !state) return fail(WG_ERR_BAD_ARG, "bad arguments");
+  if (B == 0 || L == 0) return WG_OK;
+  std::lock_guard<std::mutex> lk(g_mu);
+  const size_t sB = (size_t)B, sL = (size_t)L, Lz = sL + g_prev.nl - 1;
+  // arena: gait-major staging (largest user: com, B x L x 6), time-major zx, zy, com, zmp2, state
+  const size_t stage = sB * (sL * 6 > Lz ? sL * 6 : Lz);
+  const size_t nd = stage + 2 * sB * Lz + sB * sL * 6 + sB * sL * 2 + sB * 8;
+  if (int rc = g_prev_buf.reserve(nd * 8)) return rc;
+  double *d_stage = static_cast<double *>(g_prev_buf.p), *d_zx = d_stage + stage, *d_zy = d_zx + sB * Lz,
+         *d_com = d_zy + sB * Lz, *d_z2 = d_com + sB * sL * 6, *d_st = d_z2 + sB * sL * 2;
+  auto transpose = [&](int rows, int cols, const double *in, double *out) {
+    hipLaunchKernelGGL(wg::wg_transpose_kernel, dim3((cols + 31) / 32, (rows + 31) / 32), dim3(32, 8), 0, nullptr, rows,
+                       cols, in, out);
+  };
+  HIP_TRY(hipMemcpy(d_stage, zmp_x, sB * Lz * 8, hipMemcpyHostToDevice));
+  transpose(B, (int)Lz, d_stage, d_zx);
+  HIP_TRY(hipDeviceSynchronize());
+  HIP_TRY(hipMemcpy(d_stage, zmp_y, sB * Lz * 8, hipMemcpyHostToDevice));
+  transpose(B, (int)Lz, d_stage, d_zy);
+  HIP_TRY(hipMemcpy(d_st, state, sB * 8 * 8, hipMemcpyHostToDevice));
+  int rc = wg_preview_run_batch_dev(B, L, d_zx, d_zy, d_st, com ? d_com : nullptr, zmp2 ? d_z2 : nullptr, simulation,
+                                    nullptr);
+  if (rc) return rc;
+  HIP_TRY(hipDeviceSynchronize());
+  HIP_TRY(hipMemcpy(state, d_st, sB * 8 * 8, hipMemcpyDeviceToHost));
+  if (com) {                                                   // [L*6][B] -> [B][L*6]
+    transpose(L * 6, B, d_com, d_stage);
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(com, d_stage, sB * sL * 6 * 8, hipMemcpyDeviceToHost));
+  }
+  if (zmp2) {
+    transpose(L * 2, B, d_z2, d_stage);
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(zmp2, d_stage, sB * sL * 2 * 8, hipMemcpyDeviceToHost));
+  }
+  HIP_TRY(hipGetLastError());
+  return WG_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,93 @@
+// wg_preview_device.hpp -- Kajita stage-1 preview control, batched over independent gaits.
+//
+// Device-side replacement for L consecutive calls of
+//   PreviewControl::OneIterationOfPreview      src/PreviewControl/PreviewControl.cpp:324-374
+//   (and OneIterationOfPreview1D               :376-420, the same arithmetic on one axis)
+// with the cart-table matrices and gains the class holds after ComputeOptimalWeights (:198-322) or
+// ReadPrecomputedFile (:134-194).
+//
+// One step of the reference, per axis:   u  = -(Kx x) + Ks s + sum_{i<Nl} F[i] zmp[l+i]      (sum ascending in i, on top of the
+//                                                                                            state term)
+//                                        x  = A x + u B;   p = C x;   s += zmp[l] - p         (Simulation only)
+// The 2 Nl multiply-adds of the window dominate; the additions form one dependent chain that starts from a state-dependent
+// value, so within a gait nothing can be reordered without changing bits.  The parallel axis is the batch:
+// one lane = one (gait, axis) pair, 64 independent chains per wave, ZMP references stored time-major so that the
+// window reads of a wave are single 512-byte rows; F[i] is wave-uniform (scalar loads).
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace wg {
+
+struct PreviewConst {
+  double A01, A02, A12;   // m_A: [[1, T, T*T/2], [0, 1, T], [0, 0, 1]]
+  double B0, B1, B2;      // m_B: [T*T*T/6, T*T/2, T]
+  double C2;              // m_C: [1, 0, -zc/9.81]
+  double Kx0, Kx1, Kx2, Ks;
+  int nl;
+};
+
+// zx, zy:  [(L + nl - 1)][B]   time-major ZMP references (entry t of gait g at t*B + g)
+// state:   [B][8]              x[3], y[3], sxzmp, syzmp  (read, advanced L steps, written back)
+// com:     [L][6][B] or NULL   x[0..2], y[0..2] after each step
+// zmp2:    [L][2][B] or NULL   zmpx2, zmpy2 of each step
+__global__ void __launch_bounds__(256)
+wg_preview_kernel(int B, int L, PreviewConst K, const double *__restrict__ F, const double *__restrict__ zx,
+                  const double *__restrict__ zy, double *__restrict__ state, double *__restrict__ com,
+                  double *__restrict__ zmp2, int simulation) {
+  const int g = blockIdx.x * blockDim.x + threadIdx.x;
+  const int axis = blockIdx.y;
+  if (g >= B) return;
+  const double *__restrict__ z = axis ? zy : zx;
+  double *st = state + (size_t)g * 8;
+  double x0 = st[3 * axis], x1 = st[3 * axis + 1], x2 = st[3 * axis + 2], s = st[6 + axis];
+  const size_t sB = (size_t)B;
+  const int nl = K.nl;
+  for (int l = 0; l < L; ++l) {
+    // r = MAL_RET_A_by_B(m_Kx, x): 1x3 by 3x1, products summed k ascending from 0.0 (:338)
+    double r = 0.0;
+    r += K.Kx0 * x0; r += K.Kx1 * x1; r += K.Kx2 * x2;
+    double u = -r + K.Ks * s;                                       // :339
+    const double *zl = z + (size_t)l * sB + g;
+    int i = 0;
+    for (; i + 8 <= nl; i += 8) {                                   // :346-347, the loads run ahead of the add chain
+      const double z0 = zl[(size_t)(i + 0) * sB], z1 = zl[(size_t)(i + 1) * sB], z2 = zl[(size_t)(i + 2) * sB],
+                   z3 = zl[(size_t)(i + 3) * sB], z4 = zl[(size_t)(i + 4) * sB], z5 = zl[(size_t)(i + 5) * sB],
+                   z6 = zl[(size_t)(i + 6) * sB], z7 = zl[(size_t)(i + 7) * sB];
+      u += F[i + 0] * z0; u += F[i + 1] * z1; u += F[i + 2] * z2; u += F[i + 3] * z3;
+      u += F[i + 4] * z4; u += F[i + 5] * z5; u += F[i + 6] * z6; u += F[i + 7] * z7;
+    }
+    for (; i < nl; ++i) u += F[i] * zl[(size_t)i * sB];
+    // x = MAL_RET_A_by_B(m_A, x) + ux * m_B  (:355): every product of the 3x3 by 3x1 prod is formed, zeros included
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0;
+    a0 += 1.0 * x0; a0 += K.A01 * x1; a0 += K.A02 * x2;
+    a1 += 0.0 * x0; a1 += 1.0 * x1;   a1 += K.A12 * x2;
+    a2 += 0.0 * x0; a2 += 0.0 * x1;   a2 += 1.0 * x2;
+    x0 = a0 + u * K.B0; x1 = a1 + u * K.B1; x2 = a2 + u * K.B2;
+    double p = 0.0;                                                  // :358-360
+    p += 1.0 * x0; p += 0.0 * x1; p += K.C2 * x2;
+    if (simulation) s += (zl[0] - p);                                // :367-368
+    if (com) {
+      double *c = com + ((size_t)l * 6 + 3 * axis) * sB + g;
+      c[0] = x0; c[sB] = x1; c[2 * sB] = x2;
+    }
+    if (zmp2) zmp2[((size_t)l * 2 + axis) * sB + g] = p;
+  }
+  st[3 * axis] = x0; st[3 * axis + 1] = x1; st[3 * axis + 2] = x2; st[6 + axis] = s;
+}
+
+// [B][cols] (gait-major) <-> [cols][B] (time-major) on the device, for the host-pointer entry point
+__global__ void wg_transpose_kernel(int rows, int cols, const double *__restrict__ in, double *__restrict__ out) {
+  __shared__ double tile[32][33];
+  const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+  for (int j = threadIdx.y; j < 32; j += blockDim.y) {
+    const int r = r0 + j, c = c0 + threadIdx.x;
+    if (r < rows && c < cols) tile[j][threadIdx.x] = in[(size_t)r * cols + c];
+  }
+  __syncthreads();
+  for (int j = threadIdx.y; j < 32; j += blockDim.y) {
+    const int c = c0 + j, r = r0 + threadIdx.x;
+    if (r < rows && c < cols) out[(size_t)c * rows + r] = tile[threadIdx.x][j];
+  }
+}
+
+}  // namespace wg

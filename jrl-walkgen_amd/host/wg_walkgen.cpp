@@ -6,6 +6,8 @@
 #include <cassert>
 #include <cmath>
 #include <cstdio>
+#include <cstring>
+#include <fstream>
 #include <iostream>
 #include <stdexcept>
 
@@ -260,6 +262,157 @@ void ZMPVelocityReferencedQP::OnLine(double time, deque<ZMPPosition> &FinalZMPTr
 }
 
 // ---- PatternGeneratorInterfacePrivate (Herdt branch) ------------------------------------------------------------------------
+// ---- OptimalControllerSolver / PreviewControl ------------------------------------------------------------------------------
+OptimalControllerSolver::OptimalControllerSolver(const vector<double> &A, const vector<double> &b, const vector<double> &c,
+                                                 double Q, double R, unsigned int Nl)
+    : m_A(A), m_b(b), m_c(c), m_Q(Q), m_R(R), m_Nl(Nl) {}
+
+void OptimalControllerSolver::ComputeWeights(unsigned int Mode) {   // OptimalControllerSolver.cpp:200-352
+  const int n = (int)m_b.size();
+  m_K.assign(n, 0.0);
+  m_F.assign(m_Nl, 0.0);
+  const int mode = (Mode == MODE_WITHOUT_INITIALPOS) ? WG_RICCATI_WITHOUT_INITIALPOS : WG_RICCATI_WITH_INITIALPOS;
+  if (wg_riccati_solve(n, m_A.data(), m_b.data(), m_c.data(), m_Q, m_R, (int)m_Nl, mode, m_K.data(), m_F.data()) != WG_OK)
+    wg_throw("wg_riccati_solve");
+}
+
+PreviewControl::PreviewControl(SimplePluginManager *lSPM, unsigned int defaultMode, bool lAutoComputeWeights)
+    : SimplePlugin(lSPM) {                                          // PreviewControl.cpp:37-77
+  m_AutoComputeWeights = lAutoComputeWeights;
+  m_DefaultWeightComputationMode = defaultMode;
+  m_SamplingPeriod = 0.0; m_PreviewControlTime = 0.0; m_Zc = 0.0; m_SizeOfPreviewWindow = 0;
+  m_Kx[0] = m_Kx[1] = m_Kx[2] = 0.0; m_Ks = 0;
+  m_Coherent = false; m_Uploaded = false;
+  string aMethodName[3] = {":samplingperiod", ":previewcontroltime", ":comheight"};
+  for (int i = 0; i < 3; i++)
+    if (!RegisterMethod(aMethodName[i])) cerr << "Unable to register " << aMethodName[i] << endl;
+}
+PreviewControl::~PreviewControl() {}
+
+void PreviewControl::SetSamplingPeriod(double v) {                  // :98-107
+  if (m_SamplingPeriod != v) m_Coherent = false;
+  m_SamplingPeriod = v;
+  if (m_AutoComputeWeights) ComputeOptimalWeights(m_DefaultWeightComputationMode);
+}
+void PreviewControl::SetPreviewControlTime(double v) {              // :109-119
+  if (m_PreviewControlTime != v) m_Coherent = false;
+  m_PreviewControlTime = v;
+  if (m_AutoComputeWeights) ComputeOptimalWeights(m_DefaultWeightComputationMode);
+}
+void PreviewControl::SetHeightOfCoM(double v) {                     // :121-131
+  if (m_Zc != v) m_Coherent = false;
+  m_Zc = v;
+  if (m_AutoComputeWeights) ComputeOptimalWeights(m_DefaultWeightComputationMode);
+}
+
+void PreviewControl::ReadPrecomputedFile(string aFileName) {        // :138-194: the numbers pass through a float
+  ifstream aif(aFileName.c_str(), ifstream::in);
+  if (!aif.is_open()) { cerr << "PreviewControl - Unable to open " << aFileName << endl; return; }
+  aif >> m_Zc; aif >> m_SamplingPeriod; aif >> m_PreviewControlTime;
+  float r;
+  for (int i = 0; i < 3; i++) { aif >> r; m_Kx[i] = r; }
+  aif >> r; m_Ks = r;
+  m_SizeOfPreviewWindow = (unsigned int)(m_PreviewControlTime / m_SamplingPeriod);
+  m_F.assign(m_SizeOfPreviewWindow, 0.0);
+  for (unsigned int i = 0; i < m_SizeOfPreviewWindow; i++) { aif >> r; m_F[i] = r; }
+  m_Coherent = true; m_Uploaded = false;
+}
+
+void PreviewControl::ComputeOptimalWeights(unsigned int mode) {     // :198-322
+  const double T = m_SamplingPeriod;
+  if (T == 0.0) return;
+  if (m_PreviewControlTime == 0.0) return;
+  const int Nl = (int)(m_PreviewControlTime / T);
+  m_F.assign(Nl, 0.0);
+  double K[4] = {0, 0, 0, 0};
+  if (mode == OptimalControllerSolver::MODE_WITHOUT_INITIALPOS) {
+    if (wg_riccati_gains(T, m_Zc, 1.0, 1e-6, Nl, WG_RICCATI_WITHOUT_INITIALPOS, K, m_F.data()) != WG_OK) wg_throw("wg_riccati_gains");
+    m_Ks = K[0]; m_Kx[0] = K[1]; m_Kx[1] = K[2]; m_Kx[2] = K[3];
+  } else if (mode == OptimalControllerSolver::MODE_WITH_INITIALPOS) {
+    if (wg_riccati_gains(T, m_Zc, 1.0, 1e-5, Nl, WG_RICCATI_WITH_INITIALPOS, K, m_F.data()) != WG_OK) wg_throw("wg_riccati_gains");
+    m_Ks = K[0]; m_Kx[0] = K[0]; m_Kx[1] = K[1]; m_Kx[2] = K[2];
+  }
+  m_SizeOfPreviewWindow = (unsigned int)(m_PreviewControlTime / m_SamplingPeriod);
+  m_F.resize(m_SizeOfPreviewWindow);
+  m_Coherent = true; m_Uploaded = false;
+}
+
+void PreviewControl::Upload() {
+  if (m_Uploaded) return;
+  wg_preview_gains_t g;
+  memset(&g, 0, sizeof g);
+  g.T = m_SamplingPeriod; g.zc = m_Zc; g.Ks = m_Ks; g.Kx[0] = m_Kx[0]; g.Kx[1] = m_Kx[1]; g.Kx[2] = m_Kx[2];
+  g.nl = (int)m_SizeOfPreviewWindow;
+  if (wg_preview_configure(&g, m_F.data()) != WG_OK) wg_throw("wg_preview_configure");
+  m_Uploaded = true;
+}
+
+int PreviewControl::RunBatch(int B, int L, const double *zmp_x, const double *zmp_y, double *state, double *com, double *zmp2,
+                             bool Simulation) {
+  Upload();
+  if (wg_preview_run_batch(B, L, zmp_x, zmp_y, state, com, zmp2, Simulation ? 1 : 0) != WG_OK) wg_throw("wg_preview_run_batch");
+  return 0;
+}
+
+int PreviewControl::OneIterationOfPreview(vector<double> &x, vector<double> &y, double &sxzmp, double &syzmp,
+                                          deque<ZMPPosition> &ZMPPositions, unsigned int lindex, double &zmpx2, double &zmpy2,
+                                          bool Simulation) {         // :324-374
+  const unsigned int nl = m_SizeOfPreviewWindow;
+  if (ZMPPositions.size() < nl) throw runtime_error("ZMPPositions.size()<m_SizeOfPreviewWindow:");   // LTHROW, :341-344
+  if (ZMPPositions.size() < lindex + nl) throw runtime_error("PreviewControl: preview window runs past the ZMP queue");
+  vector<double> zx(nl), zy(nl);
+  for (unsigned int i = 0; i < nl; i++) { zx[i] = ZMPPositions[lindex + i].px; zy[i] = ZMPPositions[lindex + i].py; }
+  double st[8] = {x[0], x[1], x[2], y[0], y[1], y[2], sxzmp, syzmp}, z2[2] = {0, 0};
+  RunBatch(1, 1, zx.data(), zy.data(), st, 0, z2, Simulation);
+  for (int i = 0; i < 3; i++) { x[i] = st[i]; y[i] = st[3 + i]; }
+  sxzmp = st[6]; syzmp = st[7]; zmpx2 = z2[0]; zmpy2 = z2[1];
+  return 0;
+}
+
+template <class Q>
+static int preview_1d(PreviewControl &pc, unsigned int nl, vector<double> &x, double &sxzmp, Q &ZMPPositions, unsigned int lindex,
+                      double &zmpx2, bool Simulation) {              // :376-420, :422-...
+  if (ZMPPositions.size() < nl) throw runtime_error("ZMPPositions.size()<m_SizeOfPreviewWindow");   // the reference exit(0)s here
+  vector<double> zx(nl), zy(nl, 0.0);
+  if (ZMPPositions.size() >= lindex + nl)
+    for (unsigned int i = 0; i < nl; i++) zx[i] = ZMPPositions[lindex + i];
+  else
+    throw runtime_error("PreviewControl: preview window runs past the ZMP queue");
+  double st[8] = {x[0], x[1], x[2], 0, 0, 0, sxzmp, 0}, z2[2] = {0, 0};
+  pc.RunBatch(1, 1, zx.data(), zy.data(), st, 0, z2, Simulation);
+  for (int i = 0; i < 3; i++) x[i] = st[i];
+  sxzmp = st[6]; zmpx2 = z2[0];
+  return 0;
+}
+int PreviewControl::OneIterationOfPreview1D(vector<double> &x, double &sxzmp, deque<double> &ZMPPositions, unsigned int lindex,
+                                            double &zmpx2, bool Simulation) {
+  return preview_1d(*this, m_SizeOfPreviewWindow, x, sxzmp, ZMPPositions, lindex, zmpx2, Simulation);
+}
+int PreviewControl::OneIterationOfPreview1D(vector<double> &x, double &sxzmp, vector<double> &ZMPPositions, unsigned int lindex,
+                                            double &zmpx2, bool Simulation) {
+  return preview_1d(*this, m_SizeOfPreviewWindow, x, sxzmp, ZMPPositions, lindex, zmpx2, Simulation);
+}
+
+void PreviewControl::print() {                                       // :470-...
+  cout << "Zc: " << m_Zc << " T: " << m_SamplingPeriod << " preview time: " << m_PreviewControlTime << endl;
+  cout << "Ks: " << m_Ks << " Kx: " << m_Kx[0] << " " << m_Kx[1] << " " << m_Kx[2] << endl;
+  for (size_t i = 0; i < m_F.size(); i++) cout << "F[" << i << "]: " << m_F[i] << endl;
+}
+
+void PreviewControl::CallMethod(string &Method, istringstream &astrm) {   // :515-540
+  if (Method == ":samplingperiod") { string aws; if (astrm.good()) { double x; astrm >> x; SetSamplingPeriod(x); } }
+  else if (Method == ":previewcontroltime") { if (astrm.good()) { double x; astrm >> x; SetPreviewControlTime(x); } }
+  else if (Method == ":comheight") { if (astrm.good()) { double x; astrm >> x; SetHeightOfCoM(x); } }
+  else if (Method == ":computeweightsofpreview") {
+    if (astrm.good()) {
+      string initialpos;
+      astrm >> initialpos;
+      if (initialpos == "withinitialpos") ComputeOptimalWeights(OptimalControllerSolver::MODE_WITH_INITIALPOS);
+      else if (initialpos == "withoutinitialpos") ComputeOptimalWeights(OptimalControllerSolver::MODE_WITHOUT_INITIALPOS);
+    }
+  }
+}
+
 namespace {
 
 class PatternGeneratorInterfacePrivate : public virtual PatternGeneratorInterface, SimplePluginManager, SimplePlugin {

@@ -67,6 +67,14 @@ def lib():
     if _lib is None:
         if not os.path.exists(LIB_PATH):
             raise WgError(f"{LIB_PATH} missing: run `python -c 'import __graft_entry__ as g; g.build()'`")
+        # One HIP runtime per process: PyTorch-ROCm bundles its own libamdhip64 (same SONAME as /opt/rocm's).  If the
+        # product library were loaded first and torch later, two runtimes would coexist and the second one finds no GPU;
+        # with torch first the loader binds libwg_mpc.so to the runtime already in the process, and torch tensors'
+        # device pointers / streams can be handed to the _dev entry points.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         _lib = C.CDLL(LIB_PATH)
         _lib.wg_last_error.restype = C.c_char_p
         _lib.wg_qp_lds_bytes.restype = C.c_size_t
@@ -88,6 +96,9 @@ def lib():
         _lib.wg_riccati_solve.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_double, C.c_int,
                                           C.c_int, C.c_void_p, C.c_void_p]
         _lib.wg_riccati_gains.argtypes = [C.c_double] * 4 + [C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+        _lib.wg_preview_configure.argtypes = [C.c_void_p, C.c_void_p]
+        _lib.wg_preview_run_batch.argtypes = [C.c_int, C.c_int] + [C.c_void_p] * 5 + [C.c_int]
+        _lib.wg_preview_run_batch_dev.argtypes = [C.c_int, C.c_int] + [C.c_void_p] * 5 + [C.c_int, C.c_void_p]
     return _lib
 
 
@@ -321,3 +332,47 @@ def dimitrov_tick_batch(polys, states, want_out=True, max_iter=0):
     _check(lib().wg_dimitrov_tick_batch(B, C.addressof(polys), C.addressof(states),
                                         C.addressof(outs) if outs is not None else None, int(max_iter)))
     return outs
+
+
+# ---- Kajita stage-1 preview control (PreviewControl::OneIterationOfPreview, batched) ----
+class PreviewGains(C.Structure):        # wg_preview_gains_t
+    _fields_ = [("T", C.c_double), ("zc", C.c_double), ("Ks", C.c_double), ("Kx", C.c_double * 3), ("nl", C.c_int),
+                ("pad_", C.c_int)]
+
+
+def preview_gains(T, zc, preview_time, mode=RICCATI_WITHOUT_INITIALPOS):
+    """PreviewControl::ComputeOptimalWeights (PreviewControl.cpp:198-322): (PreviewGains, F[nl])."""
+    nl = int(preview_time / T)
+    R = 1e-6 if mode == RICCATI_WITHOUT_INITIALPOS else 1e-5
+    K, F = riccati_gains(T, zc, 1.0, R, nl, mode)
+    g = PreviewGains()
+    g.T, g.zc, g.nl = T, zc, nl
+    if mode == RICCATI_WITHOUT_INITIALPOS:
+        g.Ks = K[0]; g.Kx[0], g.Kx[1], g.Kx[2] = K[1], K[2], K[3]
+    else:
+        g.Ks = K[0]; g.Kx[0], g.Kx[1], g.Kx[2] = K[0], K[1], K[2]
+    return g, np.ascontiguousarray(F)
+
+
+def preview_configure(gains, F):
+    F = np.ascontiguousarray(F, dtype=np.float64)
+    assert F.shape == (gains.nl,)
+    _check(lib().wg_preview_configure(C.byref(gains), _hp(F)))
+
+
+def preview_run_batch(zmp_x, zmp_y, state, L, simulation=True, want_com=True, want_zmp=True):
+    """Host-pointer entry point: zmp_x/zmp_y [B, L+nl-1], state [B, 8] (advanced in place).  Returns (com, zmp2)."""
+    zmp_x = np.ascontiguousarray(zmp_x, dtype=np.float64); zmp_y = np.ascontiguousarray(zmp_y, dtype=np.float64)
+    B = zmp_x.shape[0]
+    nl = int(lib().wg_preview_window())
+    assert zmp_x.shape == zmp_y.shape == (B, L + nl - 1) and state.shape == (B, 8) and state.flags.c_contiguous
+    com = np.zeros((B, L, 6)) if want_com else None
+    z2 = np.zeros((B, L, 2)) if want_zmp else None
+    _check(lib().wg_preview_run_batch(B, L, _hp(zmp_x), _hp(zmp_y), _hp(state), _hp(com), _hp(z2), int(bool(simulation))))
+    return com, z2
+
+
+def preview_run_batch_dev(B, L, zx_tm_ptr, zy_tm_ptr, state_ptr, com_tm_ptr=None, zmp2_tm_ptr=None, simulation=True,
+                          stream=None):
+    _check(lib().wg_preview_run_batch_dev(B, L, zx_tm_ptr, zy_tm_ptr, state_ptr, com_tm_ptr, zmp2_tm_ptr,
+                                          int(bool(simulation)), stream))

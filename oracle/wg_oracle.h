@@ -75,6 +75,10 @@ int wgo_dimitrov_tick(const wgo_pldp_model_t *M, const double *OptB, const doubl
                       double Tctrl, double com_height, const wg_zmp_polytope_t *polys, wg_dimitrov_state_t *st,
                       wg_dimitrov_out_t *out, int max_iter);
 
+/* ---- Kajita stage-1 preview-control iteration (preview_oracle.c); arguments as wg_preview_run_batch ---------------- */
+int wgo_preview_run(const wg_preview_gains_t *g, const double *F, int B, int L, const double *zmp_x, const double *zmp_y,
+                    double *state, double *com, double *zmp2, int simulation);
+
 #ifdef __cplusplus
 }
 #endif

@@ -57,3 +57,27 @@ def test_facade_equals_python_replay_of_the_control_loop(tmp_path):
     assert rows.shape == want.shape and rows.shape[0] > 4000
     # same arithmetic on both sides; the only difference is the 13-digit text round trip of the trace
     assert np.abs(rows - want).max() < 1e-9
+
+
+def test_kajita_stage1_driver_matches_oracle(tmp_path):
+    """BASELINE config[0] plumbing (jrl-walkgen_amd/host/test_kajita_preview.cpp): TestKajita2003's StraightWalking step
+    sequence through the facade's PreviewControl on the GPU -- the reference's one-call-per-step pattern and the
+    batched run agree inside the driver; here its trace is compared with the oracle, bit for bit (%.17g round-trips)."""
+    from test_preview_oracle import oracle_run
+    exe = os.path.join(ROOT, "jrl-walkgen_amd", "bin", "test_kajita_preview")
+    assert os.path.exists(exe), "build first: python -c 'import __graft_entry__ as g; g.build()'"
+    out = tmp_path / "kajita.dat"
+    r = subprocess.run([exe, str(out)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    rows = np.loadtxt(out)
+    g, F = wg.preview_gains(0.005, 0.814, 1.6, wg.RICCATI_WITHOUT_INITIALPOS)
+    L = rows.shape[0]
+    assert L > 2500 and g.nl == 320
+    # the queue the driver built: its first L samples are in the trace, the tail rests at the last footprint
+    zx = np.concatenate([rows[:, 5], np.full(g.nl - 1, rows[-1, 5])]); zy = np.concatenate([rows[:, 6], np.full(g.nl - 1, rows[-1, 6])])
+    st = np.zeros((1, 8))
+    com, z2 = oracle_run(g, F, zx[None, :], zy[None, :], st, L)
+    assert np.array_equal(rows[:, 1], com[0, :, 0]) and np.array_equal(rows[:, 2], com[0, :, 3])
+    assert np.array_equal(rows[:, 3], z2[0, :, 0]) and np.array_equal(rows[:, 4], z2[0, :, 1])
+    # walked 14 x 0.2 m, ends at rest between the feet
+    assert abs(rows[-1, 1] - 2.8) < 1e-3 and abs(rows[-1, 2] - rows[-1, 6]) < 1e-3
