@@ -401,6 +401,23 @@ int wg_preview_run_batch(int B, int L, const double *zmp_x, const double *zmp_y,
 int wg_preview_run_batch_dev(int B, int L, const double *zmp_x_tm, const double *zmp_y_tm, double *state, double *com_tm,
                              double *zmp2_tm, int simulation, void *hip_stream);
 
+/* Invariant Hessian block on the matrix cores, batched over models -----------------------------------------------------
+ *
+ * wg_gramian_batch computes, for B models that differ in QP sampling period T[b] and CoM height h[b],
+ *     Q_b = beta I + alpha Uv'Uv + gamma Uz'Uz      (N x N, row-major, one block after the other)
+ * i.e. GeneratorVelRef::build_invariant_part (src/ZMPRefTrajectoryGeneration/generator-vel-ref.cpp:587-614) on the maps
+ * of RigidBodySystem::compute_dyn_cjerk (src/PreviewControl/rigid-body-system.cpp:377-452) -- the one GEMM-shaped step
+ * of the path.  One wavefront per model; Uv and Uz are generated in registers from (T, h) and multiplied with
+ * v_mfma_f64_16x16x4_f64 (WG_GRAMIAN_F64) or v_mfma_f32_16x16x4_f32 (WG_GRAMIAN_F32, operands rounded to float,
+ * result widened).  The matrix cores fuse and reorder the sums: results match the host loop of wg_mpc_configure (which
+ * keeps the reference's order, because the tick is bit-exact) to rounding only -- 1e-14 / 1e-6 relative. */
+#define WG_GRAMIAN_F64 0
+#define WG_GRAMIAN_F32 1
+int wg_gramian_batch(int B, int N, const double *T, const double *h, double alpha, double beta, double gamma, int precision,
+                     double *Qb);
+int wg_gramian_batch_dev(int B, int N, const double *T, const double *h, double alpha, double beta, double gamma,
+                         int precision, double *Qb, void *hip_stream);
+
 #ifdef __cplusplus
 }
 #endif

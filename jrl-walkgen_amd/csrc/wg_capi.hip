@@ -815,3 +815,48 @@ int wg_preview_run_batch(int B, int L, const double *zmp_x, const double *zmp_y,
 }
 
 }  // extern "C"
+
+// ---- invariant Hessian block on the matrix cores (fleets with per-gait models) -----------------------------------------
+#include "wg_gramian_device.hpp"
+
+namespace {
+DevBuf g_gram_buf;
+bool g_gram_hooked = false;
+}  // namespace
+
+extern "C" {
+
+int wg_gramian_batch_dev(int B, int N, const double *T, const double *h, double alpha, double beta, double gamma,
+                         int precision, double *Qb, void *hip_stream) {
+  if (int rc = ensure_device()) return rc;
+  if (B < 0 || N < 1 || N > 32 || !T || !h || !Qb) return fail(WG_ERR_BAD_ARG, "need B >= 0, 1 <= N <= 32, non-null arrays");
+  if (precision != WG_GRAMIAN_F64 && precision != WG_GRAMIAN_F32) return fail(WG_ERR_BAD_ARG, "unknown precision %d", precision);
+  if (B == 0) return WG_OK;
+  hipStream_t st = reinterpret_cast<hipStream_t>(hip_stream);
+  if (precision == WG_GRAMIAN_F32)
+    hipLaunchKernelGGL(wg::wg_gramian_kernel<true>, dim3(B), dim3(64), 0, st, B, N, T, h, alpha, beta, gamma, Qb);
+  else
+    hipLaunchKernelGGL(wg::wg_gramian_kernel<false>, dim3(B), dim3(64), 0, st, B, N, T, h, alpha, beta, gamma, Qb);
+  HIP_TRY(hipGetLastError());
+  return WG_OK;
+}
+
+int wg_gramian_batch(int B, int N, const double *T, const double *h, double alpha, double beta, double gamma, int precision,
+                     double *Qb) {
+  if (int rc = ensure_device()) return rc;
+  if (B < 0 || N < 1 || N > 32 || !T || !h || !Qb) return fail(WG_ERR_BAD_ARG, "need B >= 0, 1 <= N <= 32, non-null arrays");
+  if (B == 0) return WG_OK;
+  std::lock_guard<std::mutex> lk(g_mu);
+  if (!g_gram_hooked) { g_release_hooks.push_back([] { g_gram_buf.release(); }); g_gram_hooked = true; }
+  const size_t sB = (size_t)B, nq = sB * N * N;
+  if (int rc = g_gram_buf.reserve((2 * sB + nq) * 8)) return rc;
+  double *dT = static_cast<double *>(g_gram_buf.p), *dh = dT + sB, *dQ = dh + sB;
+  HIP_TRY(hipMemcpy(dT, T, sB * 8, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(dh, h, sB * 8, hipMemcpyHostToDevice));
+  if (int rc = wg_gramian_batch_dev(B, N, dT, dh, alpha, beta, gamma, precision, dQ, nullptr)) return rc;
+  HIP_TRY(hipDeviceSynchronize());
+  HIP_TRY(hipMemcpy(Qb, dQ, nq * 8, hipMemcpyDeviceToHost));
+  return WG_OK;
+}
+
+}  // extern "C"

@@ -97,6 +97,8 @@ def lib():
                                           C.c_int, C.c_void_p, C.c_void_p]
         _lib.wg_riccati_gains.argtypes = [C.c_double] * 4 + [C.c_int, C.c_int, C.c_void_p, C.c_void_p]
         _lib.wg_preview_configure.argtypes = [C.c_void_p, C.c_void_p]
+        _lib.wg_gramian_batch.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p] + [C.c_double] * 3 + [C.c_int, C.c_void_p]
+        _lib.wg_gramian_batch_dev.argtypes = _lib.wg_gramian_batch.argtypes + [C.c_void_p]
         _lib.wg_preview_run_batch.argtypes = [C.c_int, C.c_int] + [C.c_void_p] * 5 + [C.c_int]
         _lib.wg_preview_run_batch_dev.argtypes = [C.c_int, C.c_int] + [C.c_void_p] * 5 + [C.c_int, C.c_void_p]
     return _lib
@@ -376,3 +378,17 @@ def preview_run_batch_dev(B, L, zx_tm_ptr, zy_tm_ptr, state_ptr, com_tm_ptr=None
                           stream=None):
     _check(lib().wg_preview_run_batch_dev(B, L, zx_tm_ptr, zy_tm_ptr, state_ptr, com_tm_ptr, zmp2_tm_ptr,
                                           int(bool(simulation)), stream))
+
+
+# ---- invariant Hessian block on the matrix cores ----
+GRAMIAN_F64 = 0
+GRAMIAN_F32 = 1
+
+
+def gramian_batch(N, T, h, alpha, beta, gamma, precision=GRAMIAN_F64):
+    """Q_b[B, N, N] for models with sampling periods T[B] and CoM heights h[B] (wg_gramian_batch)."""
+    T = np.ascontiguousarray(T, dtype=np.float64); h = np.ascontiguousarray(h, dtype=np.float64)
+    B = T.shape[0]
+    Qb = np.zeros((B, N, N))
+    _check(lib().wg_gramian_batch(B, int(N), _hp(T), _hp(h), alpha, beta, gamma, int(precision), _hp(Qb)))
+    return Qb

@@ -112,6 +112,16 @@ static void build_tables(const wg_model_t *m, tables_t *t) {
     }
 }
 
+/* the invariant Hessian block alone (N x N, row-major): checker of wg_gramian_batch */
+int wgo_invariant_hessian(const wg_model_t *m, double *Qb) {
+  if (!m || !Qb || m->N < 1 || m->N > NMAXH) return -1;
+  static tables_t t;
+  build_tables(m, &t);
+  for (int i = 0; i < m->N; i++)
+    for (int j = 0; j < m->N; j++) Qb[i * m->N + j] = t.Qb[i][j];
+  return 0;
+}
+
 /* ZMPVelocityReferencedQP::InitOnLine, ZMPVelocityReferencedQP.cpp:212-319 */
 void wgo_gait_init(const wg_model_t *m, wg_gait_state_t *s, const double com0[3],
                    const double left_xyt[3], const double right_xyt[3]) {

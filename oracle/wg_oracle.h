@@ -49,6 +49,8 @@ void wgo_gait_init(const wg_model_t *model, wg_gait_state_t *state, const double
 /* one tick at time state->clock (the caller advances the clock, see tests/herdt_replay.py);
  * out and dump may be NULL.  Returns 0, or <0 if the sizes are unsupported. */
 int wgo_mpc_tick(const wg_model_t *model, wg_gait_state_t *state, wg_tick_out_t *out, wgo_qp_dump_t *dump);
+/* Q_b = beta I + alpha Uv'Uv + gamma Uz'Uz of the model (N x N, row-major), summed in the reference's order */
+int wgo_invariant_hessian(const wg_model_t *model, double *Qb);
 /* NULL (default): the tick solves with wgo_ql_solve; otherwise with the given ql0001_ entry point (the reference's own
  * compiled qld.cpp from oracle/_ref/libqld_ref.so) */
 void wgo_set_reference_ql(void *ql0001_entry);
