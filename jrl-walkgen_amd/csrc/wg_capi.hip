@@ -274,13 +274,31 @@ inline bool tick_compact(const wg_model_t &m);
 inline int tick_smax(const wg_model_t &m) { return tick_compact(m) ? 2 : wg::kSMax; }
 inline int tick_max_n(const wg_model_t &m) { return 2 * m.N + 2 * tick_smax(m); }
 inline int tick_max_m(const wg_model_t &m) { return 1 + 4 * m.N + 5 * tick_smax(m); }
-// compact problem view (no G / A matrices in LDS) exists for N == 16; WG_TICK_DENSE=1 forces the generic one
+// Problem views of the tick kernel (template argument of wg_mpc_tick_kernel):
+//   16  compact  rows in registers, no G / A anywhere: N == 16 with at most two previewed steps (the benchmark model)
+//    0  dense    G and A as LDS matrices: any other model whose matrices fit the CU's 160 KiB
+//   -1  element  G / A regenerated per element from the compact tables: what does not fit (N = 32: n <= 72, m <= 149)
+// WG_TICK_DENSE=1 forces the dense view, WG_TICK_VIEW=element the element view (tests).
 inline bool tick_compact(const wg_model_t &m) {
   const char *e = getenv("WG_TICK_DENSE");
-  return m.N == 16 && m.N * m.T <= 2.0 * m.step_period + 1e-12 && !(e && atoi(e) != 0);
+  const char *v = getenv("WG_TICK_VIEW");
+  return m.N == 16 && m.N * m.T <= 2.0 * m.step_period + 1e-12 && !(e && atoi(e) != 0) && !(v && *v);
+}
+inline size_t tick_lds_for(const wg_model_t &m, int view) {
+  const size_t ql = (wg::QlDims(tick_max_n(m), tick_max_m(m), tick_max_m(m), view == 0).bytes() + 15) & ~(size_t)15;
+  const int gvld = view == 16 ? wg::kGvLd : (view == -1 ? wg::kGvLdElem : 0);
+  return ql + wg::TickLds::bytes(m.N, tick_smax(m), gvld);
+}
+inline int tick_view(const wg_model_t &m) {
+  if (tick_compact(m)) return 16;
+  // the element view parks the pre-solve scratch on Z (n >= 2N): tiny horizons whose Z is smaller than that stay dense
+  const bool overlay_fits = wg::TickLds::pre_bytes(m.N, tick_smax(m)) <= (size_t)8 * (2 * m.N) * ((2 * m.N) | 1);
+  const char *v = getenv("WG_TICK_VIEW");
+  if (v && v[0] == 'e' && overlay_fits) return -1;
+  return (tick_lds_for(m, 0) <= 160 * 1024 || !overlay_fits) ? 0 : -1;
 }
 inline size_t tick_ql_bytes(const wg_model_t &m) {
-  size_t b = wg::QlDims(tick_max_n(m), tick_max_m(m), tick_max_m(m), !tick_compact(m)).bytes();
+  size_t b = wg::QlDims(tick_max_n(m), tick_max_m(m), tick_max_m(m), tick_view(m) == 0).bytes();
   return (b + 15) & ~(size_t)15;
 }
 }  // namespace
@@ -372,7 +390,7 @@ int wg_mpc_configure(const wg_model_t *model) {
   if (model->N < 2 || model->N > wg::kNMaxH) return fail(WG_ERR_BAD_ARG, "N=%d outside [2,%d]", model->N, wg::kNMaxH);
   if ((int)(model->T / model->Tctrl) != WG_SAMPLES_PER_TICK)
     return fail(WG_ERR_BAD_ARG, "T/Tctrl must be %d", WG_SAMPLES_PER_TICK);
-  size_t lds = tick_ql_bytes(*model) + wg::TickLds::bytes(model->N, tick_smax(*model), tick_compact(*model));
+  size_t lds = tick_lds_for(*model, tick_view(*model));
   if (lds > 160 * 1024) return fail(WG_ERR_TOO_LARGE, "tick needs %zu B of LDS > 160 KiB", lds);
   std::lock_guard<std::mutex> lk(g_mu);
   static wg::TickTables host_tables;
@@ -386,7 +404,7 @@ int wg_mpc_configure(const wg_model_t *model) {
 
 size_t wg_mpc_tick_lds_bytes(void) {
   if (!g_model_set) return 0;
-  return tick_ql_bytes(g_model) + wg::TickLds::bytes(g_model.N, tick_smax(g_model), tick_compact(g_model));
+  return tick_lds_for(g_model, tick_view(g_model));
 }
 
 int wg_mpc_tick_batch_dev(int B, wg_gait_state_t *states, wg_tick_out_t *outs, int *diag, int advance_calls, int *hist,
@@ -397,20 +415,24 @@ int wg_mpc_tick_batch_dev(int B, wg_gait_state_t *states, wg_tick_out_t *outs, i
   if (hist && (!hist_len || hist_cap <= 0)) return fail(WG_ERR_BAD_ARG, "hist needs hist_len and hist_cap > 0");
   if (B == 0) return WG_OK;
   const size_t qlb = tick_ql_bytes(g_model);
-  size_t lds = qlb + wg::TickLds::bytes(g_model.N, tick_smax(g_model), tick_compact(g_model));
+  const int view = tick_view(g_model);
+  size_t lds = tick_lds_for(g_model, view);
   if (const char *pad = getenv("WG_TICK_LDS_PAD")) lds += (size_t)atoi(pad);   // experiments: lower the residency
-  const bool compact = tick_compact(g_model);
   if (lds > 64 * 1024)
-    HIP_TRY(hipFuncSetAttribute(compact ? reinterpret_cast<const void *>(wg_mpc_tick_kernel<16>)
-                                        : reinterpret_cast<const void *>(wg_mpc_tick_kernel<0>),
+    HIP_TRY(hipFuncSetAttribute(view == 16  ? reinterpret_cast<const void *>(wg_mpc_tick_kernel<16>)
+                                : view == 0 ? reinterpret_cast<const void *>(wg_mpc_tick_kernel<0>)
+                                            : reinterpret_cast<const void *>(wg_mpc_tick_kernel<-1>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   const int grid = B;                             // one gait per block; the dispatcher balances uneven iteration counts
   hipStream_t st = reinterpret_cast<hipStream_t>(hip_stream);
-  if (compact)
+  if (view == 16)
     hipLaunchKernelGGL(wg_mpc_tick_kernel<16>, dim3(grid), dim3(64), lds, st, B, g_model, g_tables_dev, states, outs, diag,
                        advance_calls, hist, hist_cap, hist_len, (unsigned)qlb);
-  else
+  else if (view == 0)
     hipLaunchKernelGGL(wg_mpc_tick_kernel<0>, dim3(grid), dim3(64), lds, st, B, g_model, g_tables_dev, states, outs, diag,
+                       advance_calls, hist, hist_cap, hist_len, (unsigned)qlb);
+  else
+    hipLaunchKernelGGL(wg_mpc_tick_kernel<-1>, dim3(grid), dim3(64), lds, st, B, g_model, g_tables_dev, states, outs, diag,
                        advance_calls, hist, hist_cap, hist_len, (unsigned)qlb);
   HIP_TRY(hipGetLastError());
   return WG_OK;

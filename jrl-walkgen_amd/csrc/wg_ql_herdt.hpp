@@ -270,4 +270,58 @@ struct HerdtProb {
   }
 };
 
+// Element view of the same QP for any horizon (N <= 32, up to kSMaxQ previewed steps): G and A are never stored, every
+// element is regenerated from the compact tables on access.  It plugs into the solver's generic (lane-strided) paths
+// like DenseProb does, trading speed for LDS: at N = 32 (n <= 72, m <= 149) the dense matrices alone would need
+// 42 KB + 87 KB, more than a CU has next to Z and R.  Same values as the dense assembly, element by element.
+// border block: x-group rows (jerk-x rows and x-foot rows) only meet x-foot columns, y-group rows only y-foot columns, so
+// one half-width table suffices: Gv[i][c'] with c' the column index inside the row's own group
+constexpr int kGvLdElem = kSMaxQ;
+struct HerdtElemProb {
+  static constexpr bool kCompact = false;
+  static constexpr int kNM = 0;
+  int N, ns;
+  const double *Qb;       // global, N x kQbLd
+  const double *u;        // LDS, N
+  double *Gv;             // LDS, n x kGvLdElem: G(i, 2N + c) of the row's own column group
+  double *gd;             // LDS, n
+  const double *rowA, *rowB;
+  const int *rowK, *stepidx;
+  const double *V_f;
+  __device__ __forceinline__ double G(const QlView &q, int i, int j) const {
+    if (i == j) return gd[i];
+    if (j < i) { const int t = i; i = j; j = t; }
+    if (j < 2 * N) {
+      if (i < N && j < N) return Qb[i * kQbLd + j];
+      if (i >= N && j >= N) return Qb[(i - N) * kQbLd + (j - N)];
+      return 0.0;
+    }
+    const int c = j - 2 * N;
+    const bool xcol = c < ns, xrow = (i < N) || (i >= 2 * N && i < 2 * N + ns);
+    if (xcol != xrow) return 0.0;                 // never written by the assembly: stays +0.0 in the dense matrix
+    return Gv[i * kGvLdElem + (xcol ? c : c - ns)];
+  }
+  __device__ __forceinline__ double Gd(const QlView &, int i) const { return gd[i]; }
+  __device__ __forceinline__ void setGd(const QlView &, int i, double v) const { gd[i] = v; }
+  __device__ __forceinline__ double A(const QlView &, int k, int i) const {
+    if (k == 0) return 0.0;
+    const double a = rowA[k], b = rowB[k];
+    const int kk = rowK[k];
+    if (k <= 4 * N) {
+      const int r = kk;
+      if (i < N) return (i <= r) ? 0.0 + (0.0 + a * u[r - i]) * -1.0 : 0.0;
+      if (i < 2 * N) { const int c = i - N; return (c <= r) ? 0.0 + (0.0 + b * u[r - c]) * -1.0 : 0.0; }
+      int j = i - 2 * N;
+      if (j < ns) { const double v = (stepidx[r] == j + 1) ? 1.0 : 0.0; return 0.0 + (0.0 + a * v) * 1.0; }
+      j -= ns;
+      { const double v = (stepidx[r] == j + 1) ? 1.0 : 0.0; return 0.0 + (0.0 + b * v) * 1.0; }
+    }
+    if (kk < 0 || i < 2 * N) return 0.0;
+    int j = i - 2 * N;
+    if (j < ns) return 0.0 + (0.0 + a * V_f[kk * kSMaxQ + j]) * -1.0;
+    j -= ns;
+    return 0.0 + (0.0 + b * V_f[kk * kSMaxQ + j]) * -1.0;
+  }
+};
+
 }  // namespace wg

@@ -159,16 +159,19 @@ struct TickLds {
     const int m = 1 + 4 * N + 5 * smax;
     return sizeof(Sup) * (N + 1) + 8 * pre_doubles(N, m);
   }
-  // compact: the pre-solve group lives elsewhere (overlay), and the compact view's tables are present
-  __host__ __device__ static size_t bytes(int N, int smax = kSMax, bool compact = false) {
+  // gvld > 0: a table view (compact: kGvLd, element: kGvLdElem) -- its tables are present and the pre-solve group lives
+  // elsewhere (overlay); gvld == 0: dense view, G and A are LDS matrices of the solver area
+  __host__ __device__ static size_t bytes(int N, int smax = kSMax, int gvld = 0) {
     const int m = 1 + 4 * N + 5 * smax;
     const int nmax = 2 * N + 2 * smax;
-    size_t b = sizeof(Sup) + 8 * (size_t)(kSMax * kSMax + 8 + 2 * m + 16 + (compact ? N + nmax * kGvLd + nmax : 0)) +
+    const bool compact = gvld > 0;
+    size_t b = sizeof(Sup) + 8 * (size_t)(kSMax * kSMax + 8 + 2 * m + 16 + (compact ? N + nmax * gvld + nmax : 0)) +
                4 * (size_t)(((N + 1) & ~1) + ((m + 1) & ~1)) + ((sizeof(wg_gait_state_t) + 15) & ~(size_t)15);
     if (!compact) b += pre_bytes(N, smax);
     return (b + 15) & ~(size_t)15;
   }
-  __device__ void carve(char *base, int N, int smax, bool compact, char *overlay) {
+  __device__ void carve(char *base, int N, int smax, int gvld, char *overlay) {
+    const bool compact = gvld > 0;
     const int m = 1 + 4 * N + 5 * smax;
     char *p = base;
     st = reinterpret_cast<wg_gait_state_t *>(p); p += (sizeof(wg_gait_state_t) + 15) & ~(size_t)15;
@@ -177,7 +180,7 @@ struct TickLds {
     V_f = d; d += kSMax * kSMax; sup_angles = d; d += 8;
     rowA = d; d += m; rowB = d; d += m; misc = d; d += 16;
     uvec = Gv = gd = nullptr;
-    if (compact) { const int nmax = 2 * N + 2 * smax; uvec = d; d += N; Gv = d; d += nmax * kGvLd; gd = d; d += nmax; }
+    if (compact) { const int nmax = 2 * N + 2 * smax; uvec = d; d += N; Gv = d; d += nmax * gvld; gd = d; d += nmax; }
     int *ip = reinterpret_cast<int *>(d);
     stepidx = ip; ip += (N + 1) & ~1; rowK = ip; ip += (m + 1) & ~1;
     char *o = compact ? overlay : reinterpret_cast<char *>(ip);
@@ -438,7 +441,9 @@ __device__ inline void poly3_set(double *c, double FT, double FP, double p0, dou
 // ---------------------------------------------------------------------------
 struct TickDiag { int ifail, n_iter, nact, n, m, ns; };
 
-template <int NH>   // NH == 16: compact problem view (no G / A matrices in LDS); NH == 0: generic dense view
+// NH == 16: compact problem view (rows in registers, no G / A anywhere); NH == 0: generic dense view (G, A in LDS);
+// NH == -1: element view (any N <= 32: G / A regenerated per element from the compact tables, wg_ql_herdt.hpp)
+template <int NH>
 __device__ inline TickDiag mpc_tick(const wg_model_t &m, const TickTables *__restrict__ tb, wg_gait_state_t *gstate,
                                     wg_tick_out_t *out, double *lds_ql, char *lds_tick, int *hist, int hist_cap,
                                     int *hist_len) {
@@ -449,7 +454,9 @@ __device__ inline TickDiag mpc_tick(const wg_model_t &m, const TickTables *__res
   TickLds L;
   // compact: the pre-solve group is overlaid on Z, the first array of the solver's area (QlView::carve without G)
   static_assert(sizeof(Sup) % 8 == 0, "Sup must keep doubles aligned");
-  L.carve(lds_tick, N, (NH == 16) ? 2 : kSMax, NH == 16, reinterpret_cast<char *>(lds_ql));
+  constexpr int kGvStride = (NH == 16) ? kGvLd : (NH == -1 ? kGvLdElem : 0);
+  constexpr int kGvOff = (NH == -1) ? 0 : 1;
+  L.carve(lds_tick, N, (NH == 16) ? 2 : kSMax, kGvStride, reinterpret_cast<char *>(lds_ql));
   wg_gait_state_t *s = L.st;
 #ifdef WG_PROFILE
   unsigned long long tk0 = clock64(), tk1 = 0, tk2 = 0, tk3 = 0;
@@ -575,7 +582,8 @@ __device__ inline TickDiag mpc_tick(const wg_model_t &m, const TickTables *__res
   const int n = 2 * N + 2 * ns;
   const int mq = 1 + 4 * N + 5 * ns;     // rows incl. the dummy row 0 (qp-problem.cpp:248)
   constexpr bool kCompactView = (NH == 16);
-  QlDims D(n, mq, mq, !kCompactView, true, kCompactView ? 2 * NH + 4 : 0);   // ordered sums run the static length
+  constexpr bool kTableView = (NH == 16) || (NH == -1);   // Hessian / constraints kept as compact tables
+  QlDims D(n, mq, mq, !kTableView, true, kCompactView ? 2 * NH + 4 : 0);   // ordered sums run the static length
   QlView q;
   q.carve(lds_ql, D, 0);
 
@@ -618,10 +626,10 @@ __device__ inline TickDiag mpc_tick(const wg_model_t &m, const TickTables *__res
   for (int i = lane; i < n; i += 64) { q.xl[i] = -1e8; q.xu[i] = 1e8; }   // qp-problem.cpp:118-121
 
   // ---- Hessian ----
-  if constexpr (kCompactView) {
-    // compact view: Qb and u as small LDS tables, the 2ns border columns (symmetric) and the diagonal
+  if constexpr (kTableView) {
+    // table views: Qb and u as small LDS tables, the 2ns border columns (symmetric) and the diagonal
     for (int d = lane; d < N; d += 64) L.uvec[d] = tb->Uz[d][0];                 // Uz[r][c] = u[r-c]
-    for (int e = lane; e < n * kGvLd; e += 64) L.Gv[e] = 0.0;
+    for (int e = lane; e < n * kGvStride; e += 64) L.Gv[e] = 0.0;
     for (int i = lane; i < 2 * N; i += 64) L.gd[i] = tb->Qb[i % N][i % N];
     WG_WSYNC();
     for (int e = lane; e < N * ns; e += 64) {
@@ -629,8 +637,9 @@ __device__ inline TickDiag mpc_tick(const wg_model_t &m, const TickTables *__res
       double p = 0.0;
       for (int k = 0; k < N; k++) { const double v = (L.stepidx[k] == j + 1) ? 1.0 : 0.0; p += tb->Uz[k][i] * v; }
       p *= -m.gamma;
-      L.Gv[i * kGvLd + j] = 0.0 + p;                                        // x block  x  x-foot column
-      L.Gv[(N + i) * kGvLd + ns + j] = 0.0 + p;                             // y block  x  y-foot column
+      // kGvOff: the compact view stores both column groups side by side, the element view folds them (wg_ql_herdt.hpp)
+      L.Gv[i * kGvStride + j] = 0.0 + p;                                        // x block  x  x-foot column
+      L.Gv[(N + i) * kGvStride + kGvOff * ns + j] = 0.0 + p;                    // y block  x  y-foot column
     }
     for (int e = lane; e < ns * ns; e += 64) {
       const int i = e % ns, j = e / ns;
@@ -641,7 +650,7 @@ __device__ inline TickDiag mpc_tick(const wg_model_t &m, const TickTables *__res
       }
       p *= m.gamma;
       if (i == j) { L.gd[2 * N + i] = 0.0 + p; L.gd[2 * N + ns + i] = 0.0 + p; }
-      else { L.Gv[(2 * N + i) * kGvLd + j] = 0.0 + p; L.Gv[(2 * N + ns + i) * kGvLd + ns + j] = 0.0 + p; }
+      else { L.Gv[(2 * N + i) * kGvStride + j] = 0.0 + p; L.Gv[(2 * N + ns + i) * kGvStride + kGvOff * ns + j] = 0.0 + p; }
     }
     // the border rows' Gv entries toward the border columns mirror the lower-left block (symmetry is exact:
     // (VT Uz)(j,i) and (UzT V)(i,j) are the same products in the same order)
@@ -685,7 +694,7 @@ __device__ inline TickDiag mpc_tick(const wg_model_t &m, const TickTables *__res
     double bacc = 0.0;
     if (r >= 1 && r <= 4 * N) {
       const int i = kk;
-      if constexpr (!kCompactView) {
+      if constexpr (!kTableView) {
         for (int c = 0; c < N; c++) {
           const double u = tb->Uz[i][c];
           const double px = 0.0 + a * u, py = 0.0 + bb * u;
@@ -703,10 +712,10 @@ __device__ inline TickDiag mpc_tick(const wg_model_t &m, const TickTables *__res
       bacc += (0.0 + a * L.VcX[i]) * 1.0;
       bacc += (0.0 + bb * L.VcY[i]) * 1.0;
     } else {
-      if constexpr (!kCompactView) for (int c = 0; c < n; c++) AmL(r, c) = 0.0;
+      if constexpr (!kTableView) for (int c = 0; c < n; c++) AmL(r, c) = 0.0;
       if (r > 4 * N && kk >= 0) {
         const int k = kk;
-        if constexpr (!kCompactView) {
+        if constexpr (!kTableView) {
           for (int j = 0; j < ns; j++) {
             const double vf = L.V_f[k * kSMax + j];
             const double px = 0.0 + a * vf, py = 0.0 + bb * vf;
@@ -735,6 +744,13 @@ __device__ inline TickDiag mpc_tick(const wg_model_t &m, const TickTables *__res
     prob.rowA = L.rowA; prob.rowB = L.rowB; prob.rowK = L.rowK; prob.stepidx = L.stepidx; prob.V_f = L.V_f;
     prob.R2 = tb->R2; prob.Z2 = tb->Z2; prob.diag_b = tb->diag_b; prob.blocks_ok = tb->blocks_ok; prob.ns = ns;
     prob.load_rows(lane);
+    qr = ql_solve(q, prob, 1e-8, hist, hist_cap);
+  } else if constexpr (NH == -1) {
+    if (lane == 0 && fabs(L.gd[n - 1]) == 0.0) L.gd[n - 1] = 1e-8;               // qld.cpp:442-444 (nmax == n)
+    WG_WSYNC();
+    HerdtElemProb prob;
+    prob.N = N; prob.ns = ns; prob.Qb = &tb->Qb[0][0]; prob.u = L.uvec; prob.Gv = L.Gv; prob.gd = L.gd;
+    prob.rowA = L.rowA; prob.rowB = L.rowB; prob.rowK = L.rowK; prob.stepidx = L.stepidx; prob.V_f = L.V_f;
     qr = ql_solve(q, prob, 1e-8, hist, hist_cap);
   } else {
     if (lane == 0 && fabs(GmL(n - 1, n - 1)) == 0.0) GmL(n - 1, n - 1) = 1e-8;   // qld.cpp:442-444 (nmax == n)

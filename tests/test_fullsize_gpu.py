@@ -4,7 +4,7 @@ At BASELINE.json's size (4096 gaits x 200 ticks) the oracle cannot follow every 
 checked through size-independent properties -- determinism, batch-composition invariance (a gait's trajectory does not
 depend on its neighbours or its slot), shard consistency, physical sanity -- plus a seeded sample of gaits followed
 bit-for-bit by the oracle over the whole 200 ticks.  Edge sizes: n = 1, config-5-sized dense QPs (n = 72, m = 149),
-ragged batches, other horizons N through the dense tick policy, and a horizon that cannot fit LDS."""
+ragged batches, other horizons N through the dense tick policy, config 5's N = 32 through the element view."""
 import ctypes as C
 import importlib
 import os
@@ -126,31 +126,27 @@ def test_dense_qp_edge_sizes_bit_exact():
     assert int(res["ifail"][3]) == 0
 
 
-@pytest.mark.parametrize("N,T,step", [(8, 0.1, 0.8), (12, 0.1, 0.8), (16, 0.05, 0.8), (20, 0.1, 0.8)])
-def test_other_horizons_run_through_the_dense_policy_bit_exact(N, T, step):
-    """The register-resident problem view is instantiated for N = 16 with <= 2 previewed steps; every other model goes
-    through the generic (dense, LDS) policy of the same solver and must agree with the oracle just the same."""
-    wg.init(0)
+def _horizon_vs_oracle(N, T, step, B, ticks, redraw):
     pt = C.CDLL(os.path.join(ol.ORACLE_DIR, "libwg_oracle_ptrig.so"))
     model = wg.model_defaults()
     model.N = N; model.T = T; model.t_double = T; model.step_period = step
     model.Tctrl = T / 20.0                                         # the ABI fixes 20 control samples per tick
     wg.mpc_configure(model)
     try:
-        B = 6
         st = _start(model, B)
         ref = _start(model, B)
         rng = np.random.default_rng(N)
         per_tick = int(round(T / model.Tctrl))
         sizes = set()
-        for t in range(40):
-            if t % 15 == 0:
+        for t in range(ticks):
+            if t % redraw == 0:
                 for g in range(B):
                     v = [rng.uniform(-0.1, 0.3), rng.uniform(-0.1, 0.1), rng.uniform(-0.2, 0.2)]
                     for s in (st[g], ref[g]):
                         s.vref[0], s.vref[1], s.vref[2] = v
             adv = 1 if t == 0 else (per_tick - 1 if t == 1 else per_tick)
             _, diag, _, _ = wg.mpc_tick_batch(st, want_out=False, advance_calls=adv)
+            assert (diag[:, 0] == 0).all(), diag[:, 0]
             sizes |= set(int(v) for v in diag[:, 3])
             for g in range(B):
                 c = ref[g].clock
@@ -159,17 +155,39 @@ def test_other_horizons_run_through_the_dense_policy_bit_exact(N, T, step):
                 ref[g].clock = c
                 assert pt.wgo_mpc_tick(C.byref(model), C.byref(ref[g]), None, None) == 0
             assert bytes(memoryview(st).cast("B")) == bytes(memoryview(ref).cast("B")), t
-        assert max(sizes) > 2 * N                                  # foot-placement variables did appear
+        return sizes
     finally:
         wg.mpc_configure(wg.model_defaults())
 
 
-def test_horizon_that_cannot_fit_lds_is_refused():
+@pytest.mark.parametrize("N,T,step", [(8, 0.1, 0.8), (12, 0.1, 0.8), (16, 0.05, 0.8), (20, 0.1, 0.8)])
+def test_other_horizons_run_through_the_dense_policy_bit_exact(N, T, step):
+    """The register-resident problem view is instantiated for N = 16 with <= 2 previewed steps; every other model goes
+    through the generic (dense, LDS) policy of the same solver and must agree with the oracle just the same."""
+    wg.init(0)
+    sizes = _horizon_vs_oracle(N, T, step, B=6, ticks=40, redraw=15)
+    assert max(sizes) > 2 * N                                      # foot-placement variables did appear
+
+
+def test_config5_horizon_32_runs_through_the_element_view_bit_exact():
+    """BASELINE config 5's problem size (N = 32, foot-placement variables kept: n up to 72, m up to 149), in fp64: its
+    dense matrices do not fit a CU's LDS, so the tick regenerates G / A per element from the compact tables."""
+    wg.init(0)
+    sizes = _horizon_vs_oracle(32, 0.1, 0.8, B=5, ticks=36, redraw=12)
+    assert max(sizes) == 72 and min(sizes) >= 64                   # all four previewed steps appeared
+
+
+@pytest.mark.parametrize("N", [8, 20])
+def test_element_view_equals_dense_view_on_small_horizons(N, monkeypatch):
+    wg.init(0)
+    monkeypatch.setenv("WG_TICK_VIEW", "element")
+    sizes = _horizon_vs_oracle(N, 0.1, 0.8, B=4, ticks=30, redraw=10)
+    assert max(sizes) > 2 * N
+
+
+def test_horizon_beyond_the_tables_is_refused():
     wg.init(0)
     model = wg.model_defaults()
-    model.N = 32                                                   # config 5's horizon: n <= 72, m <= 149, dense tick view
-    rc = wg.lib().wg_mpc_configure(C.byref(model))
-    assert rc == -4 and b"LDS" in wg.lib().wg_last_error()        # WG_ERR_TOO_LARGE, nothing launched
     model.N = 48
     assert wg.lib().wg_mpc_configure(C.byref(model)) == -2        # WG_ERR_BAD_ARG: beyond the table size
     wg.mpc_configure(wg.model_defaults())
