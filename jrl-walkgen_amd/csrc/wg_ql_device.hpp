@@ -48,6 +48,10 @@ __device__ __forceinline__ double uni(double v) {
   hi = __builtin_amdgcn_readfirstlane(hi);
   return __hiloint2double(hi, lo);
 }
+// A wave-uniform predicate as a scalar: every lane computes the same value redundantly, so taking lane 0's copy is the
+// identity -- but it tells the compiler the branch is uniform (s_cbranch on SCC instead of exec-mask juggling), which
+// also keeps everything assigned under it (nact, knext, loop counters, LDS addresses) in scalar registers.
+#define WG_UBOOL(c) (uni((int)(c)) != 0)
 // value of `v` in lane `src` (src must be wave-uniform): two v_readlane_b32, no LDS round trip
 __device__ __forceinline__ double rl(double v, int src) {
   int lo = __builtin_amdgcn_readlane(__double2loint(v), src);
@@ -186,20 +190,23 @@ __device__ __forceinline__ int wave_min_int(int v) {
   return v;
 }
 
+// norm of a rotation, qld.cpp:1921-1926 / 2005-2010:  t = max(|p|,|q|);  t * sqrt((p/t)^2 + (q/t)^2).
+// This sits on the sequential chain of every sweep.  One of the two quotients is x/|x| = +-1 EXACTLY (IEEE division is
+// exact there), its square is exactly 1.0, and a + b == b + a: so only the other quotient is a real division.  Same
+// bits as the reference's two divisions for finite operands (0/0 stays NaN); half the divide latency on the chain.
+__device__ __forceinline__ double givens_norm(double p, double qq) {
+  const double ap = fabs(p), aq = fabs(qq);
+  const bool pbig = ap >= aq;                      // maxd(): a >= b ? a : b
+  const double t = pbig ? ap : aq;
+  const double d = (pbig ? qq : p) / t;
+  return t * sqrt(1.0 + d * d);
+}
 // qld.cpp:1921-1930 / 2005-2014
 __device__ __forceinline__ void givens(double p, double qq, double &ga, double &gb, double &nrm) {
-  double t = maxd(fabs(p), fabs(qq));
-  double d1 = p / t, d2 = qq / t;
-  double sum = t * sqrt(d1 * d1 + d2 * d2);
+  const double sum = givens_norm(p, qq);
   ga = p / sum;
   gb = qq / sum;
   nrm = sum;
-}
-// norm only (the part of the rotation that sits on the sequential chain)
-__device__ __forceinline__ double givens_norm(double p, double qq) {
-  double t = maxd(fabs(p), fabs(qq));
-  double d1 = p / t, d2 = qq / t;
-  return t * sqrt(d1 * d1 + d2 * d2);
 }
 __device__ __forceinline__ bool significant(double base, double delta_abs) {
   double temp = base + delta_abs * .1;
@@ -253,6 +260,68 @@ __device__ __forceinline__ void backsub(const QlView &q, const double *s, int na
     if (lane == 0) q.ww[i] = v;
     WG_WSYNC();
   }
+}
+
+// Back substitution for n <= 36 (the compact view), restructured around its dependent chain.
+// Row j needs sum_{k>j} R(j,k) w_k summed ascending in k, and its FIRST term carries the value produced last (w_{j+1}):
+// the additions of a row are one chain, (nact-j-1) x 8 cycles plus the divide, and nothing else may sit on it.
+//   * lane k keeps w_k and forms the products R(j-1,k) w_k for the NEXT row while the current row's chain runs; they
+//     go to a double-buffered LDS vector (entries outside (j, nact) are written as +0.0: adding them changes nothing);
+//   * every lane then runs the row's chain redundantly on LDS-broadcast operands, the first chunk prefetched one row
+//     ahead, the first term formed in registers from R(j,j+1) and the w just computed.
+// The v_readlane form above costs ~40 cycles per term (two readlanes + add, serialised); this one ~8.
+// buf: 2 * kBsLen doubles of LDS (the four scratch vectors are contiguous).
+constexpr int kBsLen = 48;
+__device__ __forceinline__ void backsub_lds(const QlView &q, const double *s, int nact, int lane, double *buf) {
+  const bool mine = lane < nact;
+  const double sreg = mine ? s[lane] : 0.0;
+  const double dreg = mine ? Rp(lane, lane) : 1.0;
+  if (lane < kBsLen) { buf[lane] = 0.0; buf[kBsLen + lane] = 0.0; }
+  const int col = mine ? lane : 0;
+  double w = 0.0, wprev = 0.0;
+  double p0 = 0.0, p1 = 0.0, p2 = 0.0, p3 = 0.0, p4 = 0.0, p5 = 0.0, p6 = 0.0, p7 = 0.0;   // row j's terms k = j+2 .. j+9
+  double rcur = 0.0;                                       // R(j, j+1)
+  double rr = Rp(nact >= 2 ? nact - 2 : 0, col);           // R(j-1, lane) of the row whose products are formed next
+  for (int j = nact - 1; j >= 0; --j) {
+    const double *bj = buf + (j & 1) * kBsLen;
+    double *bn = buf + ((j & 1) ^ 1) * kBsLen;
+    const int jn = j >= 1 ? j - 1 : 0, jnn = j >= 2 ? j - 2 : 0;
+    // products of the next row (j-1) with the multipliers known so far (k >= j+1); nothing here waits on LDS: R(j-1, .)
+    // was fetched one row ahead, and a wave's LDS operations execute in order (the barrier only pins the compiler)
+    {
+      const double val = (lane >= j + 1 && mine) ? rr * w : 0.0;
+      if (lane < kBsLen) bn[lane] = val;
+      rr = Rp(jnn, col);
+    }
+    __builtin_amdgcn_wave_barrier();
+    const double n0 = bn[j + 1], n1 = bn[j + 2], n2 = bn[j + 3], n3 = bn[j + 4], n4 = bn[j + 5], n5 = bn[j + 6],
+                 n6 = bn[j + 7], n7 = bn[j + 8];           // prefetch: the next row's first terms
+    const double rnext = Rp(jn, jn + 1);
+    const double sj = rl(sreg, j), dj = rl(dreg, j);
+    double sum = 0.0;
+    if (j + 1 < nact) {
+      sum += rcur * wprev;
+      sum += p0; sum += p1; sum += p2; sum += p3;
+      if (j + 6 < nact) {
+        sum += p4; sum += p5; sum += p6; sum += p7;
+        if (j + 10 < nact) {
+          double a0 = bj[j + 10], a1 = bj[j + 11], a2 = bj[j + 12], a3 = bj[j + 13];
+          for (int k = j + 10; k < nact; k += 4) {
+            const int kn = k + 4 < kBsLen - 4 ? k + 4 : kBsLen - 4;                // clamped: unused past the end
+            const double b0 = bj[kn], b1 = bj[kn + 1], b2 = bj[kn + 2], b3 = bj[kn + 3];
+            sum += a0; sum += a1; sum += a2; sum += a3;
+            a0 = b0; a1 = b1; a2 = b2; a3 = b3;
+          }
+        }
+      }
+    }
+    const double v = (sj - sum) / dj;
+    if (lane == j) w = v;
+    wprev = v;
+    p0 = n0; p1 = n1; p2 = n2; p3 = n3; p4 = n4; p5 = n5; p6 = n6; p7 = n7; rcur = rnext;
+  }
+  if (mine) q.ww[lane] = w;
+  WG_WSYNC();
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -409,10 +478,10 @@ __device__ __forceinline__ int pick_drop(const QlView &q, int nact, double res, 
   int idx = bidx;
   double v = best;
   wave_argmax_first(v, idx);
+  idx = uni(idx);
   if (idx < 0) return -1;
   // fetch the winning lane's temp
-  double t = __shfl(bestt, idx & 63);
-  ratio = t;
+  ratio = rl(bestt, idx & 63);
   return idx;
 }
 
@@ -602,7 +671,12 @@ __device__ __forceinline__ bool independent_coordinate(const QlView &q, const P 
 // The solver.  Problem data must already be in LDS: G (copy of C, patched per
 // qld.cpp:442-444), A, d, b (INNER sign: b = -b_user, qld.cpp:469-475), xl, xu.
 // hist: optional global add(+code)/drop(-code) log written by lane 0.
+#ifdef WG_BACKSUB_READLANE
 #define WG_BACKSUB(q, s, nact, lane) backsub(q, s, nact, lane)
+#else
+#define WG_BACKSUB(q, s, nact, lane) \
+  do { if constexpr (P::kNM > 0 && P::kNM + 12 <= kBsLen) backsub_lds(q, s, nact, lane, q.sc0); else backsub(q, s, nact, lane); } while (0)
+#endif
 #define WG_SWEEP(q, s, nu, nact, lane) \
   do { if constexpr (P::kNM > 0) sweep_flat(q, s, nu, nact, lane); else sweep(q, s, nu, nact, lane); } while (0)
 
@@ -647,7 +721,7 @@ __device__ inline QlResult ql_solve(const QlView &q, P &prob, double vsmall, int
       }
     }
     for (int k = lane; k < n; k += 64) q.wa[m + k] = 1.0;
-    fatal = wave_min_int(fatal);
+    fatal = uni(wave_min_int(fatal));
     if (fatal != 0x7fffffff) { info = -fatal; early_exit = true; }
   }
   PT(0);
@@ -674,11 +748,12 @@ __device__ inline QlResult ql_solve(const QlView &q, P &prob, double vsmall, int
       }
       diag = wave_max(dl);
     }
+    diag = uni(diag);
     bool need_shift = diag > 0.0;
     PT(1);
     bool factored = false;
     if constexpr (P::kCompact) {
-      if (!need_shift && prob.blocks_ok) factored = prob.factor(q, vsmall, lane);
+      if (!need_shift && prob.blocks_ok) factored = WG_UBOOL(prob.factor(q, vsmall, lane));
     }
     if (!factored) {
     for (;;) {
@@ -701,7 +776,7 @@ __device__ inline QlResult ql_solve(const QlView &q, P &prob, double vsmall, int
           } else q.sc0[j] = temp;
         }
         WG_WSYNC();
-        if (q.slot[0] != 0.0) { jfail = i; tfail = q.slot[1]; break; }
+        if (WG_UBOOL(q.slot[0] != 0.0)) { jfail = i; tfail = q.slot[1]; break; }
         double rii = Rp(i, i);
         for (int j = i + 1 + lane; j < n; j += 64) Rp(i, j) = q.sc0[j] / rii;
         WG_WSYNC();
@@ -728,7 +803,7 @@ __device__ inline QlResult ql_solve(const QlView &q, P &prob, double vsmall, int
         q.slot[2] = dnew;
       }
       WG_WSYNC();
-      diag = q.slot[2];
+      diag = uni(q.slot[2]);
       need_shift = true;
     }
 
@@ -865,14 +940,14 @@ __device__ inline QlResult ql_solve(const QlView &q, P &prob, double vsmall, int
         WG_WSYNC();
       }
       PT(7);
-      { double sm = xmag_sum(q, prob, vfact, lane); xmag = maxd(xmag, sm); }
+      { double sm = uni(xmag_sum(q, prob, vfact, lane)); xmag = maxd(xmag, sm); }
       PT(8);
       if (iflag == itref) { st = ST_RESID; continue; }      // :1226
       // first inequality with a negative multiplier, :1233-1249
       int kd = 0x7fffffff;
       for (int k = lane; k < nact; k += 64)
         if (q.lam[k] < 0.0 && q.iact[k] > me) { kd = k < kd ? k : kd; }
-      kd = wave_min_int(kd);
+      kd = uni(wave_min_int(kd));
       if (kd != 0x7fffffff) {
         LOG_EVENT(-q.iact[kd]);
         nact = drop_constraint(q, kd, nact, nact, lane);
@@ -959,22 +1034,23 @@ __device__ inline QlResult ql_solve(const QlView &q, P &prob, double vsmall, int
         double v = bestv;
         int kk = key;
         wave_argmax_first(v, kk);
+        kk = uni(kk);
         if (kk < 0) { bestv = 0.0; bidx = -1; }
         else {
           int src = -1;
           // the lane that owns the winning key
           unsigned long long mask = __ballot(key == kk);
           src = __ffsll((long long)mask) - 1;
-          bestv = __shfl(bestv, src);
-          bestres = __shfl(bestres, src);
-          bidx = __shfl(bidx, src);
+          bestv = rl(bestv, src);
+          bestres = rl(bestres, src);
+          bidx = __builtin_amdgcn_readlane(bidx, src);
         }
       }
       double cvmax = bestv;
       if (bidx >= 0) { res = bestres; knext = bidx; }
       PT(9);
       info = 0;
-      if (cvmax <= vsmall) { st = ST_CONVERGED; continue; }  // :1336
+      if (WG_UBOOL(cvmax <= vsmall)) { st = ST_CONVERGED; continue; }  // :1336
 
       // ---- has the objective stopped increasing?  :1343-1408 ----
       ++jfinc;
@@ -999,9 +1075,9 @@ __device__ inline QlResult ql_solve(const QlView &q, P &prob, double vsmall, int
           for (int i = 0; i < n; ++i) { fdiff += q.sc0[i]; fdiffa += q.sc1[i]; }
           info = 2;
           double sum = fdiffa + fdiff;
-          if (sum <= fdiffa) { st = ST_CONVERGED; continue; }
+          if (WG_UBOOL(sum <= fdiffa)) { st = ST_CONVERGED; continue; }
           double temp = fdiffa + onha * fdiff;
-          if (temp <= sum) { st = ST_CONVERGED; continue; }
+          if (WG_UBOOL(temp <= sum)) { st = ST_CONVERGED; continue; }
           jfinc = 0;
           info = 0;
         }
@@ -1083,11 +1159,11 @@ __device__ inline QlResult ql_solve(const QlView &q, P &prob, double vsmall, int
           if (lane == 0 && blockIdx.x == 2 && iterc == 3) { for (int i = 0; i < n; i++) printf("GPUW %d %.17g %.17g\n", i, q.ww[i], Zm(i, nact)); }
           if (lane == 0) printf("GPU blk %d it %d knext %d nact %d suma %.17g sumb %.17g sumc %.17g wa %.17g\n", (int)blockIdx.x, iterc, knext, nact, suma, sumb, sumc, knext <= m ? q.wa[knext - 1] : 0.0);
 #endif
-          if (!significant(sumb, fabs(suma)) || !(sumb > vsmall)) route = 1;
+          if (WG_UBOOL(!significant(sumb, fabs(suma)) || !(sumb > vsmall))) route = 1;
           else {
             sumc = sqrt(sumc);
             if (knext <= m) sumc /= q.wa[knext - 1];
-            if (significant(sumc, fabs(suma))) route = 0;
+            if (WG_UBOOL(significant(sumc, fabs(suma)))) route = 0;
             else {                                          // :1538-1540
               WG_BACKSUB(q, s, nact, lane);
               route = independent_coordinate(q, prob, knext, nact, vsmall, lane) ? 0 : 2;
@@ -1122,7 +1198,7 @@ __device__ inline QlResult ql_solve(const QlView &q, P &prob, double vsmall, int
             PT(16);
             if (kdrop >= 0) {                               // :1734-1743
               double temp = 1.0 - ratio / parinc;
-              if (temp <= 0.0) kdrop = -1;
+              if (WG_UBOOL(temp <= 0.0)) kdrop = -1;
               else { step = ratio * sumy; parinc = ratio; res = temp * res; }
             }
           }
@@ -1171,10 +1247,10 @@ __device__ inline QlResult ql_solve(const QlView &q, P &prob, double vsmall, int
       LOG_EVENT(knext);
       WG_WSYNC();
       PT(18);
-      double sm = xmag_sum(q, prob, vfact, lane);                 // :1776-1786
+      double sm = uni(xmag_sum(q, prob, vfact, lane));            // :1776-1786
       xmag = maxd(xmag, sm);
       PT(19);
-      if (sm < xmagr * xmag) st = ST_RESET;
+      if (WG_UBOOL(sm < xmagr * xmag)) st = ST_RESET;
       else if (itref <= 0) st = ST_SCAN;
       else st = ST_RESID;
       continue;

@@ -225,7 +225,7 @@ struct HerdtProb {
           if (temp < vsmall) q.slot[0] = 1.0; else { q.slot[0] = 0.0; Rp(i, i) = sqrt(temp); }
         }
         WG_WSYNC();
-        if (q.slot[0] != 0.0) { ok = false; break; }
+        if (WG_UBOOL(q.slot[0] != 0.0)) { ok = false; break; }
       }
       const double rii = Rp(i, i);
       if (col && j > i) Rp(i, j) = temp / rii;

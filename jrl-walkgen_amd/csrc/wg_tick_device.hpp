@@ -578,7 +578,7 @@ __device__ inline TickDiag mpc_tick(const wg_model_t &m, const TickTables *__res
 #ifdef WG_PROFILE
   tk1 = clock64();
 #endif
-  const int ns = (int)L.misc[0];
+  const int ns = uni((int)L.misc[0]);     // the same in every lane: keep it (and n, m, every solver address) scalar
   const int n = 2 * N + 2 * ns;
   const int mq = 1 + 4 * N + 5 * ns;     // rows incl. the dummy row 0 (qp-problem.cpp:248)
   constexpr bool kCompactView = (NH == 16);
