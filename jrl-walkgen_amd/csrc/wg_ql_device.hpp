@@ -154,7 +154,9 @@ __device__ unsigned long long g_prof[32];
 #define PT_DECL unsigned long long pt_acc[24] = {0}; unsigned long long pt_last = clock64();
 #define PT(k) do { unsigned long long t_ = clock64(); pt_acc[k] += t_ - pt_last; pt_last = t_; } while (0)
 #define PT_FLUSH do { if ((threadIdx.x & 63) == 0) for (int k_ = 0; k_ < 24; ++k_) atomicAdd(&g_prof[k_], pt_acc[k_]); } while (0)
+#define PT_COUNT(k) do { if ((threadIdx.x & 63) == 0) atomicAdd(&g_prof[k], 1ull); } while (0)
 #else
+#define PT_COUNT(k) do {} while (0)
 #define PT_DECL
 #define PT(k) do {} while (0)
 #define PT_FLUSH do {} while (0)
@@ -1126,16 +1128,19 @@ __device__ inline QlResult ql_solve(const QlView &q, P &prob, double vsmall, int
               q.sc0[lane] = wi * zi; q.sc1[lane] = fabs(wi * zi); q.sc2[lane] = zi * zi;
             }
             WG_WSYNC();
+            // three ordered sums of NM terms: lane 0 adds the first vector, lane 1 the second, lane 2 the third (the
+            // scratch vectors are contiguous) -- one 8-cycle add chain per lane instead of three interleaved ones in all
+            const double *src = q.sc0 + (lane < 3 ? lane : 0) * (int)(q.sc1 - q.sc0);
+            double acc = 0.0;
 #pragma unroll
             for (int i0 = 0; i0 < NM; i0 += kOsChunk) {
-              double ta[kOsChunk], tb[kOsChunk], tc[kOsChunk];
+              double t[kOsChunk];
 #pragma unroll
-              for (int i = 0; i < kOsChunk; ++i)
-                if (i0 + i < NM) { ta[i] = q.sc0[i0 + i]; tb[i] = q.sc1[i0 + i]; tc[i] = q.sc2[i0 + i]; }
+              for (int i = 0; i < kOsChunk; ++i) if (i0 + i < NM) t[i] = src[i0 + i];
 #pragma unroll
-              for (int i = 0; i < kOsChunk; ++i)
-                if (i0 + i < NM) { suma += ta[i]; sumb += tb[i]; sumc += tc[i]; }
+              for (int i = 0; i < kOsChunk; ++i) if (i0 + i < NM) acc += t[i];
             }
+            suma = rl(acc, 0); sumb = rl(acc, 1); sumc = rl(acc, 2);
             WG_WSYNC();
           } else if (n <= 60) {
             double ta = 0.0, tb = 0.0, tc = 0.0;
@@ -1165,6 +1170,7 @@ __device__ inline QlResult ql_solve(const QlView &q, P &prob, double vsmall, int
             if (knext <= m) sumc /= q.wa[knext - 1];
             if (WG_UBOOL(significant(sumc, fabs(suma)))) route = 0;
             else {                                          // :1538-1540
+              PT_COUNT(29);
               WG_BACKSUB(q, s, nact, lane);
               route = independent_coordinate(q, prob, knext, nact, vsmall, lane) ? 0 : 2;
             }
@@ -1173,6 +1179,8 @@ __device__ inline QlResult ql_solve(const QlView &q, P &prob, double vsmall, int
       }
       route = uni(route);
       PT(13);
+      PT_COUNT(28);
+      if (route != 0) PT_COUNT(30);
       if (route != 0) {
         if (route == 1) WG_BACKSUB(q, s, nact, lane);
         kdrop = pick_drop(q, nact, res, ratio, lane);

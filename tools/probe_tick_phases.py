@@ -29,6 +29,6 @@ names = ["norms", "diagchk", "chol", "inverse", "resid/reset+shift", "ZT*ww(resi
          "scan", "fdiff/wx", "newnormal ZTa", "sweep", "route sums", "step-pre", "backsub(step)", "pickdrop", "step/upd/drop", "add",
          "xmag(add)", "tail", "TICK pre (lane0)", "TICK assembly", "TICK post", "(sweep ph1)", "(sweep ph2)", "(sweep ph3)"]
 tot = v[:24].sum()
-print(f"gait-ticks={n} mean QL iters={its/n:.1f} cycles/tick={tot/n:.0f}  sweeps/tick={v[28]/n:.1f} rotations/sweep={v[27]/max(v[28],1):.1f}")
+print(f"gait-ticks={n} mean QL iters={its/n:.1f} cycles/tick={tot/n:.0f}  route decisions/tick={v[28]/n:.1f} of which coordinate checks {v[29]/n:.2f}, dependent routes {v[30]/n:.2f}")
 for k, nme in enumerate(names):
     print(f"{k:2d} {nme:22s} {v[k]/n:12.0f} cyc/tick  {100*v[k]/tot:5.1f}%")
