@@ -151,9 +151,9 @@ struct DenseProb {
 // ---- optional in-kernel phase timers (diagnostic build only: -DWG_PROFILE) ----
 #ifdef WG_PROFILE
 __device__ unsigned long long g_prof[32];
-#define PT_DECL unsigned long long pt_acc[24] = {0}; unsigned long long pt_last = clock64();
+#define PT_DECL unsigned long long pt_acc[28] = {0}; unsigned long long pt_last = clock64();
 #define PT(k) do { unsigned long long t_ = clock64(); pt_acc[k] += t_ - pt_last; pt_last = t_; } while (0)
-#define PT_FLUSH do { if ((threadIdx.x & 63) == 0) for (int k_ = 0; k_ < 24; ++k_) atomicAdd(&g_prof[k_], pt_acc[k_]); } while (0)
+#define PT_FLUSH do { if ((threadIdx.x & 63) == 0) for (int k_ = 0; k_ < 28; ++k_) if (k_ < 21 || k_ > 23) atomicAdd(&g_prof[k_], pt_acc[k_]); } while (0)
 #define PT_COUNT(k) do { if ((threadIdx.x & 63) == 0) atomicAdd(&g_prof[k], 1ull); } while (0)
 #else
 #define PT_COUNT(k) do {} while (0)
@@ -858,6 +858,7 @@ __device__ inline QlResult ql_solve(const QlView &q, P &prob, double vsmall, int
         xmag = 0.0;
         vfact = 1.0;
         WG_WSYNC();
+        PT(24);
       } else {                                              // :1031-1099
         iflag = 2;
         for (int i = lane; i < n; i += 64) {
@@ -888,6 +889,7 @@ __device__ inline QlResult ql_solve(const QlView &q, P &prob, double vsmall, int
           s[k] = sk;
         }
         WG_WSYNC();
+        PT(25);
       }
       if (nact > 0) {                                       // :1104-1170
         // forward substitution with R^T, column oriented (sums ascend in j)
@@ -903,6 +905,7 @@ __device__ inline QlResult ql_solve(const QlView &q, P &prob, double vsmall, int
             if (i1 > j && i1 < nact) sum1 += Rp(j, i1) * sj;
           }
         }
+        PT(26);
         for (int i = lane; i < n; i += 64) {
           double sum = 0.0;
           WG_UNROLL

@@ -37,6 +37,7 @@ struct HerdtProb {
   const int *rowK, *stepidx;
   const double *V_f;
   const double *R2, *Z2;  // global: constant 2N x 2N factor blocks (packed R, dense Z, ld 2N)
+  const unsigned long long *z2sign;   // global: signs of the (zero) upper-right block of Z2
   double diag_b;          // the constant block's contribution to ql0002's diagonal test
   int blocks_ok;
   int ns;
@@ -203,8 +204,40 @@ struct HerdtProb {
   __device__ __forceinline__ bool factor(const QlView &q, double vsmall, int lane) const {
     const int n = q.n;
     constexpr int M2 = 2 * NH;
-    for (int e = lane; e < M2 * (M2 + 1) / 2; e += 64) q.R[e] = R2[e];
-    for (int e = lane; e < M2 * M2; e += 64) { const int i = e % M2, j = e / M2; Zm(i, j) = Z2[e]; }
+    // C = blockdiag(Qb, Qb) + border: the constant factor blocks are blockdiag(Rb, Rb) and blockdiag(Zb, Zb) with exact
+    // zeros in between (the cross-block products of the recurrences are x * 0), so only the first diagonal block is
+    // fetched from global memory -- 392 doubles instead of 1552 -- all loads issued before the first LDS store.
+    {
+      constexpr int NR = NH * (NH + 1) / 2, TR = (NR + 63) / 64, TZ = (NH * NH + 63) / 64;
+      double rv[TR], zv[TZ];
+#pragma unroll
+      for (int t = 0; t < TR; ++t) { const int e = lane + 64 * t; rv[t] = e < NR ? R2[e] : 0.0; }
+#pragma unroll
+      for (int t = 0; t < TZ; ++t) { const int e = lane + 64 * t; zv[t] = e < NH * NH ? Z2[(e % NH) + (e / NH) * M2] : 0.0; }
+#pragma unroll
+      for (int t = 0; t < TR; ++t) {
+        const int e = lane + 64 * t;
+        if (e < NR) {
+          // e = j(j+1)/2 + i, i <= j < NH: column j is the largest with j(j+1)/2 <= e
+          int j = 0;
+          while ((j + 1) * (j + 2) / 2 <= e) ++j;
+          const int i = e - j * (j + 1) / 2;
+          q.R[e] = rv[t];
+          Rp(NH + i, NH + j) = rv[t];
+        }
+      }
+      for (int e = lane; e < NH * NH; e += 64) { const int i = e % NH, j = NH + e / NH; Rp(i, j) = 0.0; }   // cross block of R
+#pragma unroll
+      for (int t = 0; t < TZ; ++t) {
+        const int e = lane + 64 * t;
+        if (e < NH * NH) {
+          const int i = e % NH, j = e / NH;
+          Zm(i, j) = zv[t]; Zm(NH + i, NH + j) = zv[t];
+          Zm(NH + i, j) = 0.0;
+          Zm(i, NH + j) = ((z2sign[e >> 6] >> (e & 63)) & 1ull) ? -0.0 : 0.0;
+        }
+      }
+    }
     for (int e = lane; e < (n - M2) * M2; e += 64) { const int i = M2 + e % (n - M2), j = e / (n - M2); Zm(i, j) = 0.0; }
     WG_WSYNC();
     // rows of R, columns >= 2N only (lane <-> column)

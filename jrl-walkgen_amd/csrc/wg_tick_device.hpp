@@ -19,6 +19,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <cmath>
+
 #include "../../include/wg_mpc.h"
 #define WG_TRIG_FN __host__ __device__ static inline
 #include "../../include/wg_trig.h"
@@ -46,6 +48,9 @@ struct TickTables {
   double Z2[4 * kNMaxH * kNMaxH];                 // its inverse, column-major ld 2N, qld.cpp:937-975
   double diag_b;                                  // diagonal test over the constant block, qld.cpp:814-843
   int blocks_ok, pad_;
+  // Z2 is blockdiag(Zb, Zb) with zeros in between, but the recurrence leaves SIGNED zeros in the upper-right block
+  // (-(x * 0) / r); bit i + j*N = sign of Z2(i, N + j).  The kernel fetches only Zb and re-creates the rest from this.
+  unsigned long long z2_cross_sign[(kNMaxH * kNMaxH + 63) / 64];
 };
 
 inline void build_tables(const wg_model_t &m, TickTables &t) {
@@ -122,6 +127,11 @@ inline void build_tables(const wg_model_t &m, TickTables &t) {
           Z(i, j + 1) = -sum / R(j + 1, j + 1);
         }
       }
+    for (auto &w : t.z2_cross_sign) w = 0ull;
+    if (t.blocks_ok)
+      for (int j = 0; j < N; ++j)
+        for (int i = 0; i < N; ++i)
+          if (std::signbit(Z(i, N + j))) t.z2_cross_sign[(i + j * N) / 64] |= 1ull << ((i + j * N) % 64);
   }
 }
 
@@ -742,7 +752,7 @@ __device__ inline TickDiag mpc_tick(const wg_model_t &m, const TickTables *__res
     HerdtProb<16> prob;
     prob.Qb = &tb->Qb[0][0]; prob.u = L.uvec; prob.Gv = L.Gv; prob.gd = L.gd;
     prob.rowA = L.rowA; prob.rowB = L.rowB; prob.rowK = L.rowK; prob.stepidx = L.stepidx; prob.V_f = L.V_f;
-    prob.R2 = tb->R2; prob.Z2 = tb->Z2; prob.diag_b = tb->diag_b; prob.blocks_ok = tb->blocks_ok; prob.ns = ns;
+    prob.R2 = tb->R2; prob.Z2 = tb->Z2; prob.z2sign = tb->z2_cross_sign; prob.diag_b = tb->diag_b; prob.blocks_ok = tb->blocks_ok; prob.ns = ns;
     prob.load_rows(lane);
     qr = ql_solve(q, prob, 1e-8, hist, hist_cap);
   } else if constexpr (NH == -1) {
