@@ -868,22 +868,29 @@ __device__ inline QlResult ql_solve(const QlView &q, P &prob, double vsmall, int
             WG_UNROLL
             for (int j = 0; j < n; ++j) acc += Gm(i, j) * q.x[j];
           }
-          WG_UNROLL
-          for (int k = 0; k < nact; ++k) {
-            int kk = q.iact[k];
-            if (kk <= m) acc -= q.lam[k] * Am(kk - 1, i);
-            else if (kk <= mn) { if (kk - m - 1 == i) acc -= q.lam[k]; }
-            else { if (kk - mn - 1 == i) acc += q.lam[k]; }
+          if constexpr (P::kCompact) acc = prob.grad_minus_active(q, nact, i < n ? i : n - 1, lane, acc);
+          else {
+            WG_UNROLL
+            for (int k = 0; k < nact; ++k) {
+              int kk = q.iact[k];
+              if (kk <= m) acc -= q.lam[k] * Am(kk - 1, i);
+              else if (kk <= mn) { if (kk - m - 1 == i) acc -= q.lam[k]; }
+              else { if (kk - mn - 1 == i) acc += q.lam[k]; }
+            }
           }
           q.ww[i] = acc;
         }
+        if constexpr (P::kCompact) { prob.row_residuals(q, q.sc0, lane); WG_WSYNC(); }
         for (int k = lane; k < nact; k += 64) {
           int kk = q.iact[k];
           double sk;
           if (kk <= m) {
-            sk = q.b[kk - 1];
-            WG_UNROLL
-            for (int i = 0; i < n; ++i) sk -= q.x[i] * Am(kk - 1, i);
+            if constexpr (P::kCompact) sk = q.sc0[kk - 1];
+            else {
+              sk = q.b[kk - 1];
+              WG_UNROLL
+              for (int i = 0; i < n; ++i) sk -= q.x[i] * Am(kk - 1, i);
+            }
           } else if (kk <= mn) { int k1 = kk - m - 1; sk = q.xl[k1] - q.x[k1]; }
           else { int k1 = kk - mn - 1; sk = -q.xu[k1] + q.x[k1]; }
           s[k] = sk;

@@ -179,6 +179,85 @@ struct HerdtProb {
     return acc;
   }
 
+  // ------------------------------------------------------------------ residual refresh (qld.cpp:1031-1099), compact forms
+  // acc_i -= sum_k lam_k * A(active row k, i), k ascending -- the parameters of active constraint k sit in lane k and are
+  // broadcast (scalar) once per k, so an element costs one LDS read (u) instead of the four dependent ones of A().
+  __device__ __forceinline__ double grad_minus_active(const QlView &q, int nact, int i, int lane, double acc) const {
+    const int m = q.m, mn = q.mn;
+    // lane k: its active constraint
+    double pa = 0.0, pb = 0.0, plam = 0.0;
+    int pr = -1, ptype = 4, pidx = -1;             // 0 CoP row, 1 foot row, 2 lower bound, 3 upper bound, 4 nothing
+    if (lane < nact) {
+      const int kk = q.iact[lane];
+      plam = q.lam[lane];
+      if (kk <= m) {
+        const int rk = kk - 1;
+        pa = rowA[rk]; pb = rowB[rk]; pr = rowK[rk];
+        ptype = (rk >= 1 && rk <= 4 * NH) ? 0 : 1;
+        if (rk == 0) ptype = 4;                    // the dummy row: all zeros
+      } else if (kk <= mn) { ptype = 2; pidx = kk - m - 1; }
+      else { ptype = 3; pidx = kk - mn - 1; }
+    }
+    const bool xb = i < NH, jerk = i < 2 * NH;
+    const int c = xb ? i : i - NH;                 // column inside the jerk block
+    int fjx = -1, fjy = -1;                        // foot column index inside its group
+    if (!jerk) { const int j = i - 2 * NH; if (j < ns) fjx = j; else fjy = j - ns; }
+    for (int k = 0; k < nact; ++k) {
+      const int type = __builtin_amdgcn_readlane(ptype, k);
+      const double lam = rl(plam, k);
+      if (type <= 1) {
+        const double a = rl(pa, k), b = rl(pb, k);
+        const int r = __builtin_amdgcn_readlane(pr, k);
+        double e = 0.0;
+        if (type == 0) {
+          if (jerk) {
+            const double ab = xb ? a : b;
+            const int rc = (c <= r) ? r - c : 0;
+            const double uu = u[rc];
+            e = (c <= r) ? 0.0 + (0.0 + ab * uu) * -1.0 : 0.0;
+          } else {
+            const int sidx = stepidx[r];
+            if (fjx >= 0) { const double v = (sidx == fjx + 1) ? 1.0 : 0.0; e = 0.0 + (0.0 + a * v) * 1.0; }
+            else { const double v = (sidx == fjy + 1) ? 1.0 : 0.0; e = 0.0 + (0.0 + b * v) * 1.0; }
+          }
+        } else if (!jerk && r >= 0) {
+          if (fjx >= 0) e = 0.0 + (0.0 + a * V_f[r * kSMaxQ + fjx]) * -1.0;
+          else e = 0.0 + (0.0 + b * V_f[r * kSMaxQ + fjy]) * -1.0;
+        }
+        acc -= lam * e;
+      } else if (type == 2) {
+        if (__builtin_amdgcn_readlane(pidx, k) == i) acc -= lam;
+      } else if (type == 3) {
+        if (__builtin_amdgcn_readlane(pidx, k) == i) acc += lam;
+      }
+    }
+    return acc;
+  }
+  // out[rk] = b[rk] - sum_i x_i A(rk, i) (i ascending) for every general row, each lane its own rows (register copies)
+  __device__ __forceinline__ void row_residuals(const QlView &q, double *out, int lane) const {
+    double xs[2 * NH];
+#pragma unroll
+    for (int c = 0; c < 2 * NH; ++c) xs[c] = q.x[c];
+    {
+      const int rk = lane + 1;
+      double sk = q.b[rk];
+#pragma unroll
+      for (int c = 0; c < NH; ++c) sk -= xs[c] * ax[c];
+#pragma unroll
+      for (int c = 0; c < NH; ++c) sk -= xs[NH + c] * ay[c];
+      if (fj >= 0) { sk -= q.x[2 * NH + fj] * fa; sk -= q.x[2 * NH + ns + fj] * fb; }
+      out[rk] = sk;
+    }
+    if (lane < 5 * ns) {
+      const int rk = 1 + 4 * NH + lane;
+      double sk = q.b[rk];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) sk -= q.x[f2c[e]] * f2v[e];
+      out[rk] = sk;
+    }
+    if (lane == 0) out[0] = q.b[0];
+  }
+
   // ------------------------------------------------------------------ ql0002's diagonal test, :814-843
   __device__ __forceinline__ double diag_check(const QlView &q, double vsmall, int lane) const {
     const int n = q.n;
