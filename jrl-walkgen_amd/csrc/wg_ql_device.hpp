@@ -196,12 +196,33 @@ __device__ __forceinline__ int wave_min_int(int v) {
 // This sits on the sequential chain of every sweep.  One of the two quotients is x/|x| = +-1 EXACTLY (IEEE division is
 // exact there), its square is exactly 1.0, and a + b == b + a: so only the other quotient is a real division.  Same
 // bits as the reference's two divisions for finite operands (0/0 stays NaN); half the divide latency on the chain.
+// sqrt(x) for 1 <= x <= 2: the compiler's own correctly-rounded f64 expansion (v_rsq_f64 + two coupled Newton steps,
+// same operations in the same order) without its range scaling (ldexp in, ldexp out) and special-value select, which
+// are exact no-ops on this interval.  Five dependent instructions shorter; bit-identical result.
+__device__ __forceinline__ double sqrt_1to2(double x) {
+  const double y = __builtin_amdgcn_rsq(x);
+  double g = x * y;
+  double h = y * 0.5;
+  const double r = __builtin_fma(-h, g, 0.5);
+  g = __builtin_fma(g, r, g);
+  h = __builtin_fma(h, r, h);
+  double d = __builtin_fma(-g, g, x);
+  g = __builtin_fma(d, h, g);
+  d = __builtin_fma(-g, g, x);
+  g = __builtin_fma(d, h, g);
+  return g;
+}
 __device__ __forceinline__ double givens_norm(double p, double qq) {
   const double ap = fabs(p), aq = fabs(qq);
   const bool pbig = ap >= aq;                      // maxd(): a >= b ? a : b
   const double t = pbig ? ap : aq;
-  const double d = (pbig ? qq : p) / t;
-  return t * sqrt(1.0 + d * d);
+  const double d = (pbig ? qq : p) / t;            // |d| <= 1
+  const double x = 1.0 + d * d;
+#ifdef WG_GENERIC_SQRT
+  return t * sqrt(x);
+#else
+  return t * sqrt_1to2(x);                         // x is in [1, 2], or NaN (which stays NaN)
+#endif
 }
 // qld.cpp:1921-1930 / 2005-2014
 __device__ __forceinline__ void givens(double p, double qq, double &ga, double &gb, double &nrm) {
