@@ -535,53 +535,65 @@ __device__ inline TickDiag mpc_tick(const wg_model_t &m, const TickTables *__res
       } else { L.VcX[i] = S.x; L.VcY[i] = S.y; }
     }
     op_preview(m, s, time, ref, L.sup, L.sup_angles, L.trunk);
-    // compute_global_reference :211-229 (only 3 distinct yaw values occur)
+    // the CoP hull changes only where the support state changes: record, per instant, which previewed state carries it
+    // (the edges themselves are formed lane-parallel below)
     {
-      // trunk[2..N] all hold the same angle (OrientationsPreview.cpp:229-233): three sin/cos pairs suffice
-      double cs3[3], sn3[3];
-      for (int e = 0; e < 3; e++) { const double yt = L.trunk[e < N ? e : N - 1]; cs3[e] = wg_cos(yt); sn3[e] = wg_sin(yt); }
+      int src = 0;
       for (int i = 0; i < N; i++) {
-        const int e = i < 2 ? i : 2;
-        L.refx[i] = ref[0] * cs3[e] - ref[1] * sn3[e];
-        L.refy[i] = ref[1] * cs3[e] + ref[0] * sn3[e];
-      }
-    }
-    // polygon edges per constraint row: build_inequalities_cop :284-314, build_inequalities_feet :317-354
-    const int mq = 1 + 4 * N + 5 * ns;
-    L.rowA[0] = 0.0; L.rowB[0] = 0.0; L.rowD[0] = 0.0; L.rowK[0] = -1;
-    {
-      // the CoP hull changes only where the support state changes; its edges are re-signed by each instant's foot
-      int hf = L.sup[0].foot, hp = L.sup[0].phase; double hy = L.sup[0].yaw;
-      double eA[4], eB[4], eD[4];
-      int last_sign = -1; bool fresh = true;
-      for (int i = 0; i < N; i++) {
-        const Sup &S = L.sup[i + 1];
-        if (S.state_changed) { hf = S.foot; hp = S.phase; hy = S.yaw; fresh = true; }
-        if (fresh || S.foot != last_sign) { hull_edges<4>(m, hf, hp, hy, S.foot, eA, eB, eD); fresh = false; last_sign = S.foot; }
-#pragma unroll
-        for (int e = 0; e < 4; e++) {
-          const int r = 1 + 4 * i + e;
-          L.rowA[r] = eA[e]; L.rowB[r] = eB[e]; L.rowD[r] = eD[e]; L.rowK[r] = i;
-        }
-      }
-    }
-    for (int r = 1 + 4 * N; r < mq; r++) { L.rowA[r] = 0.0; L.rowB[r] = 0.0; L.rowD[r] = 0.0; L.rowK[r] = -1; }
-    for (int i = 0; i < N; i++) {
-      const Sup &S = L.sup[i + 1];
-      if (S.state_changed && S.step_number > 0 && S.step_number <= ns && S.phase != WG_DS) {
-        double eA[5], eB[5], eD[5];
-        hull_edges<5>(m, L.sup[i].foot, L.sup[i].phase, L.sup[i].yaw, S.foot, eA, eB, eD);
-        const int k = S.step_number - 1;
-#pragma unroll
-        for (int e = 0; e < 5; e++) {
-          const int r = 1 + 4 * N + 5 * k + e;
-          L.rowA[r] = eA[e]; L.rowB[r] = eB[e]; L.rowD[r] = eD[e]; L.rowK[r] = k;
-        }
+        if (L.sup[i + 1].state_changed) src = i + 1;
+        L.stepidx[i] = L.stepidx[i] | (src << 8);               // low byte: step index, next: hull source state
       }
     }
     *L.sup0 = L.sup[0];
     L.misc[0] = (double)ns;
     L.misc[1] = ref[0]; L.misc[2] = ref[1]; L.misc[3] = ref[2];
+  }
+  WG_WSYNC();
+
+  // ---- lane-parallel part of the bookkeeping: one previewed instant per lane ----
+  {
+    const int ns0 = uni((int)L.misc[0]);
+    const double ref0 = L.misc[1], ref1 = L.misc[2];
+    // compute_global_reference :211-229 (trunk[2..N] all hold the same angle, OrientationsPreview.cpp:229-233)
+    if (lane < N) {
+      const int i = lane;
+      const int e = i < 2 ? i : 2;
+      const double yt = L.trunk[e < N ? e : N - 1];
+      const double cs = wg_cos(yt), sn = wg_sin(yt);
+      L.refx[i] = ref0 * cs - ref1 * sn;
+      L.refy[i] = ref1 * cs + ref0 * sn;
+    }
+    // polygon edges per constraint row: build_inequalities_cop :284-314, build_inequalities_feet :317-354
+    const int mq0 = 1 + 4 * N + 5 * ns0;
+    if (lane == 0) { L.rowA[0] = 0.0; L.rowB[0] = 0.0; L.rowD[0] = 0.0; L.rowK[0] = -1; }
+    for (int r = 1 + 4 * N + lane; r < mq0; r += 64) { L.rowA[r] = 0.0; L.rowB[r] = 0.0; L.rowD[r] = 0.0; L.rowK[r] = -1; }
+    WG_WSYNC();
+    if (lane < N) {
+      const int i = lane;
+      const int packed = L.stepidx[i];
+      const int src = packed >> 8;
+      const Sup &H = L.sup[src];                                 // the state whose hull is in force at instant i
+      const Sup &S = L.sup[i + 1];
+      double eA[4], eB[4], eD[4];
+      hull_edges<4>(m, H.foot, H.phase, H.yaw, S.foot, eA, eB, eD);   // edges re-signed by the instant's own foot
+#pragma unroll
+      for (int e = 0; e < 4; e++) {
+        const int r = 1 + 4 * i + e;
+        L.rowA[r] = eA[e]; L.rowB[r] = eB[e]; L.rowD[r] = eD[e]; L.rowK[r] = i;
+      }
+      if (S.state_changed && S.step_number > 0 && S.step_number <= ns0 && S.phase != WG_DS) {
+        double fA[5], fB[5], fD[5];
+        hull_edges<5>(m, L.sup[i].foot, L.sup[i].phase, L.sup[i].yaw, S.foot, fA, fB, fD);
+        const int k = S.step_number - 1;
+#pragma unroll
+        for (int e = 0; e < 5; e++) {
+          const int r = 1 + 4 * N + 5 * k + e;
+          L.rowA[r] = fA[e]; L.rowB[r] = fB[e]; L.rowD[r] = fD[e]; L.rowK[r] = k;
+        }
+      }
+    }
+    WG_WSYNC();
+    if (lane < N) L.stepidx[lane] &= 0xff;                       // back to the plain step index
   }
   WG_WSYNC();
 
