@@ -171,25 +171,45 @@ __device__ __forceinline__ double DenseProb::A(const QlView &q, int k, int i) co
 __device__ __forceinline__ double DenseProb::Gd(const QlView &q, int i) const { return q.G[i + i * q.ldg]; }
 __device__ __forceinline__ void DenseProb::setGd(const QlView &q, int i, double v) const { q.G[i + i * q.ldg] = v; }
 
-// arg-max over the wave: larger v wins, equal v -> smaller idx.  idx < 0 = no candidate.
-__device__ __forceinline__ void wave_argmax_first(double &v, int &idx) {
-#pragma unroll
-  for (int off = 32; off >= 1; off >>= 1) {
-    double ov = __shfl_xor(v, off);
-    int oi = __shfl_xor(idx, off);
-    bool take = (oi >= 0) && (idx < 0 || ov > v || (ov == v && oi < idx));
-    if (take) { v = ov; idx = oi; }
-  }
+// ---- wave reductions on the DPP data path (gfx9 row shifts / row broadcasts: one VALU move per 32-bit half and step, no
+// LDS crossbar, no exec-mask branching).  max / min are idempotent, so lanes without a partner just keep their own value
+// (update_dpp's `old` operand): after row_shr 1,2,4,8 lane 15 of every row holds the row's result, row_bcast:15 and
+// row_bcast:31 fold the rows into lane 63.  The __shfl_xor butterflies these replace cost ~1400 cycles per arg-max
+// (three ds_bpermute per round plus divergent selects); this is ~250.
+template <int CTRL>
+__device__ __forceinline__ int dpp_keep(int v) { return __builtin_amdgcn_update_dpp(v, v, CTRL, 0xf, 0xf, false); }
+template <int CTRL>
+__device__ __forceinline__ double dpp_keep(double v) {
+  const int lo = dpp_keep<CTRL>(__double2loint(v)), hi = dpp_keep<CTRL>(__double2hiint(v));
+  return __hiloint2double(hi, lo);
 }
 __device__ __forceinline__ double wave_max(double v) {
-#pragma unroll
-  for (int off = 32; off >= 1; off >>= 1) v = maxd(v, __shfl_xor(v, off));
-  return v;
+  v = __builtin_fmax(v, dpp_keep<0x111>(v));   // row_shr:1
+  v = __builtin_fmax(v, dpp_keep<0x112>(v));   // row_shr:2
+  v = __builtin_fmax(v, dpp_keep<0x114>(v));   // row_shr:4
+  v = __builtin_fmax(v, dpp_keep<0x118>(v));   // row_shr:8
+  v = __builtin_fmax(v, dpp_keep<0x142>(v));   // row_bcast:15
+  v = __builtin_fmax(v, dpp_keep<0x143>(v));   // row_bcast:31
+  return rl(v, 63);
 }
 __device__ __forceinline__ int wave_min_int(int v) {
-#pragma unroll
-  for (int off = 32; off >= 1; off >>= 1) { int o = __shfl_xor(v, off); v = o < v ? o : v; }
-  return v;
+  { const int o = dpp_keep<0x111>(v); v = o < v ? o : v; }
+  { const int o = dpp_keep<0x112>(v); v = o < v ? o : v; }
+  { const int o = dpp_keep<0x114>(v); v = o < v ? o : v; }
+  { const int o = dpp_keep<0x118>(v); v = o < v ? o : v; }
+  { const int o = dpp_keep<0x142>(v); v = o < v ? o : v; }
+  { const int o = dpp_keep<0x143>(v); v = o < v ? o : v; }
+  return __builtin_amdgcn_readlane(v, 63);
+}
+// arg-max over the wave: larger v wins, equal v -> smaller idx.  idx < 0 = no candidate (then idx stays < 0).
+// Candidates must be finite.  Result is wave-uniform.
+__device__ __forceinline__ void wave_argmax_first(double &v, int &idx) {
+  const double vv = idx >= 0 ? v : -__builtin_huge_val();
+  const double vmax = wave_max(vv);
+  const int key = (idx >= 0 && v == vmax) ? idx : 0x7fffffff;
+  const int kmin = wave_min_int(key);
+  v = vmax;
+  idx = kmin == 0x7fffffff ? -1 : kmin;
 }
 
 // norm of a rotation, qld.cpp:1921-1926 / 2005-2010:  t = max(|p|,|q|);  t * sqrt((p/t)^2 + (q/t)^2).
@@ -889,6 +909,9 @@ __device__ inline QlResult ql_solve(const QlView &q, P &prob, double vsmall, int
             WG_UNROLL
             for (int j = 0; j < n; ++j) acc += Gm(i, j) * q.x[j];
           }
+#ifdef WG_PROFILE
+          q.ww[i] = acc; PT(27); acc = q.ww[i];
+#endif
           if constexpr (P::kCompact) acc = prob.grad_minus_active(q, nact, i < n ? i : n - 1, lane, acc);
           else {
             WG_UNROLL

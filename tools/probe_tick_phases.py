@@ -27,7 +27,7 @@ torch.cuda.synchronize(); wg.lib().wg_prof_read(buf)
 v = np.array(list(buf), dtype=np.float64); n = B * MEAS
 names = ["norms", "diagchk", "chol", "inverse", "resid/reset+shift", "ZT*ww(resid)", "x-shift", "backsub+lam(resid)", "xmag(resid)",
          "scan", "fdiff/wx", "newnormal ZTa", "sweep", "route sums", "step-pre", "backsub(step)", "pickdrop", "step/upd/drop", "add",
-         "xmag(add)", "tail", "TICK pre (lane0)", "TICK assembly", "TICK post", "(reset body)", "(resid: gradient+s)", "(resid: forward subst)", "(free)"]
+         "xmag(add)", "tail", "TICK pre (lane0)", "TICK assembly", "TICK post", "(reset body)", "(resid: gradient+s)", "(resid: forward subst)", "(resid: d + G x)"]
 tot = v[:28].sum()
 print(f"gait-ticks={n} mean QL iters={its/n:.1f} cycles/tick={tot/n:.0f}  route decisions/tick={v[28]/n:.1f} of which coordinate checks {v[29]/n:.2f}, dependent routes {v[30]/n:.2f}")
 for k, nme in enumerate(names):
