@@ -371,9 +371,17 @@ struct HerdtProb {
       double acc = 0.0;
       if (rk >= 1 && rk <= 4 * NH) {
         // entries of the row beyond its instant are exact zeros: their products leave acc unchanged, so the
-        // loops can run the full static length (loads pipeline, no remainder handling)
+        // loops can run the full static length.  Loads are issued in groups of kZtChunk ahead of the add chain (left to
+        // itself the register-limited build waits for every pair of loads: 16 LDS round trips instead of 4).
+        constexpr int kZtChunk = 8;
 #pragma unroll
-        for (int j = 0; j < 2 * NH; ++j) acc += zc[j] * q.ww[j];
+        for (int j0 = 0; j0 < 2 * NH; j0 += kZtChunk) {
+          double zz[kZtChunk], wv[kZtChunk];
+#pragma unroll
+          for (int c = 0; c < kZtChunk; ++c) { zz[c] = zc[j0 + c]; wv[c] = q.ww[j0 + c]; }
+#pragma unroll
+          for (int c = 0; c < kZtChunk; ++c) acc += zz[c] * wv[c];
+        }
       }
       for (int j = 2 * NH; j < n; ++j) acc += zc[j] * q.ww[j];
       s[i] = acc;
