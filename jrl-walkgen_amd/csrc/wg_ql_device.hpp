@@ -130,6 +130,24 @@ struct QlView {
     slot = p; p += 8;
     iact = reinterpret_cast<int *>(p);
   }
+  // Same partition laid out for the compile-time maxima (NMAX, MMAX), whatever the actual n, m: every array then sits at
+  // a constant offset from the wave's LDS base (immediate offsets in the ds instructions, no address registers), and Z's
+  // leading dimension is the constant NMAX|1.  No G / A matrices (compact views only).
+  template <int NMAX, int MMAX, int NSC>
+  __device__ void carve_fixed(double *base, int n_, int m_, int me_) {
+    n = n_; m = m_; me = me_; mn = m_ + n_; ldg = NMAX | 1; ldz = NMAX | 1; lda = MMAX | 1;
+    double *p = base;
+    G = nullptr; A = nullptr;
+    Z = p; p += NMAX * (NMAX | 1);
+    R = p; p += NMAX * (NMAX + 1) / 2 + NMAX;
+    x = p; p += NMAX;  d = p; p += NMAX;  ww = p; p += NMAX;  wd = p; p += NMAX;
+    wx = p; p += NMAX; lam = p; p += NMAX; xl = p; p += NMAX; xu = p; p += NMAX;
+    wa = p; p += MMAX + NMAX;
+    b = p; p += MMAX;
+    sc0 = p; p += NSC; sc1 = p; p += NSC; sc2 = p; p += NSC; sc3 = p; p += NSC;
+    slot = p; p += 8;
+    iact = reinterpret_cast<int *>(p);
+  }
 };
 
 #define Zm(i, j) q.Z[(i) + (j) * q.ldz]

@@ -607,7 +607,13 @@ __device__ inline TickDiag mpc_tick(const wg_model_t &m, const TickTables *__res
   constexpr bool kTableView = (NH == 16) || (NH == -1);   // Hessian / constraints kept as compact tables
   QlDims D(n, mq, mq, !kTableView, true, kCompactView ? 2 * NH + 4 : 0);   // ordered sums run the static length
   QlView q;
-  q.carve(lds_ql, D, 0);
+  if constexpr (kCompactView) {
+    constexpr int kNmax = 2 * NH + 4, kMmax = 1 + 4 * NH + 10;     // two previewed steps at most (wg_mpc_configure)
+    // same footprint as QlDims(kNmax, kMmax, kMmax, dense = false, nsc = kNmax), which sized the LDS on the host
+    q.template carve_fixed<kNmax, kMmax, kNmax>(lds_ql, n, mq, 0);
+  } else {
+    q.carve(lds_ql, D, 0);
+  }
 
   // ---- S*c products (MV2_ = prod(S, CoM), generator-vel-ref.cpp:780-787) ----
   for (int i = lane; i < N; i += 64) {
