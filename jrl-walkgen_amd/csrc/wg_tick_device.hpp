@@ -458,7 +458,7 @@ __device__ inline TickDiag mpc_tick(const wg_model_t &m, const TickTables *__res
                                     wg_tick_out_t *out, double *lds_ql, char *lds_tick, int *hist, int hist_cap,
                                     int *hist_len) {
   const int lane = threadIdx.x & 63;
-  const int N = m.N;
+  const int N = (NH == 16) ? 16 : m.N;            // compact view: the horizon is a compile-time constant (checked by the host)
   const double T = m.T;
   const int K = WG_SAMPLES_PER_TICK;
   TickLds L;
