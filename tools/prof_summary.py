@@ -4,20 +4,20 @@ out = sys.argv[1]
 res = {"kernels": {}, "counters": {}}
 for f in glob.glob(os.path.join(out, "trace", "**", "*_kernel_stats.csv"), recursive=True):
     for r in csv.DictReader(open(f)):
-        name = r["Name"].split("(")[0].replace("void ", "").strip()
+        name = r["Name"].split("(")[0].replace("void ", "").replace("wg::", "").strip()
         if name.startswith("wg_"):
             res["kernels"][name] = {"calls": int(r["Calls"]), "avg_ns": float(r["AverageNs"]), "min_ns": float(r["MinNs"]),
                                     "max_ns": float(r["MaxNs"]), "total_ns": float(r["TotalDurationNs"])}
 for f in glob.glob(os.path.join(out, "trace", "**", "*_kernel_trace.csv"), recursive=True):
     for r in csv.DictReader(open(f)):
-        name = r["Kernel_Name"].split("(")[0].replace("void ", "").strip()
+        name = r["Kernel_Name"].split("(")[0].replace("void ", "").replace("wg::", "").strip()
         if name.startswith("wg_") and "launch" not in res["kernels"].get(name, {}):
             res["kernels"].setdefault(name, {})["launch"] = {k: r[k] for k in ("LDS_Block_Size", "Scratch_Size", "VGPR_Count", "Accum_VGPR_Count", "SGPR_Count", "Workgroup_Size_X", "Grid_Size_X")}
 for d in ("pmc1", "pmc2", "pmc3", "pmc4"):
     for f in glob.glob(os.path.join(out, d, "**", "*_counter_collection.csv"), recursive=True):
         acc = collections.defaultdict(list)
         for r in csv.DictReader(open(f)):
-            name = r["Kernel_Name"].split("(")[0].replace("void ", "").strip()
+            name = r["Kernel_Name"].split("(")[0].replace("void ", "").replace("wg::", "").strip()
             if name.startswith("wg_"):
                 acc[(name, r["Counter_Name"])].append(float(r["Counter_Value"]))
         for (name, c), v in acc.items():
