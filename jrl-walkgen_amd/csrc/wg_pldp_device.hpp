@@ -85,15 +85,12 @@ struct PldpLds {
 
 __device__ __forceinline__ int ltri(int i, int j) { return i * (i + 1) / 2 + j; }   // packed lower, j <= i
 
-// arg-min over the wave: smaller v wins, equal v -> smaller idx.  idx < 0 = no candidate.
+// arg-min over the wave: smaller v wins, equal v -> smaller idx.  idx < 0 = no candidate (then idx stays < 0).
+// On the DPP path like wave_argmax_first (wg_ql_device.hpp); candidates must be finite.
 __device__ __forceinline__ void wave_argmin_first(double &v, int &idx) {
-#pragma unroll
-  for (int off = 32; off >= 1; off >>= 1) {
-    double ov = __shfl_xor(v, off);
-    int oi = __shfl_xor(idx, off);
-    bool take = (oi >= 0) && (idx < 0 || ov < v || (ov == v && oi < idx));
-    if (take) { v = ov; idx = oi; }
-  }
+  double nv = -v;                                   // exact, order-reversing; -(+-0) compares equal either way
+  wave_argmax_first(nv, idx);
+  v = -nv;
 }
 
 // OptCholesky::AddActiveConstraint + UpdateCholeskyMatrixFortran: append `row` as active row S (S < cap checked by caller)
