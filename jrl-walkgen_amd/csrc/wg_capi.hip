@@ -285,9 +285,9 @@ inline bool tick_compact(const wg_model_t &m) {
   return m.N == 16 && m.N * m.T <= 2.0 * m.step_period + 1e-12 && !(e && atoi(e) != 0) && !(v && *v);
 }
 inline size_t tick_lds_for(const wg_model_t &m, int view) {
-  const size_t ql = (wg::QlDims(tick_max_n(m), tick_max_m(m), tick_max_m(m), view == 0).bytes() + 15) & ~(size_t)15;
+  const size_t ql = (wg::QlDims(tick_max_n(m), tick_max_m(m), tick_max_m(m), view == 0, true, 0, view != 16).bytes() + 15) & ~(size_t)15;
   const int gvld = view == 16 ? wg::kGvLd : (view == -1 ? wg::kGvLdElem : 0);
-  return ql + wg::TickLds::bytes(m.N, tick_smax(m), gvld);
+  return ql + wg::TickLds::bytes(m.N, tick_smax(m), gvld, view == 16);
 }
 inline int tick_view(const wg_model_t &m) {
   if (tick_compact(m)) return 16;
@@ -298,7 +298,7 @@ inline int tick_view(const wg_model_t &m) {
   return (tick_lds_for(m, 0) <= 160 * 1024 || !overlay_fits) ? 0 : -1;
 }
 inline size_t tick_ql_bytes(const wg_model_t &m) {
-  size_t b = wg::QlDims(tick_max_n(m), tick_max_m(m), tick_max_m(m), tick_view(m) == 0).bytes();
+  size_t b = wg::QlDims(tick_max_n(m), tick_max_m(m), tick_max_m(m), tick_view(m) == 0, true, 0, tick_view(m) != 16).bytes();
   return (b + 15) & ~(size_t)15;
 }
 }  // namespace

@@ -25,6 +25,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 namespace wg {
 
 #ifndef WG_UNROLL_N
@@ -93,13 +95,15 @@ struct QlDims {
   bool dense;   // G and A held as LDS matrices (false: the problem view regenerates them)
   bool a_lds;   // dense only: A staged in LDS (false: read in place from global memory -- large QPs)
   int nsc;      // length of each of the four scratch vectors: n, or the static length of the compact view's ordered sums
-  __host__ __device__ QlDims(int n_, int m_, int mmax_, bool dense_ = true, bool a_lds_ = true, int nsc_ = 0)
+  bool bounds;  // xl / xu held in LDS (false: the problem view supplies them -- constants for the Herdt QP)
+  __host__ __device__ QlDims(int n_, int m_, int mmax_, bool dense_ = true, bool a_lds_ = true, int nsc_ = 0,
+                             bool bounds_ = true)
       : n(n_), m(m_), mmax(mmax_), ldg(n_ | 1), ldz(n_ | 1), lda(mmax_ | 1), dense(dense_), a_lds(a_lds_),
-        nsc(nsc_ > n_ ? nsc_ : n_) {}
+        nsc(nsc_ > n_ ? nsc_ : n_), bounds(bounds_) {}
   __host__ __device__ int r_len() const { return n * (n + 1) / 2 + n; }
   __host__ __device__ int n_doubles() const {
     return (dense ? n * ldg + (a_lds ? n * lda : 0) : 0) + n * ldz + r_len()   // [G, A,] Z, R
-           + 8 * n                                  // x d ww wd wx lam xl xu
+           + (bounds ? 8 : 6) * n                   // x d ww wd wx lam [xl xu]
            + (m + n) + m                            // wa, b (inner)
            + 4 * nsc + 8;                           // scratch + scalar slots
   }
@@ -141,7 +145,7 @@ struct QlView {
     Z = p; p += NMAX * (NMAX | 1);
     R = p; p += NMAX * (NMAX + 1) / 2 + NMAX;
     x = p; p += NMAX;  d = p; p += NMAX;  ww = p; p += NMAX;  wd = p; p += NMAX;
-    wx = p; p += NMAX; lam = p; p += NMAX; xl = p; p += NMAX; xu = p; p += NMAX;
+    wx = p; p += NMAX; lam = p; p += NMAX; xl = nullptr; xu = nullptr;     // bounds come from the problem view
     wa = p; p += MMAX + NMAX;
     b = p; p += MMAX;
     sc0 = p; p += NSC; sc1 = p; p += NSC; sc2 = p; p += NSC; sc3 = p; p += NSC;
@@ -163,6 +167,8 @@ struct DenseProb {
   __device__ __forceinline__ double A(const QlView &q, int k, int i) const;
   __device__ __forceinline__ double Gd(const QlView &q, int i) const;
   __device__ __forceinline__ void setGd(const QlView &q, int i, double v) const;
+  __device__ __forceinline__ double xl(const QlView &q, int i) const;
+  __device__ __forceinline__ double xu(const QlView &q, int i) const;
 };
 #define Rp(i, j) q.R[(j) * ((j) + 1) / 2 + (i)]
 
@@ -180,6 +186,11 @@ __device__ unsigned long long g_prof[32];
 #define PT_FLUSH do {} while (0)
 #endif
 
+// per-lane parameters of the active constraints, for problem views that supply a fast residual refresh
+struct NoActiveParams {};
+template <class P, class = void> struct ActiveParamsOf { typedef NoActiveParams type; };
+template <class P> struct ActiveParamsOf<P, typename std::enable_if<P::kCompact>::type> { typedef typename P::ActiveParams type; };
+
 struct QlResult {
   int ifail, n_iter, nact, hist_len;
 };
@@ -188,6 +199,8 @@ __device__ __forceinline__ double DenseProb::G(const QlView &q, int i, int j) co
 __device__ __forceinline__ double DenseProb::A(const QlView &q, int k, int i) const { return q.A[k + i * q.lda]; }
 __device__ __forceinline__ double DenseProb::Gd(const QlView &q, int i) const { return q.G[i + i * q.ldg]; }
 __device__ __forceinline__ void DenseProb::setGd(const QlView &q, int i, double v) const { q.G[i + i * q.ldg] = v; }
+__device__ __forceinline__ double DenseProb::xl(const QlView &q, int i) const { return q.xl[i]; }
+__device__ __forceinline__ double DenseProb::xu(const QlView &q, int i) const { return q.xu[i]; }
 
 // ---- wave reductions on the DPP data path (gfx9 row shifts / row broadcasts: one VALU move per 32-bit half and step, no
 // LDS crossbar, no exec-mask branching).  max / min are idempotent, so lanes without a partner just keep their own value
@@ -911,8 +924,8 @@ __device__ inline QlResult ql_solve(const QlView &q, P &prob, double vsmall, int
           q.lam[i] = 0.0;
           int k = q.iact[i];
           if (k <= m) s[i] = q.b[k - 1];
-          else if (k > mn) s[i] = -q.xu[k - mn - 1];
-          else s[i] = q.xl[k - m - 1];
+          else if (k > mn) s[i] = -prob.xu(q, k - mn - 1);
+          else s[i] = prob.xl(q, k - m - 1);
         }
         xmag = 0.0;
         vfact = 1.0;
@@ -920,6 +933,8 @@ __device__ inline QlResult ql_solve(const QlView &q, P &prob, double vsmall, int
         PT(24);
       } else {                                              // :1031-1099
         iflag = 2;
+        typename ActiveParamsOf<P>::type ap;
+        if constexpr (P::kCompact) ap = prob.active_params(q, nact, lane);
         for (int i = lane; i < n; i += 64) {
           double acc = q.d[i];
           if constexpr (P::kCompact) acc = prob.gdot_acc(q, i, q.x, acc);
@@ -930,7 +945,7 @@ __device__ inline QlResult ql_solve(const QlView &q, P &prob, double vsmall, int
 #ifdef WG_PROFILE
           q.ww[i] = acc; PT(27); acc = q.ww[i];
 #endif
-          if constexpr (P::kCompact) acc = prob.grad_minus_active(q, nact, i < n ? i : n - 1, lane, acc);
+          if constexpr (P::kCompact) acc = prob.grad_minus_active(q, ap, nact, i, acc);
           else {
             WG_UNROLL
             for (int k = 0; k < nact; ++k) {
@@ -953,8 +968,8 @@ __device__ inline QlResult ql_solve(const QlView &q, P &prob, double vsmall, int
               WG_UNROLL
               for (int i = 0; i < n; ++i) sk -= q.x[i] * Am(kk - 1, i);
             }
-          } else if (kk <= mn) { int k1 = kk - m - 1; sk = q.xl[k1] - q.x[k1]; }
-          else { int k1 = kk - mn - 1; sk = -q.xu[k1] + q.x[k1]; }
+          } else if (kk <= mn) { int k1 = kk - m - 1; sk = prob.xl(q, k1) - q.x[k1]; }
+          else { int k1 = kk - mn - 1; sk = -prob.xu(q, k1) + q.x[k1]; }
           s[k] = sk;
         }
         WG_WSYNC();
@@ -1094,9 +1109,9 @@ __device__ inline QlResult ql_solve(const QlView &q, P &prob, double vsmall, int
       for (int k = lane; k < n; k += 64) {
         if (q.wa[m + k] <= 0.0) continue;
         bool lower = true;
-        double sum = q.xl[k] - q.x[k];
+        double sum = prob.xl(q, k) - q.x[k];
         if (sum == 0.0) continue;
-        if (sum < 0.0) { sum = q.x[k] - q.xu[k]; lower = false; }
+        if (sum < 0.0) { sum = q.x[k] - prob.xu(q, k); lower = false; }
         if (sum <= 0.0) continue;               // cvmax starts at 0
         if (bidx >= 0 && sum <= bestv) continue;
         bestv = sum; bestres = -sum; bidx = lower ? k + 1 + m : k + 1 + mn;

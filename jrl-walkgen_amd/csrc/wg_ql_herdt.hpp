@@ -45,6 +45,10 @@ struct HerdtProb {
   double ax[NH], ay[NH];  // CoP row (lane+1): x- and y-jerk parts
   double fa, fb; int fj;  // its two foot-variable entries (columns 2N+fj, 2N+ns+fj), fj < 0: none
   double f2v[4]; int f2c[4]; int f2n;   // foot-placement row (1+4N+lane), entries in column order
+  // raw edge coefficients of the lane's two rows (rowA / rowB / rowK live in LDS only until the solver starts: their
+  // storage is part of the pre-solve overlay): any row's (a, b, k) is one v_readlane away
+  double ra, rb;          // CoP row lane+1
+  double ga, gb; int gk;  // foot-placement row 1+4N+lane (gk < 0: unused row)
 
   // ------------------------------------------------------------------ element access (rare paths)
   __device__ __forceinline__ double G(const QlView &q, int i, int j) const {
@@ -59,11 +63,18 @@ struct HerdtProb {
   }
   __device__ __forceinline__ double Gd(const QlView &, int i) const { return gd[i]; }
   __device__ __forceinline__ void setGd(const QlView &, int i, double v) const { gd[i] = v; }
+  // QPProblem's bounds are the constants of qp-problem.cpp:118-121: no LDS copy
+  __device__ __forceinline__ double xl(const QlView &, int) const { return -1e8; }
+  __device__ __forceinline__ double xu(const QlView &, int) const { return 1e8; }
 
+  // row k must be wave-uniform (it is at every call site: knext, or an entry of the active set)
   __device__ __forceinline__ double A(const QlView &, int k, int i) const {
+    k = uni(k);
     if (k == 0) return 0.0;
-    const double a = rowA[k], b = rowB[k];
-    const int kk = rowK[k];
+    const bool cop = k <= 4 * NH;
+    const int src = cop ? k - 1 : k - 1 - 4 * NH;
+    const double a = cop ? rl(ra, src) : rl(ga, src), b = cop ? rl(rb, src) : rl(gb, src);
+    const int kk = cop ? (k - 1) >> 2 : __builtin_amdgcn_readlane(gk, src);
     if (k <= 4 * NH) {
       const int r = kk;
       if (i < NH) return (i <= r) ? 0.0 + (0.0 + a * u[r - i]) * -1.0 : 0.0;
@@ -86,6 +97,7 @@ struct HerdtProb {
       const int k = lane + 1;
       const double a = rowA[k], b = rowB[k];
       const int r = rowK[k];
+      ra = a; rb = b;
 #pragma unroll
       for (int c = 0; c < NH; ++c) {
         const double uu = (c <= r) ? u[r - c] : 0.0;
@@ -100,9 +112,11 @@ struct HerdtProb {
     f2n = 0;
 #pragma unroll
     for (int e = 0; e < 4; ++e) { f2v[e] = 0.0; f2c[e] = 2 * NH; }   // unused entries: value 0 on a valid column
+    ga = 0.0; gb = 0.0; gk = -1;
     if (lane < 5 * ns) {
       const int k = 1 + 4 * NH + lane;
       const int kk = rowK[k];
+      ga = rowA[k]; gb = rowB[k]; gk = kk;
       if (kk >= 0) {
         const double a = rowA[k], b = rowB[k];
         // column order: [2N+kk-1] 2N+kk [2N+ns+kk-1] 2N+ns+kk ; without a predecessor the two "-1" entries are zeros
@@ -180,34 +194,55 @@ struct HerdtProb {
   }
 
   // ------------------------------------------------------------------ residual refresh (qld.cpp:1031-1099), compact forms
-  // acc_i -= sum_k lam_k * A(active row k, i), k ascending -- the parameters of active constraint k sit in lane k and are
-  // broadcast (scalar) once per k, so an element costs one LDS read (u) instead of the four dependent ones of A().
-  __device__ __forceinline__ double grad_minus_active(const QlView &q, int nact, int i, int lane, double acc) const {
+  // acc_i -= sum_k lam_k * A(active row k, i), k ascending -- the parameters of active constraint k are collected in
+  // lane k (active_params, every lane takes part) and broadcast (scalar) once per k, so an element costs one LDS read (u).
+  struct ActiveParams { double pa, pb, plam; int pr, ptype, pidx; };
+  __device__ __forceinline__ ActiveParams active_params(const QlView &q, int nact, int lane) const {
     const int m = q.m, mn = q.mn;
-    // lane k: its active constraint
-    double pa = 0.0, pb = 0.0, plam = 0.0;
-    int pr = -1, ptype = 4, pidx = -1;             // 0 CoP row, 1 foot row, 2 lower bound, 3 upper bound, 4 nothing
+    ActiveParams P;
+    P.pa = 0.0; P.pb = 0.0; P.plam = 0.0; P.pr = -1; P.ptype = 4; P.pidx = -1;   // 0 CoP row, 1 foot row, 2 lower, 3 upper bound, 4 nothing
+    int rk = 0;
     if (lane < nact) {
       const int kk = q.iact[lane];
-      plam = q.lam[lane];
+      P.plam = q.lam[lane];
       if (kk <= m) {
-        const int rk = kk - 1;
-        pa = rowA[rk]; pb = rowB[rk]; pr = rowK[rk];
-        ptype = (rk >= 1 && rk <= 4 * NH) ? 0 : 1;
-        if (rk == 0) ptype = 4;                    // the dummy row: all zeros
-      } else if (kk <= mn) { ptype = 2; pidx = kk - m - 1; }
-      else { ptype = 3; pidx = kk - mn - 1; }
+        rk = kk - 1;
+        P.ptype = (rk >= 1 && rk <= 4 * NH) ? 0 : 1;
+        if (rk == 0) P.ptype = 4;                  // the dummy row: all zeros
+      } else if (kk <= mn) { P.ptype = 2; P.pidx = kk - m - 1; }
+      else { P.ptype = 3; P.pidx = kk - mn - 1; }
     }
+    // row rk's coefficients sit in the registers of the lane that owns the row: gather through one scratch vector
+    double *t = q.sc0;
+    t[lane + 1] = ra;
+    if (lane < 5 * ns) t[1 + 4 * NH + lane] = ga;
+    WG_WSYNC();
+    if (P.ptype <= 1) P.pa = t[rk];
+    WG_WSYNC();
+    t[lane + 1] = rb;
+    if (lane < 5 * ns) t[1 + 4 * NH + lane] = gb;
+    WG_WSYNC();
+    if (P.ptype <= 1) P.pb = t[rk];
+    WG_WSYNC();
+    int *tk = reinterpret_cast<int *>(q.sc0);
+    if (lane < 5 * ns) tk[lane] = gk;
+    WG_WSYNC();
+    if (P.ptype == 0) P.pr = (rk - 1) >> 2;
+    else if (P.ptype == 1) P.pr = tk[rk - 1 - 4 * NH];
+    WG_WSYNC();
+    return P;
+  }
+  __device__ __forceinline__ double grad_minus_active(const QlView &q, const ActiveParams &P, int nact, int i, double acc) const {
     const bool xb = i < NH, jerk = i < 2 * NH;
     const int c = xb ? i : i - NH;                 // column inside the jerk block
     int fjx = -1, fjy = -1;                        // foot column index inside its group
     if (!jerk) { const int j = i - 2 * NH; if (j < ns) fjx = j; else fjy = j - ns; }
     for (int k = 0; k < nact; ++k) {
-      const int type = __builtin_amdgcn_readlane(ptype, k);
-      const double lam = rl(plam, k);
+      const int type = __builtin_amdgcn_readlane(P.ptype, k);
+      const double lam = rl(P.plam, k);
       if (type <= 1) {
-        const double a = rl(pa, k), b = rl(pb, k);
-        const int r = __builtin_amdgcn_readlane(pr, k);
+        const double a = rl(P.pa, k), b = rl(P.pb, k);
+        const int r = __builtin_amdgcn_readlane(P.pr, k);
         double e = 0.0;
         if (type == 0) {
           if (jerk) {
@@ -226,9 +261,9 @@ struct HerdtProb {
         }
         acc -= lam * e;
       } else if (type == 2) {
-        if (__builtin_amdgcn_readlane(pidx, k) == i) acc -= lam;
+        if (__builtin_amdgcn_readlane(P.pidx, k) == i) acc -= lam;
       } else if (type == 3) {
-        if (__builtin_amdgcn_readlane(pidx, k) == i) acc += lam;
+        if (__builtin_amdgcn_readlane(P.pidx, k) == i) acc += lam;
       }
     }
     return acc;
@@ -423,6 +458,8 @@ struct HerdtElemProb {
   }
   __device__ __forceinline__ double Gd(const QlView &, int i) const { return gd[i]; }
   __device__ __forceinline__ void setGd(const QlView &, int i, double v) const { gd[i] = v; }
+  __device__ __forceinline__ double xl(const QlView &q, int i) const { return q.xl[i]; }
+  __device__ __forceinline__ double xu(const QlView &q, int i) const { return q.xu[i]; }
   __device__ __forceinline__ double A(const QlView &, int k, int i) const {
     if (k == 0) return 0.0;
     const double a = rowA[k], b = rowB[k];

@@ -171,28 +171,33 @@ struct TickLds {
   }
   // gvld > 0: a table view (compact: kGvLd, element: kGvLdElem) -- its tables are present and the pre-solve group lives
   // elsewhere (overlay); gvld == 0: dense view, G and A are LDS matrices of the solver area
-  __host__ __device__ static size_t bytes(int N, int smax = kSMax, int gvld = 0) {
+  // rows_presolve: rowA / rowB / rowK are only read while the QP is assembled and the register rows are loaded (the compact
+  // view keeps every row's coefficients in registers afterwards) -- they join the pre-solve group
+  __host__ __device__ static size_t bytes(int N, int smax = kSMax, int gvld = 0, bool rows_presolve = false) {
     const int m = 1 + 4 * N + 5 * smax;
     const int nmax = 2 * N + 2 * smax;
     const bool compact = gvld > 0;
-    size_t b = sizeof(Sup) + 8 * (size_t)(kSMax * kSMax + 8 + 2 * m + 16 + (compact ? N + nmax * gvld + nmax : 0)) +
-               4 * (size_t)(((N + 1) & ~1) + ((m + 1) & ~1)) + ((sizeof(wg_gait_state_t) + 15) & ~(size_t)15);
+    size_t b = sizeof(Sup) + 8 * (size_t)(kSMax * kSMax + 8 + (rows_presolve ? 0 : 2 * m) + 16 + (compact ? N + nmax * gvld + nmax : 0)) +
+               4 * (size_t)(((N + 1) & ~1) + (rows_presolve ? 0 : ((m + 1) & ~1))) +
+               (rows_presolve ? 0 : ((sizeof(wg_gait_state_t) + 15) & ~(size_t)15));
     if (!compact) b += pre_bytes(N, smax);
     return (b + 15) & ~(size_t)15;
   }
-  __device__ void carve(char *base, int N, int smax, int gvld, char *overlay) {
+  __device__ void carve(char *base, int N, int smax, int gvld, char *overlay, bool rows_presolve) {
     const bool compact = gvld > 0;
     const int m = 1 + 4 * N + 5 * smax;
     char *p = base;
-    st = reinterpret_cast<wg_gait_state_t *>(p); p += (sizeof(wg_gait_state_t) + 15) & ~(size_t)15;
+    if (!rows_presolve) { st = reinterpret_cast<wg_gait_state_t *>(p); p += (sizeof(wg_gait_state_t) + 15) & ~(size_t)15; }
     sup0 = reinterpret_cast<Sup *>(p); p += sizeof(Sup);
     double *d = reinterpret_cast<double *>(p);
     V_f = d; d += kSMax * kSMax; sup_angles = d; d += 8;
-    rowA = d; d += m; rowB = d; d += m; misc = d; d += 16;
+    if (!rows_presolve) { rowA = d; d += m; rowB = d; d += m; }
+    misc = d; d += 16;
     uvec = Gv = gd = nullptr;
     if (compact) { const int nmax = 2 * N + 2 * smax; uvec = d; d += N; Gv = d; d += nmax * gvld; gd = d; d += nmax; }
     int *ip = reinterpret_cast<int *>(d);
-    stepidx = ip; ip += (N + 1) & ~1; rowK = ip; ip += (m + 1) & ~1;
+    stepidx = ip; ip += (N + 1) & ~1;
+    if (!rows_presolve) { rowK = ip; ip += (m + 1) & ~1; }
     char *o = compact ? overlay : reinterpret_cast<char *>(ip);
     sup = reinterpret_cast<Sup *>(o); o += sizeof(Sup) * (N + 1);
     double *e = reinterpret_cast<double *>(o);
@@ -200,6 +205,18 @@ struct TickLds {
     trunk = e; e += N + 1; refx = e; e += N; refy = e; e += N;
     svx = e; e += N; svy = e; e += N; szx = e; e += N; szy = e; e += N;
     rowD = e; e += m;
+    if (rows_presolve) {
+      rowA = e; e += m; rowB = e; e += m; rowK = reinterpret_cast<int *>(e);
+      // the working copy of the state also lives on Z: it is written back before the solver starts and fetched again
+      // after it (mpc_tick), so that it costs no LDS while the solve is resident
+      char *q = reinterpret_cast<char *>(rowK + ((m + 1) & ~1));
+      q = reinterpret_cast<char *>((reinterpret_cast<size_t>(q) + 15) & ~(size_t)15);
+      st = reinterpret_cast<wg_gait_state_t *>(q);
+    }
+  }
+  __host__ __device__ static size_t overlay_bytes(int N, int smax) {   // what the compact view parks on Z before the solve
+    const int m = 1 + 4 * N + 5 * smax;
+    return pre_bytes(N, smax) + 16 * (size_t)m + 4 * (size_t)((m + 1) & ~1) + 16 + ((sizeof(wg_gait_state_t) + 15) & ~(size_t)15);
   }
 };
 
@@ -466,7 +483,7 @@ __device__ inline TickDiag mpc_tick(const wg_model_t &m, const TickTables *__res
   static_assert(sizeof(Sup) % 8 == 0, "Sup must keep doubles aligned");
   constexpr int kGvStride = (NH == 16) ? kGvLd : (NH == -1 ? kGvLdElem : 0);
   constexpr int kGvOff = (NH == -1) ? 0 : 1;
-  L.carve(lds_tick, N, (NH == 16) ? 2 : kSMax, kGvStride, reinterpret_cast<char *>(lds_ql));
+  L.carve(lds_tick, N, (NH == 16) ? 2 : kSMax, kGvStride, reinterpret_cast<char *>(lds_ql), NH == 16);
   wg_gait_state_t *s = L.st;
 #ifdef WG_PROFILE
   unsigned long long tk0 = clock64(), tk1 = 0, tk2 = 0, tk3 = 0;
@@ -605,11 +622,11 @@ __device__ inline TickDiag mpc_tick(const wg_model_t &m, const TickTables *__res
   const int mq = 1 + 4 * N + 5 * ns;     // rows incl. the dummy row 0 (qp-problem.cpp:248)
   constexpr bool kCompactView = (NH == 16);
   constexpr bool kTableView = (NH == 16) || (NH == -1);   // Hessian / constraints kept as compact tables
-  QlDims D(n, mq, mq, !kTableView, true, kCompactView ? 2 * NH + 4 : 0);   // ordered sums run the static length
+  QlDims D(n, mq, mq, !kTableView, true, kCompactView ? 2 * NH + 4 : 0, !kCompactView);   // ordered sums run the static length
   QlView q;
   if constexpr (kCompactView) {
     constexpr int kNmax = 2 * NH + 4, kMmax = 1 + 4 * NH + 10;     // two previewed steps at most (wg_mpc_configure)
-    // same footprint as QlDims(kNmax, kMmax, kMmax, dense = false, nsc = kNmax), which sized the LDS on the host
+    // same footprint as QlDims(kNmax, kMmax, kMmax, dense = false, nsc = kNmax, bounds = false), which sized the LDS on the host
     q.template carve_fixed<kNmax, kMmax, kNmax>(lds_ql, n, mq, 0);
   } else {
     q.carve(lds_ql, D, 0);
@@ -651,7 +668,7 @@ __device__ inline TickDiag mpc_tick(const wg_model_t &m, const TickTables *__res
     dx += qx * m.gamma; dy += qy * m.gamma;
     q.d[2 * N + j] = dx; q.d[2 * N + ns + j] = dy;
   }
-  for (int i = lane; i < n; i += 64) { q.xl[i] = -1e8; q.xu[i] = 1e8; }   // qp-problem.cpp:118-121
+  if constexpr (!kCompactView) { for (int i = lane; i < n; i += 64) { q.xl[i] = -1e8; q.xu[i] = 1e8; } }   // qp-problem.cpp:118-121
 
   // ---- Hessian ----
   if constexpr (kTableView) {
@@ -767,12 +784,27 @@ __device__ inline TickDiag mpc_tick(const wg_model_t &m, const TickTables *__res
   if constexpr (kCompactView) {
     if (lane == 0 && fabs(L.gd[n - 1]) == 0.0) L.gd[n - 1] = 1e-8;               // qld.cpp:442-444 (nmax == n)
     WG_WSYNC();
+    {
+      // the state's LDS copy sits on Z: park it in its HBM slot (L2) for the duration of the solve
+      double *dst = reinterpret_cast<double *>(gstate);
+      const double *src = reinterpret_cast<const double *>(s);
+      for (int i = lane; i < (int)(sizeof(wg_gait_state_t) / 8); i += 64) dst[i] = src[i];
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    }
     HerdtProb<16> prob;
     prob.Qb = &tb->Qb[0][0]; prob.u = L.uvec; prob.Gv = L.Gv; prob.gd = L.gd;
     prob.rowA = L.rowA; prob.rowB = L.rowB; prob.rowK = L.rowK; prob.stepidx = L.stepidx; prob.V_f = L.V_f;
     prob.R2 = tb->R2; prob.Z2 = tb->Z2; prob.z2sign = tb->z2_cross_sign; prob.diag_b = tb->diag_b; prob.blocks_ok = tb->blocks_ok; prob.ns = ns;
     prob.load_rows(lane);
     qr = ql_solve(q, prob, 1e-8, hist, hist_cap);
+    {
+      WG_WSYNC();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      const double *src = reinterpret_cast<const double *>(gstate);
+      double *dst = reinterpret_cast<double *>(s);
+      for (int i = lane; i < (int)(sizeof(wg_gait_state_t) / 8); i += 64) dst[i] = src[i];
+      WG_WSYNC();
+    }
   } else if constexpr (NH == -1) {
     if (lane == 0 && fabs(L.gd[n - 1]) == 0.0) L.gd[n - 1] = 1e-8;               // qld.cpp:442-444 (nmax == n)
     WG_WSYNC();
