@@ -789,7 +789,6 @@ __device__ inline TickDiag mpc_tick(const wg_model_t &m, const TickTables *__res
       double *dst = reinterpret_cast<double *>(gstate);
       const double *src = reinterpret_cast<const double *>(s);
       for (int i = lane; i < (int)(sizeof(wg_gait_state_t) / 8); i += 64) dst[i] = src[i];
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
     }
     HerdtProb<16> prob;
     prob.Qb = &tb->Qb[0][0]; prob.u = L.uvec; prob.Gv = L.Gv; prob.gd = L.gd;
@@ -799,10 +798,13 @@ __device__ inline TickDiag mpc_tick(const wg_model_t &m, const TickTables *__res
     qr = ql_solve(q, prob, 1e-8, hist, hist_cap);
     {
       WG_WSYNC();
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      // the stores above completed long ago (the release only waits for them); the loads go to L2 (agent-scope atomics:
+      // no stale L1 line of the tick's first read, and no L1 invalidate that would hit the other resident waves)
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
       const double *src = reinterpret_cast<const double *>(gstate);
       double *dst = reinterpret_cast<double *>(s);
-      for (int i = lane; i < (int)(sizeof(wg_gait_state_t) / 8); i += 64) dst[i] = src[i];
+      for (int i = lane; i < (int)(sizeof(wg_gait_state_t) / 8); i += 64)
+        dst[i] = __hip_atomic_load(src + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       WG_WSYNC();
     }
   } else if constexpr (NH == -1) {
