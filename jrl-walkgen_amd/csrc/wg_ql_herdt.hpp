@@ -176,10 +176,18 @@ struct HerdtProb {
     if (row < 2 * NH) {
       const int blk = (row < NH) ? 0 : NH;
       const double *qr = Qb + (row - blk) * kQbLd;
+      // the row of Q_b comes from global memory (L2): all NH loads are issued before the first use -- left to itself
+      // the register-limited build waits for each one in turn
+      double qv[NH], vv[NH];
+#pragma unroll
+      for (int k = 0; k < NH; ++k) qv[k] = qr[k];
+#pragma unroll
+      for (int k = 0; k < NH; ++k) vv[k] = v[blk + k];
+      const double gdr = gd[row];                    // hoisted: a select per term, not a branch around an LDS read
 #pragma unroll
       for (int k = 0; k < NH; ++k) {
-        const double g = (blk + k == row) ? gd[row] : qr[k];
-        acc += g * v[blk + k];
+        const double g = (blk + k == row) ? gdr : qv[k];
+        acc += g * vv[k];
       }
       for (int c = 0; c < n - 2 * NH; ++c) acc += Gv[row * kGvLd + c] * v[2 * NH + c];
       return acc;
