@@ -193,7 +193,14 @@ struct HerdtProb {
       return acc;
     }
     const int cc = row - 2 * NH;
-    for (int k = 0; k < 2 * NH; ++k) acc += Gv[k * kGvLd + cc] * v[k];
+#pragma unroll
+    for (int k0 = 0; k0 < 2 * NH; k0 += 8) {        // loads in groups of 8 ahead of the add chain
+      double gg[8], vv[8];
+#pragma unroll
+      for (int c = 0; c < 8; ++c) { gg[c] = Gv[(k0 + c) * kGvLd + cc]; vv[c] = v[k0 + c]; }
+#pragma unroll
+      for (int c = 0; c < 8; ++c) acc += gg[c] * vv[c];
+    }
     for (int c = 0; c < n - 2 * NH; ++c) {
       const double g = (c == cc) ? gd[row] : Gv[row * kGvLd + c];
       acc += g * v[2 * NH + c];

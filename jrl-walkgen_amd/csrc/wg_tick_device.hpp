@@ -519,6 +519,7 @@ __device__ inline TickDiag mpc_tick(const wg_model_t &m, const TickTables *__res
     {
       Sup prw = cur;
       prw.step_number = 0;
+      int hull_src = 0;
       for (unsigned pi = 1; pi <= (unsigned)N; pi++) {
         fsm_set_support_state(m, s->nb_steps_ssds, time, pi, prw, ref);
         if (prw.state_changed) {
@@ -529,38 +530,15 @@ __device__ inline TickDiag mpc_tick(const wg_model_t &m, const TickTables *__res
           if (prw.step_number > 0) { prw.x = 0.0; prw.y = 0.0; }
         }
         L.sup[pi] = prw;
+        // the CoP hull changes only where the support state changes: remember which previewed state carries it
+        if (prw.state_changed) hull_src = (int)pi;
+        L.stepidx[pi - 1] = hull_src << 8;                        // low byte (step index) is filled in below, per lane
       }
     }
     int ns = L.sup[N].step_number;
     constexpr int kSCap = (NH == 16) ? 2 : kSMax;   // compact kernel: N*T <= 2*step_period is checked at configure time
     if (ns > kSCap) ns = kSCap;                     // cannot happen; keeps every index in range
-    // generate_selection_matrices :137-208
-    for (int k = 0; k < kSMax; k++) { L.Vc_fX[k] = 0.0; L.Vc_fY[k] = 0.0; }
-    for (int k = 0; k < kSMax * kSMax; k++) L.V_f[k] = 0.0;
-    for (int i = 0; i < N; i++) {
-      const Sup &S = L.sup[i + 1];
-      L.VcX[i] = 0.0; L.VcY[i] = 0.0; L.stepidx[i] = 0;
-      if (S.step_number > 0) {
-        L.stepidx[i] = S.step_number;
-        if (S.step_number == 1 && S.state_changed && S.phase == WG_SS) {
-          L.Vc_fX[0] = L.sup[i].x; L.Vc_fY[0] = L.sup[i].y;
-          L.V_f[0] = 1.0;
-        } else if (S.step_number > 1 && S.step_number <= kSMax) {
-          L.V_f[(S.step_number - 1) * kSMax + (S.step_number - 2)] = -1.0;
-          L.V_f[(S.step_number - 1) * kSMax + (S.step_number - 1)] = 1.0;
-        }
-      } else { L.VcX[i] = S.x; L.VcY[i] = S.y; }
-    }
     op_preview(m, s, time, ref, L.sup, L.sup_angles, L.trunk);
-    // the CoP hull changes only where the support state changes: record, per instant, which previewed state carries it
-    // (the edges themselves are formed lane-parallel below)
-    {
-      int src = 0;
-      for (int i = 0; i < N; i++) {
-        if (L.sup[i + 1].state_changed) src = i + 1;
-        L.stepidx[i] = L.stepidx[i] | (src << 8);               // low byte: step index, next: hull source state
-      }
-    }
     *L.sup0 = L.sup[0];
     L.misc[0] = (double)ns;
     L.misc[1] = ref[0]; L.misc[2] = ref[1]; L.misc[3] = ref[2];
@@ -571,6 +549,30 @@ __device__ inline TickDiag mpc_tick(const wg_model_t &m, const TickTables *__res
   {
     const int ns0 = uni((int)L.misc[0]);
     const double ref0 = L.misc[1], ref1 = L.misc[2];
+    // generate_selection_matrices :137-208, one instant per lane.  The few scalar cells (Vc_f, V_f) are written by the
+    // lanes whose instant defines them; lanes that hit the same cell write the same value.
+    if (lane < kSMax) { L.Vc_fX[lane] = 0.0; L.Vc_fY[lane] = 0.0; }
+    if (lane < kSMax * kSMax) L.V_f[lane] = 0.0;
+    WG_WSYNC();
+    if (lane < N) {
+      const int i = lane;
+      const Sup &S = L.sup[i + 1];
+      double vx = 0.0, vy = 0.0;
+      int sidx = 0;
+      if (S.step_number > 0) {
+        sidx = S.step_number;
+        if (S.step_number == 1 && S.state_changed && S.phase == WG_SS) {
+          L.Vc_fX[0] = L.sup[i].x; L.Vc_fY[0] = L.sup[i].y;
+          L.V_f[0] = 1.0;
+        } else if (S.step_number > 1 && S.step_number <= kSMax) {
+          L.V_f[(S.step_number - 1) * kSMax + (S.step_number - 2)] = -1.0;
+          L.V_f[(S.step_number - 1) * kSMax + (S.step_number - 1)] = 1.0;
+        }
+      } else { vx = S.x; vy = S.y; }
+      L.VcX[i] = vx; L.VcY[i] = vy;
+      L.stepidx[i] = (L.stepidx[i] & ~0xff) | sidx;
+    }
+    WG_WSYNC();
     // compute_global_reference :211-229 (trunk[2..N] all hold the same angle, OrientationsPreview.cpp:229-233)
     if (lane < N) {
       const int i = lane;
