@@ -233,6 +233,9 @@ int wg_mpc_tick_batch_dev(int B, wg_gait_state_t *states, wg_tick_out_t *outs, i
 int wg_mpc_set_velref_dev(int B, wg_gait_state_t *states, const double *vref, void *hip_stream);
 /* LDS bytes one gait occupies in the tick kernel for the configured model. */
 size_t wg_mpc_tick_lds_bytes(void);
+/* the same figure for any model, without configuring it (host arithmetic: lets callers and tests reason about
+ * residency -- a gfx950 CU has 160 KiB of LDS, handed out in 1280-byte granules); 0 if N is out of range */
+size_t wg_mpc_tick_lds_bytes_for(const wg_model_t *model);
 
 /* Kajita preview-control gains (host, no device work) -----------------------
  *

@@ -402,6 +402,11 @@ int wg_mpc_configure(const wg_model_t *model) {
   return WG_OK;
 }
 
+size_t wg_mpc_tick_lds_bytes_for(const wg_model_t *model) {   // host arithmetic only: no device needed
+  if (!model || model->N < 2 || model->N > wg::kNMaxH) return 0;
+  return tick_lds_for(*model, tick_view(*model));
+}
+
 size_t wg_mpc_tick_lds_bytes(void) {
   if (!g_model_set) return 0;
   return tick_lds_for(g_model, tick_view(g_model));

@@ -60,17 +60,6 @@ __device__ __forceinline__ double rl(double v, int src) {
   int hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
   return __hiloint2double(hi, lo);
 }
-// value of `v` in the neighbouring lane (gfx9 DPP wave shifts: one VALU move per 32-bit half, no LDS, no SGPR hop)
-__device__ __forceinline__ double from_lane_below(double v) {   // lane L gets lane L-1 (wave_shr:1); lane 0 keeps its own
-  int lo = __builtin_amdgcn_update_dpp(__double2loint(v), __double2loint(v), 0x138, 0xf, 0xf, false);
-  int hi = __builtin_amdgcn_update_dpp(__double2hiint(v), __double2hiint(v), 0x138, 0xf, 0xf, false);
-  return __hiloint2double(hi, lo);
-}
-__device__ __forceinline__ double from_lane_above(double v) {   // lane L gets lane L+1 (wave_shl:1); lane 63 keeps its own
-  int lo = __builtin_amdgcn_update_dpp(__double2loint(v), __double2loint(v), 0x130, 0xf, 0xf, false);
-  int hi = __builtin_amdgcn_update_dpp(__double2hiint(v), __double2hiint(v), 0x130, 0xf, 0xf, false);
-  return __hiloint2double(hi, lo);
-}
 // sum_{j=lo}^{hi-1} v[lane j] in index order, starting from 0.0.  `v` must be 0.0 in every lane that is not in
 // [lo, hi): adding +0.0 never changes a running sum, so the loop can run in chunks of four without a remainder
 // loop (v_readlane is convergent and the compiler will not unroll it itself).  Needs hi <= 61.
@@ -426,50 +415,6 @@ __device__ __forceinline__ double ordered_sum_lds(double term, double *scratch, 
   }
   WG_WSYNC();
   return sum;
-}
-
-// back substitution (qld.cpp:1824-1851), every lane redundantly on LDS-broadcast operands.  The freshest
-// multiplier (needed first by the next row, sums ascend in j) stays in a register; the other terms are loaded
-// four at a time, one group ahead of the dependent add chain.
-__device__ __forceinline__ void backsub_pipe(const QlView &q, const double *s, int nact, int lane) {
-  double wprev = 0.0;
-  for (int i = nact - 1; i >= 0; --i) {
-    const double si = s[i], rii = Rp(i, i);
-    double sum = 0.0;
-    int j = i + 1;
-    if (j < nact) {
-      sum += Rp(i, j) * wprev;
-      ++j;
-      const int last = nact - 1;
-      double r0, r1, r2, r3, w0, w1, w2, w3;
-      if (j < nact) {
-        { const int a = j, b = j + 1 < last ? j + 1 : last, c = j + 2 < last ? j + 2 : last, d = j + 3 < last ? j + 3 : last;
-          r0 = Rp(i, a); r1 = Rp(i, b); r2 = Rp(i, c); r3 = Rp(i, d);
-          w0 = q.ww[a]; w1 = q.ww[b]; w2 = q.ww[c]; w3 = q.ww[d]; }
-        for (;;) {
-          const int jn = j + 4;
-          const bool more = jn < nact;
-          double nr0 = 0, nr1 = 0, nr2 = 0, nr3 = 0, nw0 = 0, nw1 = 0, nw2 = 0, nw3 = 0;
-          if (more) {
-            const int a = jn, b = jn + 1 < last ? jn + 1 : last, c = jn + 2 < last ? jn + 2 : last, d = jn + 3 < last ? jn + 3 : last;
-            nr0 = Rp(i, a); nr1 = Rp(i, b); nr2 = Rp(i, c); nr3 = Rp(i, d);
-            nw0 = q.ww[a]; nw1 = q.ww[b]; nw2 = q.ww[c]; nw3 = q.ww[d];
-          }
-          sum += r0 * w0;
-          if (j + 1 < nact) sum += r1 * w1;
-          if (j + 2 < nact) sum += r2 * w2;
-          if (j + 3 < nact) sum += r3 * w3;
-          if (!more) break;
-          r0 = nr0; r1 = nr1; r2 = nr2; r3 = nr3; w0 = nw0; w1 = nw1; w2 = nw2; w3 = nw3;
-          j = jn;
-        }
-      }
-    }
-    const double v = (si - sum) / rii;
-    if (lane == 0) q.ww[i] = v;
-    wprev = v;
-  }
-  WG_WSYNC();
 }
 
 // Givens sweep (qld.cpp:1992-2030) for n <= 64, written without data-dependent control flow: on a single

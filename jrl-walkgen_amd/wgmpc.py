@@ -82,6 +82,8 @@ def lib():
         _lib.wg_qp_solve_batch.argtypes = qp_args
         _lib.wg_qp_solve_batch_dev.argtypes = qp_args + [C.c_void_p]
         _lib.wg_mpc_tick_lds_bytes.restype = C.c_size_t
+        _lib.wg_mpc_tick_lds_bytes_for.restype = C.c_size_t
+        _lib.wg_mpc_tick_lds_bytes_for.argtypes = [C.c_void_p]
         _lib.wg_mpc_tick_batch.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int,
                                            C.c_void_p]
         _lib.wg_mpc_tick_batch_dev.argtypes = _lib.wg_mpc_tick_batch.argtypes + [C.c_void_p]
@@ -187,6 +189,11 @@ def gait_init(model, com0, left_xyt, right_xyt):
 
 def mpc_configure(model):
     _check(lib().wg_mpc_configure(C.byref(model)))
+
+
+def mpc_tick_lds_bytes_for(model):
+    """LDS bytes per gait the tick kernel would use for `model` (host arithmetic, no GPU needed)."""
+    return int(lib().wg_mpc_tick_lds_bytes_for(C.byref(model)))
 
 
 def mpc_tick_lds_bytes():
