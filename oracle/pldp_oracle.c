@@ -294,7 +294,7 @@ int wgo_dimitrov_tick(const wgo_pldp_model_t *M, const double *OptB, const doubl
                       wg_dimitrov_out_t *out, int max_iter) {
   const int N = M->N, n = 2 * N;
   static double A[(WG_PLDP_MMAX + 1) * 2 * WG_PLDP_N];
-  double b[WG_PLDP_MMAX], zr[2 * WG_PLDP_N], D[2 * WG_PLDP_N], X[2 * WG_PLDP_N], NewX[2 * WG_PLDP_N];
+  double b[WG_PLDP_MMAX], zr[2 * WG_PLDP_N], D[2 * WG_PLDP_N] = {0}, X[2 * WG_PLDP_N], NewX[2 * WG_PLDP_N] = {0};
   int sim[WG_PLDP_MMAX], act[WG_PLDP_MMAX];
   const double *xk = st->xk;
   int m = 0;
