@@ -228,6 +228,14 @@ int wg_mpc_tick_batch(int B, wg_gait_state_t *states, wg_tick_out_t *outs, int *
                       int *hist, int hist_cap, int *hist_len);
 int wg_mpc_tick_batch_dev(int B, wg_gait_state_t *states, wg_tick_out_t *outs, int *diag, int advance_calls,
                           int *hist, int hist_cap, int *hist_len, void *hip_stream);
+/* n_ticks consecutive ticks of every gait in ONE launch (fleet simulation, Monte-Carlo gaits).  A gait's tick t+1
+ * depends only on its own tick t, so the batch does not synchronise between ticks: resident waves pull (gait, next
+ * tick) items from a device-side queue, and a gait is offered again as soon as its tick is done.  Same results as
+ * n_ticks calls of wg_mpc_tick_batch_dev with the same advance_calls, bit for bit; the velocity references stay what they
+ * are for the whole launch (change them between launches with wg_mpc_set_velref_dev).
+ *   outs  n_ticks x B (tick-major) or NULL;  diag  n_ticks x B x 6 (tick-major) or NULL. */
+int wg_mpc_run_batch_dev(int B, wg_gait_state_t *states, int n_ticks, int advance_calls, wg_tick_out_t *outs, int *diag,
+                         void *hip_stream);
 /* NewVelRef_ <- (vx, vy, vyaw) for every gait (":setVelReference", ZMPVelocityReferencedQP.hh:103-114);
  * vref = B x 3 doubles, DEVICE pointers. */
 int wg_mpc_set_velref_dev(int B, wg_gait_state_t *states, const double *vref, void *hip_stream);

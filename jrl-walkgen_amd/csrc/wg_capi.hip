@@ -266,7 +266,8 @@ namespace {
 wg_model_t g_model;
 bool g_model_set = false;
 wg::TickTables *g_tables_dev = nullptr;
-DevBuf g_tick_state, g_tick_out, g_tick_aux;
+DevBuf g_tick_state, g_tick_out, g_tick_aux, g_run_buf;
+bool g_run_hooked = false;
 
 inline bool tick_compact(const wg_model_t &m);
 // at most two step changes fit in the preview window when N*T <= 2*step_period (each change is one step period
@@ -342,6 +343,73 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WG_TICK_WPE_
       dq[0] = dg.ifail; dq[1] = dg.n_iter; dq[2] = dg.nact; dq[3] = dg.n; dq[4] = dg.m; dq[5] = dg.ns;
     }
     WG_WSYNC();
+  }
+}
+
+// ---- many ticks per launch: a work queue of (gait, next tick) ---------------------------------------------------------------
+// A gait's tick t+1 depends only on its own tick t, so the batch need not synchronise between ticks.  One launch of
+// wg_mpc_run_kernel advances every gait by n_ticks: resident waves pull gait ids from a ring in arrival order; a wave that
+// finishes a tick appends its gait again (until the gait has done n_ticks).  All wave slots stay busy until the very end
+// of the launch, instead of draining at the end of every tick (B = 4096 is 2.3 rounds of the 1792 resident gaits: with
+// one launch per tick a quarter of the machine idles in the last round).  Results are those of n_ticks single-tick
+// launches, bit for bit: a tick only ever reads its own gait's state.
+struct wg_run_queue {
+  int head, tail;      // next ring position to take / to fill
+  int pad_[2];
+};
+
+__global__ void wg_run_queue_init_kernel(int B, int total, wg_run_queue *q, int *ring, int *done) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i == 0) { q->head = 0; q->tail = B; }
+  if (i < total) ring[i] = i < B ? i : -1;
+  if (i < B) done[i] = 0;
+}
+
+template <int NH>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WG_TICK_WPE_MIN, WG_TICK_WPE_MAX))) void wg_mpc_run_kernel(
+    int B, int n_ticks, wg_model_t model, const wg::TickTables *__restrict__ tb, wg_gait_state_t *__restrict__ states,
+    wg_tick_out_t *__restrict__ outs, int *__restrict__ diag, int advance_calls, wg_run_queue *__restrict__ q,
+    int *__restrict__ ring, int *__restrict__ done, unsigned ql_bytes) {
+  extern __shared__ __attribute__((aligned(16))) double wg_lds[];
+  const int total = B * n_ticks;
+  for (;;) {
+    int lane = threadIdx.x & 63;
+    asm volatile("" : "+v"(lane));               // opaque per item: nothing lane-dependent is hoisted out of the loop and kept alive
+    int idx = 0, g = 0, t = 0;
+    if (lane == 0) idx = atomicAdd(&q->head, 1);
+    idx = wg::uni(idx);
+    if (idx >= total) break;                     // every wave reaches this: head only grows
+    if (lane == 0) {
+      // positions are filled in order; every position below `total` is filled eventually by a wave holding an earlier one
+      while ((g = __hip_atomic_load(ring + idx, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT)) < 0) __builtin_amdgcn_s_sleep(16);
+      t = __hip_atomic_load(done + g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    g = wg::uni(g); t = wg::uni(t);
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");          // the gait's previous tick may have run on another CU
+    if (advance_calls > 0) {
+      if (lane == 0) {
+        double c = __hip_atomic_load(&states[g].clock, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (int k = 0; k < advance_calls; ++k) c += model.Tctrl;   // PatternGeneratorInterfacePrivate.cpp:1256
+        __hip_atomic_store(&states[g].clock, c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      WG_WSYNC();
+    }
+    wg::TickDiag dg = wg::mpc_tick<NH>(model, tb, states + g, outs ? outs + (size_t)t * B + g : nullptr, wg_lds,
+                                   reinterpret_cast<char *>(wg_lds) + ql_bytes, nullptr, 0, nullptr);
+    if (diag && lane == 0) {
+      int *dq = diag + ((size_t)t * B + g) * 6;
+      dq[0] = dg.ifail; dq[1] = dg.n_iter; dq[2] = dg.nact; dq[3] = dg.n; dq[4] = dg.m; dq[5] = dg.ns;
+    }
+    WG_WSYNC();
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");          // the state is in L2 before the gait is offered again
+    if (lane == 0) {
+      __hip_atomic_store(done + g, t + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (t + 1 < n_ticks) {
+        const int pos = atomicAdd(&q->tail, 1);
+        __hip_atomic_store(ring + pos, g, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
   }
 }
 
@@ -439,6 +507,50 @@ int wg_mpc_tick_batch_dev(int B, wg_gait_state_t *states, wg_tick_out_t *outs, i
   else
     hipLaunchKernelGGL(wg_mpc_tick_kernel<-1>, dim3(grid), dim3(64), lds, st, B, g_model, g_tables_dev, states, outs, diag,
                        advance_calls, hist, hist_cap, hist_len, (unsigned)qlb);
+  HIP_TRY(hipGetLastError());
+  return WG_OK;
+}
+
+int wg_mpc_run_batch_dev(int B, wg_gait_state_t *states, int n_ticks, int advance_calls, wg_tick_out_t *outs, int *diag,
+                         void *hip_stream) {
+  if (int rc = ensure_device()) return rc;
+  if (!g_model_set) return fail(WG_ERR_BAD_ARG, "wg_mpc_configure() has not been called");
+  if (B < 0 || n_ticks < 0 || !states) return fail(WG_ERR_BAD_ARG, "bad arguments");
+  if (B == 0 || n_ticks == 0) return WG_OK;
+  if ((long long)B * n_ticks > 0x3fffffffLL) return fail(WG_ERR_TOO_LARGE, "B * n_ticks = %lld work items", (long long)B * n_ticks);
+  const int total = B * n_ticks;
+  hipStream_t st = reinterpret_cast<hipStream_t>(hip_stream);
+  {
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (int rc = g_run_buf.reserve(sizeof(wg_run_queue) + (size_t)(total + B) * 4)) return rc;
+    if (!g_run_hooked) { g_release_hooks.push_back([] { g_run_buf.release(); }); g_run_hooked = true; }
+  }
+  wg_run_queue *q = static_cast<wg_run_queue *>(g_run_buf.p);
+  int *ring = reinterpret_cast<int *>(q + 1), *done = ring + total;
+  hipLaunchKernelGGL(wg_run_queue_init_kernel, dim3((total + 255) / 256), dim3(256), 0, st, B, total, q, ring, done);
+  const size_t qlb = tick_ql_bytes(g_model);
+  const int view = tick_view(g_model);
+  const size_t lds = tick_lds_for(g_model, view);
+  if (lds > 64 * 1024)
+    HIP_TRY(hipFuncSetAttribute(view == 16  ? reinterpret_cast<const void *>(wg_mpc_run_kernel<16>)
+                                : view == 0 ? reinterpret_cast<const void *>(wg_mpc_run_kernel<0>)
+                                            : reinterpret_cast<const void *>(wg_mpc_run_kernel<-1>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  // as many blocks as the device keeps resident: LDS granules (1280 B, 128 per CU), at most 8 waves of 256 registers per CU
+  int per_cu = 128 / (int)((lds + 1279) / 1280);
+  if (per_cu > 8) per_cu = 8;
+  if (per_cu < 1) per_cu = 1;
+  int grid = g_num_cu * per_cu;
+  if (grid > B) grid = B;
+  if (view == 16)
+    hipLaunchKernelGGL(wg_mpc_run_kernel<16>, dim3(grid), dim3(64), lds, st, B, n_ticks, g_model, g_tables_dev, states, outs,
+                       diag, advance_calls, q, ring, done, (unsigned)qlb);
+  else if (view == 0)
+    hipLaunchKernelGGL(wg_mpc_run_kernel<0>, dim3(grid), dim3(64), lds, st, B, n_ticks, g_model, g_tables_dev, states, outs,
+                       diag, advance_calls, q, ring, done, (unsigned)qlb);
+  else
+    hipLaunchKernelGGL(wg_mpc_run_kernel<-1>, dim3(grid), dim3(64), lds, st, B, n_ticks, g_model, g_tables_dev, states, outs,
+                       diag, advance_calls, q, ring, done, (unsigned)qlb);
   HIP_TRY(hipGetLastError());
   return WG_OK;
 }

@@ -43,6 +43,9 @@ namespace wg {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");  \
   } while (0)
 
+// lane index, opaque to the optimiser: inside a persistent loop (wg_mpc_run_kernel) nothing derived from it can be hoisted
+// out of the loop and kept alive across a whole tick (that hoisting costs ~180 spilled registers)
+__device__ __forceinline__ int wg_lane() { int l = threadIdx.x & 63; asm volatile("" : "+v"(l)); return l; }
 __device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
 __device__ __forceinline__ double uni(double v) {
   int lo = __double2loint(v), hi = __double2hiint(v);
@@ -700,8 +703,8 @@ __device__ __forceinline__ bool independent_coordinate(const QlView &q, const P 
   do { if constexpr (P::kNM > 0) sweep_flat(q, s, nu, nact, lane); else sweep(q, s, nu, nact, lane); } while (0)
 
 template <class P>
-__device__ inline QlResult ql_solve(const QlView &q, P &prob, double vsmall, int *hist, int hist_cap) {
-  const int lane = threadIdx.x & 63;
+__device__ __forceinline__ QlResult ql_solve(const QlView &q, P &prob, double vsmall, int *hist, int hist_cap) {
+  const int lane = wg_lane();
   const int n = q.n, m = q.m, me = q.me, mn = q.mn;
   QlResult out;
   out.hist_len = 0;

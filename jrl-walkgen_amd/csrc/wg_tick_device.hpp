@@ -343,6 +343,7 @@ __device__ inline void op_preview(const wg_model_t &m, wg_gait_state_t *s, doubl
     } else s->trunkT_yaw[1] = ref[2];
   } else s->trunkT_yaw[1] = 0.0;
 
+  for (int e = 0; e < 8; e++) sup_angles[e] = 0.0;             // defined contents even when a pass is abandoned (guards below)
   bool vel_ok = false, angle_ok = false;
   double first_prw = 0.0;
   const double sign_rot_vel = (s->trunkT_yaw[1] < 0.0) ? -1.0 : 1.0;
@@ -471,10 +472,10 @@ struct TickDiag { int ifail, n_iter, nact, n, m, ns; };
 // NH == 16: compact problem view (rows in registers, no G / A anywhere); NH == 0: generic dense view (G, A in LDS);
 // NH == -1: element view (any N <= 32: G / A regenerated per element from the compact tables, wg_ql_herdt.hpp)
 template <int NH>
-__device__ inline TickDiag mpc_tick(const wg_model_t &m, const TickTables *__restrict__ tb, wg_gait_state_t *gstate,
+__device__ __forceinline__ TickDiag mpc_tick(const wg_model_t &m, const TickTables *__restrict__ tb, wg_gait_state_t *gstate,
                                     wg_tick_out_t *out, double *lds_ql, char *lds_tick, int *hist, int hist_cap,
                                     int *hist_len) {
-  const int lane = threadIdx.x & 63;
+  const int lane = wg_lane();
   const int N = (NH == 16) ? 16 : m.N;            // compact view: the horizon is a compile-time constant (checked by the host)
   const double T = m.T;
   const int K = WG_SAMPLES_PER_TICK;
@@ -491,9 +492,11 @@ __device__ inline TickDiag mpc_tick(const wg_model_t &m, const TickTables *__res
 
   // ---- state: HBM -> LDS (coalesced 8-byte lanes) ----
   {
+    // agent-scope loads: in a multi-tick launch the previous tick of this gait may have run on another XCD
     const double *src = reinterpret_cast<const double *>(gstate);
     double *dst = reinterpret_cast<double *>(s);
-    for (int i = lane; i < (int)(sizeof(wg_gait_state_t) / 8); i += 64) dst[i] = src[i];
+    for (int i = lane; i < (int)(sizeof(wg_gait_state_t) / 8); i += 64)
+      dst[i] = __hip_atomic_load(src + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   WG_WSYNC();
   const double time = s->clock;

@@ -88,6 +88,7 @@ def lib():
                                            C.c_void_p]
         _lib.wg_mpc_tick_batch_dev.argtypes = _lib.wg_mpc_tick_batch.argtypes + [C.c_void_p]
         _lib.wg_mpc_set_velref_dev.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        _lib.wg_mpc_run_batch_dev.argtypes = [C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
         _lib.wg_pldp_lds_bytes.restype = C.c_size_t
         _lib.wg_pldp_configure.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
         _lib.wg_pldp_solve_batch.argtypes = [C.c_int, C.c_int] + [C.c_void_p] * 9 + [C.c_int] + [C.c_void_p] * 6
@@ -219,6 +220,11 @@ def mpc_tick_batch_dev(B, states_ptr, outs_ptr=None, diag_ptr=None, advance_call
     v = lambda p: C.c_void_p(p) if p else None
     _check(lib().wg_mpc_tick_batch_dev(B, v(states_ptr), v(outs_ptr), v(diag_ptr), advance_calls, v(hist_ptr), hist_cap,
                                        v(hist_len_ptr), v(stream)))
+
+
+def mpc_run_batch_dev(B, states_ptr, n_ticks, advance_calls=20, outs_ptr=None, diag_ptr=None, stream=None):
+    """n_ticks ticks of every gait in one launch (device-side work queue); device pointers as integers."""
+    _check(lib().wg_mpc_run_batch_dev(B, states_ptr, int(n_ticks), int(advance_calls), outs_ptr, diag_ptr, stream))
 
 
 def mpc_set_velref_dev(B, states_ptr, vref_ptr, stream=None):

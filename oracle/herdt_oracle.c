@@ -290,11 +290,16 @@ static void op_preview(const wg_model_t *m, wg_gait_state_t *s, double time, con
   unsigned step_number = 0;
   double trunk_end = 0.0;
   int na = 0;
-  while (!vel_ok) {
+  /* The reference loops `while(!TrunkVelOK)` / `while(!TrunkAngleOK)` without bound (OrientationsPreview.cpp:118, 126);
+   * for some references the conditions are never met and it hangs.  Both this restatement and the kernel stop after 64
+   * passes (tools/probe_run.py found such a gait: seed 20100, gait 2012, tick 161). */
+  int guard = 0;
+  while (!vel_ok && guard++ < 64) {
     double cur_sup_angle = (cur.foot == WG_LEFT) ? s->lf[0].theta * M_PI / 180.0 : s->rf[0].theta * M_PI / 180.0;
     if (cur.phase != WG_DS) {
       angle_ok = 0;
-      while (!angle_ok) {
+      int g2 = 0;
+      while (!angle_ok && g2++ < 64) {
         if (fabs(s->trunkT_yaw[1] - s->trunk_yaw[1]) > OP_EPS) {
           double a = s->trunk_yaw[0], b = s->trunk_yaw[1], c = 0.0;
           double d = 3.0 * (s->trunkT_yaw[1] - s->trunk_yaw[1]) / (T * T);
@@ -512,7 +517,7 @@ int wgo_mpc_tick(const wg_model_t *m, wg_gait_state_t *s, wg_tick_out_t *out, wg
   }
 
   /* --- preview_orientations ---------------------------------------------------- */
-  double sup_angles[8], trunk[NMAXH + 1];
+  double sup_angles[8] = {0, 0, 0, 0, 0, 0, 0, 0}, trunk[NMAXH + 1];
   int n_sup_angles = 0;
   op_preview(m, s, time, ref, sup, sup_angles, &n_sup_angles, trunk);
 
