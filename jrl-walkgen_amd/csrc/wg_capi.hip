@@ -266,6 +266,7 @@ namespace {
 wg_model_t g_model;
 bool g_model_set = false;
 wg::TickTables *g_tables_dev = nullptr;
+wg_model_t *g_model_dev = nullptr;     // the model in device memory (multi-tick kernel reads it through a pointer)
 DevBuf g_tick_state, g_tick_out, g_tick_aux, g_run_buf;
 bool g_run_hooked = false;
 
@@ -367,14 +368,21 @@ __global__ void wg_run_queue_init_kernel(int B, int total, wg_run_queue *q, int 
 
 template <int NH>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WG_TICK_WPE_MIN, WG_TICK_WPE_MAX))) void wg_mpc_run_kernel(
-    int B, int n_ticks, wg_model_t model, const wg::TickTables *__restrict__ tb, wg_gait_state_t *__restrict__ states,
-    wg_tick_out_t *__restrict__ outs, int *__restrict__ diag, int advance_calls, wg_run_queue *__restrict__ q,
-    int *__restrict__ ring, int *__restrict__ done, unsigned ql_bytes) {
+    int B, int n_ticks, const wg_model_t *__restrict__ model_p, const wg::TickTables *__restrict__ tb_p,
+    wg_gait_state_t *__restrict__ states_p, wg_tick_out_t *__restrict__ outs_p, int *__restrict__ diag_p, int advance_calls,
+    wg_run_queue *__restrict__ q, int *__restrict__ ring, int *__restrict__ done, unsigned ql_bytes) {
   extern __shared__ __attribute__((aligned(16))) double wg_lds[];
   const int total = B * n_ticks;
   for (;;) {
+    // Everything the tick reads through is made opaque per item, so that nothing loop-invariant (lane-derived values,
+    // model constants, table addresses) is hoisted out of the loop and kept alive across whole ticks: the register
+    // budget is the single tick's.
     int lane = threadIdx.x & 63;
-    asm volatile("" : "+v"(lane));               // opaque per item: nothing lane-dependent is hoisted out of the loop and kept alive
+    asm volatile("" : "+v"(lane));
+    const wg_model_t *mp = model_p; const wg::TickTables *tb = tb_p; wg_gait_state_t *states = states_p;
+    wg_tick_out_t *outs = outs_p; int *diag = diag_p;
+    asm volatile("" : "+s"(mp), "+s"(tb), "+s"(states), "+s"(outs), "+s"(diag));
+    const wg_model_t &model = *mp;
     int idx = 0, g = 0, t = 0;
     if (lane == 0) idx = atomicAdd(&q->head, 1);
     idx = wg::uni(idx);
@@ -463,8 +471,18 @@ int wg_mpc_configure(const wg_model_t *model) {
   std::lock_guard<std::mutex> lk(g_mu);
   static wg::TickTables host_tables;
   wg::build_tables(*model, host_tables);
-  if (!g_tables_dev) HIP_TRY(hipMalloc(reinterpret_cast<void **>(&g_tables_dev), sizeof(wg::TickTables)));
+  if (!g_tables_dev) {
+    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&g_tables_dev), sizeof(wg::TickTables)));
+    g_release_hooks.push_back([] {
+      if (g_tables_dev) (void)hipFree(g_tables_dev);
+      if (g_model_dev) (void)hipFree(g_model_dev);
+      g_tables_dev = nullptr; g_model_dev = nullptr; g_model_set = false;
+      g_tick_state.release(); g_tick_out.release(); g_tick_aux.release();
+    });
+  }
   HIP_TRY(hipMemcpy(g_tables_dev, &host_tables, sizeof host_tables, hipMemcpyHostToDevice));
+  if (!g_model_dev) HIP_TRY(hipMalloc(reinterpret_cast<void **>(&g_model_dev), sizeof(wg_model_t)));
+  HIP_TRY(hipMemcpy(g_model_dev, model, sizeof(wg_model_t), hipMemcpyHostToDevice));
   g_model = *model;
   g_model_set = true;
   return WG_OK;
@@ -543,13 +561,13 @@ int wg_mpc_run_batch_dev(int B, wg_gait_state_t *states, int n_ticks, int advanc
   int grid = g_num_cu * per_cu;
   if (grid > B) grid = B;
   if (view == 16)
-    hipLaunchKernelGGL(wg_mpc_run_kernel<16>, dim3(grid), dim3(64), lds, st, B, n_ticks, g_model, g_tables_dev, states, outs,
+    hipLaunchKernelGGL(wg_mpc_run_kernel<16>, dim3(grid), dim3(64), lds, st, B, n_ticks, g_model_dev, g_tables_dev, states, outs,
                        diag, advance_calls, q, ring, done, (unsigned)qlb);
   else if (view == 0)
-    hipLaunchKernelGGL(wg_mpc_run_kernel<0>, dim3(grid), dim3(64), lds, st, B, n_ticks, g_model, g_tables_dev, states, outs,
+    hipLaunchKernelGGL(wg_mpc_run_kernel<0>, dim3(grid), dim3(64), lds, st, B, n_ticks, g_model_dev, g_tables_dev, states, outs,
                        diag, advance_calls, q, ring, done, (unsigned)qlb);
   else
-    hipLaunchKernelGGL(wg_mpc_run_kernel<-1>, dim3(grid), dim3(64), lds, st, B, n_ticks, g_model, g_tables_dev, states, outs,
+    hipLaunchKernelGGL(wg_mpc_run_kernel<-1>, dim3(grid), dim3(64), lds, st, B, n_ticks, g_model_dev, g_tables_dev, states, outs,
                        diag, advance_calls, q, ring, done, (unsigned)qlb);
   HIP_TRY(hipGetLastError());
   return WG_OK;

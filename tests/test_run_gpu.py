@@ -1,0 +1,99 @@
+"""Multi-tick launches (wg_mpc_run_batch_dev: a device-side work queue of (gait, next tick), no batch-wide drain between
+ticks) against one launch per tick and against the CPU oracle: gait states, per-tick diagnostics and per-tick outputs
+must be the same bytes, whatever the order in which the queue happened to serve the gaits.  Shapes cover a batch smaller
+than the resident wave slots (waves poll the queue), a batch of several rounds, a single tick, and the dense view."""
+import ctypes as C
+import importlib
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import oraclelib as ol
+
+pytestmark = pytest.mark.gpu
+wg = importlib.import_module("jrl-walkgen_amd")
+
+
+def _ptrig():
+    ol.build_oracle()
+    return C.CDLL(os.path.join(ol.ORACLE_DIR, "libwg_oracle_ptrig.so"))
+
+
+def _start(model, B, rng):
+    s0 = wg.gait_init(model, [0.0316055, 0.0, 0.7116911], [0.0, 0.09, 0.0], [0.0, -0.09, 0.0])
+    s0.nb_steps_left = 2
+    arr = (wg.GaitState * B)()
+    for g in range(B):
+        C.memmove(C.byref(arr[g]), C.byref(s0), C.sizeof(wg.GaitState))
+        arr[g].vref[0], arr[g].vref[1], arr[g].vref[2] = rng.uniform(-0.1, 0.3), rng.uniform(-0.1, 0.1), rng.uniform(-0.2, 0.2)
+    return arr
+
+
+def _dev(arr):
+    return torch.frombuffer(bytearray(bytes(memoryview(arr).cast("B"))), dtype=torch.uint8).cuda()
+
+
+@pytest.mark.parametrize("B,T,want_out", [(40, 30, True), (1, 7, False), (3000, 12, False), (64, 1, True)])
+def test_run_batch_equals_single_tick_launches_and_oracle(B, T, want_out):
+    wg.init(0)
+    model = wg.model_defaults()
+    wg.mpc_configure(model)
+    rng = np.random.default_rng(B + T)
+    host = _start(model, B, rng)
+    per_tick = (model.T / model.Tctrl)
+    adv = int(round(per_tick))
+    a = _dev(host); b = _dev(host)
+    # the two special clock advances of the control loop's first ticks, the same way on both copies
+    for st in (a, b):
+        wg.mpc_tick_batch_dev(B, st.data_ptr(), None, None, 1)
+        wg.mpc_tick_batch_dev(B, st.data_ptr(), None, None, adv - 1)
+    osz = C.sizeof(wg.TickOut)
+    da = torch.zeros(T, B, 6, dtype=torch.int32, device="cuda"); db = torch.zeros_like(da)
+    oa = torch.zeros(T, B, osz, dtype=torch.uint8, device="cuda") if want_out else None
+    ob = torch.zeros_like(oa) if want_out else None
+    for t in range(T):
+        wg.mpc_tick_batch_dev(B, a.data_ptr(), oa[t].data_ptr() if want_out else None, da[t].data_ptr(), adv)
+    wg.mpc_run_batch_dev(B, b.data_ptr(), T, adv, ob.data_ptr() if want_out else None, db.data_ptr())
+    torch.cuda.synchronize()
+    assert torch.equal(a, b) and torch.equal(da, db)
+    if want_out:
+        assert torch.equal(oa, ob)
+    assert int((db[:, :, 0] != 0).sum()) == 0                     # every QP solved
+    # and the oracle, on a sample of the gaits
+    pt = _ptrig()
+    final = b.cpu().numpy().reshape(B, -1)
+    for g in sorted(set([0, B // 2, B - 1])):
+        ref = wg.GaitState()
+        C.memmove(C.byref(ref), C.byref(host[g]), C.sizeof(wg.GaitState))
+        for k in [1, adv - 1] + [adv] * T:
+            c = ref.clock
+            for _ in range(k):
+                c += model.Tctrl
+            ref.clock = c
+            assert pt.wgo_mpc_tick(C.byref(model), C.byref(ref), None, None) == 0
+        assert bytes(memoryview(ref).cast("B")) == final[g].tobytes(), g
+
+
+def test_run_batch_dense_view_and_arguments():
+    wg.init(0)
+    model = wg.model_defaults()
+    model.N = 12                                                  # dense view
+    wg.mpc_configure(model)
+    try:
+        rng = np.random.default_rng(12)
+        B, T, adv = 20, 10, 20
+        host = _start(model, B, rng)
+        a = _dev(host); b = _dev(host)
+        for t in range(T):
+            wg.mpc_tick_batch_dev(B, a.data_ptr(), None, None, adv)
+        wg.mpc_run_batch_dev(B, b.data_ptr(), T, adv)
+        torch.cuda.synchronize()
+        assert torch.equal(a, b)
+        lib = wg.lib()
+        assert lib.wg_mpc_run_batch_dev(-1, b.data_ptr(), 1, adv, None, None, None) == -2
+        assert lib.wg_mpc_run_batch_dev(B, None, 1, adv, None, None, None) == -2
+        assert lib.wg_mpc_run_batch_dev(B, b.data_ptr(), 0, adv, None, None, None) == 0     # nothing to do
+    finally:
+        wg.mpc_configure(wg.model_defaults())
