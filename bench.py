@@ -2,13 +2,15 @@
 """bench.py -- MPC ticks/s of the MI355X-native Herdt-2010 hot path.
 
 Metric (BASELINE.json): QP-MPC ticks/sec at batch = 4096 gaits per GPU, horizon N = 16, fp64.
-One *step* = one MPC tick for every gait of the batch = one launch of the fused tick kernel
-(support-state preview, orientation preview, QP assembly, QL dual active-set solve, LIPM update, feet).
+One *step* = one MPC tick for every gait of the batch (support-state preview, orientation preview, QP assembly, QL dual
+active-set solve, LIPM update, feet).  Steps between two changes of the velocity references go into ONE launch of the
+multi-tick kernel (wg_mpc_run_batch_dev): a gait's tick t+1 depends only on its own tick t, so the batch does not drain
+between ticks; results are identical to one launch per tick (tests/test_run_gpu.py; --per-tick-launch times that mode).
 Workload (SURVEY.md section 8d, config[2]): B independent gaits, common start state, per-gait piecewise-constant
 velocity references vx~U[-0.1,0.3], vy~U[-0.1,0.1], w~U[-0.2,0.2] redrawn every 5 s (50 ticks) from
 MT19937-64 seeded 20100 + global gait index.  All inputs are resident in HBM before the timed region.
 
-    python bench.py                       # 1 GPU, K = 200 steps, W = 20 warm-up steps
+    python bench.py                       # 1 GPU, K = 200 steps, W = 50 warm-up steps
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
            bench.py --gpus N --steps K --warmup W      # weak scaling: 4096 gaits per GPU, one RCCL broadcast
 """
@@ -110,7 +112,9 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=50)
+    ap.add_argument("--per-tick-launch", action="store_true", help="one launch per tick (wg_mpc_tick_batch_dev) instead of "
+                    "one launch per stretch of constant velocity references")
     ap.add_argument("--batch", type=int, default=BATCH_PER_GPU, help="gaits per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -154,43 +158,66 @@ def main():
     sp, dp = states.data_ptr(), diag.data_ptr()
     dstride = B * 6 * 4
 
-    def step(t):
+    def launches(t0, t1):
+        """[(first tick, number of ticks)] covering ticks [t0, t1): the control loop's first two ticks advance the clock
+        by 1 and 19 control periods and go alone; otherwise one launch per stretch of constant references."""
+        out = []
+        t = t0
+        while t < t1:
+            if t < 2 or args.per_tick_launch:
+                n = 1
+            else:
+                n = min(t1, (t // REDRAW_TICKS + 1) * REDRAW_TICKS) - t
+            out.append((t, n))
+            t += n
+        return out
+
+    def redraw(t):
         if t % REDRAW_TICKS == 0:
             wg.mpc_set_velref_dev(B, sp, vtab[t // REDRAW_TICKS].data_ptr(), sh)
+
+    def fire(t, n):
         adv = 1 if t == 0 else (19 if t == 1 else 20)
-        wg.mpc_tick_batch_dev(B, sp, None, dp + t * dstride, adv, stream=sh)
+        if n == 1 and (t < 2 or args.per_tick_launch):
+            wg.mpc_tick_batch_dev(B, sp, None, dp + t * dstride, adv, stream=sh)
+        else:
+            wg.mpc_run_batch_dev(B, sp, n, adv, None, dp + t * dstride, stream=sh)
 
     with torch.cuda.stream(stream):
-        for t in range(W):
-            step(t)
+        for t, n in launches(0, W):
+            redraw(t)
+            fire(t, n)
     torch.cuda.synchronize(dev)
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(K)]
+    timed = launches(W, W + K)
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in timed]
 
     shard.barrier()
     torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
     with torch.cuda.stream(stream):
-        for k in range(K):
-            t = W + k
-            if t % REDRAW_TICKS == 0:
-                wg.mpc_set_velref_dev(B, sp, vtab[t // REDRAW_TICKS].data_ptr(), sh)
+        for k, (t, n) in enumerate(timed):
+            redraw(t)
             ev[k][0].record(stream)
-            wg.mpc_tick_batch_dev(B, sp, None, dp + t * dstride, 1 if t == 0 else (19 if t == 1 else 20), stream=sh)
+            fire(t, n)
             ev[k][1].record(stream)
     torch.cuda.synchronize(dev)
     shard.barrier()
     elapsed = time.perf_counter() - t0
     elapsed = shard.max_over_ranks(elapsed, dev)
 
-    kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+    durs = [a.elapsed_time(b) for a, b in ev]
+    kern_ms_total = float(np.sum(durs))
+    kern_ms = float(np.mean(durs))
+    ticks_per_launch = max(n for _, n in timed)
     d = diag[W:].cpu().numpy().reshape(-1, 6)
     n_fail = int((d[:, 0] != 0).sum())
-    alg_bytes_per_launch = float(algorithmic_bytes(d[:, 3].astype(np.float64), d[:, 4].astype(np.float64)).sum() / K)
+    alg_bytes_total = float(algorithmic_bytes(d[:, 3].astype(np.float64), d[:, 4].astype(np.float64)).sum())
+    alg_bytes_per_launch = alg_bytes_total / len(timed)
     ticks_total = shard.sum_over_ranks(B * K, dev)
     value = ticks_total / elapsed
 
     if rank == 0:
-        achieved = alg_bytes_per_launch / (kern_ms * 1e-3) / 1e9
+        achieved = alg_bytes_total / (kern_ms_total * 1e-3) / 1e9          # = bytes per launch / average launch duration
         traffic = None
         pmc = os.path.join(ROOT, "profiles", "round1_pmc_summary.json")
         if os.path.exists(pmc):
@@ -208,10 +235,14 @@ def main():
                        "batch_per_gpu": B, "horizon_N": int(model.N), "qp_T": model.T,
                        "velocity_refs": "U[-0.1,0.3] x U[-0.1,0.1] x U[-0.2,0.2], redrawn every 50 ticks, "
                                         "MT19937-64 seed 20100+gait",
-                       "sharding": "gaits by contiguous index range, one RCCL broadcast of the model block"},
+                       "sharding": "gaits by contiguous index range, one RCCL broadcast of the model block",
+                       "launch": ("one launch per tick (wg_mpc_tick_batch_dev)" if args.per_tick_launch else
+                                  "one launch per stretch of constant references (wg_mpc_run_batch_dev, device-side work "
+                                  "queue): %d launches, up to %d ticks each" % (len(timed), ticks_per_launch))},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "wg_mpc_tick_kernel", "kernel_ms": kern_ms,
+                         "kernel": "wg_mpc_tick_kernel" if args.per_tick_launch else "wg_mpc_run_kernel",
+                         "kernel_ms": kern_ms, "launches": len(timed), "ticks_per_launch": ticks_per_launch,
                          "algorithmic_bytes_per_launch": alg_bytes_per_launch},
             "solver": {"mean_iterations": float(d[:, 1].mean()), "max_iterations": int(d[:, 1].max()),
                        "mean_active": float(d[:, 2].mean()), "failed_qps": n_fail,

@@ -3,7 +3,7 @@
 set -u
 export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-bash $R/tools/prof.sh tick bench.py --steps 50 --warmup 10 --no-cpu-baseline > $R/gpurun_out/prof_tick.log 2>&1
+bash $R/tools/prof.sh tick bench.py --steps 200 --warmup 50 --no-cpu-baseline > $R/gpurun_out/prof_tick.log 2>&1
 cd /tmp
 for spec in "dimitrov tools/probe_dimitrov.py" "pldp tools/probe_pldp.py" "preview tools/probe_preview.py"; do
   set -- $spec

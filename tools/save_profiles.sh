@@ -11,14 +11,16 @@ python - "$TAG" <<'PY'
 import json, sys
 tag = sys.argv[1]
 s = json.load(open(f'profiles/{tag}_tick_rocprofv3_summary.json'))
-k = 'wg_mpc_tick_kernel<16>'
+k = 'wg_mpc_run_kernel<16>'
 h = s['hbm'][k]
 out = {"kernel": k, "hbm_bytes_per_launch": h['hbm_bytes_per_launch'],
        "read_bytes_per_launch_corrected": h['read_bytes_per_launch_corrected'],
        "write_bytes_per_launch": h['write_bytes_per_launch'],
-       "known_bytes_per_launch": {"state_read": 2 * 4947968, "state_write": 2 * 4947968, "diag_write": 98304},
+       "ticks_per_launch": 49.6,
+       "known_bytes_per_tick": {"state_read": 2 * 4947968, "state_write": 2 * 4947968, "diag_write": 98304},
        "source": f"profiles/{tag}_tick_rocprofv3_summary.json: separate rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE passes of "
-                 "`python bench.py --steps 50 --warmup 10 --no-cpu-baseline` (B=4096 gaits per launch), tools/prof.sh. Units and "
+                 "`python bench.py --steps 200 --warmup 50 --no-cpu-baseline` (B=4096 gaits, 50 ticks per launch of the multi-tick "
+                 "kernel; the mean is over one 48-tick and four 50-tick launches), tools/prof.sh. Units and "
                  "correction per MI355X_MICROARCH.md: KiB x1024; FETCH_SIZE doubled (gfx950 tallies 128-B requests at 64 B). The "
                  "state is written twice and read twice per tick (it is parked in its HBM slot during the solve to free LDS); "
                  "WRITE_SIZE equals those bytes + diagnostics (no scratch: the kernel has no spills).",
