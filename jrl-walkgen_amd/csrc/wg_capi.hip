@@ -393,7 +393,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WG_TICK_WPE_
       t = __hip_atomic_load(done + g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     g = wg::uni(g); t = wg::uni(t);
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");          // the gait's previous tick may have run on another CU
+    // the gait's previous tick may have run on another CU / XCD: its state is read with agent-scope loads (mpc_tick), the
+    // ring entry was read with acquire -- no further invalidate here
     if (advance_calls > 0) {
       if (lane == 0) {
         double c = __hip_atomic_load(&states[g].clock, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

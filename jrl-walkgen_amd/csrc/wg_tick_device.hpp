@@ -803,9 +803,10 @@ __device__ __forceinline__ TickDiag mpc_tick(const wg_model_t &m, const TickTabl
     qr = ql_solve(q, prob, 1e-8, hist, hist_cap);
     {
       WG_WSYNC();
-      // the stores above completed long ago (the release only waits for them); the loads go to L2 (agent-scope atomics:
-      // no stale L1 line of the tick's first read, and no L1 invalidate that would hit the other resident waves)
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      // the stores above completed long ago (the release only waits for them: they are in L2 then, which is where the
+      // loads go -- agent-scope atomics: no stale L1 line of the tick's first read, no L1 invalidate that would hit the
+      // other resident waves, and no L2 write-back: the same CU reads back what it wrote)
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
       const double *src = reinterpret_cast<const double *>(gstate);
       double *dst = reinterpret_cast<double *>(s);
       for (int i = lane; i < (int)(sizeof(wg_gait_state_t) / 8); i += 64)
