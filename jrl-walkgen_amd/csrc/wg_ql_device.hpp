@@ -258,7 +258,7 @@ __device__ __forceinline__ double sqrt_1to2(double x) {
 __device__ __forceinline__ double givens_norm(double p, double qq) {
   const double ap = fabs(p), aq = fabs(qq);
   const bool pbig = ap >= aq;                      // maxd(): a >= b ? a : b
-  const double t = pbig ? ap : aq;
+  const double t = __builtin_fmax(ap, aq);         // the value of the select (finite operands), one instruction
   const double d = (pbig ? qq : p) / t;            // |d| <= 1
   const double x = 1.0 + d * d;
 #ifdef WG_GENERIC_SQRT
