@@ -338,55 +338,61 @@ __device__ __forceinline__ void backsub(const QlView &q, const double *s, int na
 // The v_readlane form above costs ~40 cycles per term (two readlanes + add, serialised); this one ~8.
 // buf: 2 * kBsLen doubles of LDS (the four scratch vectors are contiguous).
 constexpr int kBsLen = 48;
-__device__ __forceinline__ void backsub_lds(const QlView &q, const double *s, int nact, int lane, double *buf) {
-  const bool mine = lane < nact;
-  const double sreg = mine ? s[lane] : 0.0;
-  const double dreg = mine ? Rp(lane, lane) : 1.0;
-  if (lane < kBsLen) { buf[lane] = 0.0; buf[kBsLen + lane] = 0.0; }
-  const int col = mine ? lane : 0;
-  double w = 0.0, wprev = 0.0;
-  double p0 = 0.0, p1 = 0.0, p2 = 0.0, p3 = 0.0, p4 = 0.0, p5 = 0.0, p6 = 0.0, p7 = 0.0;   // row j's terms k = j+2 .. j+9
-  double rcur = 0.0;                                       // R(j, j+1)
-  double rr = Rp(nact >= 2 ? nact - 2 : 0, col);           // R(j-1, lane) of the row whose products are formed next
-  for (int j = nact - 1; j >= 0; --j) {
-    const double *bj = buf + (j & 1) * kBsLen;
-    double *bn = buf + ((j & 1) ^ 1) * kBsLen;
-    const int jn = j >= 1 ? j - 1 : 0, jnn = j >= 2 ? j - 2 : 0;
-    // products of the next row (j-1) with the multipliers known so far (k >= j+1); nothing here waits on LDS: R(j-1, .)
-    // was fetched one row ahead, and a wave's LDS operations execute in order (the barrier only pins the compiler)
-    {
-      const double val = (lane >= j + 1 && mine) ? rr * w : 0.0;
-      if (lane < kBsLen) bn[lane] = val;
-      rr = Rp(jnn, col);
-    }
-    __builtin_amdgcn_wave_barrier();
-    const double n0 = bn[j + 1], n1 = bn[j + 2], n2 = bn[j + 3], n3 = bn[j + 4], n4 = bn[j + 5], n5 = bn[j + 6],
-                 n6 = bn[j + 7], n7 = bn[j + 8];           // prefetch: the next row's first terms
-    const double rnext = Rp(jn, jn + 1);
-    const double sj = rl(sreg, j), dj = rl(dreg, j);
-    double sum = 0.0;
-    if (j + 1 < nact) {
-      sum += rcur * wprev;
-      sum += p0; sum += p1; sum += p2; sum += p3;
-      if (j + 6 < nact) {
-        sum += p4; sum += p5; sum += p6; sum += p7;
-        if (j + 10 < nact) {
-          double a0 = bj[j + 10], a1 = bj[j + 11], a2 = bj[j + 12], a3 = bj[j + 13];
-          for (int k = j + 10; k < nact; k += 4) {
-            const int kn = k + 4 < kBsLen - 4 ? k + 4 : kBsLen - 4;                // clamped: unused past the end
-            const double b0 = bj[kn], b1 = bj[kn + 1], b2 = bj[kn + 2], b3 = bj[kn + 3];
-            sum += a0; sum += a1; sum += a2; sum += a3;
-            a0 = b0; a1 = b1; a2 = b2; a3 = b3;
-          }
+// one row of backsub_lds: P = {terms k = j+2 .. j+9, R(j, j+1)} prefetched by the previous row, Nx receives the same for
+// row j-1.  Two copies of this body with P / Nx swapped make the hand-over a renaming instead of nine register moves.
+struct BsState { double w, wprev, rr, sreg, dreg; int col, nact, lane; bool mine; };
+__device__ __forceinline__ void bs_row(const QlView &q, double *buf, int j, BsState &S, const double (&P)[9], double (&Nx)[9]) {
+  const double *bj = buf + (j & 1) * kBsLen;
+  double *bn = buf + ((j & 1) ^ 1) * kBsLen;
+  const int jn = j >= 1 ? j - 1 : 0, jnn = j >= 2 ? j - 2 : 0;
+  const int nact = S.nact, lane = S.lane;
+  // products of the next row (j-1) with the multipliers known so far (k >= j+1); nothing here waits on LDS: R(j-1, .)
+  // was fetched one row ahead, and a wave's LDS operations execute in order (the barrier only pins the compiler)
+  {
+    const double val = (lane >= j + 1 && S.mine) ? S.rr * S.w : 0.0;
+    if (lane < kBsLen) bn[lane] = val;
+    S.rr = Rp(jnn, S.col);
+  }
+  __builtin_amdgcn_wave_barrier();
+#pragma unroll
+  for (int e = 0; e < 8; ++e) Nx[e] = bn[j + 1 + e];        // prefetch: the next row's first terms
+  Nx[8] = Rp(jn, jn + 1);
+  const double sj = rl(S.sreg, j), dj = rl(S.dreg, j);
+  double sum = 0.0;
+  if (j + 1 < nact) {
+    sum += P[8] * S.wprev;
+    sum += P[0]; sum += P[1]; sum += P[2]; sum += P[3];
+    if (j + 6 < nact) {
+      sum += P[4]; sum += P[5]; sum += P[6]; sum += P[7];
+      if (j + 10 < nact) {
+        double a0 = bj[j + 10], a1 = bj[j + 11], a2 = bj[j + 12], a3 = bj[j + 13];
+        for (int k = j + 10; k < nact; k += 4) {
+          const int kn = k + 4 < kBsLen - 4 ? k + 4 : kBsLen - 4;                  // clamped: unused past the end
+          const double b0 = bj[kn], b1 = bj[kn + 1], b2 = bj[kn + 2], b3 = bj[kn + 3];
+          sum += a0; sum += a1; sum += a2; sum += a3;
+          a0 = b0; a1 = b1; a2 = b2; a3 = b3;
         }
       }
     }
-    const double v = (sj - sum) / dj;
-    if (lane == j) w = v;
-    wprev = v;
-    p0 = n0; p1 = n1; p2 = n2; p3 = n3; p4 = n4; p5 = n5; p6 = n6; p7 = n7; rcur = rnext;
   }
-  if (mine) q.ww[lane] = w;
+  const double v = (sj - sum) / dj;
+  if (lane == j) S.w = v;
+  S.wprev = v;
+}
+__device__ __forceinline__ void backsub_lds(const QlView &q, const double *s, int nact, int lane, double *buf) {
+  BsState S;
+  S.mine = lane < nact; S.nact = nact; S.lane = lane;
+  S.sreg = S.mine ? s[lane] : 0.0;
+  S.dreg = S.mine ? Rp(lane, lane) : 1.0;
+  if (lane < kBsLen) { buf[lane] = 0.0; buf[kBsLen + lane] = 0.0; }
+  S.col = S.mine ? lane : 0;
+  S.w = 0.0; S.wprev = 0.0;
+  S.rr = Rp(nact >= 2 ? nact - 2 : 0, S.col);               // R(j-1, lane) of the row whose products are formed next
+  double A9[9] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0}, B9[9];
+  int j = nact - 1;
+  for (; j >= 1; j -= 2) { bs_row(q, buf, j, S, A9, B9); bs_row(q, buf, j - 1, S, B9, A9); }
+  if (j == 0) bs_row(q, buf, 0, S, A9, B9);
+  if (S.mine) q.ww[lane] = S.w;
   WG_WSYNC();
 }
 
