@@ -466,25 +466,36 @@ __device__ __forceinline__ void sweep_flat(const QlView &q, double *s, int nu, i
   }
   WG_WSYNC();
   {
+    // phase 3: lane i carries row i of Z through the rotations.  Operands of rotation c -- Z(i, c-1) and the pair
+    // (ga, gb) -- are fetched three rotations ahead into one of three register sets used in turn (an unroll by three, so
+    // that handing a set on is a renaming, not a move).
     const int i = lane < n ? lane : n - 1;                  // surplus lanes shadow row n-1
     const int ldz = q.ldz;
     double *zp = q.Z + i + (nu - 1) * ldz;                  // Z(i, c)
     double carry = zp[0];
-    double zl = zp[-ldz];
-    double ga = gab[2 * (nu - 1)], gb = gab[2 * (nu - 1) + 1];
-    int c1 = nu - 2 > nact ? nu - 2 : nact + 1;             // rotation after the current one (clamped)
-    double zl1 = q.Z[i + (c1 - 1) * ldz], ga1 = gab[2 * c1], gb1 = gab[2 * c1 + 1];
-    for (int c = nu - 1; c > nact; --c) {
-      const int c2 = c - 2 > nact ? c - 2 : nact + 1;       // two rotations ahead (clamped: value unused past the end)
-      const double zl2 = q.Z[i + (c2 - 1) * ldz], ga2 = gab[2 * c2], gb2 = gab[2 * c2 + 1];
-      const bool skip = (gb == 0.0);
-      const double t_r = ga * zl + gb * carry;
-      const double z_r = ga * carry - gb * zl;
+    struct Op { double zl, ga, gb; };
+    auto fetch = [&](int c) -> Op {                         // operands of rotation c (clamped: unused past the end)
+      const int cc = c > nact ? c : nact + 1;
+      Op o; o.zl = q.Z[i + (cc - 1) * ldz]; o.ga = gab[2 * cc]; o.gb = gab[2 * cc + 1];
+      return o;
+    };
+    auto rotate = [&](const Op &o) {
+      const bool skip = (o.gb == 0.0);
+      const double t_r = o.ga * o.zl + o.gb * carry;
+      const double z_r = o.ga * carry - o.gb * o.zl;
       zp[0] = skip ? carry : z_r;
-      carry = skip ? zl : t_r;
+      carry = skip ? o.zl : t_r;
       zp -= ldz;
-      zl = zl1; ga = ga1; gb = gb1;
-      zl1 = zl2; ga1 = ga2; gb1 = gb2;
+    };
+    Op s0 = fetch(nu - 1), s1 = fetch(nu - 2), s2 = fetch(nu - 3);
+    int c = nu - 1;
+    for (;;) {
+      { const Op nx = fetch(c - 3); rotate(s0); s0 = nx; }
+      if (--c <= nact) break;
+      { const Op nx = fetch(c - 3); rotate(s1); s1 = nx; }
+      if (--c <= nact) break;
+      { const Op nx = fetch(c - 3); rotate(s2); s2 = nx; }
+      if (--c <= nact) break;
     }
     zp[0] = carry;                                           // Z(i, nact)
   }
