@@ -5,7 +5,9 @@ Metric (BASELINE.json): QP-MPC ticks/sec at batch = 4096 gaits per GPU, horizon 
 One *step* = one MPC tick for every gait of the batch (support-state preview, orientation preview, QP assembly, QL dual
 active-set solve, LIPM update, feet).  Steps between two changes of the velocity references go into ONE launch of the
 multi-tick kernel (wg_mpc_run_batch_dev): a gait's tick t+1 depends only on its own tick t, so the batch does not drain
-between ticks; results are identical to one launch per tick (tests/test_run_gpu.py; --per-tick-launch times that mode).
+between ticks; results are identical to one launch per tick (tests/test_run_gpu.py).  The JSON line also carries that
+mode's rate, measured in the same process on the following ticks ("per_tick_launch"); --per-tick-launch makes it the
+primary figure.
 Workload (SURVEY.md section 8d, config[2]): B independent gaits, common start state, per-gait piecewise-constant
 velocity references vx~U[-0.1,0.3], vy~U[-0.1,0.1], w~U[-0.2,0.2] redrawn every 5 s (50 ticks) from
 MT19937-64 seeded 20100 + global gait index.  All inputs are resident in HBM before the timed region.
@@ -117,6 +119,7 @@ def main():
                     "one launch per stretch of constant velocity references")
     ap.add_argument("--batch", type=int, default=BATCH_PER_GPU, help="gaits per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-per-tick-leg", action="store_true", help="skip the secondary one-launch-per-tick measurement")
     args = ap.parse_args()
 
     # CPU baseline first: it forks one worker per host core, which must happen before this process touches the GPU
@@ -149,7 +152,7 @@ def main():
     B = args.batch
     lo, hi = rank * B, (rank + 1) * B                         # weak scaling: B gaits per GPU
     K, W = args.steps, args.warmup
-    n_seg = (K + W + REDRAW_TICKS - 1) // REDRAW_TICKS
+    n_seg = (K + W + min(K, 100) + REDRAW_TICKS - 1) // REDRAW_TICKS
     vtab = torch.from_numpy(velocity_table(lo, hi, n_seg)).to(dev)
     states = start_states(model, B).to(dev)
     diag = torch.zeros(K + W, B, 6, dtype=torch.int32, device=dev)
@@ -205,6 +208,23 @@ def main():
     elapsed = time.perf_counter() - t0
     elapsed = shard.max_over_ranks(elapsed, dev)
 
+    # secondary figure, same process: one launch per tick (the batch drains between ticks) over the next ticks
+    alt = None
+    if not args.per_tick_launch and not args.no_per_tick_leg:
+        K2 = min(K, 100)
+        need = W + K + K2
+        if need <= vtab.shape[0] * REDRAW_TICKS:
+            shard.barrier(); torch.cuda.synchronize(dev)
+            t1 = time.perf_counter()
+            with torch.cuda.stream(stream):
+                for t in range(W + K, need):
+                    redraw(t)
+                    wg.mpc_tick_batch_dev(B, sp, None, None, 20, stream=sh)
+            torch.cuda.synchronize(dev); shard.barrier()
+            e2 = shard.max_over_ranks(time.perf_counter() - t1, dev)
+            alt = {"value": shard.sum_over_ranks(B * K2, dev) / e2, "steps": K2, "ms_per_step": 1e3 * e2 / K2,
+                   "note": "same workload continued with one launch per tick (wg_mpc_tick_batch_dev)"}
+
     durs = [a.elapsed_time(b) for a, b in ev]
     kern_ms_total = float(np.sum(durs))
     kern_ms = float(np.mean(durs))
@@ -248,6 +268,8 @@ def main():
                        "mean_active": float(d[:, 2].mean()), "failed_qps": n_fail,
                        "n_hist": {str(int(k)): int(v) for k, v in zip(*np.unique(d[:, 3], return_counts=True))}},
         }
+        if alt is not None:
+            line["per_tick_launch"] = alt
         if cpu_line is not None:
             line["cpu_baseline"] = cpu_line
         print(json.dumps(line), flush=True)
