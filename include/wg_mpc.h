@@ -233,7 +233,9 @@ int wg_mpc_tick_batch_dev(int B, wg_gait_state_t *states, wg_tick_out_t *outs, i
  * tick) items from a device-side queue, and a gait is offered again as soon as its tick is done.  Same results as
  * n_ticks calls of wg_mpc_tick_batch_dev with the same advance_calls, bit for bit; the velocity references stay what they
  * are for the whole launch (change them between launches with wg_mpc_set_velref_dev).
- *   outs  n_ticks x B (tick-major) or NULL;  diag  n_ticks x B x 6 (tick-major) or NULL. */
+ *   outs  n_ticks x B (tick-major) or NULL;  diag  n_ticks x B x 6 (tick-major) or NULL.
+ * No add/drop history in this mode.  The queue lives in a library-owned device buffer: one such launch in flight per
+ * process at a time (launches on one stream are fine -- they run one after the other). */
 int wg_mpc_run_batch_dev(int B, wg_gait_state_t *states, int n_ticks, int advance_calls, wg_tick_out_t *outs, int *diag,
                          void *hip_stream);
 /* NewVelRef_ <- (vx, vy, vyaw) for every gait (":setVelReference", ZMPVelocityReferencedQP.hh:103-114);
