@@ -768,8 +768,8 @@ wg_dimitrov_tick_kernel(int B, const wg::DimitrovConst *__restrict__ K, const wg
                         wg_dimitrov_state_t *states, wg_dimitrov_out_t *outs, int max_iter) {
   extern __shared__ __attribute__((aligned(16))) unsigned char dim_lds[];
   const int N = K->N;
-  for (int g = blockIdx.x; g < B; g += gridDim.x)
-    wg::dimitrov_tick(*K, dim_lds, polys + (size_t)g * N, states + g, outs ? outs + g : nullptr, max_iter);
+  const int g = blockIdx.x;                       // one gait per block (grid == B), like the Herdt tick
+  if (g < B) wg::dimitrov_tick(*K, dim_lds, polys + (size_t)g * N, states + g, outs ? outs + g : nullptr, max_iter);
 }
 
 namespace {
@@ -838,10 +838,7 @@ int wg_dimitrov_tick_batch_dev(int B, const wg_zmp_polytope_t *polys, wg_dimitro
   if (lds > 64 * 1024)
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(wg_dimitrov_tick_kernel),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  int per_cu = (int)((160 * 1024) / lds);
-  if (per_cu < 1) per_cu = 1;
-  int grid = g_num_cu * per_cu * 2;
-  if (grid > B) grid = B;
+  const int grid = B;
   hipLaunchKernelGGL(wg_dimitrov_tick_kernel, dim3(grid), dim3(64), lds, reinterpret_cast<hipStream_t>(hip_stream), B,
                      g_dim_dev, polys, states, outs, max_iter);
   HIP_TRY(hipGetLastError());
