@@ -918,10 +918,26 @@ int wg_preview_run_batch_dev(int B, int L, const double *zmp_x_tm, const double 
   if (!g_prev_set) return fail(WG_ERR_BAD_ARG, "wg_preview_configure() has not been called");
   if (B < 0 || L < 0 || !zmp_x_tm || !zmp_y_tm || !state) return fail(WG_ERR_BAD_ARG, "bad arguments");
   if (B == 0 || L == 0) return WG_OK;
-  const int threads = B >= 4096 ? 256 : 64;                   // small batches: more blocks, one wave each
-  hipLaunchKernelGGL(wg::wg_preview_kernel, dim3((B + threads - 1) / threads, 2), dim3(threads), 0,
-                     reinterpret_cast<hipStream_t>(hip_stream), B, L, g_prev, g_prev_F, zmp_x_tm, zmp_y_tm, state, com_tm,
-                     zmp2_tm, simulation);
+  hipStream_t st = reinterpret_cast<hipStream_t>(hip_stream);
+  const char *force = getenv("WG_PREVIEW_KERNEL");            // "l2" / "ring": tests compare the two
+  // The ring kernel keeps one wave per CU (its window fills the LDS): it wins while the batch is too small to give every
+  // SIMD several waves of the L2 kernel (measured: B = 4096: 0.62 vs 0.43 G gait-steps/s; B = 32768: 1.18 vs 1.50), and
+  // a few steps do not repay filling the ring.
+  const bool ring = force ? force[0] == 'r' : (L >= 8 && (long long)B * 2 <= (long long)g_num_cu * 64 * 2);
+  if (ring) {
+    int R = g_prev.nl < 288 ? g_prev.nl : 288;                 // 288 x 512 B = 144 KB of the CU's 160 KB
+    if (R < 1) R = 1;
+    const size_t lds = (size_t)R * 64 * 8;
+    if (lds > 64 * 1024)
+      HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(wg::wg_preview_ring_kernel),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(wg::wg_preview_ring_kernel, dim3((B + 63) / 64, 2), dim3(64), lds, st, B, L, g_prev, R, g_prev_F,
+                       zmp_x_tm, zmp_y_tm, state, com_tm, zmp2_tm, simulation);
+  } else {
+    const int threads = B >= 4096 ? 256 : 64;                  // small batches: more blocks, one wave each
+    hipLaunchKernelGGL(wg::wg_preview_kernel, dim3((B + threads - 1) / threads, 2), dim3(threads), 0, st, B, L, g_prev,
+                       g_prev_F, zmp_x_tm, zmp_y_tm, state, com_tm, zmp2_tm, simulation);
+  }
   HIP_TRY(hipGetLastError());
   return WG_OK;
 }

@@ -75,6 +75,84 @@ wg_preview_kernel(int B, int L, PreviewConst K, const double *__restrict__ F, co
   st[3 * axis] = x0; st[3 * axis + 1] = x1; st[3 * axis + 2] = x2; st[6 + axis] = s;
 }
 
+// The same iteration with the preview window staged in LDS.  wg_preview_kernel re-reads the whole window from L2 at every
+// step (nl x 512 B per wave-step; measured: the L2 rate, not the ALUs, sets its speed).  Consecutive steps share all but one
+// sample, so this kernel keeps the most recent R samples of its 64 gait-axes in an LDS ring (R x 512 B, up to 144 KB: one
+// wave per CU) and fetches one new row per step; taps beyond R (none when nl <= R) still come from L2.  The taps are
+// visited in the same order (i ascending: the ring is read from the current slot to the end, then from the start), so
+// the sums are the same bits.
+__global__ void __launch_bounds__(64)
+wg_preview_ring_kernel(int B, int L, PreviewConst K, int R, const double *__restrict__ F, const double *__restrict__ zx,
+                       const double *__restrict__ zy, double *__restrict__ state, double *__restrict__ com,
+                       double *__restrict__ zmp2, int simulation) {
+  extern __shared__ __attribute__((aligned(16))) double wg_ring[];      // [R][64]
+  const int lane = threadIdx.x;
+  const int g0 = blockIdx.x * 64 + lane;
+  const bool valid = g0 < B;
+  const int g = valid ? g0 : B - 1;                                     // surplus lanes shadow the last gait (no stores)
+  const int axis = blockIdx.y;
+  const double *__restrict__ z = axis ? zy : zx;
+  const size_t sB = (size_t)B;
+  const int nl = K.nl;
+  const int Lz = L + nl - 1;
+  for (int t = 0; t < R; ++t) wg_ring[t * 64 + lane] = (t < Lz) ? z[(size_t)t * sB + g] : 0.0;
+  double *st = state + (size_t)g * 8;
+  double x0 = st[3 * axis], x1 = st[3 * axis + 1], x2 = st[3 * axis + 2], s = st[6 + axis];
+  int k = 0;                                                            // ring slot of sample l
+  for (int l = 0; l < L; ++l) {
+    const int tn = l + R;                                               // the sample that replaces slot k after this step
+    const double znew = (tn < Lz) ? z[(size_t)tn * sB + g] : 0.0;       // issued early: needed at the end of the step
+    double r = 0.0;
+    r += K.Kx0 * x0; r += K.Kx1 * x1; r += K.Kx2 * x2;
+    double u = -r + K.Ks * s;
+    const double *zl = z + (size_t)l * sB + g;
+    const double z_l = wg_ring[k * 64 + lane];
+    int i = 0;
+    const int nring = nl < R ? nl : R;                                  // taps served by the ring
+    const int first = (R - k) < nring ? (R - k) : nring;                // taps in slots k .. R-1
+    {
+      const double *rp = wg_ring + k * 64 + lane;
+      int c = 0;
+      for (; c + 8 <= first; c += 8, i += 8, rp += 8 * 64) {
+        const double a0 = rp[0], a1 = rp[64], a2 = rp[128], a3 = rp[192], a4 = rp[256], a5 = rp[320], a6 = rp[384], a7 = rp[448];
+        u += F[i + 0] * a0; u += F[i + 1] * a1; u += F[i + 2] * a2; u += F[i + 3] * a3;
+        u += F[i + 4] * a4; u += F[i + 5] * a5; u += F[i + 6] * a6; u += F[i + 7] * a7;
+      }
+      for (; c < first; ++c, ++i, rp += 64) u += F[i] * rp[0];
+    }
+    {
+      const double *rp = wg_ring + lane;                                // wrapped part: slots 0 .. k-1
+      const int second = nring - first;
+      int c = 0;
+      for (; c + 8 <= second; c += 8, i += 8, rp += 8 * 64) {
+        const double a0 = rp[0], a1 = rp[64], a2 = rp[128], a3 = rp[192], a4 = rp[256], a5 = rp[320], a6 = rp[384], a7 = rp[448];
+        u += F[i + 0] * a0; u += F[i + 1] * a1; u += F[i + 2] * a2; u += F[i + 3] * a3;
+        u += F[i + 4] * a4; u += F[i + 5] * a5; u += F[i + 6] * a6; u += F[i + 7] * a7;
+      }
+      for (; c < second; ++c, ++i, rp += 64) u += F[i] * rp[0];
+    }
+    for (; i < nl; ++i) u += F[i] * zl[(size_t)i * sB];                 // taps beyond the ring (nl > R)
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0;
+    a0 += 1.0 * x0; a0 += K.A01 * x1; a0 += K.A02 * x2;
+    a1 += 0.0 * x0; a1 += 1.0 * x1;   a1 += K.A12 * x2;
+    a2 += 0.0 * x0; a2 += 0.0 * x1;   a2 += 1.0 * x2;
+    x0 = a0 + u * K.B0; x1 = a1 + u * K.B1; x2 = a2 + u * K.B2;
+    double p = 0.0;
+    p += 1.0 * x0; p += 0.0 * x1; p += K.C2 * x2;
+    if (simulation) s += (z_l - p);
+    if (valid) {
+      if (com) {
+        double *c = com + ((size_t)l * 6 + 3 * axis) * sB + g;
+        c[0] = x0; c[sB] = x1; c[2 * sB] = x2;
+      }
+      if (zmp2) zmp2[((size_t)l * 2 + axis) * sB + g] = p;
+    }
+    wg_ring[k * 64 + lane] = znew;
+    k = (k + 1 == R) ? 0 : k + 1;
+  }
+  if (valid) { st[3 * axis] = x0; st[3 * axis + 1] = x1; st[3 * axis + 2] = x2; st[6 + axis] = s; }
+}
+
 // [B][cols] (gait-major) <-> [cols][B] (time-major) on the device, for the host-pointer entry point
 __global__ void wg_transpose_kernel(int rows, int cols, const double *__restrict__ in, double *__restrict__ out) {
   __shared__ double tile[32][33];

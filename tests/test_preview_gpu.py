@@ -36,6 +36,31 @@ def test_batch_matches_oracle_bit_for_bit(B, L, nl_cut, sim):
         assert np.array_equal(s_gpu[:, 6:], s_cpu[:, 6:])         # errors untouched without Simulation
 
 
+@pytest.mark.parametrize("kernel", ["l2", "ring"])
+def test_both_kernels_match_oracle(kernel, monkeypatch):
+    """the LDS-ring kernel (window staged in LDS, taps read from the current slot round the ring) and the L2 kernel are
+    picked by batch size; force each and hold both to the oracle"""
+    monkeypatch.setenv("WG_PREVIEW_KERNEL", kernel)
+    wg.init(0)
+    g, F = ini_gains()
+    wg.preview_configure(g, F)
+    rng = np.random.default_rng(77)
+    for B, L in ((130, 45), (64, 9)):
+        ZX, ZY = zmpref.random_batch(rng, B, L, g.nl)
+        s_gpu = rng.normal(0, 0.01, (B, 8)); s_cpu = s_gpu.copy()
+        com, z2 = wg.preview_run_batch(ZX, ZY, s_gpu, L)
+        com_o, z2_o = oracle_run(g, F, ZX, ZY, s_cpu, L)
+        assert np.array_equal(com, com_o) and np.array_equal(z2, z2_o) and np.array_equal(s_gpu, s_cpu)
+    # a window longer than the ring (the tail of the taps comes from L2)
+    g2, F2 = wg.preview_gains(0.005, 0.814, 2.0)                  # nl = 400 > 288
+    wg.preview_configure(g2, F2)
+    ZX, ZY = zmpref.random_batch(rng, 70, 20, g2.nl)
+    s_gpu = np.zeros((70, 8)); s_cpu = s_gpu.copy()
+    com, z2 = wg.preview_run_batch(ZX, ZY, s_gpu, 20)
+    com_o, z2_o = oracle_run(g2, F2, ZX, ZY, s_cpu, 20)
+    assert np.array_equal(com, com_o) and np.array_equal(z2, z2_o) and np.array_equal(s_gpu, s_cpu)
+
+
 def test_device_entry_point_time_major_and_chunked_calls():
     """resident data, time-major layout; two calls of L/2 steps == one call of L steps (the queue slides)"""
     import torch
