@@ -4,7 +4,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 wg = importlib.import_module("jrl-walkgen_amd"); wg.init(0)
 B = int(os.environ.get("PB", "4096")); T = int(os.environ.get("PT", "50")); REPS = 4
-model = wg.model_defaults(); wg.mpc_configure(model)
+model = wg.model_defaults()
+if os.environ.get("PN"): model.N = int(os.environ["PN"])
+wg.mpc_configure(model)
 rng = np.random.default_rng(20100)
 s0 = wg.gait_init(model, [0.0316055, 0.0, 0.7116911], [0.0, 0.09, 0.0], [0.0, -0.09, 0.0]); s0.nb_steps_left = 2
 one = bytes(memoryview(s0).cast("B"))
