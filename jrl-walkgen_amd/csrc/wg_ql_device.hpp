@@ -154,6 +154,7 @@ struct QlView {
 struct QlView;
 struct DenseProb {
   static constexpr bool kCompact = false;
+  static constexpr bool kRowOps = false;   // no structured row products: rows are read element by element
   static constexpr int kNM = 0;        // no compile-time bound on n
   __device__ __forceinline__ double G(const QlView &q, int i, int j) const;
   __device__ __forceinline__ double A(const QlView &q, int k, int i) const;
@@ -751,8 +752,11 @@ __device__ __forceinline__ QlResult ql_solve(const QlView &q, P &prob, double vs
     } else {
       for (int k = lane; k < m; k += 64) {
         double sum = 0.0;
-        WG_UNROLL
-        for (int i = 0; i < n; ++i) { double a = Am(k, i); sum += a * a; }
+        if constexpr (P::kRowOps) sum = prob.row_sqnorm(q, k);
+        else {
+          WG_UNROLL
+          for (int i = 0; i < n; ++i) { double a = Am(k, i); sum += a * a; }
+        }
         if (sum > 0.0) sum = 1.0 / sqrt(sum);
         else if (q.b[k] == 0.0) {}
         else if (k + 1 <= me || q.b[k] > 0.0) fatal = k + 1 < fatal ? k + 1 : fatal;
@@ -1055,15 +1059,21 @@ __device__ __forceinline__ QlResult ql_solve(const QlView &q, P &prob, double vs
         if (wak <= 0.0) continue;
         double bk = q.b[k];
         double sum = -bk;
-        WG_UNROLL
-        for (int i = 0; i < n; ++i) sum += q.x[i] * Am(k, i);
+        if constexpr (P::kRowOps) sum = prob.template row_dot<false>(q, k, q.x, sum);
+        else {
+          WG_UNROLL
+          for (int i = 0; i < n; ++i) sum += q.x[i] * Am(k, i);
+        }
         double sumx = -sum * wak;
         if (k + 1 <= me) sumx = fabs(sumx);
         if (sumx <= 0.0) continue;              // cvmax starts at 0 (:1256)
         if (bidx >= 0 && sumx <= bestv) continue;
         double temp = fabs(bk);
-        WG_UNROLL
-        for (int i = 0; i < n; ++i) temp += fabs(q.x[i] * Am(k, i));
+        if constexpr (P::kRowOps) temp = prob.template row_dot<true>(q, k, q.x, temp);
+        else {
+          WG_UNROLL
+          for (int i = 0; i < n; ++i) temp += fabs(q.x[i] * Am(k, i));
+        }
         double tempa = temp + fabs(sum);
         if (tempa <= temp) continue;
         temp += onha * fabs(sum);

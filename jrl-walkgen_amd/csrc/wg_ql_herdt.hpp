@@ -26,6 +26,7 @@ constexpr int kQbLd = 32;   // row stride of TickTables::Qb (== kNMaxH)
 template <int NH>
 struct HerdtProb {
   static constexpr bool kCompact = true;
+  static constexpr bool kRowOps = false;       // the compact view has its own register-row paths
   static constexpr int kNM = 2 * NH + 2 * 2;   // n <= 2N + 2*2: at most two previewed steps (checked by wg_mpc_configure)
   static_assert(4 * NH == 64, "one CoP row per lane needs 4N == 64");
   // ---- LDS / global tables (wave-uniform pointers) ----
@@ -449,6 +450,7 @@ struct HerdtProb {
 constexpr int kGvLdElem = kSMaxQ;
 struct HerdtElemProb {
   static constexpr bool kCompact = false;
+  static constexpr bool kRowOps = true;        // row products walk the row's structure instead of calling A() per element
   static constexpr int kNM = 0;
   int N, ns;
   const double *Qb;       // global, N x kQbLd
@@ -493,6 +495,50 @@ struct HerdtElemProb {
     if (j < ns) return 0.0 + (0.0 + a * V_f[kk * kSMaxQ + j]) * -1.0;
     j -= ns;
     return 0.0 + (0.0 + b * V_f[kk * kSMaxQ + j]) * -1.0;
+  }
+  // acc (+)= sum_i v[i] * A(k, i)  (ABS: |v[i] * A(k, i)|), i ascending, over the row's structural non-zeros only: the
+  // skipped entries are exact zeros, whose products leave a running sum unchanged.  Same element expressions as A().
+  template <bool ABS>
+  __device__ __forceinline__ double row_dot(const QlView &, int k, const double *v, double acc) const {
+    if (k == 0) return acc;
+    const double a = rowA[k], b = rowB[k];
+    const int kk = rowK[k];
+    if (k <= 4 * N) {
+      const int r = kk;
+      for (int c = 0; c <= r; ++c) { const double t = v[c] * (0.0 + (0.0 + a * u[r - c]) * -1.0); acc += ABS ? fabs(t) : t; }
+      for (int c = 0; c <= r; ++c) { const double t = v[N + c] * (0.0 + (0.0 + b * u[r - c]) * -1.0); acc += ABS ? fabs(t) : t; }
+      const int j = stepidx[r] - 1;
+      if (j >= 0 && j < ns) {
+        { const double t = v[2 * N + j] * (0.0 + (0.0 + a * 1.0) * 1.0); acc += ABS ? fabs(t) : t; }
+        { const double t = v[2 * N + ns + j] * (0.0 + (0.0 + b * 1.0) * 1.0); acc += ABS ? fabs(t) : t; }
+      }
+      return acc;
+    }
+    if (kk < 0) return acc;
+    for (int j = 0; j < ns; ++j) { const double t = v[2 * N + j] * (0.0 + (0.0 + a * V_f[kk * kSMaxQ + j]) * -1.0); acc += ABS ? fabs(t) : t; }
+    for (int j = 0; j < ns; ++j) { const double t = v[2 * N + ns + j] * (0.0 + (0.0 + b * V_f[kk * kSMaxQ + j]) * -1.0); acc += ABS ? fabs(t) : t; }
+    return acc;
+  }
+  __device__ __forceinline__ double row_sqnorm(const QlView &, int k) const {
+    double sum = 0.0;
+    if (k == 0) return sum;
+    const double a = rowA[k], b = rowB[k];
+    const int kk = rowK[k];
+    if (k <= 4 * N) {
+      const int r = kk;
+      for (int c = 0; c <= r; ++c) { const double e = 0.0 + (0.0 + a * u[r - c]) * -1.0; sum += e * e; }
+      for (int c = 0; c <= r; ++c) { const double e = 0.0 + (0.0 + b * u[r - c]) * -1.0; sum += e * e; }
+      const int j = stepidx[r] - 1;
+      if (j >= 0 && j < ns) {
+        { const double e = 0.0 + (0.0 + a * 1.0) * 1.0; sum += e * e; }
+        { const double e = 0.0 + (0.0 + b * 1.0) * 1.0; sum += e * e; }
+      }
+      return sum;
+    }
+    if (kk < 0) return sum;
+    for (int j = 0; j < ns; ++j) { const double e = 0.0 + (0.0 + a * V_f[kk * kSMaxQ + j]) * -1.0; sum += e * e; }
+    for (int j = 0; j < ns; ++j) { const double e = 0.0 + (0.0 + b * V_f[kk * kSMaxQ + j]) * -1.0; sum += e * e; }
+    return sum;
   }
 };
 

@@ -5,7 +5,9 @@ sys.path.insert(0, ROOT)
 os.environ["WG_LIB_PATH"] = os.path.join(ROOT, "jrl-walkgen_amd", "lib", "libwg_mpc_prof.so")
 wg = importlib.import_module("jrl-walkgen_amd"); wg.init(0)
 B = int(os.environ.get("PB", "1024")); WARM = 60; MEAS = 20
-model = wg.model_defaults(); wg.mpc_configure(model)
+model = wg.model_defaults()
+if os.environ.get("PN"): model.N = int(os.environ["PN"])
+wg.mpc_configure(model)
 rng = np.random.default_rng(20100)
 states = (wg.GaitState * B)()
 s0 = wg.gait_init(model, [0.0316055, 0.0, 0.7116911], [0.0, 0.09, 0.0], [0.0, -0.09, 0.0]); s0.nb_steps_left = 2
