@@ -61,7 +61,7 @@ std::vector<void (*)()> g_release_hooks;   // device buffers owned by the later 
 }  // namespace
 
 // ---------------------------------------------------------------------------
-// Dense batched QP kernel: one wavefront (= one workgroup) per QP, grid-stride.
+// Dense batched QP kernel: one wavefront (= one workgroup) per QP.
 // Replaces ql0001_ (qld.hh:27-31) for B problems at once.
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(64) void wg_ql_dense_kernel(
@@ -73,7 +73,8 @@ __global__ __launch_bounds__(64) void wg_ql_dense_kernel(
     int *__restrict__ hist, int hist_cap, int *__restrict__ hist_len, int a_in_lds) {
   extern __shared__ __attribute__((aligned(16))) double wg_lds[];
   const int lane = threadIdx.x & 63;
-  for (int qp = blockIdx.x; qp < B; qp += gridDim.x) {
+  const int qp = blockIdx.x;                     // one QP per block (grid == B): nothing lane-dependent lives across QPs
+  if (qp < B) {
     const int n = n_arr ? n_arr[qp] : nmax;
     const int m = m_arr ? m_arr[qp] : mmax - 1;
     const int me = me_arr ? me_arr[qp] : 0;
@@ -192,12 +193,7 @@ int wg_qp_solve_batch_dev(int B, int nmax, int mmax, const int *n, const int *m,
   if (lds > 64 * 1024)
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(wg_ql_dense_kernel),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  int per_cu = (int)((160 * 1024) / lds);
-  if (per_cu < 1) per_cu = 1;
-  if (per_cu > 16) per_cu = 16;
-  if (const char *ov = getenv("WG_WAVES_PER_CU")) { int v = atoi(ov); if (v > 0) per_cu = v; }  // tuning knob
-  int grid = g_num_cu * per_cu;
-  if (grid > B) grid = B;
+  const int grid = B;
   hipStream_t st = reinterpret_cast<hipStream_t>(hip_stream);
   hipLaunchKernelGGL(wg_ql_dense_kernel, dim3(grid), dim3(64), lds, st, B, nmax, mmax, n, m, me, C, d, A, b,
                      xl, xu, eps, x, u, ifail, n_iter, iact, nact, hist, hist_cap, hist_len, a_in_lds);
@@ -631,11 +627,12 @@ wg_pldp_kernel(int B, int mcap, const wg::PldpModel *__restrict__ model, const i
   const wg::PldpModel &M = *model;
   const int n = 2 * M.N;
   const size_t aslot = (size_t)(mcap + 1) * n;
-  for (int p = blockIdx.x; p < B; p += gridDim.x) {
+  const int p = blockIdx.x;                        // one problem per block (grid == B)
+  if (p < B) {
     int mp = m[p];
     if (mp < 0 || mp > mcap) {                      // refuse rather than index out of the slot
       if (threadIdx.x == 0) { ret[p] = WG_PLDP_BAD_INPUT; if (n_iter) n_iter[p] = 0; if (n_active) n_active[p] = 0; }
-      continue;
+      return;
     }
     wg::pldp_problem(M, pldp_lds, mcap, mp, D + (size_t)p * n, A + p * aslot, b + (size_t)p * mcap,
                      zmpref + (size_t)p * n, xkyk + (size_t)p * 6, similar + (size_t)p * mcap, n_removed[p], starting[p],
@@ -699,11 +696,7 @@ int wg_pldp_solve_batch_dev(int B, int mcap, const int *m, const double *D, cons
   if (lds > 64 * 1024)
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(wg_pldp_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)lds));
-  int per_cu = (int)((160 * 1024) / lds);
-  if (per_cu < 1) per_cu = 1;
-  if (per_cu > 8) per_cu = 8;
-  int grid = g_num_cu * per_cu * 2;
-  if (grid > B) grid = B;
+  const int grid = B;
   hipLaunchKernelGGL(wg_pldp_kernel, dim3(grid), dim3(64), lds, reinterpret_cast<hipStream_t>(hip_stream), B, mcap,
                      g_pldp_dev, m, D, A, b, zmpref, xkyk, similar, n_removed, starting, max_iter, states, X, ret, n_iter,
                      active, n_active);

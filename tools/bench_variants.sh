@@ -5,7 +5,7 @@ out=gpurun_out/variants.txt
 : > $out
 run() {  # label, lib, waves_per_cu
   echo "== $1 lib=$2 wpc=$3" >> $out
-  WG_TICK_LDS_PAD=${4:-0} WG_LIB_PATH=$PWD/jrl-walkgen_amd/lib/$2 WG_WAVES_PER_CU=$3 python bench.py --no-cpu-baseline --steps 100 --warmup 20 2>&1 \
+  WG_TICK_LDS_PAD=${4:-0} WG_LIB_PATH=$PWD/jrl-walkgen_amd/lib/$2 python bench.py --per-tick-launch --no-per-tick-leg --no-cpu-baseline --steps 100 --warmup 20 2>&1 \
     | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d['value'], d['roofline']['kernel_ms'])" >> $out 2>&1
 }
 for spec in "$@"; do IFS=: read lib wpc pad <<< "$spec"; run "$spec" "$lib" "$wpc" "$pad"; done
