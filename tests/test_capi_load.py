@@ -73,8 +73,12 @@ def test_cpp_facade_builds_and_fails_loudly_without_gpu(tmp_path):
               "PatternGeneratorJRL::SimplePlugin::RegisterMethod", "PatternGeneratorJRL::ZMPVelocityReferencedQP::OnLine",
               "PatternGeneratorJRL::ZMPVelocityReferencedQP::InitOnLine"):
         assert s in syms, s
+    fleet = os.path.join(ROOT, "jrl-walkgen_amd", "bin", "fleet_bench")
+    assert os.path.exists(fleet), "run __graft_entry__.build()"
     if torch.cuda.is_available():
         return
+    r = subprocess.run([fleet, "--batch", "8", "--ticks", "4"], capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0 and "FAILED" in r.stderr          # plain C++ over the C ABI: no device, no result
     out = tmp_path / "t.dat"
     r = subprocess.run([exe, str(out)], capture_output=True, text=True, timeout=120)
     assert r.returncode != 0 and "FAILED" in r.stderr

@@ -81,3 +81,14 @@ def test_kajita_stage1_driver_matches_oracle(tmp_path):
     assert np.array_equal(rows[:, 3], z2[0, :, 0]) and np.array_equal(rows[:, 4], z2[0, :, 1])
     # walked 14 x 0.2 m, ends at rest between the feet
     assert abs(rows[-1, 1] - 2.8) < 1e-3 and abs(rows[-1, 2] - rows[-1, 6]) < 1e-3
+
+
+def test_cpp_fleet_bench_runs_through_the_c_abi():
+    """jrl-walkgen_amd/host/fleet_bench.cpp: the fleet path from plain C++ (hipMalloc'd states, wg_mpc_run_batch_dev and
+    wg_mpc_tick_batch_dev) -- both launch modes advance every gait by the same number of ticks"""
+    exe = os.path.join(ROOT, "jrl-walkgen_amd", "bin", "fleet_bench")
+    assert os.path.exists(exe)
+    for flags in ([], ["--per-tick"]):
+        r = subprocess.run([exe, "--batch", "300", "--ticks", "60", *flags], capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stdout + r.stderr
+        assert "%d ticks done in all" % (300 * (50 + 60)) in r.stdout, r.stdout
