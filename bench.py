@@ -55,6 +55,18 @@ def start_states(model, B):
     return torch.frombuffer(bytearray(one * B), dtype=torch.uint8)
 
 
+def launch_plan(t0, t1, per_tick=False, redraw=REDRAW_TICKS):
+    """[(first tick, number of ticks)] covering ticks [t0, t1): the control loop's first two ticks advance the clock by 1
+    and 19 control periods and go alone; otherwise one launch per stretch of constant references (or per tick)."""
+    out = []
+    t = t0
+    while t < t1:
+        n = 1 if (t < 2 or per_tick) else min(t1, (t // redraw + 1) * redraw) - t
+        out.append((t, n))
+        t += n
+    return out
+
+
 def algorithmic_bytes(n, m):
     """Bytes the reference moves per tick at its own solver boundary (ql0001_ arguments):
     read 8*(n^2 + n + mmax*n + mmax + 2n), written 8*(n + m + 2n), with mmax = m + 1."""
@@ -162,18 +174,7 @@ def main():
     dstride = B * 6 * 4
 
     def launches(t0, t1):
-        """[(first tick, number of ticks)] covering ticks [t0, t1): the control loop's first two ticks advance the clock
-        by 1 and 19 control periods and go alone; otherwise one launch per stretch of constant references."""
-        out = []
-        t = t0
-        while t < t1:
-            if t < 2 or args.per_tick_launch:
-                n = 1
-            else:
-                n = min(t1, (t // REDRAW_TICKS + 1) * REDRAW_TICKS) - t
-            out.append((t, n))
-            t += n
-        return out
+        return launch_plan(t0, t1, args.per_tick_launch)
 
     def redraw(t):
         if t % REDRAW_TICKS == 0:
