@@ -414,6 +414,77 @@ int wg_preview_run_batch(int B, int L, const double *zmp_x, const double *zmp_y,
 int wg_preview_run_batch_dev(int B, int L, const double *zmp_x_tm, const double *zmp_y_tm, double *state, double *com_tm,
                              double *zmp2_tm, int simulation, void *hip_stream);
 
+/* Kajita stage-1 inputs: ZMP reference queue and feet trajectories of a step sequence, batched over gaits ------------
+ *
+ * wg_zmpdisc_batch replaces, for each of B independent gaits,
+ *     ZMPDiscretization::GetZMPDiscretization                  src/ZMPRefTrajectoryGeneration/ZMPDiscretization.cpp:143-173
+ * = InitOnLine (:319-513: rest phase of 2 preview windows, then OnLineAddFoot (:573-1020) for every step after the
+ * first) + EndPhaseOfTheWalking (:1129-1300), i.e. what PatternGeneratorInterfacePrivate::CreateZMPReferences
+ * (PatternGeneratorInterfacePrivate.cpp:1870-1882) obtains for ":stepseq" in Kajita mode -- with
+ *     FilterOutValues (:1045-1109) on the window of InitializeFilter (:240-262),
+ *     UpdateCurrentSupportFootPosition (:515-558),
+ *     FootTrajectoryGenerationStandard::UpdateFootPosition / SetParameters
+ *         src/FootTrajectoryGeneration/FootTrajectoryGenerationStandard.cpp:411-566, 150-186,
+ *     Polynome::Compute, Polynome3/4/5::SetParameters   src/Mathematics/Polynome.cpp:44-53, PolynomeFoot.cpp:41-57, 100-120, 174-195.
+ * The steps are RelativeFootPosition records (pgtypes.hh:100-108) as StepStackHandler::ReadStepSequenceAccordingToWalkMode
+ * (StepStackHandler.cpp:128-175) leaves them: theta in DEGREES, SStime / DStime = the configured support times,
+ * stepType 1.  Output per gait: L = wg_zmpdisc_length(model, steps, n_steps) samples at period T of
+ *     the filtered ZMP reference (px, py) -- the queue PreviewControl::OneIterationOfPreview reads,
+ *     its heading theta and stepType, and both feet (x, y, z, theta, omega, omega2, stepType).
+ *   steps      B x smax  (gait b uses the first n_steps[b]; 2 <= n_steps[b] <= smax <= WG_ZMPDISC_MAX_STEPS)
+ *   init_feet  B x 6     left x, y, theta, right x, y, theta at the start (EvaluateStartingState's outputs)
+ *   lcap       row length of the per-gait output arrays (>= every gait's L; samples past L are left untouched)
+ *   zmp        B x lcap x 2  (px, py);  zmp_theta B x lcap;  zmp_type B x lcap   (may be NULL each)
+ *   left, right  B x lcap x 6;  left_type, right_type  B x lcap                      (may be NULL each)
+ *   length     B         L of each gait, or a negative code: WG_ZMPDISC_BAD_INPUT (n_steps out of range, a phase that
+ *                        does not fit its own sample count -- the reference would write out of bounds), WG_ZMPDISC_CAPACITY
+ * The _dev variant takes device pointers and writes the ZMP queue TIME-MAJOR, zmp_x_tm / zmp_y_tm [lcap][B], exactly
+ * what wg_preview_run_batch_dev reads, so that step sequences go to CoM trajectories without leaving the device; samples
+ * past a gait's L repeat its last value there (a gait at rest), so that one preview launch can cover a ragged batch. */
+#define WG_ZMPDISC_MAX_STEPS 64
+#define WG_ZMPDISC_BAD_INPUT (-1)
+#define WG_ZMPDISC_CAPACITY (-2)
+typedef struct wg_zmpdisc_model {
+  double T;                           /* m_SamplingPeriod  0.005 */
+  double preview_time;                /* m_PreviewControlTime  1.6 */
+  double t_single, t_double;          /* m_Tsingle, m_Tdble  (":singlesupporttime", ":doublesupporttime") */
+  double step_height;                 /* m_StepHeight  (":stepheight") */
+  double omega;                       /* m_Omega, degrees  (":omega") */
+  double modulation;                  /* m_ModulationSupportCoefficient = 0.9   ZMPDiscretization.cpp:99 */
+  double zmp_neutral[2];              /* m_ZMPNeutralPosition = 0, 0            :107-108 */
+  double zmp_shift[4];                /* m_ZMPShift (step types 3, 4, 5)        :103-105, 693-718 */
+  double foot_b, foot_h, foot_f;      /* m_FootB, m_FootH, m_FootF  FootTrajectoryGenerationStandard.cpp:68-71 */
+} wg_zmpdisc_model_t;
+typedef struct wg_rel_step {
+  double sx, sy, theta;               /* RelativeFootPosition, theta in degrees */
+  double ss_time, ds_time;            /* SStime, DStime (ds_time == 0 => the model's times, :608-612) */
+  int step_type, pad_;
+} wg_rel_step_t;
+void wg_zmpdisc_defaults(wg_zmpdisc_model_t *model);
+/* number of samples GetZMPDiscretization produces for this sequence (host arithmetic), or a negative code */
+int wg_zmpdisc_length(const wg_zmpdisc_model_t *model, const wg_rel_step_t *steps, int n_steps);
+int wg_zmpdisc_batch(const wg_zmpdisc_model_t *model, int B, int smax, const wg_rel_step_t *steps, const int *n_steps,
+                     const double *init_feet, int lcap, double *zmp, double *zmp_theta, int *zmp_type, double *left,
+                     int *left_type, double *right, int *right_type, int *length);
+int wg_zmpdisc_batch_dev(const wg_zmpdisc_model_t *model, int B, int smax, const wg_rel_step_t *steps,
+                         const int *n_steps, const double *init_feet, int lcap, double *zmp_x_tm, double *zmp_y_tm,
+                         int *length, void *hip_stream);
+
+/* ZMP polytopes of a feet trajectory (host) ----------------------------------------------------------------------------
+ *
+ * wg_foot_constraints replaces FootConstraintsAsLinearSystem::BuildLinearConstraintInequalities
+ *     src/Mathematics/FootConstraintsAsLinearSystem.cpp:258-539   (+ ComputeLinearSystem :97-256,
+ *     FindSimilarConstraints :55-92, ComputeConvexHull::DoComputeConvexHull src/Mathematics/ConvexHull.cpp:88-203):
+ * one polytope per support phase of a 5 ms feet trajectory, A_j . zmp + B_j >= 0, with its validity interval -- the
+ * queue ZMPConstrainedQPFastFormulation::BuildConstraintMatrices (:759-1022) walks to fill the wg_zmp_polytope_t of each
+ * previewed instant.  Host code: it runs once per step sequence, not per tick.
+ *   n            samples;  time n;  left, right  n x 6 (x, y, z, theta, omega, omega2);  left_type n (stepType)
+ *   sole_w, sole_h   getSoleSize outputs;  constraint_x, constraint_y  the security margins (ConstraintOnX / Y)
+ *   polys, t_start, t_end   up to cap entries;  returns the number of polytopes (may exceed cap) or a negative code */
+int wg_foot_constraints(int n, const double *time, const double *left, const int *left_type, const double *right,
+                        double sole_w, double sole_h, double constraint_x, double constraint_y, int cap,
+                        wg_zmp_polytope_t *polys, double *t_start, double *t_end);
+
 /* Invariant Hessian block on the matrix cores, batched over models -----------------------------------------------------
  *
  * wg_gramian_batch computes, for B models that differ in QP sampling period T[b] and CoM height h[b],

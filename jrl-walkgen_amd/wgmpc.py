@@ -104,6 +104,13 @@ def lib():
         _lib.wg_gramian_batch_dev.argtypes = _lib.wg_gramian_batch.argtypes + [C.c_void_p]
         _lib.wg_preview_run_batch.argtypes = [C.c_int, C.c_int] + [C.c_void_p] * 5 + [C.c_int]
         _lib.wg_preview_run_batch_dev.argtypes = [C.c_int, C.c_int] + [C.c_void_p] * 5 + [C.c_int, C.c_void_p]
+        _lib.wg_zmpdisc_defaults.argtypes = [C.c_void_p]
+        _lib.wg_zmpdisc_length.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+        _lib.wg_zmpdisc_batch.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int] + \
+            [C.c_void_p] * 8
+        _lib.wg_zmpdisc_batch_dev.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int] + \
+            [C.c_void_p] * 4
+        _lib.wg_foot_constraints.argtypes = [C.c_int] + [C.c_void_p] * 4 + [C.c_double] * 4 + [C.c_int] + [C.c_void_p] * 3
     return _lib
 
 
@@ -391,6 +398,79 @@ def preview_run_batch_dev(B, L, zx_tm_ptr, zy_tm_ptr, state_ptr, com_tm_ptr=None
                           stream=None):
     _check(lib().wg_preview_run_batch_dev(B, L, zx_tm_ptr, zy_tm_ptr, state_ptr, com_tm_ptr, zmp2_tm_ptr,
                                           int(bool(simulation)), stream))
+
+
+# ---- Kajita stage-1 inputs: ZMPDiscretization, batched; FootConstraintsAsLinearSystem (host) ----
+ZMPDISC_MAX_STEPS = 64
+
+
+class ZmpDiscModel(C.Structure):        # wg_zmpdisc_model_t
+    _fields_ = [(k, C.c_double) for k in ("T", "preview_time", "t_single", "t_double", "step_height", "omega",
+                                          "modulation")] + \
+               [("zmp_neutral", C.c_double * 2), ("zmp_shift", C.c_double * 4)] + \
+               [(k, C.c_double) for k in ("foot_b", "foot_h", "foot_f")]
+
+
+class RelStep(C.Structure):             # wg_rel_step_t
+    _fields_ = [(k, C.c_double) for k in ("sx", "sy", "theta", "ss_time", "ds_time")] + \
+               [("step_type", C.c_int), ("pad_", C.c_int)]
+
+
+def zmpdisc_defaults():
+    m = ZmpDiscModel()
+    lib().wg_zmpdisc_defaults(C.byref(m))
+    return m
+
+
+def rel_steps(triples, ss_time, ds_time, step_type=1):
+    """(RelStep * S) from [S, 3] (sx, sy, theta in degrees), as StepStackHandler leaves a ":stepseq" (walk mode 0)."""
+    t = np.asarray(triples, dtype=np.float64).reshape(-1, 3)
+    steps = (RelStep * len(t))()
+    for i, (sx, sy, th) in enumerate(t):
+        steps[i] = RelStep(sx, sy, th, ss_time, ds_time, step_type, 0)
+    return steps
+
+
+def zmpdisc_length(model, steps, n_steps=None):
+    return int(lib().wg_zmpdisc_length(C.byref(model), C.addressof(steps), len(steps) if n_steps is None else int(n_steps)))
+
+
+def zmpdisc_batch(model, steps, n_steps, init_feet, smax, lcap, want_feet=True):
+    """steps: (RelStep * (B*smax)); n_steps [B]; init_feet [B, 6].  Returns a dict of arrays and `length` [B]."""
+    n_steps = np.ascontiguousarray(n_steps, dtype=np.int32); B = n_steps.shape[0]
+    init_feet = np.ascontiguousarray(init_feet, dtype=np.float64)
+    assert init_feet.shape == (B, 6) and len(steps) == B * smax
+    r = dict(zmp=np.zeros((B, lcap, 2)), zmp_theta=np.zeros((B, lcap)), zmp_type=np.zeros((B, lcap), np.int32),
+             length=np.zeros(B, np.int32))
+    if want_feet:
+        r.update(left=np.zeros((B, lcap, 6)), right=np.zeros((B, lcap, 6)), left_type=np.zeros((B, lcap), np.int32),
+                 right_type=np.zeros((B, lcap), np.int32))
+    g = lambda k: _hp(r[k]) if k in r else None  # noqa: E731
+    _check(lib().wg_zmpdisc_batch(C.byref(model), B, int(smax), C.addressof(steps), _hp(n_steps), _hp(init_feet), int(lcap),
+                                  g("zmp"), g("zmp_theta"), g("zmp_type"), g("left"), g("left_type"), g("right"),
+                                  g("right_type"), _hp(r["length"])))
+    return r
+
+
+def zmpdisc_batch_dev(model, B, smax, steps_ptr, n_steps_ptr, init_feet_ptr, lcap, zx_tm_ptr, zy_tm_ptr, length_ptr,
+                      stream=None):
+    _check(lib().wg_zmpdisc_batch_dev(C.byref(model), int(B), int(smax), steps_ptr, n_steps_ptr, init_feet_ptr, int(lcap),
+                                      zx_tm_ptr, zy_tm_ptr, length_ptr, stream))
+
+
+def foot_constraints(time, left, left_type, right, sole_w, sole_h, constraint_x, constraint_y, cap=256):
+    """wg_foot_constraints: (polys (ZmpPolytope * n), t_start[n], t_end[n])."""
+    time = np.ascontiguousarray(time, dtype=np.float64); left = np.ascontiguousarray(left, dtype=np.float64)
+    right = np.ascontiguousarray(right, dtype=np.float64); left_type = np.ascontiguousarray(left_type, dtype=np.int32)
+    n = time.shape[0]
+    assert left.shape == right.shape == (n, 6) and left_type.shape == (n,)
+    polys = (ZmpPolytope * cap)(); ts = np.zeros(cap); te = np.zeros(cap)
+    k = lib().wg_foot_constraints(n, _hp(time), _hp(left), _hp(left_type), _hp(right), float(sole_w), float(sole_h),
+                                  float(constraint_x), float(constraint_y), cap, C.addressof(polys), _hp(ts), _hp(te))
+    _check(min(k, 0))
+    if k > cap:
+        raise WgError("foot_constraints: %d polytopes, capacity %d" % (k, cap))
+    return polys, ts[:k], te[:k], k
 
 
 # ---- invariant Hessian block on the matrix cores ----

@@ -81,6 +81,17 @@ int wgo_dimitrov_tick(const wgo_pldp_model_t *M, const double *OptB, const doubl
 int wgo_preview_run(const wg_preview_gains_t *g, const double *F, int B, int L, const double *zmp_x, const double *zmp_y,
                     double *state, double *com, double *zmp2, int simulation);
 
+/* ---- ZMPDiscretization / FootConstraintsAsLinearSystem restatement (zmpdisc_oracle.c) ------------------------------ */
+int wgo_zmpdisc_length(const wg_zmpdisc_model_t *model, const wg_rel_step_t *steps, int n_steps);
+/* arguments as wg_zmpdisc_batch (include/wg_mpc.h) for one gait, plus the sample times (may be NULL); returns L */
+int wgo_zmpdisc(const wg_zmpdisc_model_t *model, const wg_rel_step_t *steps, int n_steps, const double *init_feet,
+                int lcap, double *zmp, double *zmp_theta, int *zmp_type, double *left, int *left_type, double *right,
+                int *right_type, double *time);
+/* arguments as wg_foot_constraints */
+int wgo_foot_constraints(int n, const double *time, const double *left, const int *left_type, const double *right,
+                         double sole_w, double sole_h, double constraint_x, double constraint_y, int cap,
+                         wg_zmp_polytope_t *polys, double *t_start, double *t_end);
+
 #ifdef __cplusplus
 }
 #endif

@@ -8,6 +8,11 @@
         - the 225 QPs the Herdt oracle assembles while replaying the EmergencyStop scenario.
   preview_control_parameters.npz : the reference's precomputed Kajita gains
         /root/reference/src/data/PreviewControlParameters.ini  (Zc, T, preview time, Kx[3], Ks, F[320]), as data.
+  kajita_zmpdisc_datref.npz : the columns of the reference's golden files
+        /root/reference/tests/TestKajita2003{StraightWalking,PbFlorentSeq1}TestFGPI.datref.cmake
+        that hold the outputs of ZMPDiscretization (tests/TestObject.cpp:344-385): time (1), left foot x y z (11-13),
+        theta omega omega2 (20-22), right foot (23-25, 32-34), world-frame ZMP reference (35-36), as data, plus the
+        step sequences of tests/TestKajita2003.cpp:95-152 (inputs).
 """
 import os
 import sys
@@ -31,8 +36,28 @@ def preview_ini():
                         Kx=v[3:6], Ks=v[6], F=v[7:7 + nl])
 
 
+STRAIGHT = [0.0, -0.105, 0.0] + [0.2, 0.21, 0.0, 0.2, -0.21, 0.0] * 7 + [0.0, 0.21, 0.0]
+PBFLORENT1 = [0, 0.1, 0, -0.0398822, -0.232351, 4.6646, -0.0261703, 0.199677, 4.6646, -0.0471999, -0.256672, 4.6646,
+              -0.0305785, 0.200634, 4.6646, -0.0507024, -0.245393, 4.6646, -0.0339626, 0.197227, 4.6646,
+              -0.0527259, -0.228579, 4.6646, -0.0362332, 0.199282, 4.6646, -0.0540087, -0.21638, 4.6646,
+              -0.0373302, 0.196611, 4.6646, -0.0536928, -0.199019, 4.6646, -0.0372245, 0.204021, 4.6646,
+              -0.0529848, -0.196642, 4.6646, -0.0355124, 0.2163, 4.6646, -0.000858977, -0.204807, 0.0767924, 0, 0.2, 0]
+KAJITA_COLS = [0, 10, 11, 12, 19, 20, 21, 22, 23, 24, 31, 32, 33, 34, 35]
+
+
+def kajita_datrefs():
+    out = {}
+    for name, seq in (("StraightWalking", STRAIGHT), ("PbFlorentSeq1", PBFLORENT1)):
+        d = np.loadtxt("/root/reference/tests/TestKajita2003%sTestFGPI.datref.cmake" % name)
+        out[name + "_rows"] = d[:, KAJITA_COLS]
+        out[name + "_steps"] = np.array(seq, dtype=float).reshape(-1, 3)
+    out["columns"] = np.array(KAJITA_COLS) + 1
+    np.savez_compressed(os.path.join(HERE, "kajita_zmpdisc_datref.npz"), **out)
+
+
 def main():
     preview_ini()
+    kajita_datrefs()
     datref = np.loadtxt(REF)
     np.savez_compressed(os.path.join(HERE, "herdt_emergency_stop_datref.npz"), datref=datref)
 

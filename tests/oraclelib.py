@@ -187,3 +187,36 @@ def pldp_solve(M, st, D, m, A, b, zmpref, xkyk, similar, n_removed, starting, ma
                                  C.c_int(n_removed), C.c_int(1 if starting else 0), C.c_int(max_iter), _d(X),
                                  C.byref(nit), _i(act), C.byref(nact))
     return dict(ret=rc, X=X, n_iter=nit.value, active=act[:nact.value].copy())
+
+
+# ---- ZMPDiscretization / FootConstraintsAsLinearSystem restatement (oracle/zmpdisc_oracle.c) ----
+def zmpdisc(model, steps, init_feet, n_steps=None, lib=None):
+    """wgo_zmpdisc for one gait: dict(zmp [L,2], zmp_theta, zmp_type, left [L,6], left_type, right, right_type, time)."""
+    lib = lib or oracle()
+    S = len(steps) if n_steps is None else int(n_steps)
+    lib.wgo_zmpdisc_length.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+    L = lib.wgo_zmpdisc_length(C.byref(model), C.addressof(steps), S)
+    if L < 0:
+        return dict(length=L)
+    r = dict(zmp=np.zeros((L, 2)), zmp_theta=np.zeros(L), zmp_type=np.zeros(L, np.int32), left=np.zeros((L, 6)),
+             left_type=np.zeros(L, np.int32), right=np.zeros((L, 6)), right_type=np.zeros(L, np.int32), time=np.zeros(L))
+    f = np.ascontiguousarray(init_feet, dtype=np.float64)
+    vp = lambda a: a.ctypes.data_as(C.c_void_p)  # noqa: E731
+    lib.wgo_zmpdisc.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int] + [C.c_void_p] * 8
+    r["length"] = lib.wgo_zmpdisc(C.byref(model), C.addressof(steps), S, vp(f), L, vp(r["zmp"]), vp(r["zmp_theta"]),
+                                  vp(r["zmp_type"]), vp(r["left"]), vp(r["left_type"]), vp(r["right"]), vp(r["right_type"]),
+                                  vp(r["time"]))
+    return r
+
+
+def foot_constraints(poly_type, time, left, left_type, right, sole_w, sole_h, cx, cy, cap=256):
+    """wgo_foot_constraints: (polys (poly_type * cap), t_start, t_end, count)."""
+    lib = oracle()
+    time = np.ascontiguousarray(time, dtype=np.float64); left = np.ascontiguousarray(left, dtype=np.float64)
+    right = np.ascontiguousarray(right, dtype=np.float64); left_type = np.ascontiguousarray(left_type, dtype=np.int32)
+    polys = (poly_type * cap)(); ts = np.zeros(cap); te = np.zeros(cap)
+    vp = lambda a: a.ctypes.data_as(C.c_void_p)  # noqa: E731
+    lib.wgo_foot_constraints.argtypes = [C.c_int] + [C.c_void_p] * 4 + [C.c_double] * 4 + [C.c_int] + [C.c_void_p] * 3
+    k = lib.wgo_foot_constraints(time.shape[0], vp(time), vp(left), vp(left_type), vp(right), sole_w, sole_h, cx, cy, cap,
+                                 C.addressof(polys), vp(ts), vp(te))
+    return polys, ts[:max(k, 0)], te[:max(k, 0)], k

@@ -1,0 +1,114 @@
+"""ZMPDiscretization / FootConstraintsAsLinearSystem, CPU side.
+
+The oracle restatement (oracle/zmpdisc_oracle.c) is pinned to the reference's own golden files: the feet columns and the
+world-frame ZMP-reference columns of TestKajita2003{StraightWalking,PbFlorentSeq1}TestFGPI.datref are the deques
+ZMPDiscretization::GetZMPDiscretization fills, popped one sample per control step
+(DoubleStagePreviewControlStrategy.cpp:128-150, tests/TestObject.cpp:354-382).  The files are written with 8 significant
+digits after `filterprecision` truncates at 1e-7 (tests/TestObject.cpp:344-347), hence the tolerance."""
+import importlib
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import oraclelib as ol  # noqa: E402
+
+wg = importlib.import_module("jrl-walkgen_amd")
+GOLD = np.load(os.path.join(ROOT, "tests", "golden", "kajita_zmpdisc_datref.npz"))
+
+
+def kajita_model():
+    """tests/CommonTools.cpp:57-65 (CommonInitialization) + the constructor defaults of ZMPDiscretization.cpp:78-131"""
+    m = wg.ZmpDiscModel()
+    m.T, m.preview_time, m.t_single, m.t_double, m.step_height, m.omega, m.modulation = 0.005, 1.6, 0.78, 0.02, 0.07, 0.0, 0.9
+    m.foot_b, m.foot_h, m.foot_f = 0.1, 0.105, 0.13      # HRP-2 ankle geometry; without effect while omega = 0
+    return m
+
+
+def golden_case(name):
+    rows = GOLD[name + "_rows"]
+    steps = wg.rel_steps(GOLD[name + "_steps"], 0.78, 0.02)
+    init = [rows[0, 1], rows[0, 2], rows[0, 4], rows[0, 7], rows[0, 8], rows[0, 10]]   # what EvaluateStartingState returned
+    return rows, steps, init
+
+
+@pytest.mark.parametrize("name", ["StraightWalking", "PbFlorentSeq1"])
+def test_oracle_matches_reference_golden(name):
+    rows, steps, init = golden_case(name)
+    m = kajita_model()
+    r = ol.zmpdisc(m, steps, init)
+    n = rows.shape[0]
+    nl = int(m.preview_time / m.T)
+    assert r["length"] == n + 2 * nl          # the run stops when two preview windows are left on the queue
+    tol = 2e-7
+    assert np.abs(rows[:, 0] - (np.arange(n) + 1) * m.T).max() < 1e-9
+    assert np.abs(rows[:, 13:15] - r["zmp"][:n]).max() < tol
+    for c0, key in ((1, "left"), (7, "right")):
+        assert np.abs(rows[:, c0:c0 + 3] - r[key][:n, :3]).max() < tol        # x, y, z
+        assert np.abs(rows[:, c0 + 3:c0 + 6] - r[key][:n, 3:6]).max() < tol    # theta, omega, omega2
+    # the walk really turns / really lifts the feet in these files
+    assert r["left"][:, 2].max() > 0.069 and r["right"][:, 2].max() > 0.069
+    if name == "PbFlorentSeq1":
+        assert abs(r["left"][:, 3]).max() > 60.0
+
+
+def test_length_formula_and_bad_input():
+    m = kajita_model()
+    lib = ol.oracle()
+    import ctypes as C
+    lib.wgo_zmpdisc_length.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+    steps = wg.rel_steps(GOLD["StraightWalking_steps"], 0.78, 0.02)
+    assert lib.wgo_zmpdisc_length(C.byref(m), C.addressof(steps), 16) == 640 + 15 * 160 + 2 + 960
+    assert lib.wgo_zmpdisc_length(C.byref(m), C.addressof(steps), 1) < 0
+    # a double-support time below half a sample has no samples for the hand-over: the reference indexes [-1] there
+    bad = wg.rel_steps(GOLD["StraightWalking_steps"], 0.78, 0.002)
+    assert ol.zmpdisc(m, bad, [0, 0.095, 0, 0, -0.095, 0])["length"] < 0
+
+
+def test_portable_trig_variant_agrees():
+    """the bit-exact partner of the HIP kernel (include/wg_trig.h) against the libm oracle pinned above"""
+    import ctypes as C
+    import subprocess
+    so = os.path.join(ol.ORACLE_DIR, "libwg_oracle_ptrig.so")
+    subprocess.check_call(["make", "-s", "-C", ol.ORACLE_DIR, "libwg_oracle_ptrig.so"])
+    pt = C.CDLL(so)
+    rows, steps, init = golden_case("PbFlorentSeq1")
+    m = kajita_model()
+    a = ol.zmpdisc(m, steps, init)
+    b = ol.zmpdisc(m, steps, init, lib=pt)
+    assert a["length"] == b["length"]
+    for k in ("zmp", "left", "right", "zmp_theta"):
+        assert np.abs(a[k] - b[k]).max() < 1e-13
+    assert (a["zmp_type"] == b["zmp_type"]).all() and (a["left_type"] == b["left_type"]).all()
+
+
+def test_foot_constraints_of_the_golden_walk():
+    """BuildLinearConstraintInequalities on the StraightWalking feet: one polytope per support phase, each contains its
+    centre and the ZMP reference of its own interval (the unfiltered reference sits under the stance foot)."""
+    rows, steps, init = golden_case("StraightWalking")
+    m = kajita_model()
+    r = ol.zmpdisc(m, steps, init)
+    sole_w, sole_h, cx, cy = 0.24, 0.138, 0.04, 0.04
+    polys, ts, te, k = ol.foot_constraints(wg.ZmpPolytope, r["time"], r["left"], r["left_type"], r["right"], sole_w, sole_h,
+                                           cx, cy)
+    assert k == 1 + 15 + 14 + 1                # rest (+ first hand-over), 15 single supports, 14 double supports between, end
+    assert (np.diff(ts) > 0).all() and np.allclose(te[:-1], ts[1:]) and te[-1] == r["time"][-1]
+    for q in range(k):
+        P = polys[q]
+        A = np.array([[P.A[j][0], P.A[j][1]] for j in range(P.nrows)]); B = np.array(P.B[:P.nrows])
+        c = np.array(P.centre[:])
+        assert (A @ c + B > 0).all()
+        if q % 2 == 1:                           # single supports
+            assert P.nrows == 4
+            assert list(P.similar[:4]) == [0, 0, -2, -2]
+            sel = (r["time"] >= ts[q] + 0.1) & (r["time"] < te[q] - 0.1)
+            z = r["zmp"][sel]
+            # x half-extent 0.08, y half-extent 0.029 around the stance foot; the reference ZMP is the support-frame origin
+            assert (z @ A.T + B > -0.02).all()
+    # single-support polytope of an unrotated foot is the box of FootConstraintsAsLinearSystem.cpp:283-292
+    P = polys[1]
+    xs = sorted(-P.B[j] / P.A[j][0] for j in range(4) if P.A[j][1] == 0.0)
+    assert np.isclose(xs[1] - xs[0], sole_w - 2 * cx)
