@@ -1024,3 +1024,150 @@ int wg_gramian_batch(int B, int N, const double *T, const double *h, double alph
 }
 
 }  // extern "C"
+
+// ---- Kajita stage-1 inputs: ZMPDiscretization, batched (one lane per gait) ----------------------------------------------
+#include "wg_zmpdisc_device.hpp"
+
+namespace {
+DevBuf g_zd_buf;
+bool g_zd_hooked = false;
+
+// InitializeFilter, ZMPDiscretization.cpp:240-262 (sin from include/wg_trig.h: same bits on host and device)
+int zd_make_const(const wg_zmpdisc_model_t *model, wg::ZdConst *K) {
+  if (!model) return fail(WG_ERR_BAD_ARG, "null model");
+  if (!(model->T > 0.0)) return fail(WG_ERR_BAD_ARG, "sampling period must be positive");
+  const int n = (int)floor(0.05 / model->T);
+  if (n < 1 || n + 1 > WG_ZD_WIN_MAX)
+    return fail(WG_ERR_BAD_ARG, "filter window of %d taps unsupported (1 < taps <= %d)", n + 1, WG_ZD_WIN_MAX);
+  K->M = *model;
+  K->nwin = n + 1;
+  K->pad_ = 0;
+  double sum = 0;
+  for (int i = 0; i < n + 1; i++) {
+    const double tmp = wg_sin((WG_ZD_PI * i) / n);
+    K->win[i] = tmp * tmp;
+  }
+  for (int i = 0; i < n + 1; i++) sum += K->win[i];
+  for (int i = 0; i < n + 1; i++) K->win[i] /= sum;
+  for (int i = n + 1; i < WG_ZD_WIN_MAX; i++) K->win[i] = 0.0;
+  return WG_OK;
+}
+
+int zd_launch(const wg::ZdConst &K, int B, int smax, const wg_rel_step_t *steps, const int *n_steps,
+              const double *init_feet, int lcap, const wg::ZdOut &O, int *length, hipStream_t st) {
+  const size_t lds = (size_t)K.nwin * 3 * 2 * 64 * 8;
+  if (lds > 64 * 1024)
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(wg::wg_zmpdisc_kernel),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(wg::wg_zmpdisc_kernel, dim3((B + 63) / 64), dim3(64), lds, st, K, B, smax, steps, n_steps, init_feet,
+                     lcap, O, length);
+  HIP_TRY(hipGetLastError());
+  return WG_OK;
+}
+}  // namespace
+
+extern "C" {
+
+void wg_zmpdisc_defaults(wg_zmpdisc_model_t *m) {
+  if (!m) return;
+  memset(m, 0, sizeof *m);
+  m->T = 0.005;                    // ZMPRefTrajectoryGeneration's members as PatternGeneratorInterfacePrivate.cpp sets them
+  m->preview_time = 1.6;
+  m->t_single = 0.78;
+  m->t_double = 0.02;
+  m->step_height = 0.07;
+  m->omega = 0.0;
+  m->modulation = 0.9;             // ZMPDiscretization.cpp:99
+}
+
+int wg_zmpdisc_length(const wg_zmpdisc_model_t *model, const wg_rel_step_t *steps, int n_steps) {
+  if (!model || !steps) return WG_ZMPDISC_BAD_INPUT;
+  return wg::zd_length(*model, steps, n_steps);
+}
+
+int wg_zmpdisc_batch_dev(const wg_zmpdisc_model_t *model, int B, int smax, const wg_rel_step_t *steps, const int *n_steps,
+                         const double *init_feet, int lcap, double *zmp_x_tm, double *zmp_y_tm, int *length,
+                         void *hip_stream) {
+  if (int rc = ensure_device()) return rc;
+  wg::ZdConst K;
+  if (int rc = zd_make_const(model, &K)) return rc;
+  if (B < 0 || smax < 2 || smax > WG_ZMPDISC_MAX_STEPS || lcap < 1 || !steps || !n_steps || !init_feet || !zmp_x_tm || !zmp_y_tm)
+    return fail(WG_ERR_BAD_ARG, "need B >= 0, 2 <= smax <= %d, lcap >= 1, non-null arrays", WG_ZMPDISC_MAX_STEPS);
+  if (B == 0) return WG_OK;
+  wg::ZdOut O;
+  memset(&O, 0, sizeof O);
+  O.zx = zmp_x_tm;
+  O.zy = zmp_y_tm;
+  return zd_launch(K, B, smax, steps, n_steps, init_feet, lcap, O, length, reinterpret_cast<hipStream_t>(hip_stream));
+}
+
+int wg_zmpdisc_batch(const wg_zmpdisc_model_t *model, int B, int smax, const wg_rel_step_t *steps, const int *n_steps,
+                     const double *init_feet, int lcap, double *zmp, double *zmp_theta, int *zmp_type, double *left,
+                     int *left_type, double *right, int *right_type, int *length) {
+  if (int rc = ensure_device()) return rc;
+  wg::ZdConst K;
+  if (int rc = zd_make_const(model, &K)) return rc;
+  if (B < 0 || smax < 2 || smax > WG_ZMPDISC_MAX_STEPS || lcap < 1 || !steps || !n_steps || !init_feet || !length)
+    return fail(WG_ERR_BAD_ARG, "need B >= 0, 2 <= smax <= %d, lcap >= 1, non-null arrays", WG_ZMPDISC_MAX_STEPS);
+  if (B == 0) return WG_OK;
+  std::lock_guard<std::mutex> lk(g_mu);
+  if (!g_zd_hooked) { g_release_hooks.push_back([] { g_zd_buf.release(); }); g_zd_hooked = true; }
+  const size_t sB = (size_t)B, sL = (size_t)lcap, row = sB * sL;
+  // arena (8-byte units): steps | init_feet | zx zy ztheta | left right (6 rows each) | ints: n_steps length ztype ltype rtype
+  const size_t n_step_d = (sB * smax * sizeof(wg_rel_step_t) + 7) / 8;
+  const size_t nd = n_step_d + sB * 6 + 3 * row + 12 * row, ni = 2 * sB + 3 * row;
+  if (int rc = g_zd_buf.reserve(nd * 8 + ni * 4 + 64)) return rc;
+  double *d0 = static_cast<double *>(g_zd_buf.p);
+  wg_rel_step_t *d_steps = reinterpret_cast<wg_rel_step_t *>(d0);
+  double *d_feet = d0 + n_step_d, *d_zx = d_feet + sB * 6, *d_zy = d_zx + row, *d_zt = d_zy + row, *d_l = d_zt + row,
+         *d_r = d_l + 6 * row;
+  int *d_ns = reinterpret_cast<int *>(d_r + 6 * row), *d_len = d_ns + sB, *d_zty = d_len + sB, *d_lty = d_zty + row,
+      *d_rty = d_lty + row;
+  HIP_TRY(hipMemcpy(d_steps, steps, sB * smax * sizeof(wg_rel_step_t), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(d_feet, init_feet, sB * 6 * 8, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(d_ns, n_steps, sB * 4, hipMemcpyHostToDevice));
+  wg::ZdOut O;
+  memset(&O, 0, sizeof O);
+  if (zmp) { O.zx = d_zx; O.zy = d_zy; }
+  if (zmp_theta) O.ztheta = d_zt;
+  if (zmp_type) O.ztype = d_zty;
+  if (left) O.left = d_l;
+  if (left_type) O.ltype = d_lty;
+  if (right) O.right = d_r;
+  if (right_type) O.rtype = d_rty;
+  if (int rc = zd_launch(K, B, smax, d_steps, d_ns, d_feet, lcap, O, d_len, nullptr)) return rc;
+  HIP_TRY(hipDeviceSynchronize());
+  HIP_TRY(hipMemcpy(length, d_len, sB * 4, hipMemcpyDeviceToHost));
+  // time-major device arrays -> the caller's gait-major arrays, samples below each gait's length only
+  std::vector<double> hd;
+  std::vector<int> hi;
+  auto fetch_d = [&](const double *dev, int comps, double *dst, int dst_stride, int dst_off) -> int {
+    hd.resize(row * comps);
+    HIP_TRY(hipMemcpy(hd.data(), dev, row * comps * 8, hipMemcpyDeviceToHost));
+    for (size_t b = 0; b < sB; b++)
+      for (int l = 0; l < length[b]; l++)
+        for (int c = 0; c < comps; c++)
+          dst[(b * sL + l) * dst_stride + dst_off + c] = hd[((size_t)l * comps + c) * sB + b];
+    return WG_OK;
+  };
+  auto fetch_i = [&](const int *dev, int *dst) -> int {
+    hi.resize(row);
+    HIP_TRY(hipMemcpy(hi.data(), dev, row * 4, hipMemcpyDeviceToHost));
+    for (size_t b = 0; b < sB; b++)
+      for (int l = 0; l < length[b]; l++) dst[b * sL + l] = hi[(size_t)l * sB + b];
+    return WG_OK;
+  };
+  if (zmp) {
+    if (int rc = fetch_d(d_zx, 1, zmp, 2, 0)) return rc;
+    if (int rc = fetch_d(d_zy, 1, zmp, 2, 1)) return rc;
+  }
+  if (zmp_theta) if (int rc = fetch_d(d_zt, 1, zmp_theta, 1, 0)) return rc;
+  if (left) if (int rc = fetch_d(d_l, 6, left, 6, 0)) return rc;
+  if (right) if (int rc = fetch_d(d_r, 6, right, 6, 0)) return rc;
+  if (zmp_type) if (int rc = fetch_i(d_zty, zmp_type)) return rc;
+  if (left_type) if (int rc = fetch_i(d_lty, left_type)) return rc;
+  if (right_type) if (int rc = fetch_i(d_rty, right_type)) return rc;
+  return WG_OK;
+}
+
+}  // extern "C"
