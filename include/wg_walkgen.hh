@@ -268,6 +268,91 @@ class PreviewControl : public SimplePlugin {
 };
 
 // ---- PatternGeneratorInterface ---------------------------------------------------------------------------------------------
+// ZMPDiscretization (src/ZMPRefTrajectoryGeneration/ZMPDiscretization.hh): the ZMP reference and feet trajectories of a
+// step sequence, Kajita mode.  Same entry points as the reference; every sample comes from wg_zmpdisc_batch (GPU).  The
+// on-line calls (OnLineAddFoot after InitOnLine) re-run the sequence known so far and append the new samples: the
+// producer is deterministic, so this equals continuing from the reference's member state.
+class ZMPDiscretization : public ZMPRefTrajectoryGeneration {
+ public:
+  ZMPDiscretization(SimplePluginManager *lSPM, std::string DataFile = "", const HumanoidModel *aHS = 0);
+  ~ZMPDiscretization();
+  void GetZMPDiscretization(std::deque<ZMPPosition> &ZMPPositions, std::deque<COMState> &COMStates,
+                            std::deque<RelativeFootPosition> &RelativeFootPositions,
+                            std::deque<FootAbsolutePosition> &LeftFootAbsolutePositions,
+                            std::deque<FootAbsolutePosition> &RightFootAbsolutePositions, double Xmax,
+                            COMState &lStartingCOMState, double lStartingZMPPosition[3],
+                            FootAbsolutePosition &InitLeftFootAbsolutePosition,
+                            FootAbsolutePosition &InitRightFootAbsolutePosition);
+  int InitOnLine(std::deque<ZMPPosition> &FinalZMPPositions, std::deque<COMState> &COMStates,
+                 std::deque<FootAbsolutePosition> &FinalLeftFootAbsolutePositions,
+                 std::deque<FootAbsolutePosition> &FinalRightFootAbsolutePositions,
+                 FootAbsolutePosition &InitLeftFootAbsolutePosition, FootAbsolutePosition &InitRightFootAbsolutePosition,
+                 std::deque<RelativeFootPosition> &RelativeFootPositions, COMState &lStartingCOMState,
+                 double lStartingZMPPosition[3]);
+  void OnLine(double time, std::deque<ZMPPosition> &FinalZMPPositions, std::deque<COMState> &COMStates,
+              std::deque<FootAbsolutePosition> &FinalLeftFootAbsolutePositions,
+              std::deque<FootAbsolutePosition> &FinalRightFootAbsolutePositions);
+  void OnLineAddFoot(RelativeFootPosition &NewRelativeFootPosition, std::deque<ZMPPosition> &FinalZMPPositions,
+                     std::deque<COMState> &COMStates, std::deque<FootAbsolutePosition> &FinalLeftFootAbsolutePositions,
+                     std::deque<FootAbsolutePosition> &FinalRightFootAbsolutePositions, bool EndSequence);
+  void EndPhaseOfTheWalking(std::deque<ZMPPosition> &ZMPPositions, std::deque<COMState> &FinalCOMStates,
+                            std::deque<FootAbsolutePosition> &LeftFootAbsolutePositions,
+                            std::deque<FootAbsolutePosition> &RightFootAbsolutePositions);
+  int ReturnOptimalTimeToRegenerateAStep();
+  void SetZMPShift(std::vector<double> &ZMPShift);
+  void CallMethod(std::string &Method, std::istringstream &strm);
+  const wg_zmpdisc_model_t &Model();
+
+ private:
+  // runs the whole sequence on the GPU and appends samples [from, to) (to < 0: up to the end phase / with it)
+  void Produce(bool with_end, size_t from, std::deque<ZMPPosition> &Z, std::deque<COMState> &Cs,
+               std::deque<FootAbsolutePosition> &L, std::deque<FootAbsolutePosition> &R);
+  wg_zmpdisc_model_t Model_;
+  std::vector<wg_rel_step_t> Steps_;
+  double InitFeet_[6];
+  double StartTime_;
+  size_t Produced_;                 // samples handed out so far (without an end phase)
+};
+
+// StepStackHandler (src/StepStackHandler.hh), the part ":stepseq" needs: walk mode 0
+class StepStackHandler {
+ public:
+  StepStackHandler() : m_SingleSupportTime(0.78), m_DoubleSupportTime(0.02), m_WalkMode(0) {}
+  void SetSingleTimeSupport(double v) { m_SingleSupportTime = v; }
+  void SetDoubleTimeSupport(double v) { m_DoubleSupportTime = v; }
+  int GetWalkMode() const { return m_WalkMode; }
+  void ReadStepSequenceAccordingToWalkMode(std::istringstream &strm);    // StepStackHandler.cpp:128-175
+  void CopyRelativeFootPosition(std::deque<RelativeFootPosition> &lRelativeFootPositions, bool PerformClean);
+
+ private:
+  std::deque<RelativeFootPosition> m_RelativeFootPositions;
+  double m_SingleSupportTime, m_DoubleSupportTime;
+  int m_WalkMode;
+};
+
+// LinearConstraintInequality_t (pgtypes.hh:168-177): A is rows x 2 (row-major), B rows x 1
+struct LinearConstraintInequality_s {
+  std::vector<double> A, B, Center;
+  std::vector<int> SimilarConstraints;
+  double StartingTime, EndingTime;
+};
+typedef LinearConstraintInequality_s LinearConstraintInequality_t;
+
+// FootConstraintsAsLinearSystem (src/Mathematics/FootConstraintsAsLinearSystem.hh) over wg_foot_constraints
+class FootConstraintsAsLinearSystem : public SimplePlugin {
+ public:
+  FootConstraintsAsLinearSystem(SimplePluginManager *aSPM, const HumanoidModel *aHS);
+  ~FootConstraintsAsLinearSystem();
+  int BuildLinearConstraintInequalities(std::deque<FootAbsolutePosition> &LeftFootAbsolutePositions,
+                                        std::deque<FootAbsolutePosition> &RightFootAbsolutePositions,
+                                        std::deque<LinearConstraintInequality_t *> &QueueOfLConstraintInequalities,
+                                        double ConstraintOnX, double ConstraintOnY);
+  void CallMethod(std::string &Method, std::istringstream &strm);
+
+ private:
+  HumanoidModel m_HS;
+};
+
 class PatternGeneratorInterface {
  public:
   PatternGeneratorInterface(const HumanoidModel *) {}

@@ -148,6 +148,7 @@ wg_zmpdisc_kernel(ZdConst K, int B, int smax, const wg_rel_step_t *__restrict__ 
   if (length) length[g] = Ltot;
   if (Ltot < 0) return;
 
+  const bool want_feet = O.left || O.right || O.ltype || O.rtype;   // otherwise only each phase's last sample is evaluated
   ZdRings R;
   R.nwin = K.nwin;
   R.nf = 2 * K.nwin;
@@ -334,23 +335,32 @@ wg_zmpdisc_kernel(ZdConst K, int B, int smax, const wg_rel_step_t *__restrict__ 
       // FilterOutValues, :1051-1105.  slot of unfiltered sample q (q <= gen - 1): slot_top - (gen - 1 - q), wrapped
       double l0 = 0.0, l1 = 0.0;
       const int o = nz - 1 - 2;
-      for (int j = 0; j < K.nwin; j++) {
-        int r = i - j + 2;
-        const double wj = K.win[j];
-        if (r < 0) {
-          if (kind == ZD_INIT) {
-            l0 += wj * z2x; l1 += wj * z2y;
-          } else if (-r < o) {
-            const int q = (o + r) % R.nf;
-            l0 += wj * R.F(q, 0); l1 += wj * R.F(q, 1);
-          } else {
-            l0 += wj * f0x; l1 += wj * f0y;
-          }
-        } else {
-          if (r >= nZ) r = nZ - 1;
-          int slot = slot_top - (gen - 1 - r);
-          if (slot < 0) slot += R.nwin;
+      if (i + 3 >= K.nwin && i + 2 < nZ) {          // every tap inside the phase: r = i + 2 - j is sample gen - 1 - j
+        int slot = slot_top;
+        for (int j = 0; j < K.nwin; j++) {
+          const double wj = K.win[j];
           l0 += wj * R.Z(slot, 0); l1 += wj * R.Z(slot, 1);
+          slot = slot == 0 ? R.nwin - 1 : slot - 1;
+        }
+      } else {
+        for (int j = 0; j < K.nwin; j++) {
+          int r = i - j + 2;
+          const double wj = K.win[j];
+          if (r < 0) {
+            if (kind == ZD_INIT) {
+              l0 += wj * z2x; l1 += wj * z2y;
+            } else if (-r < o) {
+              const int q = (o + r) % R.nf;
+              l0 += wj * R.F(q, 0); l1 += wj * R.F(q, 1);
+            } else {
+              l0 += wj * f0x; l1 += wj * f0y;
+            }
+          } else {
+            if (r >= nZ) r = nZ - 1;
+            int slot = slot_top - (gen - 1 - r);
+            if (slot < 0) slot += R.nwin;
+            l0 += wj * R.Z(slot, 0); l1 += wj * R.Z(slot, 1);
+          }
         }
       }
       // theta, stepType and the feet of sample i
@@ -367,6 +377,7 @@ wg_zmpdisc_kernel(ZdConst K, int B, int smax, const wg_rel_step_t *__restrict__ 
         const int k = i - n1;
         th = zd_poly(qzt, 4, (unsigned)k * M.T) + theta0;
         ty = type_ss;
+        if (want_feet || i == nZ - 1) {
         // UpdateFootPosition: local index k + 1 (the last double-support sample is the initial one)
         ZdFoot &sup = who == 1 ? fl : fr;
         ZdFoot &non = who == 1 ? fr : fl;
@@ -410,6 +421,7 @@ wg_zmpdisc_kernel(ZdConst K, int B, int smax, const wg_rel_step_t *__restrict__ 
         non.x += ct * dX;
         non.y += stt * dX;
         non.z += dFZ;
+        }
       } else {                                      // value-initialised tail
         th = 0.0; ty = 0;
         fl.x = fl.y = fl.z = fl.theta = fl.omega = fl.omega2 = 0.0; fl.type = 0;

@@ -1,8 +1,8 @@
 // test_kajita_preview.cpp -- BASELINE config[0] plumbing: the step sequence of the reference's
-// TestKajita2003 StraightWalking (tests/TestKajita2003.cpp:96-124) through stage 1 only -- a ZMP reference queue under
-// the stance feet, then PreviewControl (include/wg_walkgen.hh) -- on the GPU.  The first steps go through
+// TestKajita2003 StraightWalking (tests/TestKajita2003.cpp:96-124) through stage 1 only -- the ZMP reference queue and feet
+// of ZMPDiscretization, then PreviewControl (both include/wg_walkgen.hh) -- on the GPU.  The first steps go through
 // OneIterationOfPreview one call at a time (the reference's call pattern, ZMPPreviewControlWithMultiBodyZMP.cpp), the
-// whole run through RunBatch; both must agree bit for bit.  Writes "t com_x com_y zmp_x zmp_y zmpref_x zmpref_y".
+// whole run through RunBatch; both must agree bit for bit.  Writes "t com_x com_y zmp_x zmp_y zmpref_x zmpref_y lf_x lf_y lf_z rf_x rf_y rf_z".
 #include <cstdio>
 #include <cstring>
 #include <deque>
@@ -28,27 +28,52 @@ int main(int argc, char **argv) {
     const double T = pc.SamplingPeriod();
     const unsigned nl = (unsigned)(pc.PreviewControlTime() / T);
 
-    // ":stepseq 0.0 -0.105 0.0  0.2 0.21 0.0  0.2 -0.21 0.0 ... 0.0 0.21 0.0" (16 triples), single support 0.78 s,
-    // double support 0.02 s (CommonInitialization), ZMP under the stance foot, linear hand-over in double support
-    const int nsteps = 16;
-    double sx[nsteps], sy[nsteps];
-    sx[0] = 0.0; sy[0] = -0.105;
-    for (int k = 1; k < nsteps - 1; k++) { sx[k] = 0.2; sy[k] = (k % 2) ? 0.21 : -0.21; }
-    sx[nsteps - 1] = 0.0; sy[nsteps - 1] = 0.21;
-    std::deque<ZMPPosition> zq;
-    auto push = [&](double x, double y) { ZMPPosition z; memset(&z, 0, sizeof z); z.px = x; z.py = y; z.time = zq.size() * T; zq.push_back(z); };
-    const int n_ss = (int)(0.78 / T + 0.5), n_ds = (int)(0.02 / T + 0.5), n_rest = (int)(1.6 / T + 0.5);
-    for (int i = 0; i < n_rest; i++) push(0.0, 0.0);
-    double fx = 0.0, fy = 0.0, px = 0.0, py = 0.0;
-    for (int k = 0; k < nsteps; k++) {
-      fx += sx[k]; fy += sy[k];
-      for (int i = 0; i < n_ds; i++) { const double a = (i + 1.0) / n_ds; push(px + a * (fx - px), py + a * (fy - py)); }
-      for (int i = 0; i < n_ss; i++) push(fx, fy);
-      px = fx; py = fy;
+    // CommonInitialization (tests/CommonTools.cpp:57-65) and StraightWalking's ":stepseq" (tests/TestKajita2003.cpp:104-120)
+    // through StepStackHandler and ZMPDiscretization::GetZMPDiscretization, as PatternGeneratorInterfacePrivate does for
+    // ":stepseq" in Kajita mode (m_StepSequence :562-571, CreateZMPReferences :1870-1882)
+    HumanoidModel robot = HumanoidModel::sampleRobot();
+    ZMPDiscretization zmpd(&spm, "", &robot);
+    const char *cmds[] = {":omega 0.0", ":stepheight 0.07", ":singlesupporttime 0.78", ":doublesupporttime 0.02"};
+    for (const char *c : cmds) { std::istringstream s(c); std::string m; s >> m; spm.CallMethod(m, s); }
+    StepStackHandler ssh;
+    ssh.SetSingleTimeSupport(0.78);
+    ssh.SetDoubleTimeSupport(0.02);
+    {
+      std::istringstream s("0.0 -0.105 0.0 0.2 0.21 0.0 0.2 -0.21 0.0 0.2 0.21 0.0 0.2 -0.21 0.0 0.2 0.21 0.0 0.2 -0.21 0.0 "
+                           "0.2 0.21 0.0 0.2 -0.21 0.0 0.2 0.21 0.0 0.2 -0.21 0.0 0.2 0.21 0.0 0.2 -0.21 0.0 0.2 0.21 0.0 "
+                           "0.2 -0.21 0.0 0.0 0.21 0.0");
+      ssh.ReadStepSequenceAccordingToWalkMode(s);
     }
-    const double ex = fx, ey = fy - 0.105;
-    for (int i = 0; i < n_ds; i++) { const double a = (i + 1.0) / n_ds; push(px + a * (ex - px), py + a * (ey - py)); }
-    for (int i = 0; i < n_rest + (int)nl; i++) push(ex, ey);
+    std::deque<RelativeFootPosition> rel;
+    ssh.CopyRelativeFootPosition(rel, true);
+    std::deque<ZMPPosition> zq;
+    std::deque<COMState> cq;
+    std::deque<FootAbsolutePosition> lq, rq;
+    FootAbsolutePosition il, ir;
+    memset(&il, 0, sizeof il); memset(&ir, 0, sizeof ir);
+    il.x = 0.0094903; il.y = 0.095; ir.x = 0.0094903; ir.y = -0.095;     // EvaluateStartingState on HRP-2's half-sitting pose
+    COMState c0;
+    double z0[3] = {0, 0, 0};
+    zmpd.SetCurrentTime(0.0);
+    zmpd.GetZMPDiscretization(zq, cq, rel, lq, rq, 0.0, c0, z0, il, ir);
+    if (zq.size() != lq.size() || zq.size() != rq.size() || zq.size() != cq.size()) throw std::runtime_error("deque sizes differ");
+    // the same sequence fed on line: InitOnLine with the first steps, OnLineAddFoot for the others, then the end phase
+    {
+      ZMPDiscretization online(&spm, "", &robot);
+      for (const char *c : cmds) { std::istringstream s(c); std::string m; s >> m; spm.CallMethod(m, s); }
+      std::deque<RelativeFootPosition> first(rel.begin(), rel.begin() + 3);
+      std::deque<ZMPPosition> z2q; std::deque<COMState> c2q; std::deque<FootAbsolutePosition> l2q, r2q;
+      online.SetCurrentTime(0.0);
+      online.InitOnLine(z2q, c2q, l2q, r2q, il, ir, first, c0, z0);
+      for (size_t i = 3; i < rel.size(); i++) online.OnLineAddFoot(rel[i], z2q, c2q, l2q, r2q, false);
+      online.EndPhaseOfTheWalking(z2q, c2q, l2q, r2q);
+      if (z2q.size() != zq.size()) throw std::runtime_error("on-line and off-line sequences differ in length");
+      for (size_t i = 0; i < zq.size(); i++)
+        if (z2q[i].px != zq[i].px || z2q[i].py != zq[i].py || l2q[i].x != lq[i].x || l2q[i].z != lq[i].z || r2q[i].y != rq[i].y ||
+            z2q[i].time != zq[i].time)
+          throw std::runtime_error("on-line and off-line sequences differ");
+    }
+    const double ex = zq.back().px, ey = zq.back().py;
     const int L = (int)zq.size() - (int)nl + 1;
 
     // (a) the reference's call pattern for the first 40 control steps
@@ -70,7 +95,8 @@ int main(int argc, char **argv) {
     FILE *f = fopen(out, "w");
     if (!f) throw std::runtime_error("cannot open output file");
     for (int l = 0; l < L; l++)
-      fprintf(f, "%.3f %.17g %.17g %.17g %.17g %.17g %.17g\n", (l + 1) * T, com[6 * l], com[6 * l + 3], z2[2 * l], z2[2 * l + 1], zx[l], zy[l]);
+      fprintf(f, "%.3f %.17g %.17g %.17g %.17g %.17g %.17g %.17g %.17g %.17g %.17g %.17g %.17g\n", (l + 1) * T, com[6 * l],
+              com[6 * l + 3], z2[2 * l], z2[2 * l + 1], zx[l], zy[l], lq[l].x, lq[l].y, lq[l].z, rq[l].x, rq[l].y, rq[l].z);
     fclose(f);
     printf("TestKajita2003StraightWalking stage 1: %d control steps, final CoM (%.6f, %.6f), last footprint (%.3f, %.3f)\n", L,
            com[6 * (L - 1)], com[6 * (L - 1) + 3], ex, ey);

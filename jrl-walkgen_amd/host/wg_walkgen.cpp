@@ -413,6 +413,222 @@ void PreviewControl::CallMethod(string &Method, istringstream &astrm) {   // :51
   }
 }
 
+// ---- ZMPDiscretization ------------------------------------------------------------------------------------------------------
+// ZMPDiscretization.cpp:78-131
+ZMPDiscretization::ZMPDiscretization(SimplePluginManager *lSPM, string, const HumanoidModel *aHS)
+    : ZMPRefTrajectoryGeneration(lSPM) {
+  wg_zmpdisc_defaults(&Model_);
+  m_ModulationSupportCoefficient = 0.9;      // :99
+  m_SamplingPeriod = Model_.T; m_PreviewControlTime = Model_.preview_time;
+  m_Tsingle = Model_.t_single; m_Tdble = Model_.t_double; m_StepHeight = Model_.step_height; m_Omega = Model_.omega;
+  if (aHS) {                                 // FootTrajectoryGenerationStandard.cpp:62-71: lDepth is the ankle's height
+    Model_.foot_b = aHS->anklePosition[0];
+    Model_.foot_h = aHS->anklePosition[2];
+    Model_.foot_f = aHS->anklePosition[2] - aHS->anklePosition[0];
+  }
+  for (int i = 0; i < 6; i++) InitFeet_[i] = 0.0;
+  StartTime_ = 0.0;
+  Produced_ = 0;
+  string aMethodName[3] = {":prevzmpinitprofil", ":zeroinitprofil", ":previewcontroltime"};   // :1302-1322
+  for (int i = 0; i < 3; i++)
+    if (!RegisterMethod(aMethodName[i])) cerr << "Unable to register " << aMethodName[i] << endl;
+}
+ZMPDiscretization::~ZMPDiscretization() {}
+
+void ZMPDiscretization::CallMethod(string &Method, istringstream &strm) {   // :1323-1345
+  if (Method == ":previewcontroltime") strm >> m_PreviewControlTime;
+  ZMPRefTrajectoryGeneration::CallMethod(Method, strm);
+}
+void ZMPDiscretization::SetZMPShift(vector<double> &ZMPShift) {             // :305-314
+  for (size_t i = 0; i < ZMPShift.size() && i < 4; i++) Model_.zmp_shift[i] = ZMPShift[i];
+}
+int ZMPDiscretization::ReturnOptimalTimeToRegenerateAStep() {               // :1122-1127
+  return 2 * (int)(m_PreviewControlTime / m_SamplingPeriod);
+}
+const wg_zmpdisc_model_t &ZMPDiscretization::Model() {
+  Model_.T = m_SamplingPeriod; Model_.preview_time = m_PreviewControlTime;
+  Model_.t_single = m_Tsingle; Model_.t_double = m_Tdble; Model_.step_height = m_StepHeight; Model_.omega = m_Omega;
+  Model_.modulation = m_ModulationSupportCoefficient;
+  return Model_;
+}
+
+void ZMPDiscretization::Produce(bool with_end, size_t from, deque<ZMPPosition> &Z, deque<COMState> &Cs,
+                                deque<FootAbsolutePosition> &L, deque<FootAbsolutePosition> &R) {
+  const wg_zmpdisc_model_t &M = Model();
+  const int S = (int)Steps_.size();
+  const int total = wg_zmpdisc_length(&M, Steps_.data(), S);
+  if (total < 0) throw runtime_error("ZMPDiscretization: unsupported step sequence");
+  const size_t n_end = (size_t)((unsigned)round(M.t_double / (2 * M.T))) + (size_t)(int)(3.0 * M.preview_time / M.T);
+  const size_t stop = with_end ? (size_t)total : (size_t)total - n_end;
+  vector<double> zmp((size_t)total * 2), zth(total), lf((size_t)total * 6), rf((size_t)total * 6);
+  vector<int> zty(total), lty(total), rty(total);
+  int len = 0;
+  if (wg_zmpdisc_batch(&M, 1, S, Steps_.data(), &S, InitFeet_, total, zmp.data(), zth.data(), zty.data(), lf.data(), lty.data(),
+                       rf.data(), rty.data(), &len) != WG_OK)
+    wg_throw("wg_zmpdisc_batch");
+  if (len != total) throw runtime_error("ZMPDiscretization: the step sequence was refused");
+  double t = StartTime_;                     // m_CurrentTime += m_SamplingPeriod per sample
+  for (size_t i = 0; i < stop; i++, t += M.T) {
+    if (i < from) continue;
+    ZMPPosition z;
+    memset(&z, 0, sizeof z);
+    z.px = zmp[2 * i]; z.py = zmp[2 * i + 1]; z.theta = zth[i]; z.time = t; z.stepType = zty[i];
+    Z.push_back(z);
+    COMState c;
+    c.z[0] = m_ComHeight;
+    c.yaw[0] = zth[i];
+    Cs.push_back(c);
+    for (int side = 0; side < 2; side++) {
+      const double *f = (side ? rf.data() : lf.data()) + 6 * i;
+      FootAbsolutePosition a;
+      memset(&a, 0, sizeof a);
+      a.x = f[0]; a.y = f[1]; a.z = f[2]; a.theta = f[3]; a.omega = f[4]; a.omega2 = f[5];
+      a.time = t; a.stepType = side ? rty[i] : lty[i];
+      (side ? R : L).push_back(a);
+    }
+  }
+  if (!with_end) Produced_ = stop;
+  m_CurrentTime = t;
+}
+
+// :319-513
+int ZMPDiscretization::InitOnLine(deque<ZMPPosition> &FinalZMPPositions, deque<COMState> &COMStates,
+                                  deque<FootAbsolutePosition> &FinalLeftFootAbsolutePositions,
+                                  deque<FootAbsolutePosition> &FinalRightFootAbsolutePositions,
+                                  FootAbsolutePosition &InitLeftFootAbsolutePosition,
+                                  FootAbsolutePosition &InitRightFootAbsolutePosition,
+                                  deque<RelativeFootPosition> &RelativeFootPositions, COMState &, double *) {
+  if (RelativeFootPositions.size() < 2) throw runtime_error("ZMPDiscretization::InitOnLine: at least two steps are needed");
+  Steps_.clear();
+  for (size_t i = 0; i < RelativeFootPositions.size(); i++) {
+    const RelativeFootPosition &r = RelativeFootPositions[i];
+    wg_rel_step_t s;
+    memset(&s, 0, sizeof s);
+    s.sx = r.sx; s.sy = r.sy; s.theta = r.theta; s.ss_time = r.SStime; s.ds_time = r.DStime; s.step_type = r.stepType;
+    Steps_.push_back(s);
+  }
+  InitFeet_[0] = InitLeftFootAbsolutePosition.x; InitFeet_[1] = InitLeftFootAbsolutePosition.y;
+  InitFeet_[2] = InitLeftFootAbsolutePosition.theta;
+  InitFeet_[3] = InitRightFootAbsolutePosition.x; InitFeet_[4] = InitRightFootAbsolutePosition.y;
+  InitFeet_[5] = InitRightFootAbsolutePosition.theta;
+  StartTime_ = m_CurrentTime;
+  Produced_ = 0;
+  Produce(false, 0, FinalZMPPositions, COMStates, FinalLeftFootAbsolutePositions, FinalRightFootAbsolutePositions);
+  return (int)RelativeFootPositions.size();
+}
+
+void ZMPDiscretization::OnLine(double, deque<ZMPPosition> &, deque<COMState> &, deque<FootAbsolutePosition> &,
+                               deque<FootAbsolutePosition> &) {}   // :561-568: does nothing
+
+// :573-1020
+void ZMPDiscretization::OnLineAddFoot(RelativeFootPosition &r, deque<ZMPPosition> &FinalZMPPositions, deque<COMState> &COMStates,
+                                      deque<FootAbsolutePosition> &FinalLeftFootAbsolutePositions,
+                                      deque<FootAbsolutePosition> &FinalRightFootAbsolutePositions, bool EndSequence) {
+  if (Steps_.empty()) throw runtime_error("ZMPDiscretization::OnLineAddFoot before InitOnLine");
+  wg_rel_step_t s;
+  memset(&s, 0, sizeof s);
+  s.sx = r.sx; s.sy = r.sy; s.theta = r.theta; s.ss_time = r.SStime; s.ds_time = r.DStime; s.step_type = r.stepType;
+  Steps_.push_back(s);
+  Produce(EndSequence, Produced_, FinalZMPPositions, COMStates, FinalLeftFootAbsolutePositions, FinalRightFootAbsolutePositions);
+}
+
+// :1129-1300
+void ZMPDiscretization::EndPhaseOfTheWalking(deque<ZMPPosition> &ZMPPositions, deque<COMState> &FinalCOMStates,
+                                             deque<FootAbsolutePosition> &LeftFootAbsolutePositions,
+                                             deque<FootAbsolutePosition> &RightFootAbsolutePositions) {
+  if (Steps_.empty()) throw runtime_error("ZMPDiscretization::EndPhaseOfTheWalking before InitOnLine");
+  Produce(true, Produced_, ZMPPositions, FinalCOMStates, LeftFootAbsolutePositions, RightFootAbsolutePositions);
+}
+
+// :143-173
+void ZMPDiscretization::GetZMPDiscretization(deque<ZMPPosition> &FinalZMPPositions, deque<COMState> &FinalCOMStates,
+                                             deque<RelativeFootPosition> &RelativeFootPositions,
+                                             deque<FootAbsolutePosition> &LeftFootAbsolutePositions,
+                                             deque<FootAbsolutePosition> &RightFootAbsolutePositions, double,
+                                             COMState &lStartingCOMState, double lStartingZMPPosition[3],
+                                             FootAbsolutePosition &InitLeftFootAbsolutePosition,
+                                             FootAbsolutePosition &InitRightFootAbsolutePosition) {
+  InitOnLine(FinalZMPPositions, FinalCOMStates, LeftFootAbsolutePositions, RightFootAbsolutePositions,
+             InitLeftFootAbsolutePosition, InitRightFootAbsolutePosition, RelativeFootPositions, lStartingCOMState,
+             lStartingZMPPosition);
+  EndPhaseOfTheWalking(FinalZMPPositions, FinalCOMStates, LeftFootAbsolutePositions, RightFootAbsolutePositions);
+  FinalCOMStates.resize(FinalZMPPositions.size());
+}
+
+// ---- StepStackHandler (walk mode 0), StepStackHandler.cpp:128-175 -------------------------------------------------------------
+void StepStackHandler::ReadStepSequenceAccordingToWalkMode(istringstream &strm) {
+  m_RelativeFootPositions.clear();
+  RelativeFootPosition aFootPosition;
+  memset(&aFootPosition, 0, sizeof aFootPosition);
+  while (!strm.eof()) {
+    if (!strm.eof()) strm >> aFootPosition.sx; else break;
+    if (!strm.eof()) strm >> aFootPosition.sy; else break;
+    if (!strm.eof()) strm >> aFootPosition.theta; else break;
+    aFootPosition.DeviationHipHeight = 0;
+    aFootPosition.SStime = m_SingleSupportTime;
+    aFootPosition.DStime = m_DoubleSupportTime;
+    aFootPosition.stepType = 1;
+    m_RelativeFootPositions.push_back(aFootPosition);
+  }
+}
+void StepStackHandler::CopyRelativeFootPosition(deque<RelativeFootPosition> &lRelativeFootPositions, bool PerformClean) {
+  lRelativeFootPositions = m_RelativeFootPositions;
+  if (PerformClean) m_RelativeFootPositions.clear();
+}
+
+// ---- FootConstraintsAsLinearSystem ----------------------------------------------------------------------------------------------
+FootConstraintsAsLinearSystem::FootConstraintsAsLinearSystem(SimplePluginManager *aSPM, const HumanoidModel *aHS)
+    : SimplePlugin(aSPM) {
+  if (aHS == 0) throw runtime_error("FootConstraintsAsLinearSystem: a HumanoidModel is required");
+  m_HS = *aHS;
+}
+FootConstraintsAsLinearSystem::~FootConstraintsAsLinearSystem() {}
+void FootConstraintsAsLinearSystem::CallMethod(string &, istringstream &) {}   // FootConstraintsAsLinearSystem.cpp:541-545
+
+// :258-539
+int FootConstraintsAsLinearSystem::BuildLinearConstraintInequalities(deque<FootAbsolutePosition> &LeftFootAbsolutePositions,
+                                                                     deque<FootAbsolutePosition> &RightFootAbsolutePositions,
+                                                                     deque<LinearConstraintInequality_t *> &Queue,
+                                                                     double ConstraintOnX, double ConstraintOnY) {
+  if (LeftFootAbsolutePositions.size() != RightFootAbsolutePositions.size()) return -1;
+  const size_t n = LeftFootAbsolutePositions.size();
+  vector<double> time(n), lf(6 * n), rf(6 * n);
+  vector<int> lty(n);
+  for (size_t i = 0; i < n; i++) {
+    const FootAbsolutePosition &l = LeftFootAbsolutePositions[i], &r = RightFootAbsolutePositions[i];
+    time[i] = l.time;
+    lty[i] = l.stepType;
+    const double lv[6] = {l.x, l.y, l.z, l.theta, l.omega, l.omega2}, rv[6] = {r.x, r.y, r.z, r.theta, r.omega, r.omega2};
+    for (int c = 0; c < 6; c++) { lf[6 * i + c] = lv[c]; rf[6 * i + c] = rv[c]; }
+  }
+  int cap = 64;
+  vector<wg_zmp_polytope_t> polys;
+  vector<double> ts, te;
+  int k;
+  for (;;) {
+    polys.resize(cap); ts.resize(cap); te.resize(cap);
+    k = wg_foot_constraints((int)n, time.data(), lf.data(), lty.data(), rf.data(), m_HS.soleWidth, m_HS.soleHeight,
+                            ConstraintOnX, ConstraintOnY, cap, polys.data(), ts.data(), te.data());
+    if (k < 0) return -1;
+    if (k <= cap) break;
+    cap = k;
+  }
+  for (int q = 0; q < k; q++) {
+    LinearConstraintInequality_t *aLCI = new LinearConstraintInequality_t;
+    const wg_zmp_polytope_t &P = polys[q];
+    for (int j = 0; j < P.nrows; j++) {
+      aLCI->A.push_back(P.A[j][0]); aLCI->A.push_back(P.A[j][1]);
+      aLCI->B.push_back(P.B[j]);
+      aLCI->SimilarConstraints.push_back(P.similar[j]);
+    }
+    aLCI->Center.push_back(P.centre[0]); aLCI->Center.push_back(P.centre[1]);
+    aLCI->StartingTime = ts[q];
+    aLCI->EndingTime = te[q];
+    Queue.push_back(aLCI);
+  }
+  return 0;
+}
+
 namespace {
 
 class PatternGeneratorInterfacePrivate : public virtual PatternGeneratorInterface, SimplePluginManager, SimplePlugin {

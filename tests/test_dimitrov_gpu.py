@@ -100,3 +100,96 @@ def test_bad_polytope_and_unconfigured_calls():
     assert wg.lib().wg_dimitrov_tick_batch(1, None, None, None, 0) != 0
     bad = wg.dimitrov_defaults(); bad.N = 40
     assert wg.lib().wg_dimitrov_configure(C.byref(bad)) != 0
+
+
+def _polytopes_for_tick(polys, ts, te, k, t0, N, T):
+    """the queue walk of BuildConstraintMatrices (ZMPConstrainedQPFastFormulation.cpp:783-795, 836-840): the polytope whose
+    interval holds t0, then the next one whenever a previewed instant passes the current one's EndingTime"""
+    q = 0
+    while q < k and not (ts[q] <= t0 <= te[q]):
+        q += 1
+    assert q < k
+    sel = []
+    for i in range(N):
+        if t0 + i * T > te[q]:
+            q += 1
+        sel.append(q)
+    return sel
+
+
+def test_step_sequences_to_com_through_zmpdisc_footconstraints_and_the_tick():
+    """the Dimitrov-2008 pipeline of BuildZMPTrajectoryFromFootTrajectory (:1096-1463) with real data either side:
+    ":stepseq" -> ZMPDiscretization feet (GPU) -> FootConstraintsAsLinearSystem polytopes (library, host) -> one fused tick
+    per 0.1 s (GPU), against the oracle tick on the same polytopes, bit for bit, while the CoM follows the footprints.
+    PLDP leaves its solutions up to its tolerance (1e-8) outside a constraint (ComputeAlpha, PLDPSolver.cpp:617-618) and
+    then refuses the hot start of a later tick for being more than 1e-8 outside (:611-616, its exit(0) path): with real
+    footprints most gaits end that way after a few steps -- on the GPU at the same tick with the same state."""
+    from test_zmpdisc_oracle import kajita_model
+    from test_zmpdisc_gpu import gait_steps, random_fleet
+    model, K = _setup()
+    N = model.N
+    M = ol.pldp_setup(N, K["iPu"], K["Px"], K["Pu"])
+    lib = ol.oracle()
+    dp = lambda a: a.ctypes.data_as(C.POINTER(C.c_double))  # noqa: E731
+    zm = kajita_model()
+    zm.t_single, zm.t_double = 0.7, 0.13                 # phase boundaries off the 0.1 s grid of the previewed instants
+    B, smax = 6, 9
+    steps, n_steps, init = random_fleet(np.random.default_rng(31), B, smax, zm, exotic=False)
+    init[:] = [0.0, 0.095, 0.0, 0.0, -0.095, 0.0]       # axis-aligned soles: ComputeLinearSystem's slope form stays tame
+    for b in range(B):
+        for i in range(smax):
+            s = steps[b * smax + i]
+            s.theta = 0.0; s.ss_time, s.ds_time = zm.t_single, 0.0
+    lens = [wg.zmpdisc_length(zm, gait_steps(steps, b, smax, int(n_steps[b]))) for b in range(B)]
+    r = wg.zmpdisc_batch(zm, steps, n_steps, init, smax, max(lens))
+    queues = []
+    for b in range(B):
+        L = lens[b]
+        time = np.cumsum(np.full(L, zm.T)) - zm.T
+        queues.append(wg.foot_constraints(time, r["left"][b, :L], r["left_type"][b, :L], r["right"][b, :L], 0.24, 0.138,
+                                          0.02, 0.02))
+        assert [queues[b][0][q].nrows for q in range(queues[b][3])][:4] == [4, 4, 6, 4]
+    n_ticks = int(min((q[2][-1] - N * model.T) / model.T for q in queues)) - 1
+    assert n_ticks > 40
+    sg = (wg.DimitrovState * B)(); so = (wg.DimitrovState * B)()
+    for b in range(B):
+        sg[b].starting = so[b].starting = 1
+    t0 = 0.0
+    inside = 0.0
+    alive = np.ones(B, bool)
+    lived = np.zeros(B, int)
+    for it in range(n_ticks):
+        polys = (wg.ZmpPolytope * (B * N))()
+        for b in range(B):
+            pq, ts, te, k = queues[b]
+            for i, q in enumerate(_polytopes_for_tick(pq, ts, te, k, t0, N, model.T)):
+                C.memmove(C.byref(polys[b * N + i]), C.byref(pq[q]), C.sizeof(wg.ZmpPolytope))
+        outs = wg.dimitrov_tick_batch(polys, sg)
+        for b in range(B):
+            if not alive[b]:
+                C.memmove(C.byref(sg[b]), C.byref(so[b]), C.sizeof(wg.DimitrovState))
+                continue
+            oo = wg.DimitrovOut()
+            rc = lib.wgo_dimitrov_tick(C.byref(M), dp(K["OptB"]), dp(K["OptC"]), dp(K["iLQ"]), C.c_double(model.T),
+                                       C.c_double(model.Tctrl), C.c_double(model.com_height),
+                                       C.byref(polys, b * N * C.sizeof(wg.ZmpPolytope)), C.byref(so[b]), C.byref(oo),
+                                       C.c_int(0))
+            assert outs[b].ret == rc, (it, b, rc, outs[b].ret)
+            assert bytes(sg[b]) == bytes(so[b]), (it, b)
+            if rc != 0:
+                assert rc == -2 and (outs[b].n_iter, outs[b].n_active) == (oo.n_iter, oo.n_active)
+                alive[b] = False
+                continue
+            assert bytes(outs[b]) == bytes(oo), (it, b)
+            lived[b] = it + 1
+            # the ZMP of the first previewed instant respects the polytope it was constrained to
+            P = polys[b * N]
+            zx = so[b].xk[0] - model.com_height / 9.81 * so[b].xk[2]; zy = so[b].xk[3] - model.com_height / 9.81 * so[b].xk[5]
+            inside = min(inside, min(P.A[j][0] * zx + P.A[j][1] * zy + P.B[j] for j in range(P.nrows)))
+        t0 += model.T
+    assert inside > -1e-6
+    assert lived.min() >= 30 and lived.max() >= 55       # everyone leaves the rest phase, some walk several steps
+    for b in range(B):                                   # the CoM is where the feet are
+        i_end = int(round(lived[b] * model.T / zm.T))
+        feet_mid = 0.5 * (r["left"][b, i_end, :2] + r["right"][b, i_end, :2])
+        assert np.hypot(so[b].xk[0] - feet_mid[0], so[b].xk[3] - feet_mid[1]) < 0.15, b

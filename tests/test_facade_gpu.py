@@ -61,7 +61,7 @@ def test_facade_equals_python_replay_of_the_control_loop(tmp_path):
 
 def test_kajita_stage1_driver_matches_oracle(tmp_path):
     """BASELINE config[0] plumbing (jrl-walkgen_amd/host/test_kajita_preview.cpp): TestKajita2003's StraightWalking step
-    sequence through the facade's PreviewControl on the GPU -- the reference's one-call-per-step pattern and the
+    sequence through the facade's StepStackHandler, ZMPDiscretization and PreviewControl on the GPU -- the reference's one-call-per-step pattern and the
     batched run agree inside the driver; here its trace is compared with the oracle, bit for bit (%.17g round-trips)."""
     from test_preview_oracle import oracle_run
     exe = os.path.join(ROOT, "jrl-walkgen_amd", "bin", "test_kajita_preview")
@@ -81,6 +81,13 @@ def test_kajita_stage1_driver_matches_oracle(tmp_path):
     assert np.array_equal(rows[:, 3], z2[0, :, 0]) and np.array_equal(rows[:, 4], z2[0, :, 1])
     # walked 14 x 0.2 m, ends at rest between the feet
     assert abs(rows[-1, 1] - 2.8) < 1e-3 and abs(rows[-1, 2] - rows[-1, 6]) < 1e-3
+    # the queue and the feet are ZMPDiscretization's (facade class over wg_zmpdisc_batch): the reference's golden file
+    # TestKajita2003StraightWalkingTestFGPI.datref holds them (columns 35-36, 11-13, 23-25), to its print precision
+    gold = np.load(os.path.join(ROOT, "tests", "golden", "kajita_zmpdisc_datref.npz"))["StraightWalking_rows"]
+    n = gold.shape[0]
+    assert L == n + 2 * g.nl - g.nl + 1            # queue of n + 2 nl samples, L = queue - nl + 1 control steps
+    assert np.abs(rows[:n, 5:7] - gold[:, 13:15]).max() < 2e-7
+    assert np.abs(rows[:n, 7:10] - gold[:, 1:4]).max() < 2e-7 and np.abs(rows[:n, 10:13] - gold[:, 7:10]).max() < 2e-7
 
 
 def test_cpp_fleet_bench_runs_through_the_c_abi():
