@@ -323,11 +323,16 @@ class StepStackHandler {
   int GetWalkMode() const { return m_WalkMode; }
   void ReadStepSequenceAccordingToWalkMode(std::istringstream &strm);    // StepStackHandler.cpp:128-175
   void CopyRelativeFootPosition(std::deque<RelativeFootPosition> &lRelativeFootPositions, bool PerformClean);
+  // ":supportfoot", ":arc", ":lastsupport" (StepStackHandler.cpp:754-764, 299-457, 872-882; CallMethod :929-1040)
+  void PrepareForSupportFoot(int SupportFoot);
+  void CreateArcInStepStack(double x, double y, double R, double arc_deg, int SupportFoot);
+  void FinishOnTheLastCorrectSupportFoot();
+  void CallMethod(std::string &Method, std::istringstream &strm);
 
  private:
   std::deque<RelativeFootPosition> m_RelativeFootPositions;
   double m_SingleSupportTime, m_DoubleSupportTime;
-  int m_WalkMode;
+  int m_WalkMode, m_KeepLastCorrectSupportFoot = 1;
 };
 
 // LinearConstraintInequality_t (pgtypes.hh:168-177): A is rows x 2 (row-major), B rows x 1

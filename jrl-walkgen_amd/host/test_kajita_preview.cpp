@@ -2,7 +2,7 @@
 // TestKajita2003 StraightWalking (tests/TestKajita2003.cpp:96-124) through stage 1 only -- the ZMP reference queue and feet
 // of ZMPDiscretization, then PreviewControl (both include/wg_walkgen.hh) -- on the GPU.  The first steps go through
 // OneIterationOfPreview one call at a time (the reference's call pattern, ZMPPreviewControlWithMultiBodyZMP.cpp), the
-// whole run through RunBatch; both must agree bit for bit.  Writes "t com_x com_y zmp_x zmp_y zmpref_x zmpref_y lf_x lf_y lf_z rf_x rf_y rf_z".
+// whole run through RunBatch; both must agree bit for bit.  Writes "t com_x com_y zmp_x zmp_y zmpref_x zmpref_y lf_x lf_y lf_z rf_x rf_y rf_z lf_theta rf_theta"; a second argument "Circle" runs TurningOnTheCircle instead.
 #include <cstdio>
 #include <cstring>
 #include <deque>
@@ -17,6 +17,7 @@ using namespace PatternGeneratorJRL;
 
 int main(int argc, char **argv) {
   const char *out = argc > 1 ? argv[1] : "TestKajita2003StraightWalkingStage1.dat";
+  const bool circle = argc > 2 && std::string(argv[2]) == "Circle";   // default: StraightWalking
   try {
     SimplePluginManager spm;
     PreviewControl pc(&spm, OptimalControllerSolver::MODE_WITHOUT_INITIALPOS, false);
@@ -38,7 +39,10 @@ int main(int argc, char **argv) {
     StepStackHandler ssh;
     ssh.SetSingleTimeSupport(0.78);
     ssh.SetDoubleTimeSupport(0.02);
-    {
+    if (circle) {                      // TurningOnTheCircle, tests/TestKajita2003.cpp:68-93 (":finish" realises the sequence)
+      const char *seq[] = {":supportfoot 1", ":arc 0.0 0.75 30.0 -1", ":lastsupport"};
+      for (const char *c : seq) { std::istringstream s(c); std::string m; s >> m; ssh.CallMethod(m, s); }
+    } else {
       std::istringstream s("0.0 -0.105 0.0 0.2 0.21 0.0 0.2 -0.21 0.0 0.2 0.21 0.0 0.2 -0.21 0.0 0.2 0.21 0.0 0.2 -0.21 0.0 "
                            "0.2 0.21 0.0 0.2 -0.21 0.0 0.2 0.21 0.0 0.2 -0.21 0.0 0.2 0.21 0.0 0.2 -0.21 0.0 0.2 0.21 0.0 "
                            "0.2 -0.21 0.0 0.0 0.21 0.0");
@@ -95,10 +99,11 @@ int main(int argc, char **argv) {
     FILE *f = fopen(out, "w");
     if (!f) throw std::runtime_error("cannot open output file");
     for (int l = 0; l < L; l++)
-      fprintf(f, "%.3f %.17g %.17g %.17g %.17g %.17g %.17g %.17g %.17g %.17g %.17g %.17g %.17g\n", (l + 1) * T, com[6 * l],
-              com[6 * l + 3], z2[2 * l], z2[2 * l + 1], zx[l], zy[l], lq[l].x, lq[l].y, lq[l].z, rq[l].x, rq[l].y, rq[l].z);
+      fprintf(f, "%.3f %.17g %.17g %.17g %.17g %.17g %.17g %.17g %.17g %.17g %.17g %.17g %.17g %.17g %.17g\n", (l + 1) * T,
+              com[6 * l], com[6 * l + 3], z2[2 * l], z2[2 * l + 1], zx[l], zy[l], lq[l].x, lq[l].y, lq[l].z, rq[l].x, rq[l].y,
+              rq[l].z, lq[l].theta, rq[l].theta);
     fclose(f);
-    printf("TestKajita2003StraightWalking stage 1: %d control steps, final CoM (%.6f, %.6f), last footprint (%.3f, %.3f)\n", L,
+    printf("TestKajita2003 stage 1: %d control steps, final CoM (%.6f, %.6f), last footprint (%.3f, %.3f)\n", L,
            com[6 * (L - 1)], com[6 * (L - 1) + 3], ex, ey);
   } catch (std::exception &e) {
     std::cerr << "FAILED: " << e.what() << std::endl;

@@ -2,6 +2,8 @@
 // wg_mpc_tick_batch (HIP); this file only carries the reference's plumbing (command dispatch, the four queues, the 5 ms
 // clock) so that the reference's own test programs read the same against this library.
 #include "../../include/wg_walkgen.hh"
+#define WG_TRIG_FN static inline
+#include "../../include/wg_trig.h"
 
 #include <cassert>
 #include <cmath>
@@ -569,6 +571,67 @@ void StepStackHandler::ReadStepSequenceAccordingToWalkMode(istringstream &strm) 
     aFootPosition.DStime = m_DoubleSupportTime;
     aFootPosition.stepType = 1;
     m_RelativeFootPositions.push_back(aFootPosition);
+    m_KeepLastCorrectSupportFoot = aFootPosition.sy > 0 ? -1 : 1;
+  }
+}
+static void push_rel(deque<RelativeFootPosition> &q, double sx, double sy, double theta, double ss, double ds) {
+  RelativeFootPosition a;
+  memset(&a, 0, sizeof a);               // the reference leaves stepType uninitialised in the first two generators; 0 here
+  a.sx = sx; a.sy = sy; a.theta = theta; a.SStime = ss; a.DStime = ds; a.stepType = 0;
+  q.push_back(a);
+}
+void StepStackHandler::PrepareForSupportFoot(int SupportFoot) {            // :754-764
+  push_rel(m_RelativeFootPositions, 0, SupportFoot * 0.095, 0, m_SingleSupportTime, m_DoubleSupportTime);
+}
+void StepStackHandler::FinishOnTheLastCorrectSupportFoot() {               // :872-882
+  push_rel(m_RelativeFootPositions, 0, m_KeepLastCorrectSupportFoot * 0.19, 0, m_SingleSupportTime, m_DoubleSupportTime);
+}
+// :299-457: steps of 0.15 m along an arc of radius |(x, y)|, the last one shorter; each step is expressed in the frame of
+// the previous footprint (rotation by the accumulated heading, transposed)
+void StepStackHandler::CreateArcInStepStack(double x, double y, double R, double arc_deg, int SupportFoot) {
+  const double kPi = 3.14159265358979323846;
+  double StepMax = 0.15;
+  const double OmegaTotal = arc_deg * kPi / 180.0;
+  int DirectionRay = -1;
+  R = sqrt(x * x + y * y);
+  const int NumberOfStep = (int)floor(OmegaTotal * R / StepMax);
+  double LastStep = OmegaTotal * R - NumberOfStep * StepMax;
+  double OmegaStep = StepMax / R;
+  double LastOmegaStep = OmegaTotal - OmegaStep * NumberOfStep;
+  OmegaStep = OmegaStep * 180.0 / kPi;
+  LastOmegaStep = LastOmegaStep * 180.0 / kPi;
+  if (x < 0) { StepMax = -StepMax; LastStep = -LastStep; DirectionRay = 1; }
+  if (y < 0) { OmegaStep = -OmegaStep; LastOmegaStep = -LastOmegaStep; }
+  double Omegak = 0.0;
+  for (int i = 0; i <= NumberOfStep; i++) {
+    const bool last = i == NumberOfStep;
+    if (last && LastStep == 0.0) break;
+    const double dOmega = last ? LastOmegaStep : OmegaStep;
+    const double Omegakp = Omegak;
+    Omegak = Omegak + dOmega;
+    const double c = wg_cos(Omegak * kPi / 180.0), s = wg_sin(Omegak * kPi / 180.0);
+    const double cp = wg_cos(Omegakp * kPi / 180.0), sp = wg_sin(Omegakp * kPi / 180.0);
+    const double outer = R + DirectionRay * SupportFoot * 0.095, inner = R - DirectionRay * SupportFoot * 0.095;
+    const double lv0 = outer * s - inner * sp, lv1 = -(outer * c - inner * cp);
+    double sx = 0.0, sy = 0.0;
+    sx += c * lv0; sx += s * lv1;
+    sy += -s * lv0; sy += c * lv1;
+    push_rel(m_RelativeFootPositions, sx, sy, dOmega, m_SingleSupportTime, m_DoubleSupportTime);
+    SupportFoot = -SupportFoot;
+  }
+  m_KeepLastCorrectSupportFoot = SupportFoot;
+}
+void StepStackHandler::CallMethod(string &Method, istringstream &strm) {   // :929-1040, the commands restated here
+  if (Method == ":singlesupporttime") strm >> m_SingleSupportTime;
+  else if (Method == ":doublesupporttime") strm >> m_DoubleSupportTime;
+  else if (Method == ":walkmode") strm >> m_WalkMode;
+  else if (Method == ":supportfoot") { int f = -1; strm >> f; PrepareForSupportFoot(f); }
+  else if (Method == ":lastsupport") FinishOnTheLastCorrectSupportFoot();
+  else if (Method == ":arc") {
+    double x = 0, y = 0, arc_deg = 0;
+    int f = -1;
+    strm >> x >> y >> arc_deg >> f;
+    CreateArcInStepStack(x, y, 0.0, arc_deg, f);
   }
 }
 void StepStackHandler::CopyRelativeFootPosition(deque<RelativeFootPosition> &lRelativeFootPositions, bool PerformClean) {

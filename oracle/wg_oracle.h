@@ -92,6 +92,12 @@ int wgo_foot_constraints(int n, const double *time, const double *left, const in
                          double sole_w, double sole_h, double constraint_x, double constraint_y, int cap,
                          wg_zmp_polytope_t *polys, double *t_start, double *t_end);
 
+/* StepStackHandler's generators behind ":supportfoot", ":arc", ":lastsupport" (see zmpdisc_oracle.c); append to out[*n] */
+int wgo_steps_support_foot(int support_foot, double ss, double ds, wg_rel_step_t *out, int *n, int cap);
+int wgo_steps_last_support(int keep, double ss, double ds, wg_rel_step_t *out, int *n, int cap);
+int wgo_steps_arc(double x, double y, double arc_deg, int support_foot, double ss, double ds, wg_rel_step_t *out, int *n,
+                  int cap, int *keep);
+
 #ifdef __cplusplus
 }
 #endif

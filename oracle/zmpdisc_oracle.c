@@ -12,8 +12,8 @@
  *   FootConstraintsAsLinearSystem                src/Mathematics/FootConstraintsAsLinearSystem.cpp:55-92, 97-256, 258-539
  *   ComputeConvexHull::DoComputeConvexHull       src/Mathematics/ConvexHull.cpp:37-203
  *
- * Pinned (tests/test_zmpdisc_oracle.py) to the reference's golden files TestKajita2003StraightWalkingTestFGPI.datref and
- * TestKajita2003PbFlorentSeq1TestFGPI.datref: their columns 11-13, 20, 23-25, 32 are the feet deques and 35-36 the ZMP
+ * Pinned (tests/test_zmpdisc_oracle.py) to the reference's golden files TestKajita2003{StraightWalking, PbFlorentSeq1,
+ * Circle}TestFGPI.datref: their columns 11-13, 20-22, 23-25, 32-34 are the feet deques and 35-36 the ZMP
  * reference deque of this code, popped one sample per control step (DoubleStagePreviewControlStrategy.cpp:128-150,
  * tests/TestObject.cpp:354-382).
  *
@@ -835,4 +835,72 @@ int wgo_foot_constraints(int n, const double *time, const double *left, const in
     if (i == n - 1 && count > 0 && count - 1 < cap) t_end[count - 1] = time[i];
   }
   return count;
+}
+
+/* ---- StepStackHandler: the step generators behind ":supportfoot", ":arc", ":lastsupport" ------------------------------
+ * src/StepStackHandler.cpp:754-764 (PrepareForSupportFoot), :299-457 (CreateArcInStepStack), :872-882
+ * (FinishOnTheLastCorrectSupportFoot) -- the commands of TestKajita2003's TurningOnTheCircle (tests/TestKajita2003.cpp:68-93).
+ * The reference leaves RelativeFootPosition::stepType uninitialised in the first two; 0 here.
+ * Appends to out[*n]; *keep is m_KeepLastCorrectSupportFoot.  Returns 0, or -1 when cap is too small. */
+static int push_step(wg_rel_step_t *out, int *n, int cap, double sx, double sy, double theta, double ss, double ds) {
+  if (*n >= cap) return -1;
+  wg_rel_step_t s;
+  memset(&s, 0, sizeof s);
+  s.sx = sx;
+  s.sy = sy;
+  s.theta = theta;
+  s.ss_time = ss;
+  s.ds_time = ds;
+  s.step_type = 0;
+  out[(*n)++] = s;
+  return 0;
+}
+int wgo_steps_support_foot(int support_foot, double ss, double ds, wg_rel_step_t *out, int *n, int cap) {
+  return push_step(out, n, cap, 0, support_foot * 0.095, 0, ss, ds);
+}
+int wgo_steps_last_support(int keep, double ss, double ds, wg_rel_step_t *out, int *n, int cap) {
+  return push_step(out, n, cap, 0, keep * 0.19, 0, ss, ds);
+}
+int wgo_steps_arc(double x, double y, double arc_deg, int SupportFoot, double ss, double ds, wg_rel_step_t *out, int *n,
+                  int cap, int *keep) {
+  double StepMax = 0.15, LastStep, NumberOfStepFloat, OmegaStep, OmegaTotal = arc_deg * M_PI / 180.0, LastOmegaStep;
+  int NumberOfStep, DirectionRay = -1;
+  double R = sqrt(x * x + y * y);
+  NumberOfStepFloat = OmegaTotal * R / StepMax;
+  NumberOfStep = (int)floor(NumberOfStepFloat);
+  LastStep = OmegaTotal * R - NumberOfStep * StepMax;
+  OmegaStep = StepMax / R;
+  LastOmegaStep = OmegaTotal - OmegaStep * NumberOfStep;
+  OmegaStep = OmegaStep * 180.0 / M_PI;
+  LastOmegaStep = LastOmegaStep * 180.0 / M_PI;
+  if (x < 0) {
+    StepMax = -StepMax;
+    LastStep = -LastStep;
+    DirectionRay = 1;
+  }
+  if (y < 0) {
+    OmegaStep = -OmegaStep;
+    LastOmegaStep = -LastOmegaStep;
+  }
+  double Omegakp, Omegak = 0.0;
+  for (int i = 0; i < NumberOfStep + 1; i++) {
+    const int last = i == NumberOfStep;
+    if (last && LastStep == 0.0) break;
+    const double dOmega = last ? LastOmegaStep : OmegaStep;
+    Omegakp = Omegak;
+    Omegak = Omegak + dOmega;
+    double c = WCOS(Omegak * M_PI / 180.0), s = WSIN(Omegak * M_PI / 180.0);
+    double cp = WCOS(Omegakp * M_PI / 180.0), sp = WSIN(Omegakp * M_PI / 180.0);
+    double lv0 = (R + DirectionRay * SupportFoot * 0.095) * s - (R - DirectionRay * SupportFoot * 0.095) * sp;
+    double lv1 = -((R + DirectionRay * SupportFoot * 0.095) * c - (R - DirectionRay * SupportFoot * 0.095) * cp);
+    double a = 0.0, b = 0.0;                             /* lv2 = A lv, A = [c s; -s c] */
+    a += c * lv0;
+    a += s * lv1;
+    b += -s * lv0;
+    b += c * lv1;
+    if (push_step(out, n, cap, a, b, dOmega, ss, ds)) return -1;
+    SupportFoot = -SupportFoot;
+  }
+  *keep = SupportFoot;
+  return 0;
 }

@@ -9,7 +9,7 @@
   preview_control_parameters.npz : the reference's precomputed Kajita gains
         /root/reference/src/data/PreviewControlParameters.ini  (Zc, T, preview time, Kx[3], Ks, F[320]), as data.
   kajita_zmpdisc_datref.npz : the columns of the reference's golden files
-        /root/reference/tests/TestKajita2003{StraightWalking,PbFlorentSeq1}TestFGPI.datref.cmake
+        /root/reference/tests/TestKajita2003{StraightWalking,PbFlorentSeq1,Circle}TestFGPI.datref.cmake
         that hold the outputs of ZMPDiscretization (tests/TestObject.cpp:344-385): time (1), left foot x y z (11-13),
         theta omega omega2 (20-22), right foot (23-25, 32-34), world-frame ZMP reference (35-36), as data, plus the
         step sequences of tests/TestKajita2003.cpp:95-152 (inputs).
@@ -47,10 +47,13 @@ KAJITA_COLS = [0, 10, 11, 12, 19, 20, 21, 22, 23, 24, 31, 32, 33, 34, 35]
 
 def kajita_datrefs():
     out = {}
-    for name, seq in (("StraightWalking", STRAIGHT), ("PbFlorentSeq1", PBFLORENT1)):
+    for name, seq in (("StraightWalking", STRAIGHT), ("PbFlorentSeq1", PBFLORENT1), ("Circle", None)):
         d = np.loadtxt("/root/reference/tests/TestKajita2003%sTestFGPI.datref.cmake" % name)
         out[name + "_rows"] = d[:, KAJITA_COLS]
-        out[name + "_steps"] = np.array(seq, dtype=float).reshape(-1, 3)
+        if seq is not None:
+            out[name + "_steps"] = np.array(seq, dtype=float).reshape(-1, 3)
+    # TurningOnTheCircle's commands (tests/TestKajita2003.cpp:68-93): the steps come from StepStackHandler's generators
+    out["Circle_commands"] = np.array([":supportfoot 1", ":arc 0.0 0.75 30.0 -1", ":lastsupport", ":finish"])
     out["columns"] = np.array(KAJITA_COLS) + 1
     np.savez_compressed(os.path.join(HERE, "kajita_zmpdisc_datref.npz"), **out)
 

@@ -220,3 +220,17 @@ def foot_constraints(poly_type, time, left, left_type, right, sole_w, sole_h, cx
     k = lib.wgo_foot_constraints(time.shape[0], vp(time), vp(left), vp(left_type), vp(right), sole_w, sole_h, cx, cy, cap,
                                  C.addressof(polys), vp(ts), vp(te))
     return polys, ts[:max(k, 0)], te[:max(k, 0)], k
+
+
+def circle_steps(step_type, ss, ds, lib=None):
+    """TurningOnTheCircle's step stack (":supportfoot 1", ":arc 0.0 0.75 30.0 -1", ":lastsupport") from the oracle's
+    restatement of StepStackHandler's generators: (steps array, count)"""
+    lib = lib or oracle()
+    steps = (step_type * 64)(); n = C.c_int(0); keep = C.c_int(0)
+    lib.wgo_steps_arc.argtypes = [C.c_double] * 3 + [C.c_int] + [C.c_double] * 2 + [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+    lib.wgo_steps_support_foot.argtypes = [C.c_int, C.c_double, C.c_double, C.c_void_p, C.c_void_p, C.c_int]
+    lib.wgo_steps_last_support.argtypes = [C.c_int, C.c_double, C.c_double, C.c_void_p, C.c_void_p, C.c_int]
+    assert lib.wgo_steps_support_foot(1, ss, ds, C.addressof(steps), C.byref(n), 64) == 0
+    assert lib.wgo_steps_arc(0.0, 0.75, 30.0, -1, ss, ds, C.addressof(steps), C.byref(n), 64, C.byref(keep)) == 0
+    assert lib.wgo_steps_last_support(keep.value, ss, ds, C.addressof(steps), C.byref(n), 64) == 0
+    return steps, n.value

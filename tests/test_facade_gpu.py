@@ -90,6 +90,23 @@ def test_kajita_stage1_driver_matches_oracle(tmp_path):
     assert np.abs(rows[:n, 7:10] - gold[:, 1:4]).max() < 2e-7 and np.abs(rows[:n, 10:13] - gold[:, 7:10]).max() < 2e-7
 
 
+def test_kajita_circle_through_the_facade_matches_golden(tmp_path):
+    """TestKajita2003's TurningOnTheCircle through the facade: StepStackHandler's ":supportfoot" / ":arc" / ":lastsupport"
+    generators -> ZMPDiscretization (GPU) -> PreviewControl (GPU); queue and feet against the reference's golden file"""
+    exe = os.path.join(ROOT, "jrl-walkgen_amd", "bin", "test_kajita_preview")
+    out = tmp_path / "circle.dat"
+    r = subprocess.run([exe, str(out), "Circle"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    rows = np.loadtxt(out)
+    gold = np.load(os.path.join(ROOT, "tests", "golden", "kajita_zmpdisc_datref.npz"))["Circle_rows"]
+    n = gold.shape[0]
+    assert rows.shape[0] == n + 320 + 1
+    assert np.abs(rows[:n, 5:7] - gold[:, 13:15]).max() < 2e-7
+    assert np.abs(rows[:n, 7:10] - gold[:, 1:4]).max() < 2e-7 and np.abs(rows[:n, 10:13] - gold[:, 7:10]).max() < 2e-7
+    assert np.abs(rows[:n, 13] - gold[:, 4]).max() < 2e-7 and np.abs(rows[:n, 14] - gold[:, 10]).max() < 2e-7   # feet yaw
+    assert abs(rows[-1, 13] - 30.0) < 1e-6
+
+
 def test_cpp_fleet_bench_runs_through_the_c_abi():
     """jrl-walkgen_amd/host/fleet_bench.cpp: the fleet path from plain C++ (hipMalloc'd states, wg_mpc_run_batch_dev and
     wg_mpc_tick_batch_dev) -- both launch modes advance every gait by the same number of ticks"""

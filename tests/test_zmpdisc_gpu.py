@@ -67,7 +67,7 @@ KEYS_D = ("zmp", "zmp_theta", "left", "right")
 KEYS_I = ("zmp_type", "left_type", "right_type")
 
 
-@pytest.mark.parametrize("name", ["StraightWalking", "PbFlorentSeq1"])
+@pytest.mark.parametrize("name", ["StraightWalking", "PbFlorentSeq1", "Circle"])
 def test_gpu_matches_reference_golden_and_oracle(name):
     wg.init(0)
     rows, steps, init = golden_case(name)

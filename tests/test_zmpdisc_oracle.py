@@ -30,7 +30,11 @@ def kajita_model():
 
 def golden_case(name):
     rows = GOLD[name + "_rows"]
-    steps = wg.rel_steps(GOLD[name + "_steps"], 0.78, 0.02)
+    if name == "Circle":                           # the steps come from the (restated) arc generator
+        all_steps, S = ol.circle_steps(wg.RelStep, 0.78, 0.02)
+        steps = (wg.RelStep * S)(*[all_steps[i] for i in range(S)])
+    else:
+        steps = wg.rel_steps(GOLD[name + "_steps"], 0.78, 0.02)
     init = [rows[0, 1], rows[0, 2], rows[0, 4], rows[0, 7], rows[0, 8], rows[0, 10]]   # what EvaluateStartingState returned
     return rows, steps, init
 
@@ -53,6 +57,24 @@ def test_oracle_matches_reference_golden(name):
     assert r["left"][:, 2].max() > 0.069 and r["right"][:, 2].max() > 0.069
     if name == "PbFlorentSeq1":
         assert abs(r["left"][:, 3]).max() > 60.0
+
+
+def test_arc_walk_matches_reference_golden():
+    """TestKajita2003's TurningOnTheCircle: ":supportfoot 1", ":arc 0.0 0.75 30.0 -1", ":lastsupport" through the restated
+    StepStackHandler generators, then ZMPDiscretization: third golden file, same columns, same tolerance"""
+    rows = GOLD["Circle_rows"]
+    m = kajita_model()
+    steps, S = ol.circle_steps(wg.RelStep, 0.78, 0.02)
+    assert S == 5                                  # support foot, two 0.15 m steps, the shorter last one, last support
+    assert abs(sum(steps[i].theta for i in range(S)) - 30.0) < 1e-12
+    init = [rows[0, 1], rows[0, 2], rows[0, 4], rows[0, 7], rows[0, 8], rows[0, 10]]
+    r = ol.zmpdisc(m, steps, init, n_steps=S)
+    n = rows.shape[0]
+    assert r["length"] == n + 2 * int(m.preview_time / m.T)
+    assert np.abs(rows[:, 13:15] - r["zmp"][:n]).max() < 2e-7
+    for c0, key in ((1, "left"), (7, "right")):
+        assert np.abs(rows[:, c0:c0 + 6] - r[key][:n]).max() < 2e-7
+    assert abs(r["left"][-1, 3] - 30.0) < 1e-6 and abs(r["right"][-1, 3] - 30.0) < 1e-6   # both feet turned by the arc
 
 
 def test_length_formula_and_bad_input():

@@ -4,7 +4,7 @@ set -u
 export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 bash $R/tools/prof.sh tick bench.py --steps 200 --warmup 50 --no-cpu-baseline > $R/gpurun_out/prof_tick.log 2>&1
-for spec in "dimitrov tools/probe_dimitrov.py" "pldp tools/probe_pldp.py" "preview tools/probe_preview.py"; do
+for spec in "dimitrov tools/probe_dimitrov.py" "pldp tools/probe_pldp.py" "preview tools/probe_preview.py" "zmpdisc tools/probe_zmpdisc.py"; do
   set -- $spec
   bash $R/tools/prof.sh $1 $2 > $R/gpurun_out/prof_$1.log 2>&1
   cp $R/gpurun_out/prof_$1/trace.log $R/gpurun_out/prof_$1/run.log 2>/dev/null

@@ -1,7 +1,7 @@
 #!/bin/bash
 # copy the summaries of the last tools/prof_all.sh run (merged back under gpurun_out/) into profiles/ as <tag>_*
-TAG=${1:-round1_s2}
-for k in tick dimitrov pldp preview; do
+TAG=${1:-round1_s3}
+for k in tick dimitrov pldp preview zmpdisc; do
   python tools/prof_summary.py gpurun_out/prof_$k > gpurun_out/prof_$k/summary.txt
   cp gpurun_out/prof_$k/summary.txt profiles/${TAG}_${k}_rocprofv3_summary.txt
   cp gpurun_out/prof_$k/summary.json profiles/${TAG}_${k}_rocprofv3_summary.json
