@@ -917,7 +917,22 @@ int wg_preview_run_batch_dev(int B, int L, const double *zmp_x_tm, const double 
   // SIMD several waves of the L2 kernel (measured: B = 4096: 0.62 vs 0.43 G gait-steps/s; B = 32768: 1.18 vs 1.50), and
   // a few steps do not repay filling the ring.
   const bool ring = force ? force[0] == 'r' : (L >= 8 && (long long)B * 2 <= (long long)g_num_cu * 64 * 2);
-  if (ring) {
+  // The split-chain kernel (eight lanes per gait-axis, nothing re-read) covers the standard window sizes and wins at every
+  // batch size measured; other windows, and runs too short to repay filling its rings, use the kernels below.
+  constexpr int kSplitT = 40, kSplitK = 8;
+  const bool can_split = g_prev.nl > (kSplitK - 1) * kSplitT && g_prev.nl <= kSplitK * kSplitT;
+  const bool split = force ? (force[0] == 's' && can_split) : (can_split && L >= 4);
+  if (split) {
+    const int per_wave = 64 / kSplitK;
+    const dim3 grid((B + per_wave - 1) / per_wave, 2);
+    const size_t lds = (size_t)kSplitT * 64 * 8;
+    if (g_prev.nl == kSplitK * kSplitT)
+      hipLaunchKernelGGL((wg::wg_preview_split_kernel<kSplitT, kSplitK, true>), grid, dim3(64), lds, st, B, L, g_prev,
+                         g_prev_F, zmp_x_tm, zmp_y_tm, state, com_tm, zmp2_tm, simulation);
+    else
+      hipLaunchKernelGGL((wg::wg_preview_split_kernel<kSplitT, kSplitK, false>), grid, dim3(64), lds, st, B, L, g_prev,
+                         g_prev_F, zmp_x_tm, zmp_y_tm, state, com_tm, zmp2_tm, simulation);
+  } else if (ring) {
     int R = g_prev.nl < 288 ? g_prev.nl : 288;                 // 288 x 512 B = 144 KB of the CU's 160 KB
     if (R < 1) R = 1;
     const size_t lds = (size_t)R * 64 * 8;

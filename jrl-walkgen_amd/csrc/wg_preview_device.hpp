@@ -153,6 +153,125 @@ wg_preview_ring_kernel(int B, int L, PreviewConst K, int R, const double *__rest
   if (valid) { st[3 * axis] = x0; st[3 * axis + 1] = x1; st[3 * axis + 2] = x2; st[6 + axis] = s; }
 }
 
+// The same iteration with each chain split over K lanes.  Per step the reference's sum is ONE chain of nl dependent
+// additions (8 cycles each): 2560 cycles at nl = 320 whatever the kernel does -- but the kernels above spend far more than
+// that re-reading the window (L2) or keeping a 144 KB ring (one wave per CU).  Here K = 8 consecutive lanes own one
+// (gait, axis): lane k keeps taps [kT, (k+1)T) of the window, T = 40 -- its gains F in registers, its samples in an LDS ring
+// of T slots per lane (20 KB per wave, so the register budget, not LDS, sets the residency: two waves per SIMD).  Every step
+// each lane forms its T products at once (all 64 lanes useful), then the chain runs through the K lanes in order: pass p
+// adds lane p's products to the partial sum handed over from lane p-1 (one DPP row shift per pass).  The additions are the
+// same additions in the same order, so the bits are the same; the window slides by passing each lane's oldest sample to
+// its left neighbour (DPP) and fetching ONE new sample per (gait, axis) and step from memory.
+// Eight gait-axes per wave instead of 64: the adds of a pass are useful in one lane of eight, but nothing is re-read.
+// nl must satisfy (K-1) T < nl <= K T (281..320 for the standard 1.6 s / 5 ms window); other windows use the kernels above.
+template <int CTRL>
+__device__ __forceinline__ double pv_dpp(double v) {
+  const int lo = __builtin_amdgcn_update_dpp(__double2loint(v), __double2loint(v), CTRL, 0xf, 0xf, false);
+  const int hi = __builtin_amdgcn_update_dpp(__double2hiint(v), __double2hiint(v), CTRL, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+
+template <int T, int K, bool FULL>     // FULL: nl == K T, the last lane has T taps like the others
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
+wg_preview_split_kernel(int B, int L, PreviewConst Kc, const double *__restrict__ F, const double *__restrict__ zx,
+                        const double *__restrict__ zy, double *__restrict__ state, double *__restrict__ com,
+                        double *__restrict__ zmp2, int simulation) {
+  static_assert(K == 8, "the DPP controls below are written for groups of eight lanes");
+  extern __shared__ __attribute__((aligned(16))) double pv_ring[];      // [T][64]
+  constexpr int G = 64 / K;
+  const int lane = threadIdx.x;
+  const int k = lane & (K - 1);
+  const int g0 = blockIdx.x * G + lane / K;
+  const bool valid = g0 < B;
+  const int g = valid ? g0 : B - 1;                                     // surplus groups shadow the last gait (no stores)
+  const int axis = blockIdx.y;
+  const double *__restrict__ z = axis ? zy : zx;
+  const size_t sB = (size_t)B;
+  const int nl = Kc.nl;
+  const int Tl = nl - (K - 1) * T;                                      // taps of the last lane, 1..T
+  const int Lz = L + nl - 1;
+  const bool last = k == K - 1, first = k == 0;
+  double Fk[T];
+#pragma unroll
+  for (int t = 0; t < T; ++t) {
+    const int i = k * T + t;
+    Fk[t] = i < nl ? F[i] : 0.0;
+    pv_ring[t * 64 + lane] = (i < nl && i < Lz) ? z[(size_t)i * sB + g] : 0.0;
+  }
+  const double *st = state + (size_t)g * 8;
+  double x0 = st[3 * axis], x1 = st[3 * axis + 1], x2 = st[3 * axis + 2], s = st[6 + axis];
+  int head = 0;                                                         // ring slot of each lane's first tap
+  for (int l = 0; l < L; ++l) {
+    const int tn = l + nl;                                              // the sample that enters the window after this step
+    const double znew = (last && tn < Lz) ? z[(size_t)tn * sB + g] : 0.0;
+    double prod[T], zold = 0.0;
+    {
+      // slot of tap t: head + t, wrapped.  Two lane bases (unwrapped / wrapped) and a constant offset per tap, so that
+      // a tap costs one select, not an address computation
+      const char *b1 = reinterpret_cast<const char *>(pv_ring) + (head * 64 + lane) * 8;
+      const char *b2 = b1 - T * 512;
+      const int nowrap = T - head;                                      // taps 0 .. nowrap-1 sit at slots head .. T-1
+#pragma unroll
+      for (int t = 0; t < T; ++t) {
+        const char *b = t < nowrap ? b1 : b2;
+        const double zt = *reinterpret_cast<const double *>(b + t * 512);
+        if (t == 0) zold = zt;
+        prod[t] = Fk[t] * zt;
+      }
+    }
+    double r = 0.0;
+    r += Kc.Kx0 * x0; r += Kc.Kx1 * x1; r += Kc.Kx2 * x2;
+    double acc = -r + Kc.Ks * s;                                        // the chain starts in lane 0 of the group
+#pragma unroll
+    for (int p = 0; p < K - 1; ++p) {
+#pragma unroll
+      for (int t = 0; t < T; ++t) acc += prod[t];
+      acc = pv_dpp<0x111>(acc);                                         // row_shr:1 -- lane p+1 takes over
+    }
+    if (FULL) {
+#pragma unroll
+      for (int t = 0; t < T; ++t) acc += prod[t];
+    } else {
+#pragma unroll
+      for (int t = 0; t < T; ++t)
+        if (t < Tl) acc += prod[t];
+    }
+    const double u = pv_dpp<0x107>(acc);                                // row_shl:7 -- back to lane 0 of the group
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0;
+    a0 += 1.0 * x0; a0 += Kc.A01 * x1; a0 += Kc.A02 * x2;
+    a1 += 0.0 * x0; a1 += 1.0 * x1;    a1 += Kc.A12 * x2;
+    a2 += 0.0 * x0; a2 += 0.0 * x1;    a2 += 1.0 * x2;
+    const double n0 = a0 + u * Kc.B0, n1 = a1 + u * Kc.B1, n2 = a2 + u * Kc.B2;
+    double pz = 0.0;
+    pz += 1.0 * n0; pz += 0.0 * n1; pz += Kc.C2 * n2;
+    if (first) {                                                        // only lane 0 carries the gait's state
+      x0 = n0; x1 = n1; x2 = n2;
+      if (simulation) s += (zold - pz);
+      if (valid) {
+        if (com) {
+          double *c = com + ((size_t)l * 6 + 3 * axis) * sB + g;
+          c[0] = x0; c[sB] = x1; c[2 * sB] = x2;
+        }
+        if (zmp2) zmp2[((size_t)l * 2 + axis) * sB + g] = pz;
+      }
+    }
+    // the window slides: every lane hands its oldest sample to the left, the last lane takes the new one
+    double incoming = pv_dpp<0x101>(zold);                              // row_shl:1 -- lane k takes lane k+1's oldest
+    int wslot = head;
+    if (last) {
+      incoming = znew;
+      wslot = head + Tl;
+      if (wslot >= T) wslot -= T;
+    }
+    pv_ring[wslot * 64 + lane] = incoming;
+    head = head + 1 == T ? 0 : head + 1;
+  }
+  if (valid && first) {
+    double *so = state + (size_t)g * 8;
+    so[3 * axis] = x0; so[3 * axis + 1] = x1; so[3 * axis + 2] = x2; so[6 + axis] = s;
+  }
+}
+
 // [B][cols] (gait-major) <-> [cols][B] (time-major) on the device, for the host-pointer entry point
 __global__ void wg_transpose_kernel(int rows, int cols, const double *__restrict__ in, double *__restrict__ out) {
   __shared__ double tile[32][33];

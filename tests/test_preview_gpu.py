@@ -36,9 +36,9 @@ def test_batch_matches_oracle_bit_for_bit(B, L, nl_cut, sim):
         assert np.array_equal(s_gpu[:, 6:], s_cpu[:, 6:])         # errors untouched without Simulation
 
 
-@pytest.mark.parametrize("kernel", ["l2", "ring"])
+@pytest.mark.parametrize("kernel", ["l2", "ring", "split"])
 def test_both_kernels_match_oracle(kernel, monkeypatch):
-    """the LDS-ring kernel (window staged in LDS, taps read from the current slot round the ring) and the L2 kernel are
+    """the split-chain kernel (eight lanes per gait-axis), the LDS-ring kernel (window staged in LDS) and the L2 kernel are
     picked by batch size; force each and hold both to the oracle"""
     monkeypatch.setenv("WG_PREVIEW_KERNEL", kernel)
     wg.init(0)
