@@ -912,7 +912,7 @@ int wg_preview_run_batch_dev(int B, int L, const double *zmp_x_tm, const double 
   if (B < 0 || L < 0 || !zmp_x_tm || !zmp_y_tm || !state) return fail(WG_ERR_BAD_ARG, "bad arguments");
   if (B == 0 || L == 0) return WG_OK;
   hipStream_t st = reinterpret_cast<hipStream_t>(hip_stream);
-  const char *force = getenv("WG_PREVIEW_KERNEL");            // "l2" / "ring": tests compare the two
+  const char *force = getenv("WG_PREVIEW_KERNEL");            // "l2" / "ring" / "split": tests hold each to the oracle
   // The ring kernel keeps one wave per CU (its window fills the LDS): it wins while the batch is too small to give every
   // SIMD several waves of the L2 kernel (measured: B = 4096: 0.62 vs 0.43 G gait-steps/s; B = 32768: 1.18 vs 1.50), and
   // a few steps do not repay filling the ring.

@@ -6,6 +6,7 @@ wg = importlib.import_module("jrl-walkgen_amd"); wg.init(0)
 g, F = wg.preview_gains(0.005, 0.814, 1.6)
 wg.preview_configure(g, F)
 L = int(os.environ.get("PL", "200"))
+print("kernel:", os.environ.get("WG_PREVIEW_KERNEL", "default"))
 for B in (4096, 32768, 131072):
     Lz = L + g.nl - 1
     t = torch.arange(Lz, device="cuda", dtype=torch.float64)[:, None]
