@@ -207,3 +207,45 @@ def test_foot_constraints_match_oracle():
             P = polys[q]
             A = np.array([[P.A[j][0], P.A[j][1]] for j in range(P.nrows)]); Bv = np.array(P.B[:P.nrows])
             assert (A @ np.array(P.centre[:]) + Bv > 0).all()
+
+
+def test_empty_batches_and_bad_arguments():
+    import ctypes as C2
+    wg.init(0)
+    lib = wg.lib()
+    m = kajita_model()
+    steps = wg.rel_steps(GOLD["StraightWalking_steps"], 0.78, 0.02)
+    ns = np.array([16], np.int32); feet = np.zeros((1, 6)); ln = np.zeros(1, np.int32)
+    vp = lambda a: a.ctypes.data_as(C2.c_void_p)  # noqa: E731
+    args = (C2.addressof(steps), vp(ns), vp(feet))
+    assert lib.wg_zmpdisc_batch(C2.byref(m), 0, 16, *args, 10, None, None, None, None, None, None, None, vp(ln)) == 0      # B = 0
+    assert lib.wg_zmpdisc_batch(C2.byref(m), 1, 1, *args, 10, None, None, None, None, None, None, None, vp(ln)) == -2      # smax < 2
+    assert lib.wg_zmpdisc_batch(C2.byref(m), 1, 65, *args, 10, None, None, None, None, None, None, None, vp(ln)) == -2     # smax > 64
+    assert lib.wg_zmpdisc_batch(C2.byref(m), 1, 16, None, vp(ns), vp(feet), 10, None, None, None, None, None, None, None, vp(ln)) == -2
+    assert lib.wg_zmpdisc_batch(None, 1, 16, *args, 10, None, None, None, None, None, None, None, vp(ln)) == -2
+    bad = kajita_model(); bad.T = 0.0
+    assert lib.wg_zmpdisc_batch(C2.byref(bad), 1, 16, *args, 10, None, None, None, None, None, None, None, vp(ln)) == -2
+    fine = kajita_model(); fine.T = 0.0005                         # 101 filter taps: more than the rings hold
+    assert lib.wg_zmpdisc_batch(C2.byref(fine), 1, 16, *args, 10, None, None, None, None, None, None, None, vp(ln)) == -2
+    assert b"taps" in lib.wg_last_error()
+    # only the lengths asked for: every output pointer NULL
+    assert lib.wg_zmpdisc_batch(C2.byref(m), 1, 16, *args, 5000, None, None, None, None, None, None, None, vp(ln)) == 0
+    assert ln[0] == 4002 == lib.wg_zmpdisc_length(C2.byref(m), C2.addressof(steps), 16)
+    # a 1 ms control period (51 taps) still runs and agrees with the oracle
+    ms = kajita_model(); ms.T = 0.001; ms.preview_time = 0.4
+    two = wg.rel_steps([[0.0, -0.105, 0.0], [0.2, 0.21, 5.0], [0.0, -0.21, 0.0]], 0.3, 0.05)
+    L = wg.zmpdisc_length(ms, two)
+    r = wg.zmpdisc_batch(ms, two, [3], np.array([[0.0, 0.095, 0.0, 0.0, -0.095, 0.0]]), 3, L)
+    o = ol.zmpdisc(ms, two, [0.0, 0.095, 0.0, 0.0, -0.095, 0.0], lib=ptrig())
+    assert r["length"][0] == L == o["length"]
+    for k in KEYS_D + KEYS_I:
+        assert np.array_equal(r[k][0, :L], o[k]), k
+    # wg_foot_constraints: empty input, capacity smaller than the queue
+    assert lib.wg_foot_constraints(0, None, None, None, None, 0.24, 0.138, 0.0, 0.0, 0, None, None, None) == 0
+    g = wg.zmpdisc_batch(m, steps, [16], np.array([[0.0, 0.095, 0.0, 0.0, -0.095, 0.0]]), 16, 4002)
+    time = np.arange(4002) * m.T
+    try:
+        wg.foot_constraints(time, g["left"][0], g["left_type"][0], g["right"][0], 0.24, 0.138, 0.04, 0.04, cap=5)
+        assert False, "capacity overflow not reported"
+    except wg.WgError:
+        pass
