@@ -147,7 +147,13 @@ def main():
                               f"1 core of {os.cpu_count()} host cores",
                     "all_cores": allc}
 
-    rank, local_rank, world = shard.init_process_group("nccl")
+    # rehearsal knobs (tools/rehearse_ranks.sh): several ranks on ONE card with the gloo backend exercise the multi-rank
+    # bookkeeping where no multi-GPU node is at hand; the driver's runs use neither
+    backend = os.environ.get("WG_BENCH_BACKEND", "nccl")
+    one_card = os.environ.get("WG_BENCH_DEVICE")
+    if one_card is not None:
+        os.environ["LOCAL_RANK"] = one_card
+    rank, local_rank, world = shard.init_process_group(backend)
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():

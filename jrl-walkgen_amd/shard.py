@@ -21,6 +21,8 @@ def env_world():
 
 def init_process_group(backend):
     rank, local_rank, world = env_world()
+    if backend == "nccl" and torch.cuda.is_available():
+        torch.cuda.set_device(local_rank)          # before the group exists: RCCL binds its communicator to the current device
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
@@ -49,7 +51,10 @@ def shard_range(total, rank, world):
 
 def barrier():
     if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-        dist.barrier()
+        if dist.get_backend() == "nccl":
+            dist.barrier(device_ids=[torch.cuda.current_device()])
+        else:
+            dist.barrier()
 
 
 def max_over_ranks(value, device):
