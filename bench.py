@@ -122,6 +122,40 @@ def cpu_baseline(n_gaits, n_ticks):
     return one, allc
 
 
+def golden_parity():
+    """The second half of BASELINE's metric ("CoM RMSE vs ref"): the reference's own golden file
+    TestHerdt2010EmergencyStopTestFGPI.datref (config 2: one gait, 22.5 s) replayed with every MPC tick on the GPU through
+    the C ABI (tests/herdt_replay.py is the 5 ms control loop around the tick; no oracle call on this path)."""
+    import ctypes as C
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import herdt_replay as hr
+    datref = np.load(os.path.join(ROOT, "tests", "golden", "herdt_emergency_stop_datref.npz"))["datref"]
+    m = wg.model_defaults()
+    m.flags = 1                                          # WG_FLAG_NO_STOP_CENTERING: the file predates that branch (DESIGN 5.2)
+    s = wg.gait_init(m, [datref[0, 1], datref[0, 2], datref[0, 3]], [datref[0, 10], datref[0, 11], 0.0],
+                     [datref[0, 22], datref[0, 23], 0.0])
+    s.nb_steps_left = 2; s.nb_steps_ssds = 2; s.sup_y = 0.1
+    wg.mpc_configure(m)
+
+    def tick(model, state, want_dump):
+        arr = (wg.GaitState * 1)()
+        C.memmove(C.byref(arr[0]), C.byref(state), C.sizeof(wg.GaitState))
+        outs, _, _, _ = wg.mpc_tick_batch(arr, want_out=True)
+        C.memmove(C.byref(state), C.byref(arr[0]), C.sizeof(wg.GaitState))
+        out = wg.TickOut()
+        C.memmove(C.byref(out), C.byref(outs[0]), C.sizeof(wg.TickOut))
+        return out, None
+
+    rows = hr.replay(m, s, hr.emergency_stop_events(), 6000, tick=tick, legacy_running=True)
+    if rows.shape != datref.shape:
+        return {"error": "replay produced %s rows, the golden file has %s" % (rows.shape, datref.shape)}
+    d = rows - datref
+    return {"com_rmse_m": float(np.sqrt((d[:, 1:3] ** 2).mean())), "max_abs_err": float(np.abs(d).max()),
+            "rows": int(datref.shape[0]), "columns": int(datref.shape[1]), "tolerance": 1e-6,
+            "reference": "TestHerdt2010EmergencyStopTestFGPI.datref (the reference's golden file, printed to 1e-7), "
+                         "every MPC tick on the GPU, B = 1"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -131,6 +165,7 @@ def main():
                     "one launch per stretch of constant velocity references")
     ap.add_argument("--batch", type=int, default=BATCH_PER_GPU, help="gaits per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-parity", action="store_true", help="skip the golden-file replay (CoM RMSE) after the timed run")
     ap.add_argument("--no-per-tick-leg", action="store_true", help="skip the secondary one-launch-per-tick measurement")
     args = ap.parse_args()
 
@@ -277,6 +312,8 @@ def main():
         }
         if alt is not None:
             line["per_tick_launch"] = alt
+        if world == 1 and not args.no_parity:
+            line["parity"] = golden_parity()
         if cpu_line is not None:
             line["cpu_baseline"] = cpu_line
         print(json.dumps(line), flush=True)
