@@ -149,6 +149,14 @@ typedef struct wg_model {
                                         after the reference's golden .datref was recorded (ChangeLog
                                         [3.1.8] "Put the CoM at the center of the feet when stopping");
                                         the flag exists so the golden file can be replayed. */
+/* Where wg_mpc_configure takes the invariant Hessian block Q_b = beta I + alpha Uv'Uv + gamma Uz'Uz from
+ * (GeneratorVelRef::build_invariant_part, generator-vel-ref.cpp:587-614).  Default (neither flag): the host loop in the
+ * reference's summation order -- the tick is then bit-exact.  With a flag: the matrix cores (wg_gramian_batch), in fp64
+ * (entries equal to rounding, 1e-14) or in fp32 (operands rounded to float: BASELINE's "fp32, MFMA Gramian condensation
+ * path"; entries to 8e-8 of the largest one, which moves the jerk solution by ~1e-3 relative at N = 32 because Q_b's
+ * smallest eigenvalue is beta = 1e-5 -- a tolerance mode, not a parity mode). */
+#define WG_FLAG_GRAMIAN_MFMA_F64 2
+#define WG_FLAG_GRAMIAN_MFMA_F32 4
 
 /* Per-gait state carried from tick to tick. */
 typedef struct wg_gait_state {

@@ -465,9 +465,19 @@ int wg_mpc_configure(const wg_model_t *model) {
     return fail(WG_ERR_BAD_ARG, "T/Tctrl must be %d", WG_SAMPLES_PER_TICK);
   size_t lds = tick_lds_for(*model, tick_view(*model));
   if (lds > 160 * 1024) return fail(WG_ERR_TOO_LARGE, "tick needs %zu B of LDS > 160 KiB", lds);
+  std::vector<double> qb;                              // Q_b from the matrix cores, when the model asks for it
+  if (model->flags & (WG_FLAG_GRAMIAN_MFMA_F64 | WG_FLAG_GRAMIAN_MFMA_F32)) {
+    qb.resize((size_t)model->N * model->N);
+    const int prec = (model->flags & WG_FLAG_GRAMIAN_MFMA_F32) ? WG_GRAMIAN_F32 : WG_GRAMIAN_F64;
+    if (int rc = wg_gramian_batch(1, model->N, &model->T, &model->com_height_qp, model->alpha, model->beta, model->gamma,
+                                  prec, qb.data()))
+      return rc;
+  }
   std::lock_guard<std::mutex> lk(g_mu);
   static wg::TickTables host_tables;
-  wg::build_tables(*model, host_tables);
+  wg::build_tables(*model, host_tables, qb.empty() ? nullptr : qb.data());
+  if (!host_tables.blocks_ok && !qb.empty())
+    return fail(WG_ERR_BAD_ARG, "the matrix-core Gramian is not positive definite enough for ql0002's factorisation");
   if (!g_tables_dev) {
     HIP_TRY(hipMalloc(reinterpret_cast<void **>(&g_tables_dev), sizeof(wg::TickTables)));
     g_release_hooks.push_back([] {

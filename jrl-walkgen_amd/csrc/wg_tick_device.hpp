@@ -53,7 +53,9 @@ struct TickTables {
   unsigned long long z2_cross_sign[(kNMaxH * kNMaxH + 63) / 64];
 };
 
-inline void build_tables(const wg_model_t &m, TickTables &t) {
+// qb_override (N x N, row-major) replaces the host loop's Q_b: the matrix-core Gramian of wg_gramian_batch
+// (WG_FLAG_GRAMIAN_MFMA_*); everything derived from Q_b (factor blocks, diagonal test) then follows the override.
+inline void build_tables(const wg_model_t &m, TickTables &t, const double *qb_override = nullptr) {
   const int N = m.N;
   const double T = m.T, h = m.com_height_qp;
   for (unsigned i = 0; i < (unsigned)kNMaxH; i++)
@@ -79,7 +81,7 @@ inline void build_tables(const wg_model_t &m, TickTables &t) {
       q += pj * m.beta;
       q += pv * m.alpha;
       q += pz * m.gamma;
-      t.Qb[i][j] = q;
+      t.Qb[i][j] = qb_override ? qb_override[i * N + j] : q;
     }
   // ---- constant factor blocks: exactly ql0002's recurrences on blockdiag(Qb, Qb), eps = 1e-8 ----
   {

@@ -191,3 +191,59 @@ def test_horizon_beyond_the_tables_is_refused():
     model.N = 48
     assert wg.lib().wg_mpc_configure(C.byref(model)) == -2        # WG_ERR_BAD_ARG: beyond the table size
     wg.mpc_configure(wg.model_defaults())
+
+
+def _closed_loop(model, B, ticks, redraw, seed, oracle=False):
+    """CoM trajectories [ticks, B, 2] (+ iterations) of B gaits under seeded velocity references"""
+    pt = C.CDLL(os.path.join(ol.ORACLE_DIR, "libwg_oracle_ptrig.so")) if oracle else None
+    st = _start(model, B)
+    rng = np.random.default_rng(seed)
+    per_tick = int(round(model.T / model.Tctrl))
+    com = np.zeros((ticks, B, 2)); its = np.zeros((ticks, B), int)
+    for t in range(ticks):
+        if t % redraw == 0:
+            for g in range(B):
+                st[g].vref[0], st[g].vref[1], st[g].vref[2] = rng.uniform(-0.1, 0.3), rng.uniform(-0.1, 0.1), rng.uniform(-0.2, 0.2)
+        adv = 1 if t == 0 else (per_tick - 1 if t == 1 else per_tick)
+        if oracle:
+            for g in range(B):
+                c = st[g].clock
+                for _ in range(adv):
+                    c += model.Tctrl
+                st[g].clock = c
+                assert pt.wgo_mpc_tick(C.byref(model), C.byref(st[g]), None, None) == 0
+        else:
+            _, diag, _, _ = wg.mpc_tick_batch(st, want_out=False, advance_calls=adv)
+            assert (diag[:, 0] == 0).all(), diag[:, 0]
+            its[t] = diag[:, 1]
+        for g in range(B):
+            com[t, g] = st[g].com_x[0], st[g].com_y[0]
+    return com, its
+
+
+@pytest.mark.parametrize("N", [16, 32])
+def test_matrix_core_gramian_as_the_hessian_source(N):
+    """BASELINE config 5, literally: N = 32 with foot-placement variables, Q_b from the fp32 MFMA Gramian
+    (WG_FLAG_GRAMIAN_MFMA_F32).  Q_b's smallest eigenvalue is beta = 1e-5 and the fp32 operands cost 8e-8 of its largest
+    entry (~1), so this is a tolerance mode: against the fp64 oracle (reference-order Q_b) the closed loop stays within
+    1 mm over 6 s of walking and every QP still solves; the fp64 MFMA Gramian differs from the reference-order loop by
+    rounding only, and the closed loop by less than a micrometre."""
+    wg.init(0)
+    B, ticks, redraw = 24, 60, 20
+    base = wg.model_defaults()
+    base.N = N
+    try:
+        ref, _ = _closed_loop(base, B, ticks, redraw, seed=5, oracle=True)
+        out = {}
+        for name, flag, tol in (("f64", 2, 1e-6), ("f32", 4, 1e-3)):
+            m = wg.model_defaults(); m.N = N; m.flags = flag
+            wg.mpc_configure(m)
+            com, its = _closed_loop(m, B, ticks, redraw, seed=5)
+            dev = np.abs(com - ref).max()
+            out[name] = dev
+            assert dev < tol, (name, dev)
+            assert np.abs(com[-1] - com[0]).max() > 0.3                # they did walk
+        assert out["f32"] > out["f64"]                                 # and the fp32 operands are visible
+        print("N=%d: closed-loop CoM deviation from the fp64 oracle: f64 MFMA %.2e m, f32 MFMA %.2e m" % (N, out["f64"], out["f32"]))
+    finally:
+        wg.mpc_configure(wg.model_defaults())

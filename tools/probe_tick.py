@@ -6,6 +6,7 @@ wg = importlib.import_module("jrl-walkgen_amd"); wg.init(0)
 B = int(os.environ.get("PB", "4096")); TICKS = int(os.environ.get("PT", "200"))
 model = wg.model_defaults()
 if os.environ.get("PN"): model.N = int(os.environ["PN"])       # other horizons: dense / element view
+if os.environ.get("PFLAGS"): model.flags = int(os.environ["PFLAGS"])   # 4: Q_b from the fp32 MFMA Gramian (config 5)
 wg.mpc_configure(model)
 rng = np.random.default_rng(20100)
 states = (wg.GaitState * B)()
