@@ -699,11 +699,15 @@ class PatternGeneratorInterfacePrivate : public virtual PatternGeneratorInterfac
   PatternGeneratorInterfacePrivate(const HumanoidModel *aHDR)
       : PatternGeneratorInterface(aHDR), SimplePlugin(this), m_Model(*aHDR) {
     // PatternGeneratorInterfacePrivate.cpp:181-215: the commands this object handles itself
-    string aMethodName[6] = {":samplingperiod", ":setVelReference", ":HerdtOnline", ":setCoMPerturbationForce",
-                             ":SetAlgoForZmpTrajectory", ":wg_legacy_golden"};
-    for (int i = 0; i < 6; i++)
+    string aMethodName[13] = {":samplingperiod", ":setVelReference", ":HerdtOnline", ":setCoMPerturbationForce",
+                              ":SetAlgoForZmpTrajectory", ":wg_legacy_golden", ":stepseq", ":finish", ":supportfoot", ":arc",
+                              ":lastsupport", ":singlesupporttime", ":doublesupporttime"};
+    for (int i = 0; i < 13; i++)
       if (!SimplePlugin::RegisterMethod(aMethodName[i])) cerr << "Unable to register " << aMethodName[i] << endl;
     m_ZMPVRQP = new ZMPVelocityReferencedQP(this, "", &m_Model);
+    m_ZMPD = new ZMPDiscretization(this, "", &m_Model);                                    // :223-226
+    m_PC = new PreviewControl(this, OptimalControllerSolver::MODE_WITHOUT_INITIALPOS, true);   // :254
+    m_NL = 0;
     m_SamplingPeriod = 0.005;
     m_InternalClock = 0.0;
     m_ShouldBeRunning = false;
@@ -711,7 +715,7 @@ class PatternGeneratorInterfacePrivate : public virtual PatternGeneratorInterfac
     m_Herdt = false;
     m_NbOfHitBottom = 0;
   }
-  ~PatternGeneratorInterfacePrivate() { delete m_ZMPVRQP; }
+  ~PatternGeneratorInterfacePrivate() { delete m_ZMPVRQP; delete m_ZMPD; delete m_PC; }
 
   int ParseCmd(istringstream &strm) {                     // :1029-1039
     string aCmd;
@@ -737,7 +741,16 @@ class PatternGeneratorInterfacePrivate : public virtual PatternGeneratorInterfac
       string ZMPTrajAlgo;
       strm >> ZMPTrajAlgo;
       if (ZMPTrajAlgo == "Herdt") { m_Herdt = true; cout << "Herdt" << endl; }
-      else { m_Herdt = false; cerr << "wg: only the Herdt generator is built (asked for " << ZMPTrajAlgo << ")" << endl; }
+      else if (ZMPTrajAlgo == "Kajita") m_Herdt = false;             // the reference's default (ZMPCOM_KAJITA_2003)
+      else { m_Herdt = false; cerr << "wg: the Herdt and Kajita (stage 1) generators are built (asked for " << ZMPTrajAlgo << ")" << endl; }
+    } else if (aCmd == ":stepseq") {                                 // m_StepSequence, :562-571
+      m_SSH.ReadStepSequenceAccordingToWalkMode(strm);
+      FinishAndRealizeStepSequence();
+    } else if (aCmd == ":finish") {                                  // m_FinishAndRealizeStepSequence
+      FinishAndRealizeStepSequence();
+    } else if (aCmd == ":supportfoot" || aCmd == ":arc" || aCmd == ":lastsupport" || aCmd == ":singlesupporttime" ||
+               aCmd == ":doublesupporttime") {
+      m_SSH.CallMethod(aCmd, strm);                                  // StepStackHandler is a plugin of this manager there
     } else if (aCmd == ":wg_legacy_golden") {
       int on = 0;
       strm >> on;
@@ -774,6 +787,39 @@ class PatternGeneratorInterfacePrivate : public virtual PatternGeneratorInterfac
     m_ShouldBeRunning = true;
   }
 
+  // :881-1005 in Kajita mode, stage 1 only: the step stack -> ZMPDiscretization (CreateZMPReferences :1870-1882) -> the
+  // first preview loop over the whole queue in one launch (the reference runs it NL samples ahead of the second, multi-body
+  // stage inside DoubleStagePreviewControlStrategy; that second stage needs the robot model and is out of scope, so the
+  // CoM handed out is the cart-table one)
+  void FinishAndRealizeStepSequence() {
+    COMState lStartingCOMState;
+    double lStartingZMPPosition[3];
+    vector<double> lStartingWaistPose;
+    FootAbsolutePosition InitLeftFootAbsPos, InitRightFootAbsPos;
+    deque<RelativeFootPosition> lRelativeFootPositions;
+    m_SSH.CopyRelativeFootPosition(lRelativeFootPositions, true);
+    EvaluateStartingState(lStartingCOMState, lStartingZMPPosition, lStartingWaistPose, InitLeftFootAbsPos, InitRightFootAbsPos);
+    m_ZMPPositions.clear(); m_COMBuffer.clear(); m_LeftFootPositions.clear(); m_RightFootPositions.clear();
+    m_ZMPD->SetCurrentTime(m_InternalClock);
+    m_ZMPD->GetZMPDiscretization(m_ZMPPositions, m_COMBuffer, lRelativeFootPositions, m_LeftFootPositions,
+                                 m_RightFootPositions, 0.0, lStartingCOMState, lStartingZMPPosition, InitLeftFootAbsPos,
+                                 InitRightFootAbsPos);
+    if (!m_PC->IsCoherent()) throw runtime_error("PatternGeneratorInterface: preview-control gains are not set (:samplingperiod, :previewcontroltime, :comheight)");
+    m_NL = (unsigned)(m_PC->PreviewControlTime() / m_PC->SamplingPeriod());
+    const size_t nq = m_ZMPPositions.size();
+    if (nq < 2 * (size_t)m_NL) throw runtime_error("PatternGeneratorInterface: step sequence shorter than the preview windows");
+    const int L = (int)(nq - m_NL + 1);
+    vector<double> zx(nq), zy(nq), com((size_t)L * 6), st(8, 0.0);
+    for (size_t i = 0; i < nq; i++) { zx[i] = m_ZMPPositions[i].px; zy[i] = m_ZMPPositions[i].py; }
+    if (m_PC->RunBatch(1, L, zx.data(), zy.data(), st.data(), com.data(), 0, true) != 0) wg_throw("wg_preview_run_batch");
+    for (size_t i = 0; i < nq; i++) {
+      const size_t r = i < (size_t)L ? i : (size_t)L - 1;
+      for (int k = 0; k < 3; k++) { m_COMBuffer[i].x[k] = com[6 * r + k]; m_COMBuffer[i].y[k] = com[6 * r + 3 + k]; }
+    }
+    m_NbOfHitBottom = 0;
+    m_ShouldBeRunning = true;
+  }
+
   // CoMAndFootOnlyStrategy::EndOfMotion with m_BufferSizeLimit = 0, CoMAndFootOnlyStrategy.cpp:157-188
   int EndOfMotion() {
     if (m_LeftFootPositions.size() > 0) { m_NbOfHitBottom = 0; return 1; }
@@ -786,6 +832,9 @@ class PatternGeneratorInterfacePrivate : public virtual PatternGeneratorInterfac
                                   COMState &finalCOMState, FootAbsolutePosition &LeftFootPosition,
                                   FootAbsolutePosition &RightFootPosition) {
     m_InternalClock += m_SamplingPeriod;
+    if (!m_Herdt && m_ShouldBeRunning && m_ZMPPositions.size() <= 2 * (size_t)m_NL) {
+      m_ShouldBeRunning = false;   // DoubleStagePreviewControlStrategy::EndOfMotion: two preview windows stay on the queue
+    }
     if ((!m_ShouldBeRunning) || (EndOfMotion() < 0)) {
       m_Running = false;
       return m_Running;
@@ -834,6 +883,10 @@ class PatternGeneratorInterfacePrivate : public virtual PatternGeneratorInterfac
  private:
   HumanoidModel m_Model;
   ZMPVelocityReferencedQP *m_ZMPVRQP;
+  ZMPDiscretization *m_ZMPD;
+  PreviewControl *m_PC;
+  StepStackHandler m_SSH;
+  unsigned m_NL;
   deque<ZMPPosition> m_ZMPPositions;
   deque<COMState> m_COMBuffer;
   deque<FootAbsolutePosition> m_LeftFootPositions, m_RightFootPositions;

@@ -107,6 +107,31 @@ def test_kajita_circle_through_the_facade_matches_golden(tmp_path):
     assert abs(rows[-1, 13] - 30.0) < 1e-6
 
 
+@pytest.mark.parametrize("profile", ["StraightWalking", "PbFlorentSeq1", "Circle"])
+def test_testkajita2003_rehosted_on_the_interface(profile, tmp_path):
+    """The reference's TestKajita2003 re-hosted on PatternGeneratorInterface (jrl-walkgen_amd/host/test_kajita2003.cpp):
+    CommonInitialization + the profile's commands through ParseCmd, then RunOneStepOfTheControlLoop until it stops.  The
+    loop ends after exactly as many calls as the reference's golden file has rows, and the feet and ZMP-reference columns
+    are the golden's to its print precision; the CoM columns are stage 1's (the reference prints stage 2's) and must
+    follow the ZMP reference."""
+    exe = os.path.join(ROOT, "jrl-walkgen_amd", "bin", "test_kajita2003")
+    assert os.path.exists(exe), "build first: python -c 'import __graft_entry__ as g; g.build()'"
+    out = tmp_path / "k.dat"
+    r = subprocess.run([exe, profile, str(out)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    rows = np.loadtxt(out)
+    gold = np.load(os.path.join(ROOT, "tests", "golden", "kajita_zmpdisc_datref.npz"))[profile + "_rows"]
+    assert rows.shape == (gold.shape[0], 38)
+    tol = 2e-7
+    assert np.abs(rows[:, 0] - gold[:, 0]).max() < 1e-9                                      # time
+    assert np.abs(rows[:, [10, 11, 12, 19, 20, 21]] - gold[:, 1:7]).max() < tol               # left foot x y z theta omega omega2
+    assert np.abs(rows[:, [22, 23, 24, 31, 32, 33]] - gold[:, 7:13]).max() < tol              # right foot
+    assert np.abs(rows[:, 34:36] - gold[:, 13:15]).max() < tol                                # world-frame ZMP reference
+    # stage-1 CoM: at rest at the start, within a step length of the ZMP reference throughout, height = :comheight
+    assert np.abs(rows[:200, 1:3]).max() < 1e-3 and np.abs(rows[:, 3] - 0.8078).max() < 1e-12
+    assert np.abs(rows[:, 1:3] - rows[:, 34:36]).max() < 0.25
+
+
 def test_cpp_fleet_bench_runs_through_the_c_abi():
     """jrl-walkgen_amd/host/fleet_bench.cpp: the fleet path from plain C++ (hipMalloc'd states, wg_mpc_run_batch_dev and
     wg_mpc_tick_batch_dev) -- both launch modes advance every gait by the same number of ticks"""
