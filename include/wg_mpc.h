@@ -477,6 +477,12 @@ int wg_zmpdisc_batch(const wg_zmpdisc_model_t *model, int B, int smax, const wg_
 int wg_zmpdisc_batch_dev(const wg_zmpdisc_model_t *model, int B, int smax, const wg_rel_step_t *steps,
                          const int *n_steps, const double *init_feet, int lcap, double *zmp_x_tm, double *zmp_y_tm,
                          int *length, void *hip_stream);
+/* every output on the device, all time-major: zmp_theta_tm / types [lcap][B], left_tm / right_tm [lcap][6][B]
+ * (x, y, z, theta, omega, omega2); any output pointer may be NULL */
+int wg_zmpdisc_full_batch_dev(const wg_zmpdisc_model_t *model, int B, int smax, const wg_rel_step_t *steps,
+                              const int *n_steps, const double *init_feet, int lcap, double *zmp_x_tm, double *zmp_y_tm,
+                              double *zmp_theta_tm, int *zmp_type_tm, double *left_tm, int *left_type_tm, double *right_tm,
+                              int *right_type_tm, int *length, void *hip_stream);
 
 /* ZMP polytopes of a feet trajectory (host) ----------------------------------------------------------------------------
  *

@@ -1126,6 +1126,23 @@ int wg_zmpdisc_batch_dev(const wg_zmpdisc_model_t *model, int B, int smax, const
   return zd_launch(K, B, smax, steps, n_steps, init_feet, lcap, O, length, reinterpret_cast<hipStream_t>(hip_stream));
 }
 
+int wg_zmpdisc_full_batch_dev(const wg_zmpdisc_model_t *model, int B, int smax, const wg_rel_step_t *steps,
+                              const int *n_steps, const double *init_feet, int lcap, double *zmp_x_tm, double *zmp_y_tm,
+                              double *zmp_theta_tm, int *zmp_type_tm, double *left_tm, int *left_type_tm, double *right_tm,
+                              int *right_type_tm, int *length, void *hip_stream) {
+  if (int rc = ensure_device()) return rc;
+  wg::ZdConst K;
+  if (int rc = zd_make_const(model, &K)) return rc;
+  if (B < 0 || smax < 2 || smax > WG_ZMPDISC_MAX_STEPS || lcap < 1 || !steps || !n_steps || !init_feet)
+    return fail(WG_ERR_BAD_ARG, "need B >= 0, 2 <= smax <= %d, lcap >= 1, non-null inputs", WG_ZMPDISC_MAX_STEPS);
+  if ((zmp_x_tm == nullptr) != (zmp_y_tm == nullptr)) return fail(WG_ERR_BAD_ARG, "zmp_x_tm and zmp_y_tm go together");
+  if (B == 0) return WG_OK;
+  wg::ZdOut O;
+  O.zx = zmp_x_tm; O.zy = zmp_y_tm; O.ztheta = zmp_theta_tm; O.ztype = zmp_type_tm;
+  O.left = left_tm; O.ltype = left_type_tm; O.right = right_tm; O.rtype = right_type_tm;
+  return zd_launch(K, B, smax, steps, n_steps, init_feet, lcap, O, length, reinterpret_cast<hipStream_t>(hip_stream));
+}
+
 int wg_zmpdisc_batch(const wg_zmpdisc_model_t *model, int B, int smax, const wg_rel_step_t *steps, const int *n_steps,
                      const double *init_feet, int lcap, double *zmp, double *zmp_theta, int *zmp_type, double *left,
                      int *left_type, double *right, int *right_type, int *length) {

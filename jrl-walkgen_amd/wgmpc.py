@@ -110,6 +110,8 @@ def lib():
             [C.c_void_p] * 8
         _lib.wg_zmpdisc_batch_dev.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int] + \
             [C.c_void_p] * 4
+        _lib.wg_zmpdisc_full_batch_dev.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int] + \
+            [C.c_void_p] * 10
         _lib.wg_foot_constraints.argtypes = [C.c_int] + [C.c_void_p] * 4 + [C.c_double] * 4 + [C.c_int] + [C.c_void_p] * 3
     return _lib
 

@@ -249,3 +249,34 @@ def test_empty_batches_and_bad_arguments():
         assert False, "capacity overflow not reported"
     except wg.WgError:
         pass
+
+
+def test_full_device_entry_point_matches_the_host_one():
+    """wg_zmpdisc_full_batch_dev: every output resident and time-major; same values as the host-pointer entry point"""
+    import torch
+    wg.init(0)
+    m = kajita_model(); m.omega = 2.0
+    rng = np.random.default_rng(12)
+    B, smax = 37, 7
+    steps, n_steps, init = random_fleet(rng, B, smax, m)
+    lens = [wg.zmpdisc_length(m, gait_steps(steps, b, smax, int(n_steps[b]))) for b in range(B)]
+    lcap = max(lens)
+    host = wg.zmpdisc_batch(m, steps, n_steps, init, smax, lcap)
+    d = lambda *shape, dt=torch.float64: torch.zeros(*shape, dtype=dt, device="cuda")  # noqa: E731
+    zx, zy, zt, zty = d(lcap, B), d(lcap, B), d(lcap, B), d(lcap, B, dt=torch.int32)
+    lf, rf, lty, rty = d(lcap, 6, B), d(lcap, 6, B), d(lcap, B, dt=torch.int32), d(lcap, B, dt=torch.int32)
+    ln = d(B, dt=torch.int32)
+    d_steps = torch.from_numpy(np.frombuffer(steps, dtype=np.uint8).copy()).cuda()
+    d_ns = torch.from_numpy(n_steps).cuda(); d_init = torch.from_numpy(init).cuda()
+    rc = wg.lib().wg_zmpdisc_full_batch_dev(C.byref(m), B, smax, d_steps.data_ptr(), d_ns.data_ptr(), d_init.data_ptr(), lcap,
+                                            zx.data_ptr(), zy.data_ptr(), zt.data_ptr(), zty.data_ptr(), lf.data_ptr(),
+                                            lty.data_ptr(), rf.data_ptr(), rty.data_ptr(), ln.data_ptr(), None)
+    assert rc == 0
+    torch.cuda.synchronize()
+    assert list(ln.cpu().numpy()) == lens
+    for b in range(B):
+        L = lens[b]
+        assert np.array_equal(zx.cpu().numpy()[:L, b], host["zmp"][b, :L, 0]) and np.array_equal(zy.cpu().numpy()[:L, b], host["zmp"][b, :L, 1])
+        assert np.array_equal(zt.cpu().numpy()[:L, b], host["zmp_theta"][b, :L]) and np.array_equal(zty.cpu().numpy()[:L, b], host["zmp_type"][b, :L])
+        assert np.array_equal(lf.cpu().numpy()[:L, :, b], host["left"][b, :L]) and np.array_equal(rf.cpu().numpy()[:L, :, b], host["right"][b, :L])
+        assert np.array_equal(lty.cpu().numpy()[:L, b], host["left_type"][b, :L]) and np.array_equal(rty.cpu().numpy()[:L, b], host["right_type"][b, :L])
