@@ -187,8 +187,15 @@ int wg_qp_solve_batch_dev(int B, int nmax, int mmax, const int *n, const int *m,
   if (B == 0) return WG_OK;
   const int m_cap = m ? mmax : mmax - 1;
   size_t lds = wg::QlDims(nmax, m_cap, m_cap).bytes();
+  // A (m x n, the largest operand) is only ever read: staged in LDS it caps the residency (n = 36, m = 75: 54 KB, three QPs
+  // per CU), read in place it comes from L2 and the CU holds five -- measured 274 k vs 223 k QPs/s on the probe's QPs.  It
+  // goes to LDS only while that does not cost a resident QP (8 per CU = two waves per SIMD is the useful maximum).
   int a_in_lds = 1;
-  if (lds > 160 * 1024) { a_in_lds = 0; lds = wg::QlDims(nmax, m_cap, m_cap, true, false).bytes(); }
+  const size_t lds_noa = wg::QlDims(nmax, m_cap, m_cap, true, false).bytes();
+  auto per_cu = [](size_t l) { const size_t k = (160 * 1024) / (l ? l : 1); return k > 8 ? (size_t)8 : k; };
+  if (per_cu(lds_noa) > per_cu(lds)) a_in_lds = 0;
+  if (const char *e = getenv("WG_QL_A_IN_LDS")) a_in_lds = atoi(e) != 0;   // tests force either path
+  if (lds > 160 * 1024 || !a_in_lds) { a_in_lds = 0; lds = lds_noa; }
   if (lds > 160 * 1024) return fail(WG_ERR_TOO_LARGE, "QP (n=%d, m=%d) needs %zu B of LDS > 160 KiB", nmax, m_cap, lds);
   if (lds > 64 * 1024)
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(wg_ql_dense_kernel),

@@ -74,6 +74,20 @@ def test_herdt_shape_uniform_batch():
     assert not bad, bad[:5]
 
 
+@pytest.mark.parametrize("a_in_lds", ["0", "1"])
+def test_constraint_matrix_in_lds_or_read_in_place(a_in_lds, monkeypatch):
+    """A is staged in LDS only while that does not cost a resident QP (Herdt-sized QPs read it in place, from L2); both
+    placements are the same arithmetic and are held to the oracle"""
+    monkeypatch.setenv("WG_QL_A_IN_LDS", a_in_lds)
+    wg = _wg()
+    qps = [qpgen.herdt_like(np.random.default_rng(4100 + s), 16, 2) for s in range(64)] + \
+          [qpgen.random_pd(np.random.default_rng(4200 + s), 12, 9) for s in range(32)]
+    pk = wg.pack_qps(qps)
+    res = wg.qp_solve_batch(pk, hist_cap=512)
+    bad = _compare(qps, res, "a_in_lds=" + a_in_lds, pk)
+    assert not bad, bad[:5]
+
+
 def test_empty_batch_and_errors():
     wg = _wg()
     q = qpgen.random_pd(np.random.default_rng(1), 4, 3)
