@@ -639,7 +639,7 @@ wg_pldp_kernel(int B, int mcap, const wg::PldpModel *__restrict__ model, const i
                const double *__restrict__ D, const double *__restrict__ A, const double *__restrict__ b,
                const double *__restrict__ zmpref, const double *__restrict__ xkyk, const int *__restrict__ similar,
                const int *__restrict__ n_removed, const int *__restrict__ starting, int max_iter,
-               wg_pldp_state_t *states, double *X, int *ret, int *n_iter, int *active, int *n_active) {
+               wg_pldp_state_t *states, double *X, int *ret, int *n_iter, int *active, int *n_active, int a_in_lds) {
   extern __shared__ __attribute__((aligned(16))) unsigned char pldp_lds[];
   const wg::PldpModel &M = *model;
   const int n = 2 * M.N;
@@ -654,7 +654,7 @@ wg_pldp_kernel(int B, int mcap, const wg::PldpModel *__restrict__ model, const i
     wg::pldp_problem(M, pldp_lds, mcap, mp, D + (size_t)p * n, A + p * aslot, b + (size_t)p * mcap,
                      zmpref + (size_t)p * n, xkyk + (size_t)p * 6, similar + (size_t)p * mcap, n_removed[p], starting[p],
                      max_iter, states + p, X + (size_t)p * n, ret + p, n_iter ? n_iter + p : nullptr,
-                     active ? active + (size_t)p * mcap : nullptr, n_active ? n_active + p : nullptr);
+                     active ? active + (size_t)p * mcap : nullptr, n_active ? n_active + p : nullptr, a_in_lds != 0);
   }
 }
 
@@ -709,14 +709,20 @@ int wg_pldp_solve_batch_dev(int B, int mcap, const int *m, const double *D, cons
   if (!m || !D || !A || !b || !zmpref || !xkyk || !similar || !n_removed || !starting || !states || !X || !ret)
     return fail(WG_ERR_BAD_ARG, "null argument");
   if (B == 0) return WG_OK;
-  const size_t lds = wg::PldpLds::bytes(mcap);
+  // like the dense QP kernel: A in LDS only while that does not cost a resident problem (8 per CU is the useful maximum)
+  size_t lds = wg::PldpLds::bytes(mcap);
+  const size_t lds_noa = wg::PldpLds::bytes(mcap, WG_PLDP_ACTIVE_CAP, false, false);
+  auto per_cu = [](size_t l) { const size_t k = (160 * 1024) / (l ? l : 1); return k > 8 ? (size_t)8 : k; };
+  int a_in_lds = per_cu(lds_noa) > per_cu(lds) ? 0 : 1;
+  if (const char *e = getenv("WG_PLDP_A_IN_LDS")) a_in_lds = atoi(e) != 0;   // tests force either path
+  if (!a_in_lds) lds = lds_noa;
   if (lds > 64 * 1024)
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(wg_pldp_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)lds));
   const int grid = B;
   hipLaunchKernelGGL(wg_pldp_kernel, dim3(grid), dim3(64), lds, reinterpret_cast<hipStream_t>(hip_stream), B, mcap,
                      g_pldp_dev, m, D, A, b, zmpref, xkyk, similar, n_removed, starting, max_iter, states, X, ret, n_iter,
-                     active, n_active);
+                     active, n_active, a_in_lds);
   HIP_TRY(hipGetLastError());
   return WG_OK;
 }

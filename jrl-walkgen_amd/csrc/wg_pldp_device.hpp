@@ -43,20 +43,22 @@ struct PldpLds {
   int lda, cap, N;
   __host__ __device__ static int lda_for(int mcap) { return (mcap + 1) | 1; }
   // dense view: A staged with an odd leading dimension; structured view: 2 coefficients + the instant per row
-  __host__ __device__ static size_t bytes(int mcap, int cap = WG_PLDP_ACTIVE_CAP, bool structured = false) {
+  // a_lds (dense view only): the constraint matrix staged in LDS; false: read in place from global memory (L2)
+  __host__ __device__ static size_t bytes(int mcap, int cap = WG_PLDP_ACTIVE_CAP, bool structured = false, bool a_lds = true) {
     const size_t n = 2 * WG_PLDP_N;
-    size_t dbl = (structured ? (size_t)2 * mcap + WG_PLDP_N * WG_PLDP_N : (size_t)lda_for(mcap) * n) +
+    size_t dbl = (structured ? (size_t)2 * mcap + WG_PLDP_N * WG_PLDP_N : (a_lds ? (size_t)lda_for(mcap) * n : 0)) +
                  (size_t)cap * (cap + 1) / 2 + mcap /*b*/ + 3 * n /*c d Vk*/ + cap /*v2*/ + mcap /*tmp1*/;
     size_t ints = (size_t)mcap /*similar*/ + cap /*act*/ + mcap /*state*/ + (structured ? mcap : 0) /*slot*/;
     return dbl * 8 + ((ints * 4 + 7) & ~size_t(7));
   }
-  __device__ void carve(unsigned char *base, int mcap, int cap_ = WG_PLDP_ACTIVE_CAP, bool structured = false, int N_ = WG_PLDP_N) {
+  __device__ void carve(unsigned char *base, int mcap, int cap_ = WG_PLDP_ACTIVE_CAP, bool structured = false, int N_ = WG_PLDP_N,
+                        bool a_lds = true) {
     const int n = 2 * WG_PLDP_N;
     double *p = reinterpret_cast<double *>(base);
     lda = lda_for(mcap); cap = cap_; N = N_;
     A = nullptr; c0 = c1 = PuL = nullptr; slot = nullptr;
     if (structured) { c0 = p; p += mcap; c1 = p; p += mcap; PuL = p; p += WG_PLDP_N * WG_PLDP_N; }
-    else { A = p; p += lda * n; }
+    else if (a_lds) { A = p; p += lda * n; }
     L = p; p += cap * (cap + 1) / 2;
     b = p; p += mcap;
     c = p; p += n;
@@ -305,11 +307,12 @@ __device__ void pldp_problem(const PldpModel &M, unsigned char *lds, int mcap, i
                              const double *__restrict__ A, const double *__restrict__ bvec,
                              const double *__restrict__ zmpref, const double *__restrict__ xkyk,
                              const int *__restrict__ similar, int n_removed, int starting, int max_iter,
-                             wg_pldp_state_t *st, double *X, int *ret, int *n_iter, int *active, int *n_active) {
+                             wg_pldp_state_t *st, double *X, int *ret, int *n_iter, int *active, int *n_active,
+                             bool a_lds = true) {
   const int lane = threadIdx.x;
   const int n = 2 * M.N;
   PldpLds W;
-  W.carve(lds, mcap);
+  W.carve(lds, mcap, WG_PLDP_ACTIVE_CAP, false, WG_PLDP_N, a_lds);
   bool bad = false;
   for (int li = lane; li < m; li += 64) {
     const int sim = similar[li];
@@ -319,8 +322,13 @@ __device__ void pldp_problem(const PldpModel &M, unsigned char *lds, int mcap, i
     if (sim > 0 || li + sim < 0) bad = true;
   }
   const int ldg = m + 1;
-  for (int col = 0; col < n; col++)
-    for (int row = lane; row < m; row += 64) W.A[row + col * W.lda] = A[row + col * ldg];
+  if (a_lds) {
+    for (int col = 0; col < n; col++)
+      for (int row = lane; row < m; row += 64) W.A[row + col * W.lda] = A[row + col * ldg];
+  } else {                                         // the solver only reads A: in place, the reference's own layout
+    W.A = const_cast<double *>(A);
+    W.lda = ldg;
+  }
   if (lane < W.cap) W.v2[lane] = 0.0;
   WG_WSYNC();
   int S = 0, it = 0, rc;

@@ -72,7 +72,10 @@ def _run_lockstep(B, n_ticks, seed0, max_iter=0, mcap=wg.PLDP_MMAX):
     return stats
 
 
-def test_pldp_gaits_bit_exact():
+@pytest.mark.parametrize("a_in_lds", ["0", "1"])
+def test_pldp_gaits_bit_exact(a_in_lds, monkeypatch):
+    """both placements of the constraint matrix (staged in LDS / read in place from L2, the default at m = 128)"""
+    monkeypatch.setenv("WG_PLDP_A_IN_LDS", a_in_lds)
     st = _run_lockstep(B=24, n_ticks=45, seed0=100)
     assert st["solves"] > 600 and max(st["nact"]) >= 10 and max(st["iters"]) >= 6
 
