@@ -270,7 +270,8 @@ wg_model_t g_model;
 bool g_model_set = false;
 wg::TickTables *g_tables_dev = nullptr;
 wg_model_t *g_model_dev = nullptr;     // the model in device memory (multi-tick kernel reads it through a pointer)
-DevBuf g_tick_state, g_tick_out, g_tick_aux, g_run_buf;
+DevBuf g_tick_state, g_tick_out, g_tick_aux, g_run_buf, g_tick_z;
+std::mutex g_z_mu;
 bool g_run_hooked = false;
 
 inline bool tick_compact(const wg_model_t &m);
@@ -289,21 +290,30 @@ inline bool tick_compact(const wg_model_t &m) {
   const char *v = getenv("WG_TICK_VIEW");
   return m.N == 16 && m.N * m.T <= 2.0 * m.step_period + 1e-12 && !(e && atoi(e) != 0) && !(v && *v);
 }
+// element view: Z in a per-block slot of global memory instead of LDS (WG_TICK_Z_GLOBAL=0 keeps it in LDS: A/B tests)
+inline bool tick_z_global(int view) {
+  if (view != -1) return false;
+  const char *e = getenv("WG_TICK_Z_GLOBAL");
+  return !(e && atoi(e) == 0);
+}
+inline size_t tick_z_slot_doubles(const wg_model_t &m) { return (size_t)tick_max_n(m) * (tick_max_n(m) | 1); }
 inline size_t tick_lds_for(const wg_model_t &m, int view) {
-  const size_t ql = (wg::QlDims(tick_max_n(m), tick_max_m(m), tick_max_m(m), view == 0, true, 0, view != 16).bytes() + 15) & ~(size_t)15;
+  const size_t ql = (wg::QlDims(tick_max_n(m), tick_max_m(m), tick_max_m(m), view == 0, true, 0, view != 16, !tick_z_global(view)).bytes() + 15) & ~(size_t)15;
   const int gvld = view == 16 ? wg::kGvLd : (view == -1 ? wg::kGvLdElem : 0);
   return ql + wg::TickLds::bytes(m.N, tick_smax(m), gvld, view == 16);
 }
 inline int tick_view(const wg_model_t &m) {
   if (tick_compact(m)) return 16;
   // the element view parks the pre-solve scratch on Z (n >= 2N): tiny horizons whose Z is smaller than that stay dense
-  const bool overlay_fits = wg::TickLds::pre_bytes(m.N, tick_smax(m)) <= (size_t)8 * (2 * m.N) * ((2 * m.N) | 1);
+  // (with Z in global memory the first array of the solver area is R: (2N)(2N+1)/2 + 2N doubles at the least)
+  const bool overlay_fits = wg::TickLds::pre_bytes(m.N, tick_smax(m)) <= (size_t)8 * ((size_t)(2 * m.N) * (2 * m.N + 1) / 2 + 2 * m.N);
   const char *v = getenv("WG_TICK_VIEW");
   if (v && v[0] == 'e' && overlay_fits) return -1;
   return (tick_lds_for(m, 0) <= 160 * 1024 || !overlay_fits) ? 0 : -1;
 }
 inline size_t tick_ql_bytes(const wg_model_t &m) {
-  size_t b = wg::QlDims(tick_max_n(m), tick_max_m(m), tick_max_m(m), tick_view(m) == 0, true, 0, tick_view(m) != 16).bytes();
+  size_t b = wg::QlDims(tick_max_n(m), tick_max_m(m), tick_max_m(m), tick_view(m) == 0, true, 0, tick_view(m) != 16,
+                        !tick_z_global(tick_view(m))).bytes();
   return (b + 15) & ~(size_t)15;
 }
 }  // namespace
@@ -323,7 +333,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WG_TICK_WPE_
                                                          wg_gait_state_t *__restrict__ states,
                                                          wg_tick_out_t *__restrict__ outs, int *__restrict__ diag,
                                                          int advance_calls, int *__restrict__ hist, int hist_cap,
-                                                         int *__restrict__ hist_len, unsigned ql_bytes) {
+                                                         int *__restrict__ hist_len, unsigned ql_bytes, double *zscratch,
+                                                         unsigned zslot) {
   extern __shared__ __attribute__((aligned(16))) double wg_lds[];
   const int lane = threadIdx.x & 63;
   // one block = one gait (grid == B): no grid-stride loop, so nothing lane-dependent is hoisted out of it and kept
@@ -341,7 +352,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WG_TICK_WPE_
     }
     wg::TickDiag dg = wg::mpc_tick<NH>(model, tb, states + g, outs ? outs + g : nullptr, wg_lds,
                                    reinterpret_cast<char *>(wg_lds) + ql_bytes, hist ? hist + (size_t)g * hist_cap : nullptr,
-                                   hist_cap, hist_len ? hist_len + g : nullptr);
+                                   hist_cap, hist_len ? hist_len + g : nullptr,
+                                   zscratch ? zscratch + (size_t)blockIdx.x * zslot : nullptr);
     if (diag && lane == 0) {
       int *dq = diag + (size_t)g * 6;
       dq[0] = dg.ifail; dq[1] = dg.n_iter; dq[2] = dg.nact; dq[3] = dg.n; dq[4] = dg.m; dq[5] = dg.ns;
@@ -373,7 +385,8 @@ template <int NH>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WG_TICK_WPE_MIN, WG_TICK_WPE_MAX))) void wg_mpc_run_kernel(
     int B, int n_ticks, const wg_model_t *__restrict__ model_p, const wg::TickTables *__restrict__ tb_p,
     wg_gait_state_t *__restrict__ states_p, wg_tick_out_t *__restrict__ outs_p, int *__restrict__ diag_p, int advance_calls,
-    wg_run_queue *__restrict__ q, int *__restrict__ ring, int *__restrict__ done, unsigned ql_bytes) {
+    wg_run_queue *__restrict__ q, int *__restrict__ ring, int *__restrict__ done, unsigned ql_bytes, double *zscratch,
+    unsigned zslot) {
   extern __shared__ __attribute__((aligned(16))) double wg_lds[];
   const int total = B * n_ticks;
   for (;;) {
@@ -408,7 +421,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WG_TICK_WPE_
       WG_WSYNC();
     }
     wg::TickDiag dg = wg::mpc_tick<NH>(model, tb, states + g, outs ? outs + (size_t)t * B + g : nullptr, wg_lds,
-                                   reinterpret_cast<char *>(wg_lds) + ql_bytes, nullptr, 0, nullptr);
+                                   reinterpret_cast<char *>(wg_lds) + ql_bytes, nullptr, 0, nullptr,
+                                   zscratch ? zscratch + (size_t)blockIdx.x * zslot : nullptr);
     if (diag && lane == 0) {
       int *dq = diag + ((size_t)t * B + g) * 6;
       dq[0] = dg.ifail; dq[1] = dg.n_iter; dq[2] = dg.nact; dq[3] = dg.n; dq[4] = dg.m; dq[5] = dg.ns;
@@ -491,7 +505,7 @@ int wg_mpc_configure(const wg_model_t *model) {
       if (g_tables_dev) (void)hipFree(g_tables_dev);
       if (g_model_dev) (void)hipFree(g_model_dev);
       g_tables_dev = nullptr; g_model_dev = nullptr; g_model_set = false;
-      g_tick_state.release(); g_tick_out.release(); g_tick_aux.release();
+      g_tick_state.release(); g_tick_out.release(); g_tick_aux.release(); g_tick_z.release();
     });
   }
   HIP_TRY(hipMemcpy(g_tables_dev, &host_tables, sizeof host_tables, hipMemcpyHostToDevice));
@@ -530,15 +544,22 @@ int wg_mpc_tick_batch_dev(int B, wg_gait_state_t *states, wg_tick_out_t *outs, i
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   const int grid = B;                             // one gait per block; the dispatcher balances uneven iteration counts
   hipStream_t st = reinterpret_cast<hipStream_t>(hip_stream);
+  double *zs = nullptr;
+  const size_t zslot = tick_z_slot_doubles(g_model);
+  if (tick_z_global(view)) {
+    std::lock_guard<std::mutex> lk(g_z_mu);       // its own lock: the host-pointer entry points hold g_mu around this call
+    if (int rc = g_tick_z.reserve((size_t)grid * zslot * 8)) return rc;
+    zs = static_cast<double *>(g_tick_z.p);
+  }
   if (view == 16)
     hipLaunchKernelGGL(wg_mpc_tick_kernel<16>, dim3(grid), dim3(64), lds, st, B, g_model, g_tables_dev, states, outs, diag,
-                       advance_calls, hist, hist_cap, hist_len, (unsigned)qlb);
+                       advance_calls, hist, hist_cap, hist_len, (unsigned)qlb, zs, (unsigned)zslot);
   else if (view == 0)
     hipLaunchKernelGGL(wg_mpc_tick_kernel<0>, dim3(grid), dim3(64), lds, st, B, g_model, g_tables_dev, states, outs, diag,
-                       advance_calls, hist, hist_cap, hist_len, (unsigned)qlb);
+                       advance_calls, hist, hist_cap, hist_len, (unsigned)qlb, zs, (unsigned)zslot);
   else
     hipLaunchKernelGGL(wg_mpc_tick_kernel<-1>, dim3(grid), dim3(64), lds, st, B, g_model, g_tables_dev, states, outs, diag,
-                       advance_calls, hist, hist_cap, hist_len, (unsigned)qlb);
+                       advance_calls, hist, hist_cap, hist_len, (unsigned)qlb, zs, (unsigned)zslot);
   HIP_TRY(hipGetLastError());
   return WG_OK;
 }
@@ -574,15 +595,22 @@ int wg_mpc_run_batch_dev(int B, wg_gait_state_t *states, int n_ticks, int advanc
   if (per_cu < 1) per_cu = 1;
   int grid = g_num_cu * per_cu;
   if (grid > B) grid = B;
+  double *zs = nullptr;
+  const size_t zslot = tick_z_slot_doubles(g_model);
+  if (tick_z_global(view)) {
+    std::lock_guard<std::mutex> lk(g_z_mu);       // its own lock: the host-pointer entry points hold g_mu around this call
+    if (int rc = g_tick_z.reserve((size_t)grid * zslot * 8)) return rc;
+    zs = static_cast<double *>(g_tick_z.p);
+  }
   if (view == 16)
     hipLaunchKernelGGL(wg_mpc_run_kernel<16>, dim3(grid), dim3(64), lds, st, B, n_ticks, g_model_dev, g_tables_dev, states, outs,
-                       diag, advance_calls, q, ring, done, (unsigned)qlb);
+                       diag, advance_calls, q, ring, done, (unsigned)qlb, zs, (unsigned)zslot);
   else if (view == 0)
     hipLaunchKernelGGL(wg_mpc_run_kernel<0>, dim3(grid), dim3(64), lds, st, B, n_ticks, g_model_dev, g_tables_dev, states, outs,
-                       diag, advance_calls, q, ring, done, (unsigned)qlb);
+                       diag, advance_calls, q, ring, done, (unsigned)qlb, zs, (unsigned)zslot);
   else
     hipLaunchKernelGGL(wg_mpc_run_kernel<-1>, dim3(grid), dim3(64), lds, st, B, n_ticks, g_model_dev, g_tables_dev, states, outs,
-                       diag, advance_calls, q, ring, done, (unsigned)qlb);
+                       diag, advance_calls, q, ring, done, (unsigned)qlb, zs, (unsigned)zslot);
   HIP_TRY(hipGetLastError());
   return WG_OK;
 }

@@ -88,13 +88,15 @@ struct QlDims {
   bool a_lds;   // dense only: A staged in LDS (false: read in place from global memory -- large QPs)
   int nsc;      // length of each of the four scratch vectors: n, or the static length of the compact view's ordered sums
   bool bounds;  // xl / xu held in LDS (false: the problem view supplies them -- constants for the Herdt QP)
+  bool z_lds;   // Z held in LDS (false: the caller points QlView::Z at a per-problem slot in global memory -- large n, where
+                // Z is the operand that caps the residency; it is streamed lane-parallel, never on a serial chain)
   __host__ __device__ QlDims(int n_, int m_, int mmax_, bool dense_ = true, bool a_lds_ = true, int nsc_ = 0,
-                             bool bounds_ = true)
+                             bool bounds_ = true, bool z_lds_ = true)
       : n(n_), m(m_), mmax(mmax_), ldg(n_ | 1), ldz(n_ | 1), lda(mmax_ | 1), dense(dense_), a_lds(a_lds_),
-        nsc(nsc_ > n_ ? nsc_ : n_), bounds(bounds_) {}
+        nsc(nsc_ > n_ ? nsc_ : n_), bounds(bounds_), z_lds(z_lds_) {}
   __host__ __device__ int r_len() const { return n * (n + 1) / 2 + n; }
   __host__ __device__ int n_doubles() const {
-    return (dense ? n * ldg + (a_lds ? n * lda : 0) : 0) + n * ldz + r_len()   // [G, A,] Z, R
+    return (dense ? n * ldg + (a_lds ? n * lda : 0) : 0) + (z_lds ? n * ldz : 0) + r_len()   // [G, A,] [Z,] R
            + (bounds ? 8 : 6) * n                   // x d ww wd wx lam [xl xu]
            + (m + n) + m                            // wa, b (inner)
            + 4 * nsc + 8;                           // scratch + scalar slots
@@ -115,7 +117,8 @@ struct QlView {
     double *p = base;
     G = nullptr; A = nullptr;
     if (D.dense) { G = p; p += n * ldg; }
-    Z = p; p += n * ldz;
+    Z = nullptr;
+    if (D.z_lds) { Z = p; p += n * ldz; }
     R = p; p += D.r_len();
     if (D.dense && D.a_lds) { A = p; p += n * lda; }
     x = p; p += n;  d = p; p += n;  ww = p; p += n;  wd = p; p += n;

@@ -476,7 +476,7 @@ struct TickDiag { int ifail, n_iter, nact, n, m, ns; };
 template <int NH>
 __device__ __forceinline__ TickDiag mpc_tick(const wg_model_t &m, const TickTables *__restrict__ tb, wg_gait_state_t *gstate,
                                     wg_tick_out_t *out, double *lds_ql, char *lds_tick, int *hist, int hist_cap,
-                                    int *hist_len) {
+                                    int *hist_len, double *zglobal = nullptr) {
   const int lane = wg_lane();
   const int N = (NH == 16) ? 16 : m.N;            // compact view: the horizon is a compile-time constant (checked by the host)
   const double T = m.T;
@@ -629,7 +629,9 @@ __device__ __forceinline__ TickDiag mpc_tick(const wg_model_t &m, const TickTabl
   const int mq = 1 + 4 * N + 5 * ns;     // rows incl. the dummy row 0 (qp-problem.cpp:248)
   constexpr bool kCompactView = (NH == 16);
   constexpr bool kTableView = (NH == 16) || (NH == -1);   // Hessian / constraints kept as compact tables
-  QlDims D(n, mq, mq, !kTableView, true, kCompactView ? 2 * NH + 4 : 0, !kCompactView);   // ordered sums run the static length
+  // element view with a Z slot in global memory: Z leaves the LDS (it is the operand that caps the residency at N = 32)
+  const bool z_in_lds = !(NH == -1 && zglobal != nullptr);
+  QlDims D(n, mq, mq, !kTableView, true, kCompactView ? 2 * NH + 4 : 0, !kCompactView, z_in_lds);   // ordered sums run the static length
   QlView q;
   if constexpr (kCompactView) {
     constexpr int kNmax = 2 * NH + 4, kMmax = 1 + 4 * NH + 10;     // two previewed steps at most (wg_mpc_configure)
@@ -637,6 +639,7 @@ __device__ __forceinline__ TickDiag mpc_tick(const wg_model_t &m, const TickTabl
     q.template carve_fixed<kNmax, kMmax, kNmax>(lds_ql, n, mq, 0);
   } else {
     q.carve(lds_ql, D, 0);
+    if (!z_in_lds) q.Z = zglobal;
   }
 
   // ---- S*c products (MV2_ = prod(S, CoM), generator-vel-ref.cpp:780-787) ----
