@@ -296,11 +296,21 @@ inline bool tick_z_global(int view) {
   const char *e = getenv("WG_TICK_Z_GLOBAL");
   return !(e && atoi(e) == 0);
 }
-inline size_t tick_z_slot_doubles(const wg_model_t &m) { return (size_t)tick_max_n(m) * (tick_max_n(m) | 1); }
+// compact view (N = 16): wa, b and the border block Gv in a per-block slot of global memory (WG_TICK16_EXT=0: all in LDS)
+inline bool tick16_ext(int view) {
+  if (view != 16) return false;
+  const char *e = getenv("WG_TICK16_EXT");
+  return !(e && atoi(e) == 0);
+}
+inline size_t tick_z_slot_doubles(const wg_model_t &m, int view) {
+  if (view == 16) return (size_t)(tick_max_n(m) + 2 * tick_max_m(m)) + (size_t)tick_max_n(m) * wg::kGvLd;   // wa | b | Gv
+  return (size_t)tick_max_n(m) * (tick_max_n(m) | 1);
+}
 inline size_t tick_lds_for(const wg_model_t &m, int view) {
-  const size_t ql = (wg::QlDims(tick_max_n(m), tick_max_m(m), tick_max_m(m), view == 0, true, 0, view != 16, !tick_z_global(view)).bytes() + 15) & ~(size_t)15;
+  const size_t ql = (wg::QlDims(tick_max_n(m), tick_max_m(m), tick_max_m(m), view == 0, true, 0, view != 16, !tick_z_global(view),
+                                !tick16_ext(view)).bytes() + 15) & ~(size_t)15;
   const int gvld = view == 16 ? wg::kGvLd : (view == -1 ? wg::kGvLdElem : 0);
-  return ql + wg::TickLds::bytes(m.N, tick_smax(m), gvld, view == 16);
+  return ql + wg::TickLds::bytes(m.N, tick_smax(m), gvld, view == 16, !tick16_ext(view));
 }
 inline int tick_view(const wg_model_t &m) {
   if (tick_compact(m)) return 16;
@@ -313,7 +323,7 @@ inline int tick_view(const wg_model_t &m) {
 }
 inline size_t tick_ql_bytes(const wg_model_t &m) {
   size_t b = wg::QlDims(tick_max_n(m), tick_max_m(m), tick_max_m(m), tick_view(m) == 0, true, 0, tick_view(m) != 16,
-                        !tick_z_global(tick_view(m))).bytes();
+                        !tick_z_global(tick_view(m)), !tick16_ext(tick_view(m))).bytes();
   return (b + 15) & ~(size_t)15;
 }
 }  // namespace
@@ -545,8 +555,8 @@ int wg_mpc_tick_batch_dev(int B, wg_gait_state_t *states, wg_tick_out_t *outs, i
   const int grid = B;                             // one gait per block; the dispatcher balances uneven iteration counts
   hipStream_t st = reinterpret_cast<hipStream_t>(hip_stream);
   double *zs = nullptr;
-  const size_t zslot = tick_z_slot_doubles(g_model);
-  if (tick_z_global(view)) {
+  const size_t zslot = tick_z_slot_doubles(g_model, view);
+  if (tick_z_global(view) || tick16_ext(view)) {
     std::lock_guard<std::mutex> lk(g_z_mu);       // its own lock: the host-pointer entry points hold g_mu around this call
     if (int rc = g_tick_z.reserve((size_t)grid * zslot * 8)) return rc;
     zs = static_cast<double *>(g_tick_z.p);
@@ -596,8 +606,8 @@ int wg_mpc_run_batch_dev(int B, wg_gait_state_t *states, int n_ticks, int advanc
   int grid = g_num_cu * per_cu;
   if (grid > B) grid = B;
   double *zs = nullptr;
-  const size_t zslot = tick_z_slot_doubles(g_model);
-  if (tick_z_global(view)) {
+  const size_t zslot = tick_z_slot_doubles(g_model, view);
+  if (tick_z_global(view) || tick16_ext(view)) {
     std::lock_guard<std::mutex> lk(g_z_mu);       // its own lock: the host-pointer entry points hold g_mu around this call
     if (int rc = g_tick_z.reserve((size_t)grid * zslot * 8)) return rc;
     zs = static_cast<double *>(g_tick_z.p);

@@ -90,15 +90,17 @@ struct QlDims {
   bool bounds;  // xl / xu held in LDS (false: the problem view supplies them -- constants for the Herdt QP)
   bool z_lds;   // Z held in LDS (false: the caller points QlView::Z at a per-problem slot in global memory -- large n, where
                 // Z is the operand that caps the residency; it is streamed lane-parallel, never on a serial chain)
+  bool wab_lds; // wa and b held in LDS (false: in a per-block slot of global memory -- they are read lane-parallel once per
+                // iteration, early enough for an L2 round trip to hide; freeing them is what lets an eighth gait onto the CU)
   __host__ __device__ QlDims(int n_, int m_, int mmax_, bool dense_ = true, bool a_lds_ = true, int nsc_ = 0,
-                             bool bounds_ = true, bool z_lds_ = true)
+                             bool bounds_ = true, bool z_lds_ = true, bool wab_lds_ = true)
       : n(n_), m(m_), mmax(mmax_), ldg(n_ | 1), ldz(n_ | 1), lda(mmax_ | 1), dense(dense_), a_lds(a_lds_),
-        nsc(nsc_ > n_ ? nsc_ : n_), bounds(bounds_), z_lds(z_lds_) {}
+        nsc(nsc_ > n_ ? nsc_ : n_), bounds(bounds_), z_lds(z_lds_), wab_lds(wab_lds_) {}
   __host__ __device__ int r_len() const { return n * (n + 1) / 2 + n; }
   __host__ __device__ int n_doubles() const {
     return (dense ? n * ldg + (a_lds ? n * lda : 0) : 0) + (z_lds ? n * ldz : 0) + r_len()   // [G, A,] [Z,] R
            + (bounds ? 8 : 6) * n                   // x d ww wd wx lam [xl xu]
-           + (m + n) + m                            // wa, b (inner)
+           + (wab_lds ? (m + n) + m : 0)            // wa, b (inner)
            + 4 * nsc + 8;                           // scratch + scalar slots
   }
   __host__ __device__ size_t bytes() const {
@@ -133,7 +135,7 @@ struct QlView {
   // a constant offset from the wave's LDS base (immediate offsets in the ds instructions, no address registers), and Z's
   // leading dimension is the constant NMAX|1.  No G / A matrices (compact views only).
   template <int NMAX, int MMAX, int NSC>
-  __device__ void carve_fixed(double *base, int n_, int m_, int me_) {
+  __device__ void carve_fixed(double *base, int n_, int m_, int me_, double *ext_wab = nullptr) {
     n = n_; m = m_; me = me_; mn = m_ + n_; ldg = NMAX | 1; ldz = NMAX | 1; lda = MMAX | 1;
     double *p = base;
     G = nullptr; A = nullptr;
@@ -141,8 +143,8 @@ struct QlView {
     R = p; p += NMAX * (NMAX + 1) / 2 + NMAX;
     x = p; p += NMAX;  d = p; p += NMAX;  ww = p; p += NMAX;  wd = p; p += NMAX;
     wx = p; p += NMAX; lam = p; p += NMAX; xl = nullptr; xu = nullptr;     // bounds come from the problem view
-    wa = p; p += MMAX + NMAX;
-    b = p; p += MMAX;
+    if (ext_wab) { wa = ext_wab; b = ext_wab + (MMAX + NMAX); }
+    else { wa = p; p += MMAX + NMAX; b = p; p += MMAX; }
     sc0 = p; p += NSC; sc1 = p; p += NSC; sc2 = p; p += NSC; sc3 = p; p += NSC;
     slot = p; p += 8;
     iact = reinterpret_cast<int *>(p);

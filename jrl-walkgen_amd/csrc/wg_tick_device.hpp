@@ -175,17 +175,18 @@ struct TickLds {
   // elsewhere (overlay); gvld == 0: dense view, G and A are LDS matrices of the solver area
   // rows_presolve: rowA / rowB / rowK are only read while the QP is assembled and the register rows are loaded (the compact
   // view keeps every row's coefficients in registers afterwards) -- they join the pre-solve group
-  __host__ __device__ static size_t bytes(int N, int smax = kSMax, int gvld = 0, bool rows_presolve = false) {
+  // gv_lds = false: the border block Gv lives in a per-block slot of global memory (see mpc_tick)
+  __host__ __device__ static size_t bytes(int N, int smax = kSMax, int gvld = 0, bool rows_presolve = false, bool gv_lds = true) {
     const int m = 1 + 4 * N + 5 * smax;
     const int nmax = 2 * N + 2 * smax;
     const bool compact = gvld > 0;
-    size_t b = sizeof(Sup) + 8 * (size_t)(kSMax * kSMax + 8 + (rows_presolve ? 0 : 2 * m) + 16 + (compact ? N + nmax * gvld + nmax : 0)) +
+    size_t b = sizeof(Sup) + 8 * (size_t)(kSMax * kSMax + 8 + (rows_presolve ? 0 : 2 * m) + 16 + (compact ? N + (gv_lds ? nmax * gvld : 0) + nmax : 0)) +
                4 * (size_t)(((N + 1) & ~1) + (rows_presolve ? 0 : ((m + 1) & ~1))) +
                (rows_presolve ? 0 : ((sizeof(wg_gait_state_t) + 15) & ~(size_t)15));
     if (!compact) b += pre_bytes(N, smax);
     return (b + 15) & ~(size_t)15;
   }
-  __device__ void carve(char *base, int N, int smax, int gvld, char *overlay, bool rows_presolve) {
+  __device__ void carve(char *base, int N, int smax, int gvld, char *overlay, bool rows_presolve, double *ext_gv = nullptr) {
     const bool compact = gvld > 0;
     const int m = 1 + 4 * N + 5 * smax;
     char *p = base;
@@ -196,7 +197,12 @@ struct TickLds {
     if (!rows_presolve) { rowA = d; d += m; rowB = d; d += m; }
     misc = d; d += 16;
     uvec = Gv = gd = nullptr;
-    if (compact) { const int nmax = 2 * N + 2 * smax; uvec = d; d += N; Gv = d; d += nmax * gvld; gd = d; d += nmax; }
+    if (compact) {
+      const int nmax = 2 * N + 2 * smax;
+      uvec = d; d += N;
+      if (ext_gv) Gv = ext_gv; else { Gv = d; d += nmax * gvld; }
+      gd = d; d += nmax;
+    }
     int *ip = reinterpret_cast<int *>(d);
     stepidx = ip; ip += (N + 1) & ~1;
     if (!rows_presolve) { rowK = ip; ip += (m + 1) & ~1; }
@@ -486,7 +492,12 @@ __device__ __forceinline__ TickDiag mpc_tick(const wg_model_t &m, const TickTabl
   static_assert(sizeof(Sup) % 8 == 0, "Sup must keep doubles aligned");
   constexpr int kGvStride = (NH == 16) ? kGvLd : (NH == -1 ? kGvLdElem : 0);
   constexpr int kGvOff = (NH == -1) ? 0 : 1;
-  L.carve(lds_tick, N, (NH == 16) ? 2 : kSMax, kGvStride, reinterpret_cast<char *>(lds_ql), NH == 16);
+  // compact view with a global slot: [wa (kMmax + kNmax) | b (kMmax) | Gv (kNmax x kGvLd)] leave the LDS -- 2.6 KB, the
+  // difference between seven and eight gaits per CU.  All three are read lane-parallel, early in their phases.
+  constexpr int kExtWab = (2 * 16 + 4) + 2 * (1 + 4 * 16 + 10);
+  double *ext16 = (NH == 16) ? zglobal : nullptr;
+  L.carve(lds_tick, N, (NH == 16) ? 2 : kSMax, kGvStride, reinterpret_cast<char *>(lds_ql), NH == 16,
+          ext16 ? ext16 + kExtWab : nullptr);
   wg_gait_state_t *s = L.st;
 #ifdef WG_PROFILE
   unsigned long long tk0 = clock64(), tk1 = 0, tk2 = 0, tk3 = 0;
@@ -636,7 +647,7 @@ __device__ __forceinline__ TickDiag mpc_tick(const wg_model_t &m, const TickTabl
   if constexpr (kCompactView) {
     constexpr int kNmax = 2 * NH + 4, kMmax = 1 + 4 * NH + 10;     // two previewed steps at most (wg_mpc_configure)
     // same footprint as QlDims(kNmax, kMmax, kMmax, dense = false, nsc = kNmax, bounds = false), which sized the LDS on the host
-    q.template carve_fixed<kNmax, kMmax, kNmax>(lds_ql, n, mq, 0);
+    q.template carve_fixed<kNmax, kMmax, kNmax>(lds_ql, n, mq, 0, ext16);
   } else {
     q.carve(lds_ql, D, 0);
     if (!z_in_lds) q.Z = zglobal;

@@ -26,23 +26,25 @@ def test_library_exports_every_declared_symbol():
 
 def test_lds_footprint_matches_design():
     wg = importlib.import_module("jrl-walkgen_amd")
-    # Herdt N=16, two previewed steps: n = 36, m = 75 -> three QPs per 160 KiB CU
+    # Herdt N=16, two previewed steps: n = 36, m = 75 -> three QPs per 160 KiB CU with A staged in LDS (the launcher
+    # reads A in place instead, see wg_qp_solve_batch_dev)
     b = wg.qp_lds_bytes(36, 75)
     assert 3 * b <= 160 * 1024 < 4 * b
 
 
 def test_tick_residency_budget():
     """The tick kernel's residency is set by its LDS footprint: a gfx950 CU hands out 128 granules of
-    1280 B.  The benchmark model must stay within 18 granules (7 gaits per CU), config 5's N = 32 within 64 (2 per CU)."""
+    1280 B.  The benchmark model must stay within 16 granules (8 gaits per CU = two waves per SIMD: wa, b and the border
+    block live in a global slot), config 5's N = 32 within 32 (4 per CU: Z lives in a global slot)."""
     wg = importlib.import_module("jrl-walkgen_amd")
     gran = lambda b: -(-b // 1280)  # noqa: E731
     m = wg.Model()
     wg.lib().wg_model_defaults(ctypes.byref(m))
     b16 = wg.mpc_tick_lds_bytes_for(m)
-    assert 0 < b16 and 128 // gran(b16) >= 7, b16
+    assert 0 < b16 and 128 // gran(b16) >= 8, b16
     m.N = 32
     b32 = wg.mpc_tick_lds_bytes_for(m)
-    assert 128 // gran(b32) >= 2, b32
+    assert 128 // gran(b32) >= 4, b32
     m.N = 20                                                       # dense view
     assert 0 < wg.mpc_tick_lds_bytes_for(m) <= 160 * 1024
     m.N = 48
