@@ -1,5 +1,6 @@
 #!/bin/bash
 # Round profiles (run on the GPU box via gpurun): tick kernel with PMC passes, then kernel-trace stats of the other kernels.
+# gpurun MERGES gpurun_out/ back: remove the local gpurun_out/prof_* first, or tools/prof_summary.py averages old runs in.
 set -u
 export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
