@@ -980,19 +980,34 @@ int wg_preview_run_batch_dev(int B, int L, const double *zmp_x_tm, const double 
   const bool ring = force ? force[0] == 'r' : (L >= 8 && (long long)B * 2 <= (long long)g_num_cu * 64 * 2);
   // The split-chain kernel (eight lanes per gait-axis, nothing re-read) covers the standard window sizes and wins at every
   // batch size measured; other windows, and runs too short to repay filling its rings, use the kernels below.
-  constexpr int kSplitT = 40, kSplitK = 8;
-  const bool can_split = g_prev.nl > (kSplitK - 1) * kSplitT && g_prev.nl <= kSplitK * kSplitT;
+  constexpr int kSplitK = 8;
+  int splitT = 0;                                              // smallest instantiated T with K T >= nl
+  for (int t : {16, 24, 32, 40, 48})
+    if (!splitT && kSplitK * t >= g_prev.nl) splitT = t;
+  const bool can_split = splitT != 0 && g_prev.nl >= 64;
   const bool split = force ? (force[0] == 's' && can_split) : (can_split && L >= 4);
   if (split) {
     const int per_wave = 64 / kSplitK;
     const dim3 grid((B + per_wave - 1) / per_wave, 2);
-    const size_t lds = (size_t)kSplitT * 64 * 8;
-    if (g_prev.nl == kSplitK * kSplitT)
-      hipLaunchKernelGGL((wg::wg_preview_split_kernel<kSplitT, kSplitK, true>), grid, dim3(64), lds, st, B, L, g_prev,
-                         g_prev_F, zmp_x_tm, zmp_y_tm, state, com_tm, zmp2_tm, simulation);
-    else
-      hipLaunchKernelGGL((wg::wg_preview_split_kernel<kSplitT, kSplitK, false>), grid, dim3(64), lds, st, B, L, g_prev,
-                         g_prev_F, zmp_x_tm, zmp_y_tm, state, com_tm, zmp2_tm, simulation);
+    const size_t lds = (size_t)splitT * 64 * 8;
+    const bool full = g_prev.nl % splitT == 0;
+#define WG_SPLIT_LAUNCH(TT)                                                                                              \
+    do {                                                                                                                 \
+      if (full)                                                                                                          \
+        hipLaunchKernelGGL((wg::wg_preview_split_kernel<TT, kSplitK, true>), grid, dim3(64), lds, st, B, L, g_prev,      \
+                           g_prev_F, zmp_x_tm, zmp_y_tm, state, com_tm, zmp2_tm, simulation);                            \
+      else                                                                                                               \
+        hipLaunchKernelGGL((wg::wg_preview_split_kernel<TT, kSplitK, false>), grid, dim3(64), lds, st, B, L, g_prev,     \
+                           g_prev_F, zmp_x_tm, zmp_y_tm, state, com_tm, zmp2_tm, simulation);                            \
+    } while (0)
+    switch (splitT) {
+      case 16: WG_SPLIT_LAUNCH(16); break;
+      case 24: WG_SPLIT_LAUNCH(24); break;
+      case 32: WG_SPLIT_LAUNCH(32); break;
+      case 40: WG_SPLIT_LAUNCH(40); break;
+      default: WG_SPLIT_LAUNCH(48); break;
+    }
+#undef WG_SPLIT_LAUNCH
   } else if (ring) {
     int R = g_prev.nl < 288 ? g_prev.nl : 288;                 // 288 x 512 B = 144 KB of the CU's 160 KB
     if (R < 1) R = 1;

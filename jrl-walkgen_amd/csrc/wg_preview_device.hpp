@@ -163,7 +163,8 @@ wg_preview_ring_kernel(int B, int L, PreviewConst K, int R, const double *__rest
 // same additions in the same order, so the bits are the same; the window slides by passing each lane's oldest sample to
 // its left neighbour (DPP) and fetching ONE new sample per (gait, axis) and step from memory.
 // Eight gait-axes per wave instead of 64: the adds of a pass are useful in one lane of eight, but nothing is re-read.
-// nl must satisfy (K-1) T < nl <= K T (281..320 for the standard 1.6 s / 5 ms window); other windows use the kernels above.
+// Instantiated for T = 16, 24, 32, 40, 48: a window of nl taps uses the smallest T with K T >= nl and ceil(nl / T) lanes of
+// each group (T = 40, all eight lanes for the standard 1.6 s / 5 ms window); nl > 384 or < 64 use the kernels above.
 template <int CTRL>
 __device__ __forceinline__ double pv_dpp(double v) {
   const int lo = __builtin_amdgcn_update_dpp(__double2loint(v), __double2loint(v), CTRL, 0xf, 0xf, false);
@@ -171,7 +172,7 @@ __device__ __forceinline__ double pv_dpp(double v) {
   return __hiloint2double(hi, lo);
 }
 
-template <int T, int K, bool FULL>     // FULL: nl == K T, the last lane has T taps like the others
+template <int T, int K, bool FULL>     // FULL: nl is a multiple of T, the last used lane has T taps like the others
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
 wg_preview_split_kernel(int B, int L, PreviewConst Kc, const double *__restrict__ F, const double *__restrict__ zx,
                         const double *__restrict__ zy, double *__restrict__ state, double *__restrict__ com,
@@ -188,9 +189,10 @@ wg_preview_split_kernel(int B, int L, PreviewConst Kc, const double *__restrict_
   const double *__restrict__ z = axis ? zy : zx;
   const size_t sB = (size_t)B;
   const int nl = Kc.nl;
-  const int Tl = nl - (K - 1) * T;                                      // taps of the last lane, 1..T
+  const int Ku = (nl + T - 1) / T;                                      // lanes of the group that hold taps, 1..K
+  const int Tl = nl - (Ku - 1) * T;                                     // taps of the last of them, 1..T
   const int Lz = L + nl - 1;
-  const bool last = k == K - 1, first = k == 0;
+  const bool last = k == Ku - 1, first = k == 0;
   double Fk[T];
 #pragma unroll
   for (int t = 0; t < T; ++t) {
@@ -224,9 +226,11 @@ wg_preview_split_kernel(int B, int L, PreviewConst Kc, const double *__restrict_
     double acc = -r + Kc.Ks * s;                                        // the chain starts in lane 0 of the group
 #pragma unroll
     for (int p = 0; p < K - 1; ++p) {
+      if (p < Ku - 1) {                                                 // wave-uniform: lanes p hold T taps each
 #pragma unroll
-      for (int t = 0; t < T; ++t) acc += prod[t];
-      acc = pv_dpp<0x111>(acc);                                         // row_shr:1 -- lane p+1 takes over
+        for (int t = 0; t < T; ++t) acc += prod[t];
+        acc = pv_dpp<0x111>(acc);                                       // row_shr:1 -- lane p+1 takes over
+      }
     }
     if (FULL) {
 #pragma unroll
@@ -236,7 +240,17 @@ wg_preview_split_kernel(int B, int L, PreviewConst Kc, const double *__restrict_
       for (int t = 0; t < T; ++t)
         if (t < Tl) acc += prod[t];
     }
-    const double u = pv_dpp<0x107>(acc);                                // row_shl:7 -- back to lane 0 of the group
+    double u = acc;                                                     // the sum sits in lane Ku-1: back to lane 0 (row_shl)
+    switch (Ku) {
+      case 8: u = pv_dpp<0x107>(acc); break;
+      case 7: u = pv_dpp<0x106>(acc); break;
+      case 6: u = pv_dpp<0x105>(acc); break;
+      case 5: u = pv_dpp<0x104>(acc); break;
+      case 4: u = pv_dpp<0x103>(acc); break;
+      case 3: u = pv_dpp<0x102>(acc); break;
+      case 2: u = pv_dpp<0x101>(acc); break;
+      default: break;
+    }
     double a0 = 0.0, a1 = 0.0, a2 = 0.0;
     a0 += 1.0 * x0; a0 += Kc.A01 * x1; a0 += Kc.A02 * x2;
     a1 += 0.0 * x0; a1 += 1.0 * x1;    a1 += Kc.A12 * x2;

@@ -93,3 +93,21 @@ def test_unconfigured_and_bad_arguments_are_refused():
     assert lib.wg_preview_configure(__import__("ctypes").byref(g), F.ctypes.data) == -2
     g.nl = 5000
     assert lib.wg_preview_configure(__import__("ctypes").byref(g), F.ctypes.data) == -2
+
+
+@pytest.mark.parametrize("nl", [64, 100, 128, 160, 200, 281, 350, 384])
+def test_split_kernel_other_windows(nl, monkeypatch):
+    """the split-chain kernel is instantiated for 16, 24, 32, 40 and 48 taps per lane: a window of nl taps takes the smallest
+    of them that holds it in eight lanes and uses ceil(nl / T) lanes of each group -- every shape against the oracle"""
+    monkeypatch.setenv("WG_PREVIEW_KERNEL", "split")
+    wg.init(0)
+    g, F = wg.preview_gains(0.005, 0.814, nl * 0.005 + 1e-9)
+    assert g.nl == nl
+    wg.preview_configure(g, F)
+    rng = np.random.default_rng(nl)
+    for B, L in ((37, 50), (9, 5)):
+        ZX, ZY = zmpref.random_batch(rng, B, L, g.nl)
+        s_gpu = rng.normal(0, 0.01, (B, 8)); s_cpu = s_gpu.copy()
+        com, z2 = wg.preview_run_batch(ZX, ZY, s_gpu, L)
+        com_o, z2_o = oracle_run(g, F, ZX, ZY, s_cpu, L)
+        assert np.array_equal(com, com_o) and np.array_equal(z2, z2_o) and np.array_equal(s_gpu, s_cpu)
