@@ -168,6 +168,7 @@ wg_zmpdisc_kernel(ZdConst K, int B, int smax, const wg_rel_step_t *__restrict__ 
   double bpx = 0.0, bpy = 0.0, btheta = 0.0;        // FinalZMPPositions.back()
   double f0x = 0.0, f0y = 0.0;                      // FinalZMPPositions[0]
   int nz = 0;                                       // FinalZMPPositions.size()
+  int fslot = 0;                                    // nz mod nf: where the next filtered sample goes in its ring
 
   auto bookkeeping = [&](double zmp_theta, int &who) {   // :370-383, :619-634
     if (rel0.sy < 0) {
@@ -435,10 +436,8 @@ wg_zmpdisc_kernel(ZdConst K, int B, int smax, const wg_rel_step_t *__restrict__ 
       if (O.ztype) O.ztype[l * sB + g] = ty;
       put_foot(O.left, O.ltype, l, fl);
       put_foot(O.right, O.rtype, l, fr);
-      {
-        const int q = nz % R.nf;
-        R.F(q, 0) = l0; R.F(q, 1) = l1;
-      }
+      R.F(fslot, 0) = l0; R.F(fslot, 1) = l1;        // fslot == nz mod nf, kept by increment (no division per sample)
+      fslot = fslot + 1 == R.nf ? 0 : fslot + 1;
       if (nz == 0) { f0x = l0; f0y = l1; }
       bpx = l0; bpy = l1; btheta = th;
       cl = fl; cr = fr;
