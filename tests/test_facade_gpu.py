@@ -141,3 +141,15 @@ def test_cpp_fleet_bench_runs_through_the_c_abi():
         r = subprocess.run([exe, "--batch", "300", "--ticks", "60", *flags], capture_output=True, text=True, timeout=300)
         assert r.returncode == 0, r.stdout + r.stderr
         assert "%d ticks done in all" % (300 * (50 + 60)) in r.stdout, r.stdout
+
+
+def test_cpp_kajita_fleet_runs_through_the_c_abi():
+    """jrl-walkgen_amd/host/kajita_fleet.cpp: step sequences -> wg_zmpdisc_batch_dev -> wg_preview_run_batch_dev from plain C++
+    (hipMalloc'd buffers, one stream); the program itself compares gait 0 of the device chain with the host-pointer entry
+    points bit for bit"""
+    exe = os.path.join(ROOT, "jrl-walkgen_amd", "bin", "kajita_fleet")
+    assert os.path.exists(exe)
+    r = subprocess.run([exe, "--batch", "300", "--steps", "16"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "device chain == host entry points" in r.stdout and "4002 samples" in r.stdout, r.stdout
+    assert "gait 0 ends at x = 2.8" in r.stdout, r.stdout           # fourteen 0.2 m steps
