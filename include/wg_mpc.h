@@ -231,7 +231,9 @@ int wg_mpc_configure(const wg_model_t *model);
  *           RunOneStepOfTheControlLoop does, PatternGeneratorInterfacePrivate.cpp:1256)
  *   outs    B structs or NULL (NULL: only the state is advanced)
  *   diag    B x 6 ints {ifail, n_iter, nact, n, m, nb_prw_steps} or NULL
- *   hist    B x hist_cap active-set add(+)/drop(-) log or NULL, hist_len B or NULL */
+ *   hist    B x hist_cap active-set add(+)/drop(-) log or NULL, hist_len B or NULL
+ * The kernels keep a few solver arrays per block in a library-owned device buffer (what does not fit the CU's LDS at the
+ * residency they run at): launches of the tick entry points must not overlap -- one stream, or events between streams. */
 int wg_mpc_tick_batch(int B, wg_gait_state_t *states, wg_tick_out_t *outs, int *diag, int advance_calls,
                       int *hist, int hist_cap, int *hist_len);
 int wg_mpc_tick_batch_dev(int B, wg_gait_state_t *states, wg_tick_out_t *outs, int *diag, int advance_calls,
