@@ -1,7 +1,8 @@
-// test_herdt2010.cpp -- the reference's TestHerdt2010 "EmergencyStop" profile (tests/TestHerdt2010.cpp:88-116, 128-200,
-// 260-265, event loop tests/TestObject.cpp:515-605, row layout :344-385) driven through this build's
-// PatternGeneratorInterface.  Writes the 38-column trace to argv[1]; `--legacy` replays the revision that recorded the
-// reference's golden file (see ZMPVelocityReferencedQP::LegacyGoldenReplay).
+// test_herdt2010.cpp -- the reference's TestHerdt2010 driven through this build's PatternGeneratorInterface: the
+// "EmergencyStop" profile (tests/TestHerdt2010.cpp:88-116, 128-200, 260-265) by default, the "OnLine" profile (:64-91,
+// 231-244: twelve events over 110 s; its golden file is not in the reference tree) with `--online`; event loop
+// tests/TestObject.cpp:515-605, row layout :344-385.  Writes the 38-column trace to the path given; `--legacy` replays
+// the revision that recorded the reference's golden file (see ZMPVelocityReferencedQP::LegacyGoldenReplay).
 #include <cstdio>
 #include <cstring>
 #include <fstream>
@@ -20,12 +21,13 @@ static void cmd(PatternGeneratorInterface &aPGI, const char *c) {
 
 int main(int argc, char **argv) {
   const char *path = 0;
-  bool legacy = false;
+  bool legacy = false, online = false;
   for (int i = 1; i < argc; i++) {
     if (!strcmp(argv[i], "--legacy")) legacy = true;
+    else if (!strcmp(argv[i], "--online")) online = true;
     else path = argv[i];
   }
-  if (!path) { fprintf(stderr, "usage: %s [--legacy] out.dat\n", argv[0]); return 2; }
+  if (!path) { fprintf(stderr, "usage: %s [--legacy] [--online] out.dat\n", argv[0]); return 2; }
   try {
     HumanoidModel robot = HumanoidModel::sampleRobot();
     PatternGeneratorInterface *aPGI = patternGeneratorInterfaceFactory(&robot);
@@ -39,7 +41,7 @@ int main(int argc, char **argv) {
     cmd(*aPGI, ":SetAlgoForZmpTrajectory Herdt");
     cmd(*aPGI, ":singlesupporttime 0.7");
     cmd(*aPGI, ":doublesupporttime 0.1");
-    cmd(*aPGI, ":HerdtOnline 0.2 0.0 0.2");
+    cmd(*aPGI, online ? ":HerdtOnline 0.2 0.0 0.0" : ":HerdtOnline 0.2 0.0 0.2");
     cmd(*aPGI, ":numberstepsbeforestop 2");
 
     ofstream aof(path);
@@ -50,7 +52,8 @@ int main(int argc, char **argv) {
     FootAbsolutePosition L, R;
     unsigned long it = 0;
     bool ok = true;
-    while (ok && it < 6000) {
+    const unsigned long max_it = online ? 24000 : 6000;
+    while (ok && it < max_it) {
       it++;
       ok = aPGI->RunOneStepOfTheControlLoop(q, dq, ddq, ZMPTarget, c, L, R);
       if (ok) {
@@ -64,6 +67,19 @@ int main(int argc, char **argv) {
         aof << ZMPTarget[0] << " " << ZMPTarget[1] << " " << 0.0 << " " << 0.0 << endl;
       }
       // generateEvent, TestHerdt2010.cpp:231-265
+      if (online) {
+        static const struct { unsigned long time; const char *c; } ev[12] = {
+            {5 * 200, ":setVelReference  0.2 0.0 0.0"},    {10 * 200, ":setVelReference  0.0 0.2 0.0"},
+            {25 * 200, ":setVelReference  0.0 0.0 -10."},  {35 * 200, ":setVelReference  0.2 0.0 0.0"},
+            {45 * 200, ":setVelReference  0.0 0.0 10.0"},  {55 * 200, ":setVelReference  0.2 0.0 0.0"},
+            {65 * 200, ":setVelReference  0.0 0.0 -10."},  {75 * 200, ":setVelReference  0.2 0.0 0.0"},
+            {85 * 200, ":setVelReference  0.2 0.0 6.0832"}, {95 * 200, ":setVelReference  0.2 0.0 -6.0832"},
+            {105 * 200, ":setVelReference 0.0 0.0 0.0"},   {110 * 200, ":setVelReference  0.0 0.0 0.0"}};
+        for (int e = 0; e < 12; e++)
+          if (it == ev[e].time) cmd(*aPGI, ev[e].c);
+        if (it == 110 * 200) cmd(*aPGI, ":stoppg");
+        continue;
+      }
       if (it == 5 * 200) cmd(*aPGI, ":setVelReference  0.0 0.0 0.4");
       if (it == 10 * 200) cmd(*aPGI, ":setVelReference  0.2 0.0 -0.2");
       if (it == (unsigned long)(15.2 * 200)) cmd(*aPGI, ":setVelReference  0.0 0.0 0.0");

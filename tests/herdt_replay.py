@@ -128,6 +128,44 @@ def emergency_stop_events():
             int(20.8 * 200): stop}
 
 
+def online_walking_events():
+    """The 12-event schedule of TestHerdt2010's OnLine profile, tests/TestHerdt2010.cpp:231-244 (+ handlers :121-200).
+    Its golden file is not in the reference tree (.MISSING_LARGE_BLOBS): the scenario pins nothing against the reference,
+    it is run oracle against oracle and oracle against GPU."""
+    def vel(x, y, w):
+        def f(s):
+            s.vref[0], s.vref[1], s.vref[2] = x, y, w
+        return f
+
+    def stop(s):
+        s.vref[0], s.vref[1], s.vref[2] = 0.0, 0.0, 0.0
+        s.ending_phase = 1
+    fwd, side = vel(0.2, 0.0, 0.0), vel(0.0, 0.2, 0.0)
+    return {5 * 200: fwd, 10 * 200: side, 25 * 200: vel(0.0, 0.0, -10.0), 35 * 200: fwd, 45 * 200: vel(0.0, 0.0, 10.0),
+            55 * 200: fwd, 65 * 200: vel(0.0, 0.0, -10.0), 75 * 200: fwd, 85 * 200: vel(0.2, 0.0, 6.0832),
+            95 * 200: vel(0.2, 0.0, -6.0832), 105 * 200: vel(0.0, 0.0, 0.0), 110 * 200: stop}
+
+
+def online_walking_setup(datref):
+    """TestHerdt2010's OnLine profile (startOnLineWalking, tests/TestHerdt2010.cpp:64-91) on the same robot and start
+    state as the EmergencyStop profile; today's source semantics (no legacy switches)."""
+    m, s, _ = emergency_stop_setup(datref)
+    m.flags = 0
+    s.sup_y = s.lf[2].y                # today's InitOnLine (ZMPVelocityReferencedQP.cpp:283)
+    return m, s, online_walking_events()
+
+
+def lib_tick(lib):
+    """tick callable for replay() on any build of the oracle (libm or include/wg_trig.h trigonometry)"""
+    def tick(model, state, want_dump=False):
+        out = TickOut()
+        dump = QpDump() if want_dump else None
+        rc = lib.wgo_mpc_tick(C.byref(model), C.byref(state), C.byref(out), C.byref(dump) if dump else None)
+        assert rc == 0, rc
+        return out, dump
+    return tick
+
+
 def load_datref(path):
     return np.loadtxt(path)
 

@@ -1,0 +1,190 @@
+"""BASELINE configs 4 and 5 at their stated sizes, on one GPU, through the C ABI's device entry points (the path bench.py
+times): wg_mpc_set_velref_dev + wg_mpc_tick_batch_dev / wg_mpc_run_batch_dev on resident states.
+
+  config 4  "Herdt2010 N=16 fp64, batch=32768 sharded across 8 GPUs": the LAST shard (rank 7 of 8: global gaits
+            28 672 .. 32 767, seeds 20100 + global index) run exactly as bench.py's rank 7 would -- 200 ticks, references
+            redrawn every 50 -- with a seeded sample followed bit for bit by the CPU oracle, and the shard boundaries
+            checked against bench.py's own table generator.  (The 8-GPU launch itself needs the 8-GPU node.)
+  config 5  "Herdt2010 N=32 with foot-placement decision vars, batch=8192": the full batch through the element view, 50
+            ticks, as properties -- every QP solves, determinism (two runs, same bytes), batch-composition invariance
+            (a permuted sub-batch reproduces its gaits' bytes), multi-tick launch == one launch per tick -- plus a seeded
+            sample followed bit for bit by the oracle.  The solve is fp64 (an fp32 solver would be
+            narrower than the reference's arithmetic); the fp32 part of the config is the MFMA Gramian as Hessian source,
+            run here at full size as a tolerance mode."""
+import ctypes as C
+import importlib
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import oraclelib as ol  # noqa: E402
+
+wg = importlib.import_module("jrl-walkgen_amd")
+pytestmark = pytest.mark.gpu
+REDRAW = 50
+SZ = C.sizeof(wg.GaitState)
+
+
+def _ptrig():
+    ol.build_oracle()
+    return C.CDLL(os.path.join(ol.ORACLE_DIR, "libwg_oracle_ptrig.so"))
+
+
+def _vel(g, n_seg):
+    r = np.random.Generator(np.random.MT19937(20100 + g))          # bench.py's table: seed = 20100 + GLOBAL gait index
+    return np.stack([r.uniform(-0.1, 0.3, n_seg), r.uniform(-0.1, 0.1, n_seg), r.uniform(-0.2, 0.2, n_seg)], 1)
+
+
+def _start_bytes(model):
+    s0 = wg.gait_init(model, [0.0316055, 0.0, 0.7116911], [0.0, 0.09, 0.0], [0.0, -0.09, 0.0])
+    s0.nb_steps_left = 2
+    return s0, bytes(memoryview(s0).cast("B"))
+
+
+def _run_dev(model, gaits, n_ticks, multi_tick=True, want_diag=True):
+    """the listed GLOBAL gait indices advanced n_ticks on the device, bench.py's launch plan; returns (state bytes per
+    gait as a uint8 array [B, SZ], diag [n_ticks, B, 6])"""
+    B = len(gaits)
+    _, one = _start_bytes(model)
+    states = torch.frombuffer(bytearray(one * B), dtype=torch.uint8).cuda()
+    n_seg = (n_ticks + REDRAW - 1) // REDRAW
+    vt = torch.from_numpy(np.ascontiguousarray(np.stack([_vel(g, n_seg) for g in gaits], 1))).cuda()   # [seg, B, 3]
+    diag = torch.zeros(n_ticks, B, 6, dtype=torch.int32, device="cuda")
+    per_tick = int(round(model.T / model.Tctrl))
+    t = 0
+    while t < n_ticks:
+        if t % REDRAW == 0:
+            wg.mpc_set_velref_dev(B, states.data_ptr(), vt[t // REDRAW].data_ptr())
+        adv = 1 if t == 0 else (per_tick - 1 if t == 1 else per_tick)
+        n = 1 if (t < 2 or not multi_tick) else min(n_ticks, (t // REDRAW + 1) * REDRAW) - t
+        dp = diag[t].data_ptr() if want_diag else None
+        if n == 1:
+            wg.mpc_tick_batch_dev(B, states.data_ptr(), None, dp, adv)
+        else:
+            wg.mpc_run_batch_dev(B, states.data_ptr(), n, adv, None, dp)
+        t += n
+    torch.cuda.synchronize()
+    return states.cpu().numpy().reshape(B, SZ), diag.cpu().numpy()
+
+
+def _oracle_follow(pt, model, g, n_ticks):
+    s, _ = _start_bytes(model)
+    vt = _vel(g, (n_ticks + REDRAW - 1) // REDRAW)
+    per_tick = int(round(model.T / model.Tctrl))
+    for t in range(n_ticks):
+        if t % REDRAW == 0:
+            s.vref[0], s.vref[1], s.vref[2] = vt[t // REDRAW]
+        c = s.clock
+        for _ in range(1 if t == 0 else (per_tick - 1 if t == 1 else per_tick)):
+            c += model.Tctrl
+        s.clock = c
+        assert pt.wgo_mpc_tick(C.byref(model), C.byref(s), None, None) == 0
+    return bytes(memoryview(s).cast("B"))
+
+
+# ---------------------------------------------------------------------------------------------------------- config 4
+def test_config4_last_shard_of_eight_full_size():
+    """rank 7 of world 8, 4096 gaits per GPU: global gaits [28672, 32768)"""
+    import bench
+    shard = importlib.import_module("jrl-walkgen_amd.shard")
+    wg.init(0)
+    model = wg.model_defaults()
+    wg.mpc_configure(model)
+    B, T, world, rank = 4096, 200, 8, 7
+    lo, hi = rank * B, (rank + 1) * B
+    assert (lo, hi) == (28672, 32768)
+    if hasattr(shard, "shard_range"):
+        assert shard.shard_range(world * B, world, rank) == (lo, hi)
+    # the references this shard gets are bench.py's table for those global indices (not a re-seeded local table)
+    tab = bench.velocity_table(lo, lo + 3, 4)
+    for k in range(3):
+        assert np.array_equal(tab[:, k, :], _vel(lo + k, 4))
+    assert not np.array_equal(_vel(lo, 4), _vel(0, 4))
+    fin, diag = _run_dev(model, list(range(lo, hi)), T)
+    assert int((diag[:, :, 0] != 0).sum()) == 0                    # all 819 200 QPs of the shard solved
+    assert set(np.unique(diag[:, :, 3]).tolist()) <= {32, 34, 36} and diag[:, :, 1].max() < 200
+    st = (wg.GaitState * B).from_buffer_copy(fin.tobytes())
+    assert all(s.tick_count == T and s.running == 1 for s in st)
+    com = np.array([[s.com_x[0], s.com_y[0]] for s in st]); feet = np.array([[s.lf[2].x, s.lf[2].y, s.rf[2].x, s.rf[2].y] for s in st])
+    assert np.isfinite(com).all() and np.abs(com - 0.5 * (feet[:, :2] + feet[:, 2:])).max() < 0.35
+    assert len({r.tobytes() for r in fin}) > 4000                   # gaits really are different problems
+    # a seeded sample of the shard, every tick on the CPU oracle: same bytes
+    pt = _ptrig()
+    rng = np.random.default_rng(32768)
+    sample = sorted(set(rng.choice(B, 38, replace=False).tolist()) | {0, B - 1})
+    for k in sample:
+        assert _oracle_follow(pt, model, lo + k, T) == fin[k].tobytes(), lo + k
+    # one launch per tick on a slice of the shard: same bytes as the multi-tick launches
+    sl = list(range(lo + 1000, lo + 1300))
+    fin2, _ = _run_dev(model, sl, T, multi_tick=False, want_diag=False)
+    assert np.array_equal(fin2, fin[1000:1300])
+
+
+# ---------------------------------------------------------------------------------------------------------- config 5
+@pytest.fixture(scope="module")
+def config5_run():
+    wg.init(0)
+    model = wg.model_defaults()
+    model.N = 32
+    wg.mpc_configure(model)
+    B, T = 8192, 50
+    fin, diag = _run_dev(model, list(range(B)), T)
+    yield model, B, T, fin, diag
+    wg.mpc_configure(wg.model_defaults())
+
+
+def test_config5_full_size_solves_and_uses_all_previewed_steps(config5_run):
+    model, B, T, fin, diag = config5_run
+    assert int((diag[:, :, 0] != 0).sum()) == 0                    # 409 600 QPs, none failed
+    sizes = set(np.unique(diag[:, :, 3]).tolist())
+    assert max(sizes) == 72 and min(sizes) >= 64                    # n = 2N + 2s, s up to 4: foot-placement variables kept
+    assert int(diag[:, :, 4].max()) == 1 + 4 * 32 + 5 * 4           # m = 149
+    st = (wg.GaitState * B).from_buffer_copy(fin.tobytes())
+    assert all(s.tick_count == T and s.running == 1 for s in st)
+    com = np.array([[s.com_x[0], s.com_y[0]] for s in st]); feet = np.array([[s.lf[2].x, s.lf[2].y, s.rf[2].x, s.rf[2].y] for s in st])
+    assert np.isfinite(com).all() and np.abs(com - 0.5 * (feet[:, :2] + feet[:, 2:])).max() < 0.35
+    assert len({r.tobytes() for r in fin}) > 8000
+
+
+def test_config5_full_size_sample_followed_by_the_oracle(config5_run):
+    model, B, T, fin, diag = config5_run
+    pt = _ptrig()
+    rng = np.random.default_rng(8192)
+    sample = sorted(set(rng.choice(B, 14, replace=False).tolist()) | {0, B - 1})
+    for g in sample:
+        assert _oracle_follow(pt, model, g, T) == fin[g].tobytes(), g
+
+
+def test_config5_determinism_and_batch_composition_invariance(config5_run):
+    model, B, T, fin, diag = config5_run
+    fin_again, diag_again = _run_dev(model, list(range(B)), T)
+    assert np.array_equal(fin_again, fin) and np.array_equal(diag_again, diag)
+    perm = np.random.default_rng(5).permutation(B)[:700].tolist()    # other order, other batch size, other neighbours
+    fin_p, _ = _run_dev(model, perm, T, want_diag=False)
+    assert np.array_equal(fin_p, fin[perm])
+    sl = list(range(4000, 4400))                                   # one launch per tick == multi-tick launches
+    fin_s, _ = _run_dev(model, sl, T, multi_tick=False, want_diag=False)
+    assert np.array_equal(fin_s, fin[4000:4400])
+
+
+def test_config5_full_size_with_the_fp32_matrix_core_gramian(config5_run):
+    """the config as BASELINE words it: Q_b from the fp32 MFMA Gramian.  A tolerance mode: every QP still
+    solves at full size, iteration counts stay where they were, and the closed loop stays within 1 mm of the fp64 run
+    over these 5 s of walking."""
+    model, B, T, fin, diag = config5_run
+    m = wg.model_defaults(); m.N = 32; m.flags = 4                   # WG_FLAG_GRAMIAN_MFMA_F32
+    try:
+        wg.mpc_configure(m)
+        fin32, diag32 = _run_dev(m, list(range(B)), T)
+    finally:
+        wg.mpc_configure(model)
+    assert int((diag32[:, :, 0] != 0).sum()) == 0
+    assert abs(diag32[:, :, 1].mean() - diag[:, :, 1].mean()) < 0.5
+    a = (wg.GaitState * B).from_buffer_copy(fin.tobytes()); b = (wg.GaitState * B).from_buffer_copy(fin32.tobytes())
+    dev = max(max(abs(x.com_x[0] - y.com_x[0]), abs(x.com_y[0] - y.com_y[0])) for x, y in zip(a, b))
+    assert 0.0 < dev < 1e-3, dev
