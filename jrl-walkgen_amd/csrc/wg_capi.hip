@@ -449,6 +449,118 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WG_TICK_WPE_
   }
 }
 
+// ---- the same, with the hand-over kept inside one XCD ------------------------------------------------------------------------
+// The queue above lets a gait's next tick run anywhere, so every tick ends with an agent-scope release: on gfx950 that is a
+// write-back of ALL dirty lines of the XCD's L2 (buffer_wbl2) -- the parked state copies and solver slots of the other 255
+// resident gaits included -- and every tick starts with an invalidate of the CU's L1.  Here each XCD has its own ring: a gait
+// is adopted by the XCD that runs its first tick of the launch and stays there, so its state goes from one CU to the next
+// through that XCD's L2 alone (stores are written through L1, loads of state / ring / counters bypass L1): no L2 write-back,
+// no L1 invalidate, the constant tables stay cached.
+//   * gaits are dealt to the XCDs in eight contiguous ranges; a wave first adopts the fresh gaits of its own XCD's range,
+//     then serves its XCD's ring, and only when that is empty adopts fresh gaits of other ranges (untouched in this launch,
+//     so visible everywhere: an XCD that received no wave leaves no gait behind);
+//   * a wave that finds nothing to do exits: a gait in flight is always held by a live wave, which offers it to its own
+//     ring and takes it back if nobody else does -- every gait reaches n_ticks whatever the placement of the waves;
+//   * ring entries carry their position as a tag, so slots are reused without being cleared.
+// Counters and ring entries are only touched by read-modify-write atomics (one coherence point whatever the hardware does
+// with them); the XCD a wave runs on is read from the hardware register, not inferred from blockIdx.
+constexpr int kXcds = 8;
+struct wg_xrun_ctl {
+  struct alignas(64) { int fresh, fresh_end, head, tail; } x[kXcds];
+};
+
+__global__ void wg_xrun_init_kernel(int B, wg_xrun_ctl *ctl, unsigned long long *rings, int cap, int *done) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < kXcds) {
+    ctl->x[i].fresh = (int)((long long)B * i / kXcds);
+    ctl->x[i].fresh_end = (int)((long long)B * (i + 1) / kXcds);
+    ctl->x[i].head = 0; ctl->x[i].tail = 0;
+  }
+  if (i < kXcds * cap) rings[i] = 0ull;
+  if (i < B) done[i] = 0;
+}
+
+__device__ __forceinline__ int xrun_rmw_load(int *p) { return __hip_atomic_fetch_add(p, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ int xrun_take_fresh(wg_xrun_ctl *ctl, int y) {
+  const int end = ctl->x[y].fresh_end;                     // written before the launch, never changed
+  if (xrun_rmw_load(&ctl->x[y].fresh) >= end) return -1;
+  const int f = __hip_atomic_fetch_add(&ctl->x[y].fresh, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return f < end ? f : -1;
+}
+// every store of this wave is in L2 (vector L1 is write-through; vmcnt counts a store down when L2 has it)
+__device__ __forceinline__ void xrun_stores_done() { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); }
+
+template <int NH>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WG_TICK_WPE_MIN, WG_TICK_WPE_MAX))) void wg_mpc_run_xcd_kernel(
+    int B, int n_ticks, const wg_model_t *__restrict__ model_p, const wg::TickTables *__restrict__ tb_p,
+    wg_gait_state_t *__restrict__ states_p, wg_tick_out_t *__restrict__ outs_p, int *__restrict__ diag_p, int advance_calls,
+    wg_xrun_ctl *__restrict__ ctl_p, unsigned long long *__restrict__ rings_p, int cap, int *__restrict__ done_p,
+    unsigned ql_bytes, double *zscratch, unsigned zslot) {
+  extern __shared__ __attribute__((aligned(16))) double wg_lds[];
+  for (;;) {
+    int lane = threadIdx.x & 63;
+    asm volatile("" : "+v"(lane));
+    const wg_model_t *mp = model_p; const wg::TickTables *tb = tb_p; wg_gait_state_t *states = states_p;
+    wg_tick_out_t *outs = outs_p; int *diag = diag_p; wg_xrun_ctl *ctl = ctl_p; unsigned long long *rings = rings_p; int *done = done_p;
+    asm volatile("" : "+s"(mp), "+s"(tb), "+s"(states), "+s"(outs), "+s"(diag), "+s"(ctl), "+s"(rings), "+s"(done));
+    const wg_model_t &model = *mp;
+    int xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID, 0, 4)" : "=s"(xcc));
+    xcc &= kXcds - 1;
+    int g = -1, t = 0;
+    if (lane == 0) {
+      g = xrun_take_fresh(ctl, xcc);
+      if (g < 0) {
+        for (;;) {
+          const int h = xrun_rmw_load(&ctl->x[xcc].head), tl = xrun_rmw_load(&ctl->x[xcc].tail);
+          if (h >= tl) break;
+          int expect = h;
+          if (!__hip_atomic_compare_exchange_strong(&ctl->x[xcc].head, &expect, h + 1, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
+                                                    __HIP_MEMORY_SCOPE_AGENT))
+            continue;
+          unsigned long long *slot = rings + (size_t)xcc * cap + (h & (cap - 1));
+          unsigned long long e;
+          // the pusher reserved position h (tail) before writing the entry: a short wait at most
+          while ((unsigned)((e = __hip_atomic_fetch_or(slot, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >> 32) != (unsigned)(h + 1))
+            __builtin_amdgcn_s_sleep(4);
+          g = (int)(e & 0xffffffffull);
+          t = __hip_atomic_load(done + g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // written (L2) before the entry was
+          break;
+        }
+      }
+      for (int y = 1; g < 0 && y < kXcds; ++y) g = xrun_take_fresh(ctl, (xcc + y) & (kXcds - 1));
+    }
+    g = wg::uni(g); t = wg::uni(t);
+    if (g < 0) break;
+    if (advance_calls > 0) {
+      if (lane == 0) {
+        double c = __hip_atomic_load(&states[g].clock, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (int k = 0; k < advance_calls; ++k) c += model.Tctrl;   // PatternGeneratorInterfacePrivate.cpp:1256
+        states[g].clock = c;
+      }
+      xrun_stores_done();                                  // mpc_tick reads the state back from L2
+      WG_WSYNC();
+    }
+    wg::TickDiag dg = wg::mpc_tick<NH>(model, tb, states + g, outs ? outs + (size_t)t * B + g : nullptr, wg_lds,
+                                   reinterpret_cast<char *>(wg_lds) + ql_bytes, nullptr, 0, nullptr,
+                                   zscratch ? zscratch + (size_t)blockIdx.x * zslot : nullptr);
+    if (diag && lane == 0) {
+      int *dq = diag + ((size_t)t * B + g) * 6;
+      dq[0] = dg.ifail; dq[1] = dg.n_iter; dq[2] = dg.nact; dq[3] = dg.n; dq[4] = dg.m; dq[5] = dg.ns;
+    }
+    WG_WSYNC();
+    if (t + 1 < n_ticks) {
+      if (lane == 0) done[g] = t + 1;
+      xrun_stores_done();                                  // state and tick count are in this XCD's L2 before the gait is offered
+      if (lane == 0) {
+        const int pos = __hip_atomic_fetch_add(&ctl->x[xcc].tail, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_exchange(rings + (size_t)xcc * cap + (pos & (cap - 1)), ((unsigned long long)(unsigned)(pos + 1) << 32) | (unsigned)g,
+                              __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+  }
+}
+
 __global__ void wg_set_velref_kernel(int B, wg_gait_state_t *states, const double *vref) {
   const int g = blockIdx.x * blockDim.x + threadIdx.x;
   if (g < B) {

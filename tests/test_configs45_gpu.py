@@ -98,8 +98,7 @@ def test_config4_last_shard_of_eight_full_size():
     B, T, world, rank = 4096, 200, 8, 7
     lo, hi = rank * B, (rank + 1) * B
     assert (lo, hi) == (28672, 32768)
-    if hasattr(shard, "shard_range"):
-        assert shard.shard_range(world * B, world, rank) == (lo, hi)
+    assert shard.shard_range(world * B, rank, world) == (lo, hi)
     # the references this shard gets are bench.py's table for those global indices (not a re-seeded local table)
     tab = bench.velocity_table(lo, lo + 3, 4)
     for k in range(3):

@@ -73,7 +73,6 @@ def test_facade_todays_semantics_equals_the_oracle_over_the_full_run(tmp_path):
     d = np.abs(rows - want)
     assert d[:, [1, 2, 5, 6, 8, 9]].max() < 1e-11                   # CoM, CoM velocity, ZMP: libm vs wg_trig.h, < 1 ulp per call
     assert d.max() < 1e-7                                           # feet accelerations amplify it; the file precision is 1e-7
-    assert np.abs(rows[:3700] - GOLD[:3700]).max() < 1e-6           # and the part the golden file can pin
 
 
 def test_kajita_stage1_driver_matches_oracle(tmp_path):

@@ -58,12 +58,12 @@ def test_online_schedule_every_tick_bit_exact_vs_oracle():
             assert list(diag[0]) == [dump.ifail, dump.n_iter, dump.nact, dump.n, dump.m, out_c.nb_prw_steps]
             assert int(hlen[0]) == dump.hist_len and list(hist[0, :dump.hist_len]) == list(dump.hist[:dump.hist_len]), it
             n_ticks += 1; n_events += dump.hist_len; sizes.add(dump.n)
-        if not s_cpu.running and n_ticks > 10:
+        if not s_cpu.online:
             break
         if it in events:
             events[it](s_gpu); events[it](s_cpu)
     assert n_ticks > 1100 and n_events > 10000 and sizes == {32, 34, 36}
-    assert not s_cpu.running                                        # :stoppg brought it to rest
+    assert not s_cpu.online and it > 110 * 200                      # :stoppg ended the on-line mode
 
 
 def _gpu_tick(model, state, want_dump):
