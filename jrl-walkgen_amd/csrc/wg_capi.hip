@@ -695,22 +695,41 @@ int wg_mpc_run_batch_dev(int B, wg_gait_state_t *states, int n_ticks, int advanc
   if ((long long)B * n_ticks > 0x3fffffffLL) return fail(WG_ERR_TOO_LARGE, "B * n_ticks = %lld work items", (long long)B * n_ticks);
   const int total = B * n_ticks;
   hipStream_t st = reinterpret_cast<hipStream_t>(hip_stream);
+  // hand-over inside one XCD (default) or through one device-wide queue (WG_RUN_QUEUE=global: A/B tests)
+  bool xcd_mode = true;
+  if (const char *e = getenv("WG_RUN_QUEUE")) xcd_mode = e[0] != 'g';
+  int cap = 1;
+  while (cap < 2 * B) cap <<= 1;                   // ring slots per XCD: a gait is in at most one ring, at most once
   {
     std::lock_guard<std::mutex> lk(g_mu);
-    if (int rc = g_run_buf.reserve(sizeof(wg_run_queue) + (size_t)(total + B) * 4)) return rc;
+    const size_t need = xcd_mode ? sizeof(wg_xrun_ctl) + (size_t)kXcds * cap * 8 + (size_t)B * 4
+                                 : sizeof(wg_run_queue) + (size_t)(total + B) * 4;
+    if (int rc = g_run_buf.reserve(need)) return rc;
     if (!g_run_hooked) { g_release_hooks.push_back([] { g_run_buf.release(); }); g_run_hooked = true; }
   }
   wg_run_queue *q = static_cast<wg_run_queue *>(g_run_buf.p);
   int *ring = reinterpret_cast<int *>(q + 1), *done = ring + total;
-  hipLaunchKernelGGL(wg_run_queue_init_kernel, dim3((total + 255) / 256), dim3(256), 0, st, B, total, q, ring, done);
+  wg_xrun_ctl *xctl = static_cast<wg_xrun_ctl *>(g_run_buf.p);
+  unsigned long long *xrings = reinterpret_cast<unsigned long long *>(xctl + 1);
+  int *xdone = reinterpret_cast<int *>(xrings + (size_t)kXcds * cap);
+  if (xcd_mode) {
+    const int items = kXcds * cap > B ? kXcds * cap : B;
+    hipLaunchKernelGGL(wg_xrun_init_kernel, dim3((items + 255) / 256), dim3(256), 0, st, B, xctl, xrings, cap, xdone);
+  } else
+    hipLaunchKernelGGL(wg_run_queue_init_kernel, dim3((total + 255) / 256), dim3(256), 0, st, B, total, q, ring, done);
   const size_t qlb = tick_ql_bytes(g_model);
   const int view = tick_view(g_model);
   const size_t lds = tick_lds_for(g_model, view);
-  if (lds > 64 * 1024)
+  if (lds > 64 * 1024) {
     HIP_TRY(hipFuncSetAttribute(view == 16  ? reinterpret_cast<const void *>(wg_mpc_run_kernel<16>)
                                 : view == 0 ? reinterpret_cast<const void *>(wg_mpc_run_kernel<0>)
                                             : reinterpret_cast<const void *>(wg_mpc_run_kernel<-1>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    HIP_TRY(hipFuncSetAttribute(view == 16  ? reinterpret_cast<const void *>(wg_mpc_run_xcd_kernel<16>)
+                                : view == 0 ? reinterpret_cast<const void *>(wg_mpc_run_xcd_kernel<0>)
+                                            : reinterpret_cast<const void *>(wg_mpc_run_xcd_kernel<-1>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  }
   // as many blocks as the device keeps resident: LDS granules (1280 B, 128 per CU), at most 8 waves of 256 registers per CU
   int per_cu = 128 / (int)((lds + 1279) / 1280);
   if (per_cu > 8) per_cu = 8;
@@ -724,7 +743,17 @@ int wg_mpc_run_batch_dev(int B, wg_gait_state_t *states, int n_ticks, int advanc
     if (int rc = g_tick_z.reserve((size_t)grid * zslot * 8)) return rc;
     zs = static_cast<double *>(g_tick_z.p);
   }
-  if (view == 16)
+  if (xcd_mode) {
+    if (view == 16)
+      hipLaunchKernelGGL(wg_mpc_run_xcd_kernel<16>, dim3(grid), dim3(64), lds, st, B, n_ticks, g_model_dev, g_tables_dev, states,
+                         outs, diag, advance_calls, xctl, xrings, cap, xdone, (unsigned)qlb, zs, (unsigned)zslot);
+    else if (view == 0)
+      hipLaunchKernelGGL(wg_mpc_run_xcd_kernel<0>, dim3(grid), dim3(64), lds, st, B, n_ticks, g_model_dev, g_tables_dev, states,
+                         outs, diag, advance_calls, xctl, xrings, cap, xdone, (unsigned)qlb, zs, (unsigned)zslot);
+    else
+      hipLaunchKernelGGL(wg_mpc_run_xcd_kernel<-1>, dim3(grid), dim3(64), lds, st, B, n_ticks, g_model_dev, g_tables_dev, states,
+                         outs, diag, advance_calls, xctl, xrings, cap, xdone, (unsigned)qlb, zs, (unsigned)zslot);
+  } else if (view == 16)
     hipLaunchKernelGGL(wg_mpc_run_kernel<16>, dim3(grid), dim3(64), lds, st, B, n_ticks, g_model_dev, g_tables_dev, states, outs,
                        diag, advance_calls, q, ring, done, (unsigned)qlb, zs, (unsigned)zslot);
   else if (view == 0)
