@@ -264,7 +264,10 @@ __device__ __forceinline__ double sqrt_1to2(double x) {
 __device__ __forceinline__ double givens_norm(double p, double qq) {
   const double ap = fabs(p), aq = fabs(qq);
   const bool pbig = ap >= aq;                      // maxd(): a >= b ? a : b
-  const double t = __builtin_fmax(ap, aq);         // the value of the select (finite operands), one instruction
+  // the value of the select (finite operands) in one instruction; __builtin_fmax would first canonicalise both operands
+  // (two more v_max_f64) -- NaN operands give NaN either way, and that result is discarded wherever it can arise
+  double t;
+  asm("v_max_f64 %0, |%1|, |%2|" : "=v"(t) : "v"(p), "v"(qq));
   const double d = (pbig ? qq : p) / t;            // |d| <= 1
   const double x = 1.0 + d * d;
 #ifdef WG_GENERIC_SQRT
@@ -442,29 +445,43 @@ __device__ __forceinline__ double ordered_sum_lds(double term, double *scratch, 
 __device__ __forceinline__ void sweep_flat(const QlView &q, double *s, int nu, int nact, int lane) {
   const int n = q.n;
   if (nu - 1 <= nact) return;
-  double myP = 0.0, myQ = 0.0, myN = 0.0;
+  // Phase 1 leaves ONE value per rotation behind -- `cur` as it leaves rotation c, in chain[c - 1] -- from which lane c
+  // rebuilds its rotation afterwards: q = the value that entered (chain[c], or s[nu-1] for the first one), p = s[c-1]
+  // (untouched until phase 2), norm = chain[c-1] when q != 0 (then cur = norm), skipped when q == 0 (then cur = p).
+  // givens_norm runs unguarded on q == 0: its result (|p|, or NaN for 0/0) is discarded by the select.
+  double *chain = q.sc2;                                    // nu <= n entries
   {
     double cur = s[nu - 1];
     double p = s[nu - 2];
     for (int c = nu - 1; c > nact; --c) {
       const int nx = (c - 2 >= 0) ? c - 2 : 0;
       const double p_next = s[nx];                          // operand of the next rotation, off the chain
-      const bool z = (cur == 0.0);
-      const double nrmc = givens_norm(p, z ? 1.0 : cur);
-      const double nrm = z ? 0.0 : nrmc;
-      const bool me = (lane == c);
-      myP = me ? p : myP; myQ = me ? cur : myQ; myN = me ? nrm : myN;
-      cur = z ? p : nrmc;
+      const double nrmc = givens_norm(p, cur);
+      cur = (cur == 0.0) ? p : nrmc;
+      chain[c - 1] = cur;
       p = p_next;
     }
   }
+  WG_WSYNC();
+  double myP = 0.0, myQ = 0.0, myN = 0.0;
+  {
+    const bool mine = lane > nact && lane < nu;
+    const int c = mine ? lane : nu - 1;
+    myP = s[c - 1];
+    myQ = (c == nu - 1) ? s[nu - 1] : chain[c];
+    myN = (myQ == 0.0) ? 0.0 : chain[c - 1];
+  }
+  WG_WSYNC();
   double *gab = q.sc0;                                      // pairs {ga, gb}; sc0 and sc1 are adjacent (2n doubles)
+  bool any_skip;
   {
     const bool mine = lane > nact && lane < nu;
     const bool rot = mine && myN != 0.0;
     const double den = rot ? myN : 1.0;
     const double ga = rot ? myP / den : 1.0;
     const double gb = rot ? myQ / den : 0.0;                // gb == 0 marks a skipped rotation (q was 0)
+    // a skipped rotation is rare: when the sweep has none -- one ballot -- phase 3 runs without the selects
+    any_skip = __ballot(mine && gb == 0.0) != 0ull;
     const int cl = mine ? lane : nu - 1;                    // lanes without a rotation shadow lane nu-1 ... with ITS values
     const double ga_w = mine ? ga : rl(ga, nu - 1), gb_w = mine ? gb : rl(gb, nu - 1);
     gab[2 * cl] = ga_w; gab[2 * cl + 1] = gb_w;
@@ -493,15 +510,32 @@ __device__ __forceinline__ void sweep_flat(const QlView &q, double *s, int nu, i
       carry = skip ? o.zl : t_r;
       zp -= ldz;
     };
+    auto rotate_all = [&](const Op &o) {
+      const double t_r = o.ga * o.zl + o.gb * carry;
+      zp[0] = o.ga * carry - o.gb * o.zl;
+      carry = t_r;
+      zp -= ldz;
+    };
     Op s0 = fetch(nu - 1), s1 = fetch(nu - 2), s2 = fetch(nu - 3);
     int c = nu - 1;
-    for (;;) {
-      { const Op nx = fetch(c - 3); rotate(s0); s0 = nx; }
-      if (--c <= nact) break;
-      { const Op nx = fetch(c - 3); rotate(s1); s1 = nx; }
-      if (--c <= nact) break;
-      { const Op nx = fetch(c - 3); rotate(s2); s2 = nx; }
-      if (--c <= nact) break;
+    if (any_skip) {
+      for (;;) {
+        { const Op nx = fetch(c - 3); rotate(s0); s0 = nx; }
+        if (--c <= nact) break;
+        { const Op nx = fetch(c - 3); rotate(s1); s1 = nx; }
+        if (--c <= nact) break;
+        { const Op nx = fetch(c - 3); rotate(s2); s2 = nx; }
+        if (--c <= nact) break;
+      }
+    } else {
+      for (;;) {
+        { const Op nx = fetch(c - 3); rotate_all(s0); s0 = nx; }
+        if (--c <= nact) break;
+        { const Op nx = fetch(c - 3); rotate_all(s1); s1 = nx; }
+        if (--c <= nact) break;
+        { const Op nx = fetch(c - 3); rotate_all(s2); s2 = nx; }
+        if (--c <= nact) break;
+      }
     }
     zp[0] = carry;                                           // Z(i, nact)
   }
