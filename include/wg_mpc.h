@@ -45,6 +45,27 @@ int wg_abi_version(void);
  * reason about occupancy (160 KiB per CU on gfx950). */
 size_t wg_qp_lds_bytes(int n, int m);
 
+/* Contexts ---------------------------------------------------------------------------------------------------------------
+ *
+ * Everything the library keeps between calls lives in a context: the configured models with the device copies of their
+ * tables (wg_mpc_configure, wg_pldp_configure, wg_dimitrov_configure, wg_preview_configure), the per-launch workspaces of
+ * the tick kernels (work queue of the multi-tick launch, per-block solver slots) and the staging buffers of the
+ * host-pointer entry points.  The reference keeps the same things per object (one ZMPVelocityReferencedQP, one
+ * PreviewControl ... per PatternGeneratorInterface); a context is what one such object owns here.
+ *
+ *   - every entry point NAME(args) below has a form NAME_ctx(ctx, args) with identical semantics on that context;
+ *     NAME(args) itself works on a process-wide default context (device 0 unless wg_init chose another);
+ *   - contexts are independent: two contexts may hold different models (N = 16 and N = 32, two robots, two preview
+ *     windows) and their launches may overlap on different streams;
+ *   - launches on ONE context share its workspaces: keep them on one stream (or order them with events).  Host-pointer
+ *     entry points are synchronous and serialised per context;
+ *   - a context belongs to one device; its entry points make that device current for the calling thread;
+ *   - wg_ctx_destroy waits for the device, then frees everything the context owns. */
+typedef struct wg_ctx wg_ctx_t;
+int wg_ctx_create(int device_ordinal, wg_ctx_t **ctx);
+void wg_ctx_destroy(wg_ctx_t *ctx);
+int wg_ctx_device(const wg_ctx_t *ctx);
+
 /* Batched dense QP solve -------------------------------------------------
  *
  * Replaces, batched over B independent problems,
@@ -232,8 +253,9 @@ int wg_mpc_configure(const wg_model_t *model);
  *   outs    B structs or NULL (NULL: only the state is advanced)
  *   diag    B x 6 ints {ifail, n_iter, nact, n, m, nb_prw_steps} or NULL
  *   hist    B x hist_cap active-set add(+)/drop(-) log or NULL, hist_len B or NULL
- * The kernels keep a few solver arrays per block in a library-owned device buffer (what does not fit the CU's LDS at the
- * residency they run at): launches of the tick entry points must not overlap -- one stream, or events between streams. */
+ * The kernels keep a few solver arrays per block in a buffer of the context (what does not fit the CU's LDS at the
+ * residency they run at): launches of the tick entry points ON ONE CONTEXT must not overlap -- one stream, or events between
+ * streams; overlapping streams take one context each (wg_ctx_create). */
 int wg_mpc_tick_batch(int B, wg_gait_state_t *states, wg_tick_out_t *outs, int *diag, int advance_calls,
                       int *hist, int hist_cap, int *hist_len);
 int wg_mpc_tick_batch_dev(int B, wg_gait_state_t *states, wg_tick_out_t *outs, int *diag, int advance_calls,
@@ -244,8 +266,8 @@ int wg_mpc_tick_batch_dev(int B, wg_gait_state_t *states, wg_tick_out_t *outs, i
  * n_ticks calls of wg_mpc_tick_batch_dev with the same advance_calls, bit for bit; the velocity references stay what they
  * are for the whole launch (change them between launches with wg_mpc_set_velref_dev).
  *   outs  n_ticks x B (tick-major) or NULL;  diag  n_ticks x B x 6 (tick-major) or NULL.
- * No add/drop history in this mode.  The queue lives in a library-owned device buffer: one such launch in flight per
- * process at a time (launches on one stream are fine -- they run one after the other). */
+ * No add/drop history in this mode.  The queue lives in a buffer of the context: one such launch in flight per context at
+ * a time (launches on one stream are fine -- they run one after the other). */
 int wg_mpc_run_batch_dev(int B, wg_gait_state_t *states, int n_ticks, int advance_calls, wg_tick_out_t *outs, int *diag,
                          void *hip_stream);
 /* NewVelRef_ <- (vx, vy, vyaw) for every gait (":setVelReference", ZMPVelocityReferencedQP.hh:103-114);
@@ -517,6 +539,62 @@ int wg_gramian_batch(int B, int N, const double *T, const double *h, double alph
                      double *Qb);
 int wg_gramian_batch_dev(int B, int N, const double *T, const double *h, double alpha, double beta, double gamma,
                          int precision, double *Qb, void *hip_stream);
+
+/* The context forms of the entry points above (same arguments after the context, same semantics). ---------------------- */
+int wg_qp_solve_batch_dev_ctx(wg_ctx_t *ctx, int B, int nmax, int mmax, const int *n, const int *m, const int *me,
+                              const double *C, const double *d, const double *A, const double *b, const double *xl,
+                              const double *xu, double eps, double *x, double *u, int *ifail, int *n_iter, int *iact,
+                              int *nact, int *hist, int hist_cap, int *hist_len, void *hip_stream);
+int wg_qp_solve_batch_ctx(wg_ctx_t *ctx, int B, int nmax, int mmax, const int *n, const int *m, const int *me,
+                          const double *C, const double *d, const double *A, const double *b, const double *xl,
+                          const double *xu, double eps, double *x, double *u, int *ifail, int *n_iter, int *iact,
+                          int *nact, int *hist, int hist_cap, int *hist_len);
+int wg_mpc_configure_ctx(wg_ctx_t *ctx, const wg_model_t *model);
+size_t wg_mpc_tick_lds_bytes_ctx(wg_ctx_t *ctx);
+int wg_mpc_tick_batch_dev_ctx(wg_ctx_t *ctx, int B, wg_gait_state_t *states, wg_tick_out_t *outs, int *diag,
+                              int advance_calls, int *hist, int hist_cap, int *hist_len, void *hip_stream);
+int wg_mpc_run_batch_dev_ctx(wg_ctx_t *ctx, int B, wg_gait_state_t *states, int n_ticks, int advance_calls,
+                             wg_tick_out_t *outs, int *diag, void *hip_stream);
+int wg_mpc_tick_batch_ctx(wg_ctx_t *ctx, int B, wg_gait_state_t *states, wg_tick_out_t *outs, int *diag,
+                          int advance_calls, int *hist, int hist_cap, int *hist_len);
+int wg_mpc_set_velref_dev_ctx(wg_ctx_t *ctx, int B, wg_gait_state_t *states, const double *vref, void *hip_stream);
+int wg_pldp_configure_ctx(wg_ctx_t *ctx, int N, const double *iPu, const double *Px, const double *Pu);
+int wg_pldp_solve_batch_dev_ctx(wg_ctx_t *ctx, int B, int mcap, const int *m, const double *D, const double *A,
+                                const double *b, const double *zmpref, const double *xkyk, const int *similar,
+                                const int *n_removed, const int *starting, int max_iter, wg_pldp_state_t *states,
+                                double *X, int *ret, int *n_iter, int *active, int *n_active, void *hip_stream);
+int wg_pldp_solve_batch_ctx(wg_ctx_t *ctx, int B, int mcap, const int *m, const double *D, const double *A,
+                            const double *b, const double *zmpref, const double *xkyk, const int *similar,
+                            const int *n_removed, const int *starting, int max_iter, wg_pldp_state_t *states,
+                            double *X, int *ret, int *n_iter, int *active, int *n_active);
+int wg_dimitrov_configure_ctx(wg_ctx_t *ctx, const wg_dimitrov_model_t *model);
+int wg_dimitrov_get_constants_ctx(wg_ctx_t *ctx, double *iLQ, double *OptB, double *OptC, double *Pu, double *iPu,
+                                  double *Px);
+int wg_dimitrov_tick_batch_dev_ctx(wg_ctx_t *ctx, int B, const wg_zmp_polytope_t *polys, wg_dimitrov_state_t *states,
+                                   wg_dimitrov_out_t *outs, int max_iter, void *hip_stream);
+int wg_dimitrov_tick_batch_ctx(wg_ctx_t *ctx, int B, const wg_zmp_polytope_t *polys, wg_dimitrov_state_t *states,
+                               wg_dimitrov_out_t *outs, int max_iter);
+int wg_preview_configure_ctx(wg_ctx_t *ctx, const wg_preview_gains_t *gains, const double *F);
+int wg_preview_window_ctx(wg_ctx_t *ctx);
+int wg_preview_run_batch_dev_ctx(wg_ctx_t *ctx, int B, int L, const double *zmp_x_tm, const double *zmp_y_tm,
+                                 double *state, double *com_tm, double *zmp2_tm, int simulation, void *hip_stream);
+int wg_preview_run_batch_ctx(wg_ctx_t *ctx, int B, int L, const double *zmp_x, const double *zmp_y, double *state,
+                             double *com, double *zmp2, int simulation);
+int wg_gramian_batch_dev_ctx(wg_ctx_t *ctx, int B, int N, const double *T, const double *h, double alpha,
+                             double beta, double gamma, int precision, double *Qb, void *hip_stream);
+int wg_gramian_batch_ctx(wg_ctx_t *ctx, int B, int N, const double *T, const double *h, double alpha, double beta,
+                         double gamma, int precision, double *Qb);
+int wg_zmpdisc_batch_dev_ctx(wg_ctx_t *ctx, const wg_zmpdisc_model_t *model, int B, int smax,
+                             const wg_rel_step_t *steps, const int *n_steps, const double *init_feet, int lcap,
+                             double *zmp_x_tm, double *zmp_y_tm, int *length, void *hip_stream);
+int wg_zmpdisc_full_batch_dev_ctx(wg_ctx_t *ctx, const wg_zmpdisc_model_t *model, int B, int smax,
+                                  const wg_rel_step_t *steps, const int *n_steps, const double *init_feet, int lcap,
+                                  double *zmp_x_tm, double *zmp_y_tm, double *zmp_theta_tm, int *zmp_type_tm,
+                                  double *left_tm, int *left_type_tm, double *right_tm, int *right_type_tm,
+                                  int *length, void *hip_stream);
+int wg_zmpdisc_batch_ctx(wg_ctx_t *ctx, const wg_zmpdisc_model_t *model, int B, int smax, const wg_rel_step_t *steps,
+                         const int *n_steps, const double *init_feet, int lcap, double *zmp, double *zmp_theta,
+                         int *zmp_type, double *left, int *left_type, double *right, int *right_type, int *length);
 
 #ifdef __cplusplus
 }

@@ -196,6 +196,9 @@ class ZMPVelocityReferencedQP : public ZMPRefTrajectoryGeneration {
   bool LegacyGoldenReplay() const { return Legacy_; }
 
  private:
+  ZMPVelocityReferencedQP(const ZMPVelocityReferencedQP &);              // owns a device context: not copyable
+  ZMPVelocityReferencedQP &operator=(const ZMPVelocityReferencedQP &);
+  wg_ctx_t *Ctx_;    // this object's device-side model tables and workspaces (the reference keeps them per object too)
   wg_model_t Model_;
   wg_gait_state_t State_;
   solution_t Solution_;
@@ -264,6 +267,7 @@ class PreviewControl : public SimplePlugin {
   double m_PreviewControlTime, m_SamplingPeriod, m_Zc;
   unsigned int m_SizeOfPreviewWindow;
   bool m_Coherent, m_AutoComputeWeights, m_Uploaded;
+  wg_ctx_t *m_Ctx;   // this object's device-side gains (created with the first Upload)
   unsigned int m_DefaultWeightComputationMode;
 };
 

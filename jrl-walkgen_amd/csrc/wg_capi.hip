@@ -5,19 +5,23 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <mutex>
 #include <string>
 #include <vector>
 
 #include "../../include/wg_mpc.h"
 #include "wg_ql_device.hpp"
+#include "wg_tick_device.hpp"
+#include "wg_pldp_device.hpp"
+#include "wg_dimitrov_device.hpp"
+#include "wg_preview_device.hpp"
+#include "wg_gramian_device.hpp"
+#include "wg_zmpdisc_device.hpp"
 
 namespace {
 
 thread_local std::string g_err;
-int g_device = -1;
-int g_num_cu = 256;
-std::mutex g_mu;
 
 int fail(int code, const char *fmt, ...) {
   char buf[512];
@@ -35,12 +39,7 @@ int fail(int code, const char *fmt, ...) {
     if (e_ != hipSuccess) return fail(WG_ERR_HIP, "%s: %s", #expr, hipGetErrorString(e_)); \
   } while (0)
 
-int ensure_device() {
-  if (g_device >= 0) return WG_OK;
-  return wg_init(0);
-}
-
-// grow-only device scratch for the host-pointer entry points
+// grow-only device buffer
 struct DevBuf {
   void *p = nullptr;
   size_t cap = 0;
@@ -55,8 +54,88 @@ struct DevBuf {
   }
   void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
 };
-DevBuf g_in, g_out;
-std::vector<void (*)()> g_release_hooks;   // device buffers owned by the later sections of this file
+
+}  // namespace
+
+// Everything the library keeps between calls: configured models (device copies of their tables), the workspaces its
+// kernels need besides the caller's arrays, and the staging buffers of the host-pointer entry points.  The entry points
+// without a context argument work on one process-wide default context.
+struct wg_ctx {
+  int device = 0;
+  int num_cu = 256;
+  std::mutex mu, z_mu;
+  // Herdt-2010 tick
+  wg_model_t model;
+  bool model_set = false;
+  wg::TickTables *tables_dev = nullptr;
+  wg_model_t *model_dev = nullptr;     // the model in device memory (the multi-tick kernels read it through a pointer)
+  DevBuf tick_state, tick_out, tick_aux, run_buf, tick_z;
+  // PLDP / Dimitrov
+  wg::PldpModel *pldp_dev = nullptr;
+  int pldp_N = 0;
+  DevBuf pldp_buf;
+  wg::DimitrovConst *dim_dev = nullptr;
+  std::unique_ptr<wg::DimitrovConst> dim_host;
+  bool dim_set = false;
+  DevBuf dim_buf;
+  // preview control
+  wg::PreviewConst prev;
+  double *prev_F = nullptr;            // device copy of the window gains
+  bool prev_set = false;
+  DevBuf prev_buf;
+  // staging of the host-pointer entry points
+  DevBuf in, out, gram_buf, zd_buf;
+  void release_all() {
+    if (tables_dev) (void)hipFree(tables_dev);
+    if (model_dev) (void)hipFree(model_dev);
+    if (pldp_dev) (void)hipFree(pldp_dev);
+    if (dim_dev) (void)hipFree(dim_dev);
+    if (prev_F) (void)hipFree(prev_F);
+    tables_dev = nullptr; model_dev = nullptr; pldp_dev = nullptr; dim_dev = nullptr; prev_F = nullptr;
+    model_set = false; pldp_N = 0; dim_set = false; prev_set = false;
+    for (DevBuf *b : {&tick_state, &tick_out, &tick_aux, &run_buf, &tick_z, &pldp_buf, &dim_buf, &prev_buf, &in, &out, &gram_buf, &zd_buf})
+      b->release();
+  }
+};
+
+namespace {
+
+std::mutex g_default_mu;
+wg_ctx *g_default = nullptr;          // created by wg_init() or by the first call that needs it
+
+int make_ctx(int device_ordinal, wg_ctx **out) {
+  int count = 0;
+  hipError_t e = hipGetDeviceCount(&count);
+  if (e != hipSuccess || count <= 0)
+    return fail(WG_ERR_NO_DEVICE, "no HIP device available (%s); this library has no CPU path",
+                e == hipSuccess ? "count = 0" : hipGetErrorString(e));
+  if (device_ordinal < 0 || device_ordinal >= count)
+    return fail(WG_ERR_BAD_ARG, "device ordinal %d out of range [0,%d)", device_ordinal, count);
+  HIP_TRY(hipSetDevice(device_ordinal));
+  hipDeviceProp_t prop;
+  HIP_TRY(hipGetDeviceProperties(&prop, device_ordinal));
+  wg_ctx *c = new wg_ctx();
+  c->device = device_ordinal;
+  c->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  *out = c;
+  return WG_OK;
+}
+
+int default_ctx(wg_ctx **out) {
+  std::lock_guard<std::mutex> lk(g_default_mu);
+  if (!g_default)
+    if (int rc = make_ctx(0, &g_default)) return rc;
+  *out = g_default;
+  return WG_OK;
+}
+
+// every entry point starts here: the context's device becomes the calling thread's current device
+int use_ctx(wg_ctx *ctx) {
+  if (!ctx) return fail(WG_ERR_BAD_ARG, "null context");
+  int cur = -1;
+  if (hipGetDevice(&cur) != hipSuccess || cur != ctx->device) HIP_TRY(hipSetDevice(ctx->device));
+  return WG_OK;
+}
 
 }  // namespace
 
@@ -134,33 +213,49 @@ __global__ __launch_bounds__(64) void wg_ql_dense_kernel(
 
 extern "C" {
 
-int wg_abi_version(void) { return 1; }
+int wg_abi_version(void) { return 2; }
 
 const char *wg_last_error(void) { return g_err.c_str(); }
 
+int wg_ctx_create(int device_ordinal, wg_ctx_t **out) {
+  if (!out) return fail(WG_ERR_BAD_ARG, "null out pointer");
+  *out = nullptr;
+  return make_ctx(device_ordinal, out);
+}
+
+void wg_ctx_destroy(wg_ctx_t *ctx) {
+  if (!ctx) return;
+  {
+    std::lock_guard<std::mutex> lk(g_default_mu);
+    if (ctx == g_default) g_default = nullptr;
+  }
+  int cur = -1;
+  if (hipGetDevice(&cur) == hipSuccess && cur != ctx->device) (void)hipSetDevice(ctx->device);
+  (void)hipDeviceSynchronize();
+  ctx->release_all();
+  delete ctx;
+}
+
+int wg_ctx_device(const wg_ctx_t *ctx) { return ctx ? ctx->device : -1; }
+
 int wg_init(int device_ordinal) {
-  std::lock_guard<std::mutex> lk(g_mu);
-  int count = 0;
-  hipError_t e = hipGetDeviceCount(&count);
-  if (e != hipSuccess || count <= 0)
-    return fail(WG_ERR_NO_DEVICE, "no HIP device available (%s); this library has no CPU path",
-                e == hipSuccess ? "count = 0" : hipGetErrorString(e));
-  if (device_ordinal < 0 || device_ordinal >= count)
-    return fail(WG_ERR_BAD_ARG, "device ordinal %d out of range [0,%d)", device_ordinal, count);
-  HIP_TRY(hipSetDevice(device_ordinal));
-  hipDeviceProp_t prop;
-  HIP_TRY(hipGetDeviceProperties(&prop, device_ordinal));
-  g_num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-  g_device = device_ordinal;
+  std::lock_guard<std::mutex> lk(g_default_mu);
+  if (g_default && g_default->device == device_ordinal) return use_ctx(g_default);
+  wg_ctx *fresh = nullptr;
+  if (int rc = make_ctx(device_ordinal, &fresh)) return rc;
+  if (g_default) { g_default->release_all(); delete g_default; }
+  g_default = fresh;
   return WG_OK;
 }
 
 void wg_shutdown(void) {
-  std::lock_guard<std::mutex> lk(g_mu);
-  for (auto h : g_release_hooks) h();
-  g_in.release();
-  g_out.release();
-  g_device = -1;
+  wg_ctx *c = nullptr;
+  {
+    std::lock_guard<std::mutex> lk(g_default_mu);
+    c = g_default;
+    g_default = nullptr;
+  }
+  if (c) { c->release_all(); delete c; }
 }
 
 #ifdef WG_PROFILE
@@ -175,12 +270,8 @@ int wg_prof_read(unsigned long long *out32) {
 
 size_t wg_qp_lds_bytes(int n, int m) { return wg::QlDims(n, m, m).bytes(); }
 
-int wg_qp_solve_batch_dev(int B, int nmax, int mmax, const int *n, const int *m, const int *me,
-                          const double *C, const double *d, const double *A, const double *b,
-                          const double *xl, const double *xu, double eps, double *x, double *u,
-                          int *ifail, int *n_iter, int *iact, int *nact, int *hist, int hist_cap,
-                          int *hist_len, void *hip_stream) {
-  if (int rc = ensure_device()) return rc;
+int wg_qp_solve_batch_dev_ctx(wg_ctx_t *ctx, int B, int nmax, int mmax, const int *n, const int *m, const int *me, const double *C, const double *d, const double *A, const double *b, const double *xl, const double *xu, double eps, double *x, double *u, int *ifail, int *n_iter, int *iact, int *nact, int *hist, int hist_cap, int *hist_len, void *hip_stream) {
+  if (int rc = use_ctx(ctx)) return rc;
   if (B < 0 || nmax <= 0 || mmax <= 0) return fail(WG_ERR_BAD_ARG, "bad sizes B=%d nmax=%d mmax=%d", B, nmax, mmax);
   if (!C || !d || !A || !b || !xl || !xu || !x || !ifail) return fail(WG_ERR_BAD_ARG, "null required pointer");
   if (hist && (!hist_len || hist_cap <= 0)) return fail(WG_ERR_BAD_ARG, "hist needs hist_len and hist_cap > 0");
@@ -208,15 +299,12 @@ int wg_qp_solve_batch_dev(int B, int nmax, int mmax, const int *n, const int *m,
   return WG_OK;
 }
 
-int wg_qp_solve_batch(int B, int nmax, int mmax, const int *n, const int *m, const int *me,
-                      const double *C, const double *d, const double *A, const double *b,
-                      const double *xl, const double *xu, double eps, double *x, double *u, int *ifail,
-                      int *n_iter, int *iact, int *nact, int *hist, int hist_cap, int *hist_len) {
-  if (int rc = ensure_device()) return rc;
+int wg_qp_solve_batch_ctx(wg_ctx_t *ctx, int B, int nmax, int mmax, const int *n, const int *m, const int *me, const double *C, const double *d, const double *A, const double *b, const double *xl, const double *xu, double eps, double *x, double *u, int *ifail, int *n_iter, int *iact, int *nact, int *hist, int hist_cap, int *hist_len) {
+  if (int rc = use_ctx(ctx)) return rc;
   if (B < 0 || nmax <= 0 || mmax <= 0) return fail(WG_ERR_BAD_ARG, "bad sizes B=%d nmax=%d mmax=%d", B, nmax, mmax);
   if (!C || !d || !A || !b || !xl || !xu || !x || !ifail) return fail(WG_ERR_BAD_ARG, "null required pointer");
   if (B == 0) return WG_OK;
-  std::lock_guard<std::mutex> lk(g_mu);
+  std::lock_guard<std::mutex> lk(ctx->mu);
   const size_t sB = (size_t)B;
   // input arena
   struct Seg { const void *h; size_t bytes; size_t off; };
@@ -226,8 +314,8 @@ int wg_qp_solve_batch(int B, int nmax, int mmax, const int *n, const int *m, con
       {n, n ? sB * 4 : 0, 0},       {m, m ? sB * 4 : 0, 0}, {me, me ? sB * 4 : 0, 0}};
   size_t tot = 0;
   for (auto &s : in) { s.off = tot; tot += (s.bytes + 255) & ~(size_t)255; }
-  if (int rc = g_in.reserve(tot)) return rc;
-  char *din = static_cast<char *>(g_in.p);
+  if (int rc = ctx->in.reserve(tot)) return rc;
+  char *din = static_cast<char *>(ctx->in.p);
   for (auto &s : in)
     if (s.bytes) HIP_TRY(hipMemcpy(din + s.off, s.h, s.bytes, hipMemcpyHostToDevice));
   struct OSeg { void *h; size_t bytes; size_t off; };
@@ -241,12 +329,12 @@ int wg_qp_solve_batch(int B, int nmax, int mmax, const int *n, const int *m, con
                            {hist_len, hist_len ? sB * 4 : 0, 0}};
   size_t otot = 0;
   for (auto &s : out) { s.off = otot; otot += (s.bytes + 255) & ~(size_t)255; }
-  if (int rc = g_out.reserve(otot)) return rc;
-  char *dout = static_cast<char *>(g_out.p);
+  if (int rc = ctx->out.reserve(otot)) return rc;
+  char *dout = static_cast<char *>(ctx->out.p);
   HIP_TRY(hipMemset(dout, 0, otot));
   auto ip = [&](int k) { return in[k].bytes ? din + in[k].off : nullptr; };
   auto op = [&](int k) { return out[k].bytes ? dout + out[k].off : nullptr; };
-  int rc = wg_qp_solve_batch_dev(B, nmax, mmax, (const int *)ip(6), (const int *)ip(7), (const int *)ip(8),
+  int rc = wg_qp_solve_batch_dev_ctx(ctx, B, nmax, mmax, (const int *)ip(6), (const int *)ip(7), (const int *)ip(8),
                                  (const double *)ip(0), (const double *)ip(1), (const double *)ip(2),
                                  (const double *)ip(3), (const double *)ip(4), (const double *)ip(5), eps,
                                  (double *)op(0), (double *)op(1), (int *)op(2), (int *)op(3), (int *)op(4),
@@ -263,17 +351,8 @@ int wg_qp_solve_batch(int B, int nmax, int mmax, const int *n, const int *m, con
 // ===========================================================================
 // Herdt-2010 MPC tick, batched (include/wg_mpc.h, second half)
 // ===========================================================================
-#include "wg_tick_device.hpp"
 
 namespace {
-wg_model_t g_model;
-bool g_model_set = false;
-wg::TickTables *g_tables_dev = nullptr;
-wg_model_t *g_model_dev = nullptr;     // the model in device memory (multi-tick kernel reads it through a pointer)
-DevBuf g_tick_state, g_tick_out, g_tick_aux, g_run_buf, g_tick_z;
-std::mutex g_z_mu;
-bool g_run_hooked = false;
-
 inline bool tick_compact(const wg_model_t &m);
 // at most two step changes fit in the preview window when N*T <= 2*step_period (each change is one step period
 // after the previous one and the first previewed change is at pi >= 1): the compact kernel is sized for that
@@ -600,8 +679,8 @@ void wg_gait_init(const wg_model_t *, wg_gait_state_t *s, const double com0[3], 
   s->nb_steps_ssds = 2; s->rot_support_foot = WG_LEFT;
 }
 
-int wg_mpc_configure(const wg_model_t *model) {
-  if (int rc = ensure_device()) return rc;
+int wg_mpc_configure_ctx(wg_ctx_t *ctx, const wg_model_t *model) {
+  if (int rc = use_ctx(ctx)) return rc;
   if (!model) return fail(WG_ERR_BAD_ARG, "null model");
   if (model->N < 2 || model->N > wg::kNMaxH) return fail(WG_ERR_BAD_ARG, "N=%d outside [2,%d]", model->N, wg::kNMaxH);
   if ((int)(model->T / model->Tctrl) != WG_SAMPLES_PER_TICK)
@@ -612,29 +691,24 @@ int wg_mpc_configure(const wg_model_t *model) {
   if (model->flags & (WG_FLAG_GRAMIAN_MFMA_F64 | WG_FLAG_GRAMIAN_MFMA_F32)) {
     qb.resize((size_t)model->N * model->N);
     const int prec = (model->flags & WG_FLAG_GRAMIAN_MFMA_F32) ? WG_GRAMIAN_F32 : WG_GRAMIAN_F64;
-    if (int rc = wg_gramian_batch(1, model->N, &model->T, &model->com_height_qp, model->alpha, model->beta, model->gamma,
+    if (int rc = wg_gramian_batch_ctx(ctx, 1, model->N, &model->T, &model->com_height_qp, model->alpha, model->beta, model->gamma,
                                   prec, qb.data()))
       return rc;
   }
-  std::lock_guard<std::mutex> lk(g_mu);
-  static wg::TickTables host_tables;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  std::unique_ptr<wg::TickTables> host_tables_p(new wg::TickTables);
+  wg::TickTables &host_tables = *host_tables_p;
   wg::build_tables(*model, host_tables, qb.empty() ? nullptr : qb.data());
   if (!host_tables.blocks_ok && !qb.empty())
     return fail(WG_ERR_BAD_ARG, "the matrix-core Gramian is not positive definite enough for ql0002's factorisation");
-  if (!g_tables_dev) {
-    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&g_tables_dev), sizeof(wg::TickTables)));
-    g_release_hooks.push_back([] {
-      if (g_tables_dev) (void)hipFree(g_tables_dev);
-      if (g_model_dev) (void)hipFree(g_model_dev);
-      g_tables_dev = nullptr; g_model_dev = nullptr; g_model_set = false;
-      g_tick_state.release(); g_tick_out.release(); g_tick_aux.release(); g_tick_z.release();
-    });
-  }
-  HIP_TRY(hipMemcpy(g_tables_dev, &host_tables, sizeof host_tables, hipMemcpyHostToDevice));
-  if (!g_model_dev) HIP_TRY(hipMalloc(reinterpret_cast<void **>(&g_model_dev), sizeof(wg_model_t)));
-  HIP_TRY(hipMemcpy(g_model_dev, model, sizeof(wg_model_t), hipMemcpyHostToDevice));
-  g_model = *model;
-  g_model_set = true;
+  if (!ctx->tables_dev) HIP_TRY(hipMalloc(reinterpret_cast<void **>(&ctx->tables_dev), sizeof(wg::TickTables)));
+  // a launch of an earlier configuration may still be reading the tables
+  HIP_TRY(hipDeviceSynchronize());
+  HIP_TRY(hipMemcpy(ctx->tables_dev, &host_tables, sizeof host_tables, hipMemcpyHostToDevice));
+  if (!ctx->model_dev) HIP_TRY(hipMalloc(reinterpret_cast<void **>(&ctx->model_dev), sizeof(wg_model_t)));
+  HIP_TRY(hipMemcpy(ctx->model_dev, model, sizeof(wg_model_t), hipMemcpyHostToDevice));
+  ctx->model = *model;
+  ctx->model_set = true;
   return WG_OK;
 }
 
@@ -643,21 +717,20 @@ size_t wg_mpc_tick_lds_bytes_for(const wg_model_t *model) {   // host arithmetic
   return tick_lds_for(*model, tick_view(*model));
 }
 
-size_t wg_mpc_tick_lds_bytes(void) {
-  if (!g_model_set) return 0;
-  return tick_lds_for(g_model, tick_view(g_model));
+size_t wg_mpc_tick_lds_bytes_ctx(wg_ctx_t *ctx) {
+  if (!ctx || !ctx->model_set) return 0;
+  return tick_lds_for(ctx->model, tick_view(ctx->model));
 }
 
-int wg_mpc_tick_batch_dev(int B, wg_gait_state_t *states, wg_tick_out_t *outs, int *diag, int advance_calls, int *hist,
-                          int hist_cap, int *hist_len, void *hip_stream) {
-  if (int rc = ensure_device()) return rc;
-  if (!g_model_set) return fail(WG_ERR_BAD_ARG, "wg_mpc_configure() has not been called");
+int wg_mpc_tick_batch_dev_ctx(wg_ctx_t *ctx, int B, wg_gait_state_t *states, wg_tick_out_t *outs, int *diag, int advance_calls, int *hist, int hist_cap, int *hist_len, void *hip_stream) {
+  if (int rc = use_ctx(ctx)) return rc;
+  if (!ctx->model_set) return fail(WG_ERR_BAD_ARG, "wg_mpc_configure() has not been called on this context");
   if (B < 0 || !states) return fail(WG_ERR_BAD_ARG, "bad arguments");
   if (hist && (!hist_len || hist_cap <= 0)) return fail(WG_ERR_BAD_ARG, "hist needs hist_len and hist_cap > 0");
   if (B == 0) return WG_OK;
-  const size_t qlb = tick_ql_bytes(g_model);
-  const int view = tick_view(g_model);
-  size_t lds = tick_lds_for(g_model, view);
+  const size_t qlb = tick_ql_bytes(ctx->model);
+  const int view = tick_view(ctx->model);
+  size_t lds = tick_lds_for(ctx->model, view);
   if (const char *pad = getenv("WG_TICK_LDS_PAD")) lds += (size_t)atoi(pad);   // experiments: lower the residency
   if (lds > 64 * 1024)
     HIP_TRY(hipFuncSetAttribute(view == 16  ? reinterpret_cast<const void *>(wg_mpc_tick_kernel<16>)
@@ -667,29 +740,28 @@ int wg_mpc_tick_batch_dev(int B, wg_gait_state_t *states, wg_tick_out_t *outs, i
   const int grid = B;                             // one gait per block; the dispatcher balances uneven iteration counts
   hipStream_t st = reinterpret_cast<hipStream_t>(hip_stream);
   double *zs = nullptr;
-  const size_t zslot = tick_z_slot_doubles(g_model, view);
+  const size_t zslot = tick_z_slot_doubles(ctx->model, view);
   if (tick_z_global(view) || tick16_ext(view)) {
-    std::lock_guard<std::mutex> lk(g_z_mu);       // its own lock: the host-pointer entry points hold g_mu around this call
-    if (int rc = g_tick_z.reserve((size_t)grid * zslot * 8)) return rc;
-    zs = static_cast<double *>(g_tick_z.p);
+    std::lock_guard<std::mutex> lk(ctx->z_mu);       // its own lock: the host-pointer entry points hold ctx->mu around this call
+    if (int rc = ctx->tick_z.reserve((size_t)grid * zslot * 8)) return rc;
+    zs = static_cast<double *>(ctx->tick_z.p);
   }
   if (view == 16)
-    hipLaunchKernelGGL(wg_mpc_tick_kernel<16>, dim3(grid), dim3(64), lds, st, B, g_model, g_tables_dev, states, outs, diag,
+    hipLaunchKernelGGL(wg_mpc_tick_kernel<16>, dim3(grid), dim3(64), lds, st, B, ctx->model, ctx->tables_dev, states, outs, diag,
                        advance_calls, hist, hist_cap, hist_len, (unsigned)qlb, zs, (unsigned)zslot);
   else if (view == 0)
-    hipLaunchKernelGGL(wg_mpc_tick_kernel<0>, dim3(grid), dim3(64), lds, st, B, g_model, g_tables_dev, states, outs, diag,
+    hipLaunchKernelGGL(wg_mpc_tick_kernel<0>, dim3(grid), dim3(64), lds, st, B, ctx->model, ctx->tables_dev, states, outs, diag,
                        advance_calls, hist, hist_cap, hist_len, (unsigned)qlb, zs, (unsigned)zslot);
   else
-    hipLaunchKernelGGL(wg_mpc_tick_kernel<-1>, dim3(grid), dim3(64), lds, st, B, g_model, g_tables_dev, states, outs, diag,
+    hipLaunchKernelGGL(wg_mpc_tick_kernel<-1>, dim3(grid), dim3(64), lds, st, B, ctx->model, ctx->tables_dev, states, outs, diag,
                        advance_calls, hist, hist_cap, hist_len, (unsigned)qlb, zs, (unsigned)zslot);
   HIP_TRY(hipGetLastError());
   return WG_OK;
 }
 
-int wg_mpc_run_batch_dev(int B, wg_gait_state_t *states, int n_ticks, int advance_calls, wg_tick_out_t *outs, int *diag,
-                         void *hip_stream) {
-  if (int rc = ensure_device()) return rc;
-  if (!g_model_set) return fail(WG_ERR_BAD_ARG, "wg_mpc_configure() has not been called");
+int wg_mpc_run_batch_dev_ctx(wg_ctx_t *ctx, int B, wg_gait_state_t *states, int n_ticks, int advance_calls, wg_tick_out_t *outs, int *diag, void *hip_stream) {
+  if (int rc = use_ctx(ctx)) return rc;
+  if (!ctx->model_set) return fail(WG_ERR_BAD_ARG, "wg_mpc_configure() has not been called on this context");
   if (B < 0 || n_ticks < 0 || !states) return fail(WG_ERR_BAD_ARG, "bad arguments");
   if (B == 0 || n_ticks == 0) return WG_OK;
   if ((long long)B * n_ticks > 0x3fffffffLL) return fail(WG_ERR_TOO_LARGE, "B * n_ticks = %lld work items", (long long)B * n_ticks);
@@ -701,15 +773,14 @@ int wg_mpc_run_batch_dev(int B, wg_gait_state_t *states, int n_ticks, int advanc
   int cap = 1;
   while (cap < 2 * B) cap <<= 1;                   // ring slots per XCD: a gait is in at most one ring, at most once
   {
-    std::lock_guard<std::mutex> lk(g_mu);
+    std::lock_guard<std::mutex> lk(ctx->mu);
     const size_t need = xcd_mode ? sizeof(wg_xrun_ctl) + (size_t)kXcds * cap * 8 + (size_t)B * 4
                                  : sizeof(wg_run_queue) + (size_t)(total + B) * 4;
-    if (int rc = g_run_buf.reserve(need)) return rc;
-    if (!g_run_hooked) { g_release_hooks.push_back([] { g_run_buf.release(); }); g_run_hooked = true; }
+    if (int rc = ctx->run_buf.reserve(need)) return rc;
   }
-  wg_run_queue *q = static_cast<wg_run_queue *>(g_run_buf.p);
+  wg_run_queue *q = static_cast<wg_run_queue *>(ctx->run_buf.p);
   int *ring = reinterpret_cast<int *>(q + 1), *done = ring + total;
-  wg_xrun_ctl *xctl = static_cast<wg_xrun_ctl *>(g_run_buf.p);
+  wg_xrun_ctl *xctl = static_cast<wg_xrun_ctl *>(ctx->run_buf.p);
   unsigned long long *xrings = reinterpret_cast<unsigned long long *>(xctl + 1);
   int *xdone = reinterpret_cast<int *>(xrings + (size_t)kXcds * cap);
   if (xcd_mode) {
@@ -717,9 +788,9 @@ int wg_mpc_run_batch_dev(int B, wg_gait_state_t *states, int n_ticks, int advanc
     hipLaunchKernelGGL(wg_xrun_init_kernel, dim3((items + 255) / 256), dim3(256), 0, st, B, xctl, xrings, cap, xdone);
   } else
     hipLaunchKernelGGL(wg_run_queue_init_kernel, dim3((total + 255) / 256), dim3(256), 0, st, B, total, q, ring, done);
-  const size_t qlb = tick_ql_bytes(g_model);
-  const int view = tick_view(g_model);
-  const size_t lds = tick_lds_for(g_model, view);
+  const size_t qlb = tick_ql_bytes(ctx->model);
+  const int view = tick_view(ctx->model);
+  const size_t lds = tick_lds_for(ctx->model, view);
   if (lds > 64 * 1024) {
     HIP_TRY(hipFuncSetAttribute(view == 16  ? reinterpret_cast<const void *>(wg_mpc_run_kernel<16>)
                                 : view == 0 ? reinterpret_cast<const void *>(wg_mpc_run_kernel<0>)
@@ -734,62 +805,61 @@ int wg_mpc_run_batch_dev(int B, wg_gait_state_t *states, int n_ticks, int advanc
   int per_cu = 128 / (int)((lds + 1279) / 1280);
   if (per_cu > 8) per_cu = 8;
   if (per_cu < 1) per_cu = 1;
-  int grid = g_num_cu * per_cu;
+  int grid = ctx->num_cu * per_cu;
   if (grid > B) grid = B;
   double *zs = nullptr;
-  const size_t zslot = tick_z_slot_doubles(g_model, view);
+  const size_t zslot = tick_z_slot_doubles(ctx->model, view);
   if (tick_z_global(view) || tick16_ext(view)) {
-    std::lock_guard<std::mutex> lk(g_z_mu);       // its own lock: the host-pointer entry points hold g_mu around this call
-    if (int rc = g_tick_z.reserve((size_t)grid * zslot * 8)) return rc;
-    zs = static_cast<double *>(g_tick_z.p);
+    std::lock_guard<std::mutex> lk(ctx->z_mu);       // its own lock: the host-pointer entry points hold ctx->mu around this call
+    if (int rc = ctx->tick_z.reserve((size_t)grid * zslot * 8)) return rc;
+    zs = static_cast<double *>(ctx->tick_z.p);
   }
   if (xcd_mode) {
     if (view == 16)
-      hipLaunchKernelGGL(wg_mpc_run_xcd_kernel<16>, dim3(grid), dim3(64), lds, st, B, n_ticks, g_model_dev, g_tables_dev, states,
+      hipLaunchKernelGGL(wg_mpc_run_xcd_kernel<16>, dim3(grid), dim3(64), lds, st, B, n_ticks, ctx->model_dev, ctx->tables_dev, states,
                          outs, diag, advance_calls, xctl, xrings, cap, xdone, (unsigned)qlb, zs, (unsigned)zslot);
     else if (view == 0)
-      hipLaunchKernelGGL(wg_mpc_run_xcd_kernel<0>, dim3(grid), dim3(64), lds, st, B, n_ticks, g_model_dev, g_tables_dev, states,
+      hipLaunchKernelGGL(wg_mpc_run_xcd_kernel<0>, dim3(grid), dim3(64), lds, st, B, n_ticks, ctx->model_dev, ctx->tables_dev, states,
                          outs, diag, advance_calls, xctl, xrings, cap, xdone, (unsigned)qlb, zs, (unsigned)zslot);
     else
-      hipLaunchKernelGGL(wg_mpc_run_xcd_kernel<-1>, dim3(grid), dim3(64), lds, st, B, n_ticks, g_model_dev, g_tables_dev, states,
+      hipLaunchKernelGGL(wg_mpc_run_xcd_kernel<-1>, dim3(grid), dim3(64), lds, st, B, n_ticks, ctx->model_dev, ctx->tables_dev, states,
                          outs, diag, advance_calls, xctl, xrings, cap, xdone, (unsigned)qlb, zs, (unsigned)zslot);
   } else if (view == 16)
-    hipLaunchKernelGGL(wg_mpc_run_kernel<16>, dim3(grid), dim3(64), lds, st, B, n_ticks, g_model_dev, g_tables_dev, states, outs,
+    hipLaunchKernelGGL(wg_mpc_run_kernel<16>, dim3(grid), dim3(64), lds, st, B, n_ticks, ctx->model_dev, ctx->tables_dev, states, outs,
                        diag, advance_calls, q, ring, done, (unsigned)qlb, zs, (unsigned)zslot);
   else if (view == 0)
-    hipLaunchKernelGGL(wg_mpc_run_kernel<0>, dim3(grid), dim3(64), lds, st, B, n_ticks, g_model_dev, g_tables_dev, states, outs,
+    hipLaunchKernelGGL(wg_mpc_run_kernel<0>, dim3(grid), dim3(64), lds, st, B, n_ticks, ctx->model_dev, ctx->tables_dev, states, outs,
                        diag, advance_calls, q, ring, done, (unsigned)qlb, zs, (unsigned)zslot);
   else
-    hipLaunchKernelGGL(wg_mpc_run_kernel<-1>, dim3(grid), dim3(64), lds, st, B, n_ticks, g_model_dev, g_tables_dev, states, outs,
+    hipLaunchKernelGGL(wg_mpc_run_kernel<-1>, dim3(grid), dim3(64), lds, st, B, n_ticks, ctx->model_dev, ctx->tables_dev, states, outs,
                        diag, advance_calls, q, ring, done, (unsigned)qlb, zs, (unsigned)zslot);
   HIP_TRY(hipGetLastError());
   return WG_OK;
 }
 
-int wg_mpc_tick_batch(int B, wg_gait_state_t *states, wg_tick_out_t *outs, int *diag, int advance_calls, int *hist,
-                      int hist_cap, int *hist_len) {
-  if (int rc = ensure_device()) return rc;
-  if (!g_model_set) return fail(WG_ERR_BAD_ARG, "wg_mpc_configure() has not been called");
+int wg_mpc_tick_batch_ctx(wg_ctx_t *ctx, int B, wg_gait_state_t *states, wg_tick_out_t *outs, int *diag, int advance_calls, int *hist, int hist_cap, int *hist_len) {
+  if (int rc = use_ctx(ctx)) return rc;
+  if (!ctx->model_set) return fail(WG_ERR_BAD_ARG, "wg_mpc_configure() has not been called on this context");
   if (B < 0 || !states) return fail(WG_ERR_BAD_ARG, "bad arguments");
   if (B == 0) return WG_OK;
-  std::lock_guard<std::mutex> lk(g_mu);
+  std::lock_guard<std::mutex> lk(ctx->mu);
   const size_t sB = (size_t)B;
-  if (int rc = g_tick_state.reserve(sB * sizeof(wg_gait_state_t))) return rc;
-  if (outs) if (int rc = g_tick_out.reserve(sB * sizeof(wg_tick_out_t))) return rc;
+  if (int rc = ctx->tick_state.reserve(sB * sizeof(wg_gait_state_t))) return rc;
+  if (outs) if (int rc = ctx->tick_out.reserve(sB * sizeof(wg_tick_out_t))) return rc;
   const size_t aux_bytes = sB * 6 * 4 + (hist ? sB * hist_cap * 4 + sB * 4 : 0);
-  if (int rc = g_tick_aux.reserve(aux_bytes)) return rc;
-  HIP_TRY(hipMemcpy(g_tick_state.p, states, sB * sizeof(wg_gait_state_t), hipMemcpyHostToDevice));
-  int *d_diag = static_cast<int *>(g_tick_aux.p);
+  if (int rc = ctx->tick_aux.reserve(aux_bytes)) return rc;
+  HIP_TRY(hipMemcpy(ctx->tick_state.p, states, sB * sizeof(wg_gait_state_t), hipMemcpyHostToDevice));
+  int *d_diag = static_cast<int *>(ctx->tick_aux.p);
   int *d_hist = hist ? d_diag + sB * 6 : nullptr;
   int *d_hlen = hist ? d_hist + sB * hist_cap : nullptr;
-  HIP_TRY(hipMemset(g_tick_aux.p, 0, aux_bytes));
-  int rc = wg_mpc_tick_batch_dev(B, static_cast<wg_gait_state_t *>(g_tick_state.p),
-                                 outs ? static_cast<wg_tick_out_t *>(g_tick_out.p) : nullptr, d_diag, advance_calls,
+  HIP_TRY(hipMemset(ctx->tick_aux.p, 0, aux_bytes));
+  int rc = wg_mpc_tick_batch_dev_ctx(ctx, B, static_cast<wg_gait_state_t *>(ctx->tick_state.p),
+                                 outs ? static_cast<wg_tick_out_t *>(ctx->tick_out.p) : nullptr, d_diag, advance_calls,
                                  d_hist, hist_cap, d_hlen, nullptr);
   if (rc) return rc;
   HIP_TRY(hipDeviceSynchronize());
-  HIP_TRY(hipMemcpy(states, g_tick_state.p, sB * sizeof(wg_gait_state_t), hipMemcpyDeviceToHost));
-  if (outs) HIP_TRY(hipMemcpy(outs, g_tick_out.p, sB * sizeof(wg_tick_out_t), hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(states, ctx->tick_state.p, sB * sizeof(wg_gait_state_t), hipMemcpyDeviceToHost));
+  if (outs) HIP_TRY(hipMemcpy(outs, ctx->tick_out.p, sB * sizeof(wg_tick_out_t), hipMemcpyDeviceToHost));
   if (diag) HIP_TRY(hipMemcpy(diag, d_diag, sB * 6 * 4, hipMemcpyDeviceToHost));
   if (hist) {
     HIP_TRY(hipMemcpy(hist, d_hist, sB * hist_cap * 4, hipMemcpyDeviceToHost));
@@ -798,8 +868,8 @@ int wg_mpc_tick_batch(int B, wg_gait_state_t *states, wg_tick_out_t *outs, int *
   return WG_OK;
 }
 
-int wg_mpc_set_velref_dev(int B, wg_gait_state_t *states, const double *vref, void *hip_stream) {
-  if (int rc = ensure_device()) return rc;
+int wg_mpc_set_velref_dev_ctx(wg_ctx_t *ctx, int B, wg_gait_state_t *states, const double *vref, void *hip_stream) {
+  if (int rc = use_ctx(ctx)) return rc;
   if (B < 0 || !states || !vref) return fail(WG_ERR_BAD_ARG, "bad arguments");
   if (B == 0) return WG_OK;
   hipLaunchKernelGGL(wg_set_velref_kernel, dim3((B + 255) / 256), dim3(256), 0, reinterpret_cast<hipStream_t>(hip_stream),
@@ -811,7 +881,6 @@ int wg_mpc_set_velref_dev(int B, wg_gait_state_t *states, const double *vref, vo
 }  // extern "C"
 
 // ---- PLDP / OptCholesky back-end -----------------------------------------------------------------------------------
-#include "wg_pldp_device.hpp"
 
 __global__ void __launch_bounds__(64)
 wg_pldp_kernel(int B, int mcap, const wg::PldpModel *__restrict__ model, const int *__restrict__ m,
@@ -837,21 +906,16 @@ wg_pldp_kernel(int B, int mcap, const wg::PldpModel *__restrict__ model, const i
   }
 }
 
-namespace {
-wg::PldpModel *g_pldp_dev = nullptr;
-int g_pldp_N = 0;
-DevBuf g_pldp_buf;
-}  // namespace
-
 extern "C" {
 
 size_t wg_pldp_lds_bytes(void) { return wg::PldpLds::bytes(WG_PLDP_MMAX); }
 
-int wg_pldp_configure(int N, const double *iPu, const double *Px, const double *Pu) {
-  if (int rc = ensure_device()) return rc;
+int wg_pldp_configure_ctx(wg_ctx_t *ctx, int N, const double *iPu, const double *Px, const double *Pu) {
+  if (int rc = use_ctx(ctx)) return rc;
   if (N < 1 || N > WG_PLDP_N || !iPu || !Px || !Pu) return fail(WG_ERR_BAD_ARG, "wg_pldp_configure: 1 <= N <= %d", WG_PLDP_N);
-  static wg::PldpModel host;
-  std::lock_guard<std::mutex> lk(g_mu);
+  std::unique_ptr<wg::PldpModel> host_p(new wg::PldpModel);
+  wg::PldpModel &host = *host_p;
+  std::lock_guard<std::mutex> lk(ctx->mu);
   memset(&host, 0, sizeof host);
   host.N = N;
   memcpy(host.iPu, iPu, sizeof(double) * N * N);
@@ -865,25 +929,15 @@ int wg_pldp_configure(int N, const double *iPu, const double *Px, const double *
       host.iPuPx[i * 6 + j] = s;
       host.iPuPx[(i + N) * 6 + j + 3] = s;
     }
-  if (!g_pldp_dev) {
-    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&g_pldp_dev), sizeof(wg::PldpModel)));
-    g_release_hooks.push_back([] {
-      if (g_pldp_dev) (void)hipFree(g_pldp_dev);
-      g_pldp_dev = nullptr; g_pldp_N = 0;
-      g_pldp_buf.release();
-    });
-  }
-  HIP_TRY(hipMemcpy(g_pldp_dev, &host, sizeof host, hipMemcpyHostToDevice));
-  g_pldp_N = N;
+  if (!ctx->pldp_dev) HIP_TRY(hipMalloc(reinterpret_cast<void **>(&ctx->pldp_dev), sizeof(wg::PldpModel)));
+  HIP_TRY(hipMemcpy(ctx->pldp_dev, &host, sizeof host, hipMemcpyHostToDevice));
+  ctx->pldp_N = N;
   return WG_OK;
 }
 
-int wg_pldp_solve_batch_dev(int B, int mcap, const int *m, const double *D, const double *A, const double *b,
-                            const double *zmpref, const double *xkyk, const int *similar, const int *n_removed,
-                            const int *starting, int max_iter, wg_pldp_state_t *states, double *X, int *ret, int *n_iter,
-                            int *active, int *n_active, void *hip_stream) {
-  if (int rc = ensure_device()) return rc;
-  if (!g_pldp_N) return fail(WG_ERR_BAD_ARG, "wg_pldp_configure() has not been called");
+int wg_pldp_solve_batch_dev_ctx(wg_ctx_t *ctx, int B, int mcap, const int *m, const double *D, const double *A, const double *b, const double *zmpref, const double *xkyk, const int *similar, const int *n_removed, const int *starting, int max_iter, wg_pldp_state_t *states, double *X, int *ret, int *n_iter, int *active, int *n_active, void *hip_stream) {
+  if (int rc = use_ctx(ctx)) return rc;
+  if (!ctx->pldp_N) return fail(WG_ERR_BAD_ARG, "wg_pldp_configure() has not been called on this context");
   if (B < 0 || mcap < 1 || mcap > WG_PLDP_MMAX) return fail(WG_ERR_BAD_ARG, "need 1 <= mcap <= %d", WG_PLDP_MMAX);
   if (!m || !D || !A || !b || !zmpref || !xkyk || !similar || !n_removed || !starting || !states || !X || !ret)
     return fail(WG_ERR_BAD_ARG, "null argument");
@@ -900,31 +954,28 @@ int wg_pldp_solve_batch_dev(int B, int mcap, const int *m, const double *D, cons
                                 (int)lds));
   const int grid = B;
   hipLaunchKernelGGL(wg_pldp_kernel, dim3(grid), dim3(64), lds, reinterpret_cast<hipStream_t>(hip_stream), B, mcap,
-                     g_pldp_dev, m, D, A, b, zmpref, xkyk, similar, n_removed, starting, max_iter, states, X, ret, n_iter,
+                     ctx->pldp_dev, m, D, A, b, zmpref, xkyk, similar, n_removed, starting, max_iter, states, X, ret, n_iter,
                      active, n_active, a_in_lds);
   HIP_TRY(hipGetLastError());
   return WG_OK;
 }
 
-int wg_pldp_solve_batch(int B, int mcap, const int *m, const double *D, const double *A, const double *b,
-                        const double *zmpref, const double *xkyk, const int *similar, const int *n_removed,
-                        const int *starting, int max_iter, wg_pldp_state_t *states, double *X, int *ret, int *n_iter,
-                        int *active, int *n_active) {
-  if (int rc = ensure_device()) return rc;
-  if (!g_pldp_N) return fail(WG_ERR_BAD_ARG, "wg_pldp_configure() has not been called");
+int wg_pldp_solve_batch_ctx(wg_ctx_t *ctx, int B, int mcap, const int *m, const double *D, const double *A, const double *b, const double *zmpref, const double *xkyk, const int *similar, const int *n_removed, const int *starting, int max_iter, wg_pldp_state_t *states, double *X, int *ret, int *n_iter, int *active, int *n_active) {
+  if (int rc = use_ctx(ctx)) return rc;
+  if (!ctx->pldp_N) return fail(WG_ERR_BAD_ARG, "wg_pldp_configure() has not been called on this context");
   if (B < 0 || mcap < 1 || mcap > WG_PLDP_MMAX) return fail(WG_ERR_BAD_ARG, "need 1 <= mcap <= %d", WG_PLDP_MMAX);
   if (!m || !D || !A || !b || !zmpref || !xkyk || !similar || !n_removed || !starting || !states || !X || !ret)
     return fail(WG_ERR_BAD_ARG, "null argument");
   if (B == 0) return WG_OK;
-  std::lock_guard<std::mutex> lk(g_mu);
-  const size_t sB = (size_t)B, n = 2 * (size_t)g_pldp_N;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  const size_t sB = (size_t)B, n = 2 * (size_t)ctx->pldp_N;
   const size_t aslot = (size_t)(mcap + 1) * n;
   // one arena: doubles first, then the state structs (8-byte aligned), then ints
   const size_t nd = sB * (n /*D*/ + aslot + mcap /*b*/ + n /*zmpref*/ + 6 + n /*X*/);
   const size_t ni = sB * (1 /*m*/ + mcap /*similar*/ + 1 + 1 /*n_removed starting*/ + 1 + 1 /*ret n_iter*/ + mcap + 1 /*active n_active*/);
   const size_t bytes = nd * 8 + sB * sizeof(wg_pldp_state_t) + ni * 4;
-  if (int rc = g_pldp_buf.reserve(bytes)) return rc;
-  double *dD = static_cast<double *>(g_pldp_buf.p), *dA = dD + sB * n, *db = dA + sB * aslot, *dz = db + sB * mcap,
+  if (int rc = ctx->pldp_buf.reserve(bytes)) return rc;
+  double *dD = static_cast<double *>(ctx->pldp_buf.p), *dA = dD + sB * n, *db = dA + sB * aslot, *dz = db + sB * mcap,
          *dx = dz + sB * n, *dX = dx + sB * 6;
   wg_pldp_state_t *dst = reinterpret_cast<wg_pldp_state_t *>(dX + sB * n);
   int *dm = reinterpret_cast<int *>(dst + sB), *dsim = dm + sB, *dnr = dsim + sB * mcap, *dstart = dnr + sB,
@@ -940,7 +991,7 @@ int wg_pldp_solve_batch(int B, int mcap, const int *m, const double *D, const do
   HIP_TRY(hipMemcpy(dnr, n_removed, sB * 4, hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(dstart, starting, sB * 4, hipMemcpyHostToDevice));
   HIP_TRY(hipMemset(dret, 0, sB * (3 + mcap) * 4));
-  int rc = wg_pldp_solve_batch_dev(B, mcap, dm, dD, dA, db, dz, dx, dsim, dnr, dstart, max_iter, dst, dX, dret, dit, dact,
+  int rc = wg_pldp_solve_batch_dev_ctx(ctx, B, mcap, dm, dD, dA, db, dz, dx, dsim, dnr, dstart, max_iter, dst, dX, dret, dit, dact,
                                    dnact, nullptr);
   if (rc) return rc;
   HIP_TRY(hipDeviceSynchronize());
@@ -956,7 +1007,6 @@ int wg_pldp_solve_batch(int B, int mcap, const int *m, const double *D, const do
 }  // extern "C"
 
 // ---- Dimitrov-2008 tick around PLDP ------------------------------------------------------------------------------------
-#include "wg_dimitrov_device.hpp"
 
 __global__ void __launch_bounds__(64)
 wg_dimitrov_tick_kernel(int B, const wg::DimitrovConst *__restrict__ K, const wg_zmp_polytope_t *__restrict__ polys,
@@ -968,10 +1018,6 @@ wg_dimitrov_tick_kernel(int B, const wg::DimitrovConst *__restrict__ K, const wg
 }
 
 namespace {
-wg::DimitrovConst *g_dim_dev = nullptr;
-wg::DimitrovConst g_dim_host;
-bool g_dim_set = false;
-DevBuf g_dim_buf;
 inline size_t dimitrov_lds_bytes() {
   return wg::PldpLds::bytes(WG_PLDP_MMAX, wg::kDimitrovActiveCap, true) + (4 * 2 * WG_PLDP_N + 8) * 8 +
          ((WG_PLDP_N + 1) * 4 + 15) / 16 * 16;
@@ -986,47 +1032,42 @@ void wg_dimitrov_defaults(wg_dimitrov_model_t *m) {      // ZMPConstrainedQPFast
   m->N = 16; m->T = 0.1; m->Tctrl = 0.005; m->com_height = 0.80; m->alpha = 200.0; m->beta = 1000.0;
 }
 
-int wg_dimitrov_configure(const wg_dimitrov_model_t *model) {
-  if (int rc = ensure_device()) return rc;
+int wg_dimitrov_configure_ctx(wg_ctx_t *ctx, const wg_dimitrov_model_t *model) {
+  if (int rc = use_ctx(ctx)) return rc;
   if (!model) return fail(WG_ERR_BAD_ARG, "null model");
   if (model->N < 1 || model->N > WG_PLDP_N) return fail(WG_ERR_BAD_ARG, "N=%d outside [1,%d]", model->N, WG_PLDP_N);
   if (!(model->T > 0.0) || !(model->Tctrl > 0.0) || (int)(model->T / model->Tctrl) != WG_SAMPLES_PER_TICK)
     return fail(WG_ERR_BAD_ARG, "T/Tctrl must be %d", WG_SAMPLES_PER_TICK);
   {
-    std::lock_guard<std::mutex> lk(g_mu);
-    if (!wg::DimitrovHost::build(*model, g_dim_host))
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    if (!ctx->dim_host) ctx->dim_host.reset(new wg::DimitrovConst);
+    ctx->dim_set = false;
+    if (!wg::DimitrovHost::build(*model, (*ctx->dim_host)))
       return fail(WG_ERR_BAD_ARG, "the LQ factor or the inverse of Pu does not exist for this model");
-    if (!g_dim_dev) {
-      HIP_TRY(hipMalloc(reinterpret_cast<void **>(&g_dim_dev), sizeof(wg::DimitrovConst)));
-      g_release_hooks.push_back([] {
-        if (g_dim_dev) (void)hipFree(g_dim_dev);
-        g_dim_dev = nullptr; g_dim_set = false;
-        g_dim_buf.release();
-      });
-    }
-    HIP_TRY(hipMemcpy(g_dim_dev, &g_dim_host, sizeof g_dim_host, hipMemcpyHostToDevice));
-    g_dim_set = true;
+    if (!ctx->dim_dev) HIP_TRY(hipMalloc(reinterpret_cast<void **>(&ctx->dim_dev), sizeof(wg::DimitrovConst)));
+    HIP_TRY(hipMemcpy(ctx->dim_dev, &(*ctx->dim_host), sizeof (*ctx->dim_host), hipMemcpyHostToDevice));
+    ctx->dim_set = true;
   }
   // the PLDPSolver constructor of the reference (:104-109): same iPu, Px, Pu
-  return wg_pldp_configure(model->N, g_dim_host.pldp.iPu, g_dim_host.pldp.Px, g_dim_host.pldp.Pu);
+  return wg_pldp_configure_ctx(ctx, model->N, (*ctx->dim_host).pldp.iPu, (*ctx->dim_host).pldp.Px, (*ctx->dim_host).pldp.Pu);
 }
 
-int wg_dimitrov_get_constants(double *iLQ, double *OptB, double *OptC, double *Pu, double *iPu, double *Px) {
-  if (!g_dim_set) return fail(WG_ERR_BAD_ARG, "wg_dimitrov_configure() has not been called");
-  const size_t N = (size_t)g_dim_host.N, n = 2 * N;
-  if (iLQ) memcpy(iLQ, g_dim_host.iLQ, 8 * n * n);
-  if (OptB) memcpy(OptB, g_dim_host.OptB, 8 * n * 6);
-  if (OptC) memcpy(OptC, g_dim_host.OptC, 8 * n * n);
-  if (Pu) memcpy(Pu, g_dim_host.pldp.Pu, 8 * N * N);
-  if (iPu) memcpy(iPu, g_dim_host.pldp.iPu, 8 * N * N);
-  if (Px) memcpy(Px, g_dim_host.pldp.Px, 8 * N * 3);
+int wg_dimitrov_get_constants_ctx(wg_ctx_t *ctx, double *iLQ, double *OptB, double *OptC, double *Pu, double *iPu, double *Px) {
+  if (!ctx) return fail(WG_ERR_BAD_ARG, "null context");
+  if (!ctx->dim_set) return fail(WG_ERR_BAD_ARG, "wg_dimitrov_configure() has not been called on this context");
+  const size_t N = (size_t)(*ctx->dim_host).N, n = 2 * N;
+  if (iLQ) memcpy(iLQ, (*ctx->dim_host).iLQ, 8 * n * n);
+  if (OptB) memcpy(OptB, (*ctx->dim_host).OptB, 8 * n * 6);
+  if (OptC) memcpy(OptC, (*ctx->dim_host).OptC, 8 * n * n);
+  if (Pu) memcpy(Pu, (*ctx->dim_host).pldp.Pu, 8 * N * N);
+  if (iPu) memcpy(iPu, (*ctx->dim_host).pldp.iPu, 8 * N * N);
+  if (Px) memcpy(Px, (*ctx->dim_host).pldp.Px, 8 * N * 3);
   return WG_OK;
 }
 
-int wg_dimitrov_tick_batch_dev(int B, const wg_zmp_polytope_t *polys, wg_dimitrov_state_t *states,
-                               wg_dimitrov_out_t *outs, int max_iter, void *hip_stream) {
-  if (int rc = ensure_device()) return rc;
-  if (!g_dim_set) return fail(WG_ERR_BAD_ARG, "wg_dimitrov_configure() has not been called");
+int wg_dimitrov_tick_batch_dev_ctx(wg_ctx_t *ctx, int B, const wg_zmp_polytope_t *polys, wg_dimitrov_state_t *states, wg_dimitrov_out_t *outs, int max_iter, void *hip_stream) {
+  if (int rc = use_ctx(ctx)) return rc;
+  if (!ctx->dim_set) return fail(WG_ERR_BAD_ARG, "wg_dimitrov_configure() has not been called on this context");
   if (B < 0 || !polys || !states) return fail(WG_ERR_BAD_ARG, "bad arguments");
   if (B == 0) return WG_OK;
   const size_t lds = dimitrov_lds_bytes();
@@ -1035,30 +1076,29 @@ int wg_dimitrov_tick_batch_dev(int B, const wg_zmp_polytope_t *polys, wg_dimitro
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   const int grid = B;
   hipLaunchKernelGGL(wg_dimitrov_tick_kernel, dim3(grid), dim3(64), lds, reinterpret_cast<hipStream_t>(hip_stream), B,
-                     g_dim_dev, polys, states, outs, max_iter);
+                     ctx->dim_dev, polys, states, outs, max_iter);
   HIP_TRY(hipGetLastError());
   return WG_OK;
 }
 
-int wg_dimitrov_tick_batch(int B, const wg_zmp_polytope_t *polys, wg_dimitrov_state_t *states, wg_dimitrov_out_t *outs,
-                           int max_iter) {
-  if (int rc = ensure_device()) return rc;
-  if (!g_dim_set) return fail(WG_ERR_BAD_ARG, "wg_dimitrov_configure() has not been called");
+int wg_dimitrov_tick_batch_ctx(wg_ctx_t *ctx, int B, const wg_zmp_polytope_t *polys, wg_dimitrov_state_t *states, wg_dimitrov_out_t *outs, int max_iter) {
+  if (int rc = use_ctx(ctx)) return rc;
+  if (!ctx->dim_set) return fail(WG_ERR_BAD_ARG, "wg_dimitrov_configure() has not been called on this context");
   if (B < 0 || !polys || !states) return fail(WG_ERR_BAD_ARG, "bad arguments");
   if (B == 0) return WG_OK;
-  std::lock_guard<std::mutex> lk(g_mu);
-  const size_t sB = (size_t)B, N = (size_t)g_dim_host.N;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  const size_t sB = (size_t)B, N = (size_t)(*ctx->dim_host).N;
   const size_t pb = sB * N * sizeof(wg_zmp_polytope_t), sb = sB * sizeof(wg_dimitrov_state_t),
                ob = outs ? sB * sizeof(wg_dimitrov_out_t) : 0;
-  if (int rc = g_dim_buf.reserve(pb + sb + ob)) return rc;
-  unsigned char *base = static_cast<unsigned char *>(g_dim_buf.p);
+  if (int rc = ctx->dim_buf.reserve(pb + sb + ob)) return rc;
+  unsigned char *base = static_cast<unsigned char *>(ctx->dim_buf.p);
   wg_zmp_polytope_t *dp = reinterpret_cast<wg_zmp_polytope_t *>(base);
   wg_dimitrov_state_t *ds = reinterpret_cast<wg_dimitrov_state_t *>(base + pb);
   wg_dimitrov_out_t *dout = outs ? reinterpret_cast<wg_dimitrov_out_t *>(base + pb + sb) : nullptr;
   HIP_TRY(hipMemcpy(dp, polys, pb, hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(ds, states, sb, hipMemcpyHostToDevice));
   if (dout) HIP_TRY(hipMemset(dout, 0, ob));
-  int rc = wg_dimitrov_tick_batch_dev(B, dp, ds, dout, max_iter, nullptr);
+  int rc = wg_dimitrov_tick_batch_dev_ctx(ctx, B, dp, ds, dout, max_iter, nullptr);
   if (rc) return rc;
   HIP_TRY(hipDeviceSynchronize());
   HIP_TRY(hipMemcpy(states, ds, sb, hipMemcpyDeviceToHost));
@@ -1069,48 +1109,32 @@ int wg_dimitrov_tick_batch(int B, const wg_zmp_polytope_t *polys, wg_dimitrov_st
 }  // extern "C"
 
 // ---- Kajita stage-1 preview control -------------------------------------------------------------------------------------
-#include "wg_preview_device.hpp"
-
-namespace {
-wg::PreviewConst g_prev;
-double *g_prev_F = nullptr;          // device copy of the window gains
-bool g_prev_set = false;
-DevBuf g_prev_buf;
-}  // namespace
 
 extern "C" {
 
-int wg_preview_configure(const wg_preview_gains_t *gains, const double *F) {
-  if (int rc = ensure_device()) return rc;
+int wg_preview_configure_ctx(wg_ctx_t *ctx, const wg_preview_gains_t *gains, const double *F) {
+  if (int rc = use_ctx(ctx)) return rc;
   if (!gains || !F) return fail(WG_ERR_BAD_ARG, "null argument");
   if (gains->nl < 1 || gains->nl > WG_PREVIEW_NL_MAX) return fail(WG_ERR_BAD_ARG, "need 1 <= nl <= %d", WG_PREVIEW_NL_MAX);
   if (!(gains->T > 0.0)) return fail(WG_ERR_BAD_ARG, "sampling period must be positive");
-  std::lock_guard<std::mutex> lk(g_mu);
-  if (!g_prev_F) {
-    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&g_prev_F), sizeof(double) * WG_PREVIEW_NL_MAX));
-    g_release_hooks.push_back([] {
-      if (g_prev_F) (void)hipFree(g_prev_F);
-      g_prev_F = nullptr; g_prev_set = false;
-      g_prev_buf.release();
-    });
-  }
-  HIP_TRY(hipMemcpy(g_prev_F, F, sizeof(double) * gains->nl, hipMemcpyHostToDevice));
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  if (!ctx->prev_F) HIP_TRY(hipMalloc(reinterpret_cast<void **>(&ctx->prev_F), sizeof(double) * WG_PREVIEW_NL_MAX));
+  HIP_TRY(hipMemcpy(ctx->prev_F, F, sizeof(double) * gains->nl, hipMemcpyHostToDevice));
   const double T = gains->T;                                   // PreviewControl.cpp:203-214
-  g_prev.A01 = T; g_prev.A02 = T * T / 2.0; g_prev.A12 = T;
-  g_prev.B0 = T * T * T / 6.0; g_prev.B1 = T * T / 2.0; g_prev.B2 = T;
-  g_prev.C2 = -gains->zc / 9.81;
-  g_prev.Kx0 = gains->Kx[0]; g_prev.Kx1 = gains->Kx[1]; g_prev.Kx2 = gains->Kx[2]; g_prev.Ks = gains->Ks;
-  g_prev.nl = gains->nl;
-  g_prev_set = true;
+  ctx->prev.A01 = T; ctx->prev.A02 = T * T / 2.0; ctx->prev.A12 = T;
+  ctx->prev.B0 = T * T * T / 6.0; ctx->prev.B1 = T * T / 2.0; ctx->prev.B2 = T;
+  ctx->prev.C2 = -gains->zc / 9.81;
+  ctx->prev.Kx0 = gains->Kx[0]; ctx->prev.Kx1 = gains->Kx[1]; ctx->prev.Kx2 = gains->Kx[2]; ctx->prev.Ks = gains->Ks;
+  ctx->prev.nl = gains->nl;
+  ctx->prev_set = true;
   return WG_OK;
 }
 
-int wg_preview_window(void) { return g_prev_set ? g_prev.nl : 0; }
+int wg_preview_window_ctx(wg_ctx_t *ctx) { return (ctx && ctx->prev_set) ? ctx->prev.nl : 0; }
 
-int wg_preview_run_batch_dev(int B, int L, const double *zmp_x_tm, const double *zmp_y_tm, double *state, double *com_tm,
-                             double *zmp2_tm, int simulation, void *hip_stream) {
-  if (int rc = ensure_device()) return rc;
-  if (!g_prev_set) return fail(WG_ERR_BAD_ARG, "wg_preview_configure() has not been called");
+int wg_preview_run_batch_dev_ctx(wg_ctx_t *ctx, int B, int L, const double *zmp_x_tm, const double *zmp_y_tm, double *state, double *com_tm, double *zmp2_tm, int simulation, void *hip_stream) {
+  if (int rc = use_ctx(ctx)) return rc;
+  if (!ctx->prev_set) return fail(WG_ERR_BAD_ARG, "wg_preview_configure() has not been called on this context");
   if (B < 0 || L < 0 || !zmp_x_tm || !zmp_y_tm || !state) return fail(WG_ERR_BAD_ARG, "bad arguments");
   if (B == 0 || L == 0) return WG_OK;
   hipStream_t st = reinterpret_cast<hipStream_t>(hip_stream);
@@ -1118,28 +1142,28 @@ int wg_preview_run_batch_dev(int B, int L, const double *zmp_x_tm, const double 
   // The ring kernel keeps one wave per CU (its window fills the LDS): it wins while the batch is too small to give every
   // SIMD several waves of the L2 kernel (measured: B = 4096: 0.62 vs 0.43 G gait-steps/s; B = 32768: 1.18 vs 1.50), and
   // a few steps do not repay filling the ring.
-  const bool ring = force ? force[0] == 'r' : (L >= 8 && (long long)B * 2 <= (long long)g_num_cu * 64 * 2);
+  const bool ring = force ? force[0] == 'r' : (L >= 8 && (long long)B * 2 <= (long long)ctx->num_cu * 64 * 2);
   // The split-chain kernel (eight lanes per gait-axis, nothing re-read) covers the standard window sizes and wins at every
   // batch size measured; other windows, and runs too short to repay filling its rings, use the kernels below.
   constexpr int kSplitK = 8;
   int splitT = 0;                                              // smallest instantiated T with K T >= nl
   for (int t : {16, 24, 32, 40, 48})
-    if (!splitT && kSplitK * t >= g_prev.nl) splitT = t;
-  const bool can_split = splitT != 0 && g_prev.nl >= 64;
+    if (!splitT && kSplitK * t >= ctx->prev.nl) splitT = t;
+  const bool can_split = splitT != 0 && ctx->prev.nl >= 64;
   const bool split = force ? (force[0] == 's' && can_split) : (can_split && L >= 4);
   if (split) {
     const int per_wave = 64 / kSplitK;
     const dim3 grid((B + per_wave - 1) / per_wave, 2);
     const size_t lds = (size_t)splitT * 64 * 8;
-    const bool full = g_prev.nl % splitT == 0;
+    const bool full = ctx->prev.nl % splitT == 0;
 #define WG_SPLIT_LAUNCH(TT)                                                                                              \
     do {                                                                                                                 \
       if (full)                                                                                                          \
-        hipLaunchKernelGGL((wg::wg_preview_split_kernel<TT, kSplitK, true>), grid, dim3(64), lds, st, B, L, g_prev,      \
-                           g_prev_F, zmp_x_tm, zmp_y_tm, state, com_tm, zmp2_tm, simulation);                            \
+        hipLaunchKernelGGL((wg::wg_preview_split_kernel<TT, kSplitK, true>), grid, dim3(64), lds, st, B, L, ctx->prev,      \
+                           ctx->prev_F, zmp_x_tm, zmp_y_tm, state, com_tm, zmp2_tm, simulation);                            \
       else                                                                                                               \
-        hipLaunchKernelGGL((wg::wg_preview_split_kernel<TT, kSplitK, false>), grid, dim3(64), lds, st, B, L, g_prev,     \
-                           g_prev_F, zmp_x_tm, zmp_y_tm, state, com_tm, zmp2_tm, simulation);                            \
+        hipLaunchKernelGGL((wg::wg_preview_split_kernel<TT, kSplitK, false>), grid, dim3(64), lds, st, B, L, ctx->prev,     \
+                           ctx->prev_F, zmp_x_tm, zmp_y_tm, state, com_tm, zmp2_tm, simulation);                            \
     } while (0)
     switch (splitT) {
       case 16: WG_SPLIT_LAUNCH(16); break;
@@ -1150,36 +1174,35 @@ int wg_preview_run_batch_dev(int B, int L, const double *zmp_x_tm, const double 
     }
 #undef WG_SPLIT_LAUNCH
   } else if (ring) {
-    int R = g_prev.nl < 288 ? g_prev.nl : 288;                 // 288 x 512 B = 144 KB of the CU's 160 KB
+    int R = ctx->prev.nl < 288 ? ctx->prev.nl : 288;                 // 288 x 512 B = 144 KB of the CU's 160 KB
     if (R < 1) R = 1;
     const size_t lds = (size_t)R * 64 * 8;
     if (lds > 64 * 1024)
       HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(wg::wg_preview_ring_kernel),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(wg::wg_preview_ring_kernel, dim3((B + 63) / 64, 2), dim3(64), lds, st, B, L, g_prev, R, g_prev_F,
+    hipLaunchKernelGGL(wg::wg_preview_ring_kernel, dim3((B + 63) / 64, 2), dim3(64), lds, st, B, L, ctx->prev, R, ctx->prev_F,
                        zmp_x_tm, zmp_y_tm, state, com_tm, zmp2_tm, simulation);
   } else {
     const int threads = B >= 4096 ? 256 : 64;                  // small batches: more blocks, one wave each
-    hipLaunchKernelGGL(wg::wg_preview_kernel, dim3((B + threads - 1) / threads, 2), dim3(threads), 0, st, B, L, g_prev,
-                       g_prev_F, zmp_x_tm, zmp_y_tm, state, com_tm, zmp2_tm, simulation);
+    hipLaunchKernelGGL(wg::wg_preview_kernel, dim3((B + threads - 1) / threads, 2), dim3(threads), 0, st, B, L, ctx->prev,
+                       ctx->prev_F, zmp_x_tm, zmp_y_tm, state, com_tm, zmp2_tm, simulation);
   }
   HIP_TRY(hipGetLastError());
   return WG_OK;
 }
 
-int wg_preview_run_batch(int B, int L, const double *zmp_x, const double *zmp_y, double *state, double *com, double *zmp2,
-                         int simulation) {
-  if (int rc = ensure_device()) return rc;
-  if (!g_prev_set) return fail(WG_ERR_BAD_ARG, "wg_preview_configure() has not been called");
+int wg_preview_run_batch_ctx(wg_ctx_t *ctx, int B, int L, const double *zmp_x, const double *zmp_y, double *state, double *com, double *zmp2, int simulation) {
+  if (int rc = use_ctx(ctx)) return rc;
+  if (!ctx->prev_set) return fail(WG_ERR_BAD_ARG, "wg_preview_configure() has not been called on this context");
   if (B < 0 || L < 0 || !zmp_x || !zmp_y || !state) return fail(WG_ERR_BAD_ARG, "bad arguments");
   if (B == 0 || L == 0) return WG_OK;
-  std::lock_guard<std::mutex> lk(g_mu);
-  const size_t sB = (size_t)B, sL = (size_t)L, Lz = sL + g_prev.nl - 1;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  const size_t sB = (size_t)B, sL = (size_t)L, Lz = sL + ctx->prev.nl - 1;
   // arena: gait-major staging (largest user: com, B x L x 6), time-major zx, zy, com, zmp2, state
   const size_t stage = sB * (sL * 6 > Lz ? sL * 6 : Lz);
   const size_t nd = stage + 2 * sB * Lz + sB * sL * 6 + sB * sL * 2 + sB * 8;
-  if (int rc = g_prev_buf.reserve(nd * 8)) return rc;
-  double *d_stage = static_cast<double *>(g_prev_buf.p), *d_zx = d_stage + stage, *d_zy = d_zx + sB * Lz,
+  if (int rc = ctx->prev_buf.reserve(nd * 8)) return rc;
+  double *d_stage = static_cast<double *>(ctx->prev_buf.p), *d_zx = d_stage + stage, *d_zy = d_zx + sB * Lz,
          *d_com = d_zy + sB * Lz, *d_z2 = d_com + sB * sL * 6, *d_st = d_z2 + sB * sL * 2;
   auto transpose = [&](int rows, int cols, const double *in, double *out) {
     hipLaunchKernelGGL(wg::wg_transpose_kernel, dim3((cols + 31) / 32, (rows + 31) / 32), dim3(32, 8), 0, nullptr, rows,
@@ -1191,7 +1214,7 @@ int wg_preview_run_batch(int B, int L, const double *zmp_x, const double *zmp_y,
   HIP_TRY(hipMemcpy(d_stage, zmp_y, sB * Lz * 8, hipMemcpyHostToDevice));
   transpose(B, (int)Lz, d_stage, d_zy);
   HIP_TRY(hipMemcpy(d_st, state, sB * 8 * 8, hipMemcpyHostToDevice));
-  int rc = wg_preview_run_batch_dev(B, L, d_zx, d_zy, d_st, com ? d_com : nullptr, zmp2 ? d_z2 : nullptr, simulation,
+  int rc = wg_preview_run_batch_dev_ctx(ctx, B, L, d_zx, d_zy, d_st, com ? d_com : nullptr, zmp2 ? d_z2 : nullptr, simulation,
                                     nullptr);
   if (rc) return rc;
   HIP_TRY(hipDeviceSynchronize());
@@ -1213,18 +1236,11 @@ int wg_preview_run_batch(int B, int L, const double *zmp_x, const double *zmp_y,
 }  // extern "C"
 
 // ---- invariant Hessian block on the matrix cores (fleets with per-gait models) -----------------------------------------
-#include "wg_gramian_device.hpp"
-
-namespace {
-DevBuf g_gram_buf;
-bool g_gram_hooked = false;
-}  // namespace
 
 extern "C" {
 
-int wg_gramian_batch_dev(int B, int N, const double *T, const double *h, double alpha, double beta, double gamma,
-                         int precision, double *Qb, void *hip_stream) {
-  if (int rc = ensure_device()) return rc;
+int wg_gramian_batch_dev_ctx(wg_ctx_t *ctx, int B, int N, const double *T, const double *h, double alpha, double beta, double gamma, int precision, double *Qb, void *hip_stream) {
+  if (int rc = use_ctx(ctx)) return rc;
   if (B < 0 || N < 1 || N > 32 || !T || !h || !Qb) return fail(WG_ERR_BAD_ARG, "need B >= 0, 1 <= N <= 32, non-null arrays");
   if (precision != WG_GRAMIAN_F64 && precision != WG_GRAMIAN_F32) return fail(WG_ERR_BAD_ARG, "unknown precision %d", precision);
   if (B == 0) return WG_OK;
@@ -1237,19 +1253,17 @@ int wg_gramian_batch_dev(int B, int N, const double *T, const double *h, double 
   return WG_OK;
 }
 
-int wg_gramian_batch(int B, int N, const double *T, const double *h, double alpha, double beta, double gamma, int precision,
-                     double *Qb) {
-  if (int rc = ensure_device()) return rc;
+int wg_gramian_batch_ctx(wg_ctx_t *ctx, int B, int N, const double *T, const double *h, double alpha, double beta, double gamma, int precision, double *Qb) {
+  if (int rc = use_ctx(ctx)) return rc;
   if (B < 0 || N < 1 || N > 32 || !T || !h || !Qb) return fail(WG_ERR_BAD_ARG, "need B >= 0, 1 <= N <= 32, non-null arrays");
   if (B == 0) return WG_OK;
-  std::lock_guard<std::mutex> lk(g_mu);
-  if (!g_gram_hooked) { g_release_hooks.push_back([] { g_gram_buf.release(); }); g_gram_hooked = true; }
+  std::lock_guard<std::mutex> lk(ctx->mu);
   const size_t sB = (size_t)B, nq = sB * N * N;
-  if (int rc = g_gram_buf.reserve((2 * sB + nq) * 8)) return rc;
-  double *dT = static_cast<double *>(g_gram_buf.p), *dh = dT + sB, *dQ = dh + sB;
+  if (int rc = ctx->gram_buf.reserve((2 * sB + nq) * 8)) return rc;
+  double *dT = static_cast<double *>(ctx->gram_buf.p), *dh = dT + sB, *dQ = dh + sB;
   HIP_TRY(hipMemcpy(dT, T, sB * 8, hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(dh, h, sB * 8, hipMemcpyHostToDevice));
-  if (int rc = wg_gramian_batch_dev(B, N, dT, dh, alpha, beta, gamma, precision, dQ, nullptr)) return rc;
+  if (int rc = wg_gramian_batch_dev_ctx(ctx, B, N, dT, dh, alpha, beta, gamma, precision, dQ, nullptr)) return rc;
   HIP_TRY(hipDeviceSynchronize());
   HIP_TRY(hipMemcpy(Qb, dQ, nq * 8, hipMemcpyDeviceToHost));
   return WG_OK;
@@ -1258,12 +1272,8 @@ int wg_gramian_batch(int B, int N, const double *T, const double *h, double alph
 }  // extern "C"
 
 // ---- Kajita stage-1 inputs: ZMPDiscretization, batched (one lane per gait) ----------------------------------------------
-#include "wg_zmpdisc_device.hpp"
 
 namespace {
-DevBuf g_zd_buf;
-bool g_zd_hooked = false;
-
 // InitializeFilter, ZMPDiscretization.cpp:240-262 (sin from include/wg_trig.h: same bits on host and device)
 int zd_make_const(const wg_zmpdisc_model_t *model, wg::ZdConst *K) {
   if (!model) return fail(WG_ERR_BAD_ARG, "null model");
@@ -1317,10 +1327,8 @@ int wg_zmpdisc_length(const wg_zmpdisc_model_t *model, const wg_rel_step_t *step
   return wg::zd_length(*model, steps, n_steps);
 }
 
-int wg_zmpdisc_batch_dev(const wg_zmpdisc_model_t *model, int B, int smax, const wg_rel_step_t *steps, const int *n_steps,
-                         const double *init_feet, int lcap, double *zmp_x_tm, double *zmp_y_tm, int *length,
-                         void *hip_stream) {
-  if (int rc = ensure_device()) return rc;
+int wg_zmpdisc_batch_dev_ctx(wg_ctx_t *ctx, const wg_zmpdisc_model_t *model, int B, int smax, const wg_rel_step_t *steps, const int *n_steps, const double *init_feet, int lcap, double *zmp_x_tm, double *zmp_y_tm, int *length, void *hip_stream) {
+  if (int rc = use_ctx(ctx)) return rc;
   wg::ZdConst K;
   if (int rc = zd_make_const(model, &K)) return rc;
   if (B < 0 || smax < 2 || smax > WG_ZMPDISC_MAX_STEPS || lcap < 1 || !steps || !n_steps || !init_feet || !zmp_x_tm || !zmp_y_tm)
@@ -1333,11 +1341,8 @@ int wg_zmpdisc_batch_dev(const wg_zmpdisc_model_t *model, int B, int smax, const
   return zd_launch(K, B, smax, steps, n_steps, init_feet, lcap, O, length, reinterpret_cast<hipStream_t>(hip_stream));
 }
 
-int wg_zmpdisc_full_batch_dev(const wg_zmpdisc_model_t *model, int B, int smax, const wg_rel_step_t *steps,
-                              const int *n_steps, const double *init_feet, int lcap, double *zmp_x_tm, double *zmp_y_tm,
-                              double *zmp_theta_tm, int *zmp_type_tm, double *left_tm, int *left_type_tm, double *right_tm,
-                              int *right_type_tm, int *length, void *hip_stream) {
-  if (int rc = ensure_device()) return rc;
+int wg_zmpdisc_full_batch_dev_ctx(wg_ctx_t *ctx, const wg_zmpdisc_model_t *model, int B, int smax, const wg_rel_step_t *steps, const int *n_steps, const double *init_feet, int lcap, double *zmp_x_tm, double *zmp_y_tm, double *zmp_theta_tm, int *zmp_type_tm, double *left_tm, int *left_type_tm, double *right_tm, int *right_type_tm, int *length, void *hip_stream) {
+  if (int rc = use_ctx(ctx)) return rc;
   wg::ZdConst K;
   if (int rc = zd_make_const(model, &K)) return rc;
   if (B < 0 || smax < 2 || smax > WG_ZMPDISC_MAX_STEPS || lcap < 1 || !steps || !n_steps || !init_feet)
@@ -1350,23 +1355,20 @@ int wg_zmpdisc_full_batch_dev(const wg_zmpdisc_model_t *model, int B, int smax, 
   return zd_launch(K, B, smax, steps, n_steps, init_feet, lcap, O, length, reinterpret_cast<hipStream_t>(hip_stream));
 }
 
-int wg_zmpdisc_batch(const wg_zmpdisc_model_t *model, int B, int smax, const wg_rel_step_t *steps, const int *n_steps,
-                     const double *init_feet, int lcap, double *zmp, double *zmp_theta, int *zmp_type, double *left,
-                     int *left_type, double *right, int *right_type, int *length) {
-  if (int rc = ensure_device()) return rc;
+int wg_zmpdisc_batch_ctx(wg_ctx_t *ctx, const wg_zmpdisc_model_t *model, int B, int smax, const wg_rel_step_t *steps, const int *n_steps, const double *init_feet, int lcap, double *zmp, double *zmp_theta, int *zmp_type, double *left, int *left_type, double *right, int *right_type, int *length) {
+  if (int rc = use_ctx(ctx)) return rc;
   wg::ZdConst K;
   if (int rc = zd_make_const(model, &K)) return rc;
   if (B < 0 || smax < 2 || smax > WG_ZMPDISC_MAX_STEPS || lcap < 1 || !steps || !n_steps || !init_feet || !length)
     return fail(WG_ERR_BAD_ARG, "need B >= 0, 2 <= smax <= %d, lcap >= 1, non-null arrays", WG_ZMPDISC_MAX_STEPS);
   if (B == 0) return WG_OK;
-  std::lock_guard<std::mutex> lk(g_mu);
-  if (!g_zd_hooked) { g_release_hooks.push_back([] { g_zd_buf.release(); }); g_zd_hooked = true; }
+  std::lock_guard<std::mutex> lk(ctx->mu);
   const size_t sB = (size_t)B, sL = (size_t)lcap, row = sB * sL;
   // arena (8-byte units): steps | init_feet | zx zy ztheta | left right (6 rows each) | ints: n_steps length ztype ltype rtype
   const size_t n_step_d = (sB * smax * sizeof(wg_rel_step_t) + 7) / 8;
   const size_t nd = n_step_d + sB * 6 + 3 * row + 12 * row, ni = 2 * sB + 3 * row;
-  if (int rc = g_zd_buf.reserve(nd * 8 + ni * 4 + 64)) return rc;
-  double *d0 = static_cast<double *>(g_zd_buf.p);
+  if (int rc = ctx->zd_buf.reserve(nd * 8 + ni * 4 + 64)) return rc;
+  double *d0 = static_cast<double *>(ctx->zd_buf.p);
   wg_rel_step_t *d_steps = reinterpret_cast<wg_rel_step_t *>(d0);
   double *d_feet = d0 + n_step_d, *d_zx = d_feet + sB * 6, *d_zy = d_zx + row, *d_zt = d_zy + row, *d_l = d_zt + row,
          *d_r = d_l + 6 * row;
@@ -1417,6 +1419,153 @@ int wg_zmpdisc_batch(const wg_zmpdisc_model_t *model, int B, int smax, const wg_
   if (left_type) if (int rc = fetch_i(d_lty, left_type)) return rc;
   if (right_type) if (int rc = fetch_i(d_rty, right_type)) return rc;
   return WG_OK;
+}
+
+}  // extern "C"
+
+// ---- the same entry points on the process-wide default context -----------------------------------------------------
+extern "C" {
+
+int wg_qp_solve_batch_dev(int B, int nmax, int mmax, const int *n, const int *m, const int *me, const double *C, const double *d, const double *A, const double *b, const double *xl, const double *xu, double eps, double *x, double *u, int *ifail, int *n_iter, int *iact, int *nact, int *hist, int hist_cap, int *hist_len, void *hip_stream) {
+  wg_ctx *c = nullptr;
+  if (int rc = default_ctx(&c)) return rc;
+  return wg_qp_solve_batch_dev_ctx(c, B, nmax, mmax, n, m, me, C, d, A, b, xl, xu, eps, x, u, ifail, n_iter, iact, nact, hist, hist_cap, hist_len, hip_stream);
+}
+
+int wg_qp_solve_batch(int B, int nmax, int mmax, const int *n, const int *m, const int *me, const double *C, const double *d, const double *A, const double *b, const double *xl, const double *xu, double eps, double *x, double *u, int *ifail, int *n_iter, int *iact, int *nact, int *hist, int hist_cap, int *hist_len) {
+  wg_ctx *c = nullptr;
+  if (int rc = default_ctx(&c)) return rc;
+  return wg_qp_solve_batch_ctx(c, B, nmax, mmax, n, m, me, C, d, A, b, xl, xu, eps, x, u, ifail, n_iter, iact, nact, hist, hist_cap, hist_len);
+}
+
+int wg_mpc_configure(const wg_model_t *model) {
+  wg_ctx *c = nullptr;
+  if (int rc = default_ctx(&c)) return rc;
+  return wg_mpc_configure_ctx(c, model);
+}
+
+size_t wg_mpc_tick_lds_bytes(void) {                 // a query: does not create the default context
+  std::lock_guard<std::mutex> lk(g_default_mu);
+  return wg_mpc_tick_lds_bytes_ctx(g_default);
+}
+
+int wg_mpc_tick_batch_dev(int B, wg_gait_state_t *states, wg_tick_out_t *outs, int *diag, int advance_calls, int *hist, int hist_cap, int *hist_len, void *hip_stream) {
+  wg_ctx *c = nullptr;
+  if (int rc = default_ctx(&c)) return rc;
+  return wg_mpc_tick_batch_dev_ctx(c, B, states, outs, diag, advance_calls, hist, hist_cap, hist_len, hip_stream);
+}
+
+int wg_mpc_run_batch_dev(int B, wg_gait_state_t *states, int n_ticks, int advance_calls, wg_tick_out_t *outs, int *diag, void *hip_stream) {
+  wg_ctx *c = nullptr;
+  if (int rc = default_ctx(&c)) return rc;
+  return wg_mpc_run_batch_dev_ctx(c, B, states, n_ticks, advance_calls, outs, diag, hip_stream);
+}
+
+int wg_mpc_tick_batch(int B, wg_gait_state_t *states, wg_tick_out_t *outs, int *diag, int advance_calls, int *hist, int hist_cap, int *hist_len) {
+  wg_ctx *c = nullptr;
+  if (int rc = default_ctx(&c)) return rc;
+  return wg_mpc_tick_batch_ctx(c, B, states, outs, diag, advance_calls, hist, hist_cap, hist_len);
+}
+
+int wg_mpc_set_velref_dev(int B, wg_gait_state_t *states, const double *vref, void *hip_stream) {
+  wg_ctx *c = nullptr;
+  if (int rc = default_ctx(&c)) return rc;
+  return wg_mpc_set_velref_dev_ctx(c, B, states, vref, hip_stream);
+}
+
+int wg_pldp_configure(int N, const double *iPu, const double *Px, const double *Pu) {
+  wg_ctx *c = nullptr;
+  if (int rc = default_ctx(&c)) return rc;
+  return wg_pldp_configure_ctx(c, N, iPu, Px, Pu);
+}
+
+int wg_pldp_solve_batch_dev(int B, int mcap, const int *m, const double *D, const double *A, const double *b, const double *zmpref, const double *xkyk, const int *similar, const int *n_removed, const int *starting, int max_iter, wg_pldp_state_t *states, double *X, int *ret, int *n_iter, int *active, int *n_active, void *hip_stream) {
+  wg_ctx *c = nullptr;
+  if (int rc = default_ctx(&c)) return rc;
+  return wg_pldp_solve_batch_dev_ctx(c, B, mcap, m, D, A, b, zmpref, xkyk, similar, n_removed, starting, max_iter, states, X, ret, n_iter, active, n_active, hip_stream);
+}
+
+int wg_pldp_solve_batch(int B, int mcap, const int *m, const double *D, const double *A, const double *b, const double *zmpref, const double *xkyk, const int *similar, const int *n_removed, const int *starting, int max_iter, wg_pldp_state_t *states, double *X, int *ret, int *n_iter, int *active, int *n_active) {
+  wg_ctx *c = nullptr;
+  if (int rc = default_ctx(&c)) return rc;
+  return wg_pldp_solve_batch_ctx(c, B, mcap, m, D, A, b, zmpref, xkyk, similar, n_removed, starting, max_iter, states, X, ret, n_iter, active, n_active);
+}
+
+int wg_dimitrov_configure(const wg_dimitrov_model_t *model) {
+  wg_ctx *c = nullptr;
+  if (int rc = default_ctx(&c)) return rc;
+  return wg_dimitrov_configure_ctx(c, model);
+}
+
+int wg_dimitrov_get_constants(double *iLQ, double *OptB, double *OptC, double *Pu, double *iPu, double *Px) {
+  wg_ctx *c = nullptr;
+  if (int rc = default_ctx(&c)) return rc;
+  return wg_dimitrov_get_constants_ctx(c, iLQ, OptB, OptC, Pu, iPu, Px);
+}
+
+int wg_dimitrov_tick_batch_dev(int B, const wg_zmp_polytope_t *polys, wg_dimitrov_state_t *states, wg_dimitrov_out_t *outs, int max_iter, void *hip_stream) {
+  wg_ctx *c = nullptr;
+  if (int rc = default_ctx(&c)) return rc;
+  return wg_dimitrov_tick_batch_dev_ctx(c, B, polys, states, outs, max_iter, hip_stream);
+}
+
+int wg_dimitrov_tick_batch(int B, const wg_zmp_polytope_t *polys, wg_dimitrov_state_t *states, wg_dimitrov_out_t *outs, int max_iter) {
+  wg_ctx *c = nullptr;
+  if (int rc = default_ctx(&c)) return rc;
+  return wg_dimitrov_tick_batch_ctx(c, B, polys, states, outs, max_iter);
+}
+
+int wg_preview_configure(const wg_preview_gains_t *gains, const double *F) {
+  wg_ctx *c = nullptr;
+  if (int rc = default_ctx(&c)) return rc;
+  return wg_preview_configure_ctx(c, gains, F);
+}
+
+int wg_preview_window(void) {                        // a query: does not create the default context
+  std::lock_guard<std::mutex> lk(g_default_mu);
+  return wg_preview_window_ctx(g_default);
+}
+
+int wg_preview_run_batch_dev(int B, int L, const double *zmp_x_tm, const double *zmp_y_tm, double *state, double *com_tm, double *zmp2_tm, int simulation, void *hip_stream) {
+  wg_ctx *c = nullptr;
+  if (int rc = default_ctx(&c)) return rc;
+  return wg_preview_run_batch_dev_ctx(c, B, L, zmp_x_tm, zmp_y_tm, state, com_tm, zmp2_tm, simulation, hip_stream);
+}
+
+int wg_preview_run_batch(int B, int L, const double *zmp_x, const double *zmp_y, double *state, double *com, double *zmp2, int simulation) {
+  wg_ctx *c = nullptr;
+  if (int rc = default_ctx(&c)) return rc;
+  return wg_preview_run_batch_ctx(c, B, L, zmp_x, zmp_y, state, com, zmp2, simulation);
+}
+
+int wg_gramian_batch_dev(int B, int N, const double *T, const double *h, double alpha, double beta, double gamma, int precision, double *Qb, void *hip_stream) {
+  wg_ctx *c = nullptr;
+  if (int rc = default_ctx(&c)) return rc;
+  return wg_gramian_batch_dev_ctx(c, B, N, T, h, alpha, beta, gamma, precision, Qb, hip_stream);
+}
+
+int wg_gramian_batch(int B, int N, const double *T, const double *h, double alpha, double beta, double gamma, int precision, double *Qb) {
+  wg_ctx *c = nullptr;
+  if (int rc = default_ctx(&c)) return rc;
+  return wg_gramian_batch_ctx(c, B, N, T, h, alpha, beta, gamma, precision, Qb);
+}
+
+int wg_zmpdisc_batch_dev(const wg_zmpdisc_model_t *model, int B, int smax, const wg_rel_step_t *steps, const int *n_steps, const double *init_feet, int lcap, double *zmp_x_tm, double *zmp_y_tm, int *length, void *hip_stream) {
+  wg_ctx *c = nullptr;
+  if (int rc = default_ctx(&c)) return rc;
+  return wg_zmpdisc_batch_dev_ctx(c, model, B, smax, steps, n_steps, init_feet, lcap, zmp_x_tm, zmp_y_tm, length, hip_stream);
+}
+
+int wg_zmpdisc_full_batch_dev(const wg_zmpdisc_model_t *model, int B, int smax, const wg_rel_step_t *steps, const int *n_steps, const double *init_feet, int lcap, double *zmp_x_tm, double *zmp_y_tm, double *zmp_theta_tm, int *zmp_type_tm, double *left_tm, int *left_type_tm, double *right_tm, int *right_type_tm, int *length, void *hip_stream) {
+  wg_ctx *c = nullptr;
+  if (int rc = default_ctx(&c)) return rc;
+  return wg_zmpdisc_full_batch_dev_ctx(c, model, B, smax, steps, n_steps, init_feet, lcap, zmp_x_tm, zmp_y_tm, zmp_theta_tm, zmp_type_tm, left_tm, left_type_tm, right_tm, right_type_tm, length, hip_stream);
+}
+
+int wg_zmpdisc_batch(const wg_zmpdisc_model_t *model, int B, int smax, const wg_rel_step_t *steps, const int *n_steps, const double *init_feet, int lcap, double *zmp, double *zmp_theta, int *zmp_type, double *left, int *left_type, double *right, int *right_type, int *length) {
+  wg_ctx *c = nullptr;
+  if (int rc = default_ctx(&c)) return rc;
+  return wg_zmpdisc_batch_ctx(c, model, B, smax, steps, n_steps, init_feet, lcap, zmp, zmp_theta, zmp_type, left, left_type, right, right_type, length);
 }
 
 }  // extern "C"

@@ -113,6 +113,14 @@ bool ZMPRefTrajectoryGeneration::GetOnLineMode() { return m_OnLineMode; }
 void solution_t::reset() { NbVariables = NbConstraints = Fail = NbIterations = NbActiveConstraints = 0; JerkX = JerkY = 0.0; }
 
 static void wg_throw(const char *what) { throw runtime_error(string(what) + ": " + wg_last_error()); }
+// The reference keeps its solver set-up per object; so does the facade: every object that configures device-side state
+// (ZMPVelocityReferencedQP: model tables; PreviewControl: gains) owns a context of the C ABI.  WG_DEVICE picks the GPU.
+static wg_ctx_t *NewContext() {
+  const char *e = getenv("WG_DEVICE");
+  wg_ctx_t *c = 0;
+  if (wg_ctx_create(e ? atoi(e) : 0, &c) != WG_OK) wg_throw("wg_ctx_create");
+  return c;
+}
 
 // ZMPVelocityReferencedQP.cpp:56-135
 ZMPVelocityReferencedQP::ZMPVelocityReferencedQP(SimplePluginManager *SPM, string, const HumanoidModel *aHS)
@@ -135,13 +143,14 @@ ZMPVelocityReferencedQP::ZMPVelocityReferencedQP(SimplePluginManager *SPM, strin
     Model_.hip_vmax = fabs(aHS->hipYawVelocityMax);
   }
   memset(&State_, 0, sizeof State_);
-  if (wg_mpc_configure(&Model_) != WG_OK) wg_throw("wg_mpc_configure");
+  Ctx_ = NewContext();
+  if (wg_mpc_configure_ctx(Ctx_, &Model_) != WG_OK) { wg_ctx_destroy(Ctx_); Ctx_ = 0; wg_throw("wg_mpc_configure"); }
   const unsigned int NbMethods = 3;
   string aMethodName[NbMethods] = {":previewcontroltime", ":numberstepsbeforestop", ":stoppg"};
   for (unsigned int i = 0; i < NbMethods; i++)
     if (!RegisterMethod(aMethodName[i])) cerr << "Unable to register " << aMethodName[i] << endl;
 }
-ZMPVelocityReferencedQP::~ZMPVelocityReferencedQP() {}
+ZMPVelocityReferencedQP::~ZMPVelocityReferencedQP() { wg_ctx_destroy(Ctx_); }
 
 void ZMPVelocityReferencedQP::setCoMPerturbationForce(istringstream &strm) {   // :162-173 (stored; no reader on the path)
   strm >> PerturbationAcceleration_[2];
@@ -165,14 +174,18 @@ void ZMPVelocityReferencedQP::CallMethod(string &Method, istringstream &strm) { 
   }
   if (Method == ":stoppg") State_.ending_phase = 1;
   ZMPRefTrajectoryGeneration::CallMethod(Method, strm);
-  Model_.Tctrl = m_SamplingPeriod;
+  if (Model_.Tctrl != m_SamplingPeriod) {           // ":samplingperiod": the device copy of the model follows (or refuses)
+    const double old = Model_.Tctrl;
+    Model_.Tctrl = m_SamplingPeriod;
+    if (wg_mpc_configure_ctx(Ctx_, &Model_) != WG_OK) { Model_.Tctrl = old; m_SamplingPeriod = old; wg_throw("wg_mpc_configure"); }
+  }
 }
 
 void ZMPVelocityReferencedQP::LegacyGoldenReplay(bool on) {
   Legacy_ = on;
   if (on) Model_.flags |= WG_FLAG_NO_STOP_CENTERING;
   else Model_.flags &= ~WG_FLAG_NO_STOP_CENTERING;
-  if (wg_mpc_configure(&Model_) != WG_OK) wg_throw("wg_mpc_configure");
+  if (wg_mpc_configure_ctx(Ctx_, &Model_) != WG_OK) wg_throw("wg_mpc_configure");
 }
 
 static FootAbsolutePosition toFAP(const wg_foot_sample_t &s, double time, int stepType) {
@@ -238,7 +251,7 @@ void ZMPVelocityReferencedQP::OnLine(double time, deque<ZMPPosition> &FinalZMPTr
   if (time + 0.00001 > State_.upper_time_limit) {
     State_.clock = time;
     wg_tick_out_t out;
-    if (wg_mpc_tick_batch(1, &State_, &out, 0, 0, 0, 0, 0) != WG_OK) wg_throw("wg_mpc_tick_batch");
+    if (wg_mpc_tick_batch_ctx(Ctx_, 1, &State_, &out, 0, 0, 0, 0, 0) != WG_OK) wg_throw("wg_mpc_tick_batch");
     Solution_.NbVariables = out.n; Solution_.NbConstraints = out.m; Solution_.Fail = out.ifail;
     Solution_.NbIterations = out.n_iter; Solution_.NbActiveConstraints = out.nact;
     Solution_.JerkX = out.jerk_x; Solution_.JerkY = out.jerk_y;
@@ -284,12 +297,12 @@ PreviewControl::PreviewControl(SimplePluginManager *lSPM, unsigned int defaultMo
   m_DefaultWeightComputationMode = defaultMode;
   m_SamplingPeriod = 0.0; m_PreviewControlTime = 0.0; m_Zc = 0.0; m_SizeOfPreviewWindow = 0;
   m_Kx[0] = m_Kx[1] = m_Kx[2] = 0.0; m_Ks = 0;
-  m_Coherent = false; m_Uploaded = false;
+  m_Coherent = false; m_Uploaded = false; m_Ctx = 0;
   string aMethodName[3] = {":samplingperiod", ":previewcontroltime", ":comheight"};
   for (int i = 0; i < 3; i++)
     if (!RegisterMethod(aMethodName[i])) cerr << "Unable to register " << aMethodName[i] << endl;
 }
-PreviewControl::~PreviewControl() {}
+PreviewControl::~PreviewControl() { if (m_Ctx) wg_ctx_destroy(m_Ctx); }
 
 void PreviewControl::SetSamplingPeriod(double v) {                  // :98-107
   if (m_SamplingPeriod != v) m_Coherent = false;
@@ -345,14 +358,15 @@ void PreviewControl::Upload() {
   memset(&g, 0, sizeof g);
   g.T = m_SamplingPeriod; g.zc = m_Zc; g.Ks = m_Ks; g.Kx[0] = m_Kx[0]; g.Kx[1] = m_Kx[1]; g.Kx[2] = m_Kx[2];
   g.nl = (int)m_SizeOfPreviewWindow;
-  if (wg_preview_configure(&g, m_F.data()) != WG_OK) wg_throw("wg_preview_configure");
+  if (!m_Ctx) m_Ctx = NewContext();
+  if (wg_preview_configure_ctx(m_Ctx, &g, m_F.data()) != WG_OK) wg_throw("wg_preview_configure");
   m_Uploaded = true;
 }
 
 int PreviewControl::RunBatch(int B, int L, const double *zmp_x, const double *zmp_y, double *state, double *com, double *zmp2,
                              bool Simulation) {
   Upload();
-  if (wg_preview_run_batch(B, L, zmp_x, zmp_y, state, com, zmp2, Simulation ? 1 : 0) != WG_OK) wg_throw("wg_preview_run_batch");
+  if (wg_preview_run_batch_ctx(m_Ctx, B, L, zmp_x, zmp_y, state, com, zmp2, Simulation ? 1 : 0) != WG_OK) wg_throw("wg_preview_run_batch");
   return 0;
 }
 

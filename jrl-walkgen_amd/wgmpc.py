@@ -113,7 +113,89 @@ def lib():
         _lib.wg_zmpdisc_full_batch_dev.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int] + \
             [C.c_void_p] * 10
         _lib.wg_foot_constraints.argtypes = [C.c_int] + [C.c_void_p] * 4 + [C.c_double] * 4 + [C.c_int] + [C.c_void_p] * 3
+        # contexts: NAME_ctx(ctx, args...) for every entry point NAME(args...) that keeps or stages device-side state
+        _lib.wg_ctx_create.argtypes = [C.c_int, C.c_void_p]
+        _lib.wg_ctx_destroy.argtypes = [C.c_void_p]
+        _lib.wg_ctx_destroy.restype = None
+        _lib.wg_ctx_device.argtypes = [C.c_void_p]
+        _lib.wg_mpc_configure.argtypes = [C.c_void_p]
+        for name in CTX_ENTRY_POINTS:
+            base, fn = getattr(_lib, name), getattr(_lib, name + "_ctx")
+            fn.argtypes = [C.c_void_p] + list(base.argtypes or [])
+            fn.restype = base.restype
     return _lib
+
+
+CTX_ENTRY_POINTS = ("wg_qp_solve_batch", "wg_qp_solve_batch_dev", "wg_mpc_configure", "wg_mpc_tick_lds_bytes", "wg_mpc_tick_batch",
+                    "wg_mpc_tick_batch_dev", "wg_mpc_run_batch_dev", "wg_mpc_set_velref_dev", "wg_pldp_configure",
+                    "wg_pldp_solve_batch", "wg_pldp_solve_batch_dev", "wg_dimitrov_configure", "wg_dimitrov_get_constants",
+                    "wg_dimitrov_tick_batch", "wg_dimitrov_tick_batch_dev", "wg_preview_configure", "wg_preview_window",
+                    "wg_preview_run_batch", "wg_preview_run_batch_dev", "wg_gramian_batch", "wg_gramian_batch_dev",
+                    "wg_zmpdisc_batch", "wg_zmpdisc_batch_dev", "wg_zmpdisc_full_batch_dev")
+
+
+class Context:
+    """wg_ctx_t: one configured model with its device tables and workspaces (include/wg_mpc.h, "Contexts").  Two contexts
+    may hold different models and run overlapping launches on different streams.  Only the Herdt-tick family is wrapped
+    here (what the tests and bench.py need); every other NAME_ctx is reachable through `call`."""
+
+    def __init__(self, device=0):
+        h = C.c_void_p()
+        _check(lib().wg_ctx_create(int(device), C.byref(h)))
+        self.handle = h
+
+    def close(self):
+        if self.handle:
+            lib().wg_ctx_destroy(self.handle)
+            self.handle = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:            # noqa: BLE001 -- interpreter shutdown
+            pass
+
+    def call(self, name, *args):
+        """NAME_ctx(ctx, *args), raw"""
+        return getattr(lib(), name + "_ctx")(self.handle, *args)
+
+    def device(self):
+        return int(lib().wg_ctx_device(self.handle))
+
+    def mpc_configure(self, model):
+        _check(self.call("wg_mpc_configure", C.byref(model)))
+
+    def mpc_tick_lds_bytes(self):
+        return int(self.call("wg_mpc_tick_lds_bytes"))
+
+    def mpc_tick_batch(self, states, want_out=True, advance_calls=0, hist_cap=0):
+        B = len(states)
+        outs = (TickOut * B)() if want_out else None
+        diag = np.zeros((B, 6), dtype=np.int32)
+        hist = np.zeros((B, hist_cap), dtype=np.int32) if hist_cap else None
+        hlen = np.zeros(B, dtype=np.int32) if hist_cap else None
+        _check(self.call("wg_mpc_tick_batch", B, C.addressof(states), C.addressof(outs) if outs is not None else None,
+                         _hp(diag), advance_calls, _hp(hist), hist_cap, _hp(hlen)))
+        return outs, diag, hist, hlen
+
+    def mpc_tick_batch_dev(self, B, states_ptr, outs_ptr=None, diag_ptr=None, advance_calls=0, hist_ptr=None, hist_cap=0,
+                           hist_len_ptr=None, stream=None):
+        v = lambda p: C.c_void_p(p) if p else None
+        _check(self.call("wg_mpc_tick_batch_dev", B, v(states_ptr), v(outs_ptr), v(diag_ptr), advance_calls, v(hist_ptr),
+                         hist_cap, v(hist_len_ptr), v(stream)))
+
+    def mpc_run_batch_dev(self, B, states_ptr, n_ticks, advance_calls=20, outs_ptr=None, diag_ptr=None, stream=None):
+        _check(self.call("wg_mpc_run_batch_dev", B, states_ptr, int(n_ticks), int(advance_calls), outs_ptr, diag_ptr, stream))
+
+    def mpc_set_velref_dev(self, B, states_ptr, vref_ptr, stream=None):
+        v = lambda p: C.c_void_p(p) if p else None
+        _check(self.call("wg_mpc_set_velref_dev", B, v(states_ptr), v(vref_ptr), v(stream)))
 
 
 def _check(rc):
