@@ -45,6 +45,16 @@ int wg_abi_version(void);
  * reason about occupancy (160 KiB per CU on gfx950). */
 size_t wg_qp_lds_bytes(int n, int m);
 
+/* Sharding (host arithmetic) ---------------------------------------------------------------------------------------------
+ *
+ * Gaits are independent (the reference has no coupling between pattern generators), so a fleet of `total` gaits is split
+ * over `world` ranks -- one process per GPU -- by contiguous index range, the remainder spread over the first ranks:
+ * rank r owns the global gaits [*lo, *hi).  Every rank derives per-gait inputs (seeds, references) from the GLOBAL index,
+ * so the job's results do not depend on how it was split.  The only thing ranks exchange is the constant block
+ * wg_model_t, which rank 0 broadcasts once (host/fleet_bench.cpp: ncclBroadcast; jrl-walkgen_amd/shard.py: the same
+ * through torch.distributed). */
+int wg_shard_range(long long total, int rank, int world, long long *lo, long long *hi);
+
 /* Contexts ---------------------------------------------------------------------------------------------------------------
  *
  * Everything the library keeps between calls lives in a context: the configured models with the device copies of their

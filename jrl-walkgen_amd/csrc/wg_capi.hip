@@ -238,6 +238,15 @@ void wg_ctx_destroy(wg_ctx_t *ctx) {
 
 int wg_ctx_device(const wg_ctx_t *ctx) { return ctx ? ctx->device : -1; }
 
+int wg_shard_range(long long total, int rank, int world, long long *lo, long long *hi) {
+  if (total < 0 || world < 1 || rank < 0 || rank >= world || !lo || !hi)
+    return fail(WG_ERR_BAD_ARG, "wg_shard_range: need total >= 0, 0 <= rank < world");
+  const long long base = total / world, rem = total % world;
+  *lo = rank * base + (rank < rem ? rank : rem);
+  *hi = *lo + base + (rank < rem ? 1 : 0);
+  return WG_OK;
+}
+
 int wg_init(int device_ordinal) {
   std::lock_guard<std::mutex> lk(g_default_mu);
   if (g_default && g_default->device == device_ordinal) return use_ctx(g_default);

@@ -43,10 +43,14 @@ def broadcast_struct(obj, device, src=0):
 
 
 def shard_range(total, rank, world):
-    """Contiguous [lo, hi) slice of `total` gaits owned by `rank` (remainder spread over the first ranks)."""
-    base, rem = divmod(total, world)
-    lo = rank * base + min(rank, rem)
-    return lo, lo + base + (1 if rank < rem else 0)
+    """Contiguous [lo, hi) slice of `total` gaits owned by `rank` (remainder spread over the first ranks): the C ABI's
+    wg_shard_range (host arithmetic, include/wg_mpc.h) -- one rule for the Python harness and for host/fleet_bench.cpp."""
+    from . import wgmpc
+    lo, hi = C.c_longlong(), C.c_longlong()
+    rc = wgmpc.lib().wg_shard_range(C.c_longlong(total), int(rank), int(world), C.byref(lo), C.byref(hi))
+    if rc != 0:
+        raise ValueError(f"wg_shard_range({total}, {rank}, {world}) -> {rc}")
+    return lo.value, hi.value
 
 
 def barrier():

@@ -159,6 +159,39 @@ def test_cpp_fleet_bench_runs_through_the_c_abi():
         assert "%d ticks done in all" % (300 * (50 + 60)) in r.stdout, r.stdout
 
 
+def test_cpp_fleet_bench_rank_launcher_with_rccl():
+    """`fleet_bench --ranks 1`: the program starts one copy of itself per GPU (here one) before touching the GPU; the rank
+    creates an RCCL communicator (ncclCommInitRank), receives wg_model_t through ncclBroadcast, configures its own context
+    from it, takes its wg_shard_range and prints the job's JSON line.  World size 1 is the only size a one-GPU box can
+    run; the N > 1 path is the same code and waits for the 8-GPU node (unmeasured on hardware until then)."""
+    import json
+    import signal
+    exe = os.path.join(ROOT, "jrl-walkgen_amd", "bin", "fleet_bench")
+
+    def run(args, limit):
+        # the launcher and its ranks in their own process group, so that a hang ends with every one of them killed
+        p = subprocess.Popen([exe, *args], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, start_new_session=True)
+        try:
+            out, err = p.communicate(timeout=limit)
+        except subprocess.TimeoutExpired:
+            os.killpg(p.pid, signal.SIGKILL)
+            out, err = p.communicate()
+            raise AssertionError("fleet_bench %s hung:\n%s\n%s" % (args, out, err))
+        return subprocess.CompletedProcess(args, p.returncode, out, err)
+
+    r = run(["--ranks", "1", "--batch", "300", "--ticks", "60"], 150)
+    assert r.returncode == 0, r.stdout + r.stderr
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(line) == 1, r.stdout
+    d = json.loads(line[0])
+    assert d["n_gpus"] == 1 and d["steps"] == 60 and d["scaling"] == "weak" and d["value"] > 0
+    assert "ncclBroadcast" in d["config"]["collective"]
+    assert d["ticks_done_in_all"] == 300 * (50 + 60)
+    # more ranks than GPUs: every rank fails loudly, and so does the launcher
+    r = run(["--ranks", "2", "--batch", "8", "--ticks", "4"], 150)
+    assert r.returncode != 0 and "FAILED" in r.stderr
+
+
 def test_cpp_kajita_fleet_runs_through_the_c_abi():
     """jrl-walkgen_amd/host/kajita_fleet.cpp: step sequences -> wg_zmpdisc_batch_dev -> wg_preview_run_batch_dev from plain C++
     (hipMalloc'd buffers, one stream); the program itself compares gait 0 of the device chain with the host-pointer entry

@@ -75,3 +75,14 @@ def test_shard_range_properties():
             assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
             sizes = [hi - lo for lo, hi in spans]
             assert max(sizes) - min(sizes) <= 1
+
+
+def test_shard_range_is_the_c_abi_rule():
+    """shard.shard_range is wg_shard_range of include/wg_mpc.h (what host/fleet_bench.cpp calls); config 4's split"""
+    import ctypes as C
+    wg = importlib.import_module("jrl-walkgen_amd")
+    shard = importlib.import_module("jrl-walkgen_amd.shard")
+    assert [shard.shard_range(32768, r, 8) for r in range(8)] == [(4096 * r, 4096 * (r + 1)) for r in range(8)]
+    lo, hi = C.c_longlong(), C.c_longlong()
+    for bad in ((10, 2, 2), (10, -1, 2), (-1, 0, 1), (10, 0, 0)):
+        assert wg.lib().wg_shard_range(C.c_longlong(bad[0]), bad[1], bad[2], C.byref(lo), C.byref(hi)) == -2
