@@ -9,15 +9,21 @@
 //   src/ZMPRefTrajectoryGeneration/ZMPRefTrajectoryGeneration.hh               ZMPRefTrajectoryGeneration (on-line part)
 //   src/ZMPRefTrajectoryGeneration/ZMPVelocityReferencedQP.hh:59-131           ZMPVelocityReferencedQP
 //   src/PreviewControl/OptimalControllerSolver.hh:137-221, PreviewControl.hh:53-187   OptimalControllerSolver, PreviewControl (Kajita stage 1)
-//   include/jrl/walkgen/patterngeneratorinterface.hh:72-306                    PatternGeneratorInterface (+ factory), the methods
-//                                                                              live on this path; the others of the reference belong
-//                                                                              to generators that are out of scope and are not declared
+//   include/jrl/walkgen/patterngeneratorinterface.hh:72-306                    PatternGeneratorInterface: EVERY pure virtual of the
+//                                                                              reference, in the reference's order (same vtable
+//                                                                              layout), + both factories.  Methods that belong to
+//                                                                              generators outside this path (on-line step
+//                                                                              sequencing, Morisawa's ChangeOnLineStep) are
+//                                                                              declared and answer as documented at each one.
+//   abstract-robot-dynamics (CjrlHumanoidDynamicRobot, CjrlFoot, CjrlJoint)    include/wg_abstract_robot.hh: the methods this path
+//                                                                              calls, same names and meaning
 //
 // Differences forced by the image (documented, not hidden):
-//   * CjrlHumanoidDynamicRobot (abstract-robot-dynamics) is absent.  The path reads ~14 numbers from it
-//     (SURVEY.md 8(b)); they are the plain struct HumanoidModel.  EvaluateStartingState needs forward kinematics of the
-//     full robot, so the starting CoM / feet are fields of HumanoidModel the caller supplies.
-//   * MAL_VECTOR (jrl-mal) arguments are std::vector<double>.
+//   * abstract-robot-dynamics and jrl-mal are absent.  wg_abstract_robot.hh declares the part of their interface the path
+//     uses (robot: the ~14 numbers of SURVEY.md 8(b) + forward kinematics of the start posture; MAL_VECTOR = vectorN,
+//     a std::vector<double> with operator(), MAL_S3_VECTOR = vector3d, MAL_S4x4_MATRIX = matrix4d).
+//   * A robot can also be given as the plain struct HumanoidModel (the numbers themselves, start state supplied): fleets
+//     and tests that have no kinematic model.
 //   * There is no CPU fall-back: construction throws std::runtime_error when the HIP device or library is unusable.
 #ifndef WG_WALKGEN_HH
 #define WG_WALKGEN_HH
@@ -29,9 +35,17 @@
 #include <string>
 #include <vector>
 
+#include <stdexcept>
+
+#include "wg_abstract_robot.hh"
 #include "wg_mpc.h"
 
 namespace PatternGeneratorJRL {
+
+// thrown by the interface methods that belong to generators outside this path (documented at each declaration)
+struct NotOnThisPath : public std::logic_error {
+  explicit NotOnThisPath(const std::string &what) : std::logic_error(what + ": not on the Herdt-2010 / Kajita stage-1 path of this build") {}
+};
 
 // ---- pgtypes.hh ---------------------------------------------------------------------------------------------------
 struct COMState_s;
@@ -88,6 +102,12 @@ struct HumanoidModel {
   // file)
   static HumanoidModel sampleRobot();
 };
+// The numbers the generators read from an abstract robot, through exactly the calls the reference makes:
+// mass() (ZMPVelocityReferencedQP.cpp:68), leftFoot()->getSoleSize (relative-feet-inequalities.cpp:158-178: the LEFT foot's
+// size is used for both feet), getAnklePositionInLocalFrame (rigid-body-system.cpp:38), the hip-yaw bounds of
+// jointsBetween(waist, ankle)[1] (OrientationsPreview.cpp:42-68).  The start state stays zero: EvaluateStartingState
+// computes it from the robot's forward kinematics.
+HumanoidModel HumanoidModelFromRobot(CjrlHumanoidDynamicRobot *aHDR);
 
 // ---- SimplePlugin / SimplePluginManager -------------------------------------------------------------------------------
 class SimplePlugin;
@@ -194,6 +214,9 @@ class ZMPVelocityReferencedQP : public ZMPRefTrajectoryGeneration {
   // Y = 0.1, no stop-centring branch, Running() stays true until the queues drain.  Call before InitOnLine.
   void LegacyGoldenReplay(bool on);
   bool LegacyGoldenReplay() const { return Legacy_; }
+  // ":setfeetconstraint XY mx my" (RelativeFeetInequalities::CallMethod, relative-feet-inequalities.cpp:322-342): security
+  // margins of the ZMP polygon; the device model follows
+  void SetFeetConstraint(double SecurityMarginX, double SecurityMarginY);
 
  private:
   ZMPVelocityReferencedQP(const ZMPVelocityReferencedQP &);              // owns a device context: not copyable
@@ -326,6 +349,7 @@ class StepStackHandler {
   void SetDoubleTimeSupport(double v) { m_DoubleSupportTime = v; }
   int GetWalkMode() const { return m_WalkMode; }
   void ReadStepSequenceAccordingToWalkMode(std::istringstream &strm);    // StepStackHandler.cpp:128-175
+  void AddStepInTheStack(double sx, double sy, double theta, double sstime, double dstime);   // :850-863
   void CopyRelativeFootPosition(std::deque<RelativeFootPosition> &lRelativeFootPositions, bool PerformClean);
   // ":supportfoot", ":arc", ":lastsupport" (StepStackHandler.cpp:754-764, 299-457, 872-882; CallMethod :929-1040)
   void PrepareForSupportFoot(int SupportFoot);
@@ -362,33 +386,74 @@ class FootConstraintsAsLinearSystem : public SimplePlugin {
   HumanoidModel m_HS;
 };
 
+// include/jrl/walkgen/patterngeneratorinterface.hh:55-306 -- every pure virtual, in the reference's order
 class PatternGeneratorInterface {
  public:
+  PatternGeneratorInterface(CjrlHumanoidDynamicRobot *) {}
   PatternGeneratorInterface(const HumanoidModel *) {}
   virtual ~PatternGeneratorInterface() {}
-  // patterngeneratorinterface.hh:115-176
-  virtual bool RunOneStepOfTheControlLoop(std::vector<double> &CurrentConfiguration, std::vector<double> &CurrentVelocity,
-                                          std::vector<double> &CurrentAcceleration, std::vector<double> &ZMPTarget) = 0;
-  virtual bool RunOneStepOfTheControlLoop(std::vector<double> &CurrentConfiguration, std::vector<double> &CurrentVelocity,
-                                          std::vector<double> &CurrentAcceleration, std::vector<double> &ZMPTarget,
+  // :72  step stack (StepStackHandler::AddStepInTheStack)
+  virtual void AddStepInStack(double dx, double dy, double theta) = 0;
+  // :92  start state + copy of the step stack (PatternGeneratorInterfacePrivate.cpp:688-776; AutoFirstStep is off)
+  virtual void CommonInitializationOfWalking(COMState &lStartingCOMState, MAL_S3_VECTOR_TYPE(double) & lStartingZMPPosition,
+                                             MAL_VECTOR(&, double) BodyAnglesIni, FootAbsolutePosition &InitLeftFootAbsPos,
+                                             FootAbsolutePosition &InitRightFootAbsPos,
+                                             std::deque<RelativeFootPosition> &lRelativeFootPositions,
+                                             std::vector<double> &lCurrentJointValues, bool ClearStepStackHandler) = 0;
+  // :115-176  the control loop.  On this path (CoMAndFootOnlyStrategy) the configuration vectors are not written; their
+  // first six entries, when present, are read as the waist state for the odometry below (:1366-1375)
+  virtual bool RunOneStepOfTheControlLoop(MAL_VECTOR_TYPE(double) & CurrentConfiguration, MAL_VECTOR_TYPE(double) & CurrentVelocity,
+                                          MAL_VECTOR_TYPE(double) & CurrentAcceleration, MAL_VECTOR_TYPE(double) & ZMPTarget) = 0;
+  virtual bool RunOneStepOfTheControlLoop(MAL_VECTOR_TYPE(double) & CurrentConfiguration, MAL_VECTOR_TYPE(double) & CurrentVelocity,
+                                          MAL_VECTOR_TYPE(double) & CurrentAcceleration, MAL_VECTOR_TYPE(double) & ZMPTarget,
                                           COMPosition &COMPosition, FootAbsolutePosition &LeftFootPosition,
                                           FootAbsolutePosition &RightFootPosition) = 0;
-  virtual bool RunOneStepOfTheControlLoop(std::vector<double> &CurrentConfiguration, std::vector<double> &CurrentVelocity,
-                                          std::vector<double> &CurrentAcceleration, std::vector<double> &ZMPTarget,
+  virtual bool RunOneStepOfTheControlLoop(MAL_VECTOR_TYPE(double) & CurrentConfiguration, MAL_VECTOR_TYPE(double) & CurrentVelocity,
+                                          MAL_VECTOR_TYPE(double) & CurrentAcceleration, MAL_VECTOR_TYPE(double) & ZMPTarget,
                                           COMState &COMState, FootAbsolutePosition &LeftFootPosition,
                                           FootAbsolutePosition &RightFootPosition) = 0;
   virtual bool RunOneStepOfTheControlLoop(FootAbsolutePosition &LeftFootPosition, FootAbsolutePosition &RightFootPosition,
                                           ZMPPosition &ZMPRefPos, COMPosition &COMRefPos) = 0;
-  virtual void SetCurrentJointValues(std::vector<double> &lCurrentJointValues) = 0;   // :184
-  virtual int ParseCmd(std::istringstream &strm) = 0;                                  // :270
-  virtual void EvaluateStartingState(COMState &lStartingCOMState, double lStartingZMPPosition[3],
-                                     std::vector<double> &lStartingWaistPose, FootAbsolutePosition &InitLeftFootAbsPos,
-                                     FootAbsolutePosition &InitRightFootAbsPos) = 0;   // :279-283
-  virtual void setVelocityReference(double x, double y, double yaw) = 0;               // :294
-  virtual void setCoMPerturbationForce(double x, double y) = 0;                        // :301
+  // :184
+  virtual void SetCurrentJointValues(MAL_VECTOR(&lCurrentJointValues, double)) = 0;
+  // :187
+  virtual int GetWalkMode() const = 0;
+  // :190  leg joint velocities come from the whole-body stage (out of scope): six zeros each, the reference's initial values
+  virtual void GetLegJointVelocity(MAL_VECTOR(&dqr, double), MAL_VECTOR(&dql, double)) const = 0;
+  // :194  walk mode 0 (":stepseq" format); other walk modes throw NotOnThisPath
+  virtual void ReadSequenceOfSteps(std::istringstream &strm) = 0;
+  // :200-206  on-line step sequencing drives the Kajita / Morisawa generators from the step stack while walking: throws
+  // NotOnThisPath (Start), no effect (Stop, Add: they only set flags Start would read)
+  virtual void StartOnLineStepSequencing() = 0;
+  virtual void StopOnLineStepSequencing() = 0;
+  virtual void AddOnLineStep(double X, double Y, double Theta) = 0;
+  // :224-234  Morisawa-2007 only in the reference; any other generator answers -1 / does nothing there too (:1800-1816)
+  virtual int ChangeOnLineStep(double Time, FootAbsolutePosition &aFootAbsolutePosition, double &newtime) = 0;
+  virtual void ChangeOnLineStep(std::istringstream &strm, double &newtime) = 0;
+  // :241-258  odometry (PatternGeneratorInterfacePrivate.cpp:1632-1780)
+  virtual void UpdateAbsolutePosition(bool UpdateAbsMotionOrNot) = 0;
+  virtual void getWaistPositionAndOrientation(double TQ[7], double &Orientation) const = 0;
+  virtual void setWaistPositionAndOrientation(double TQ[7]) = 0;
+  virtual void getWaistVelocity(double &dx, double &dy, double &omega) const = 0;
+  virtual void getWaistPositionMatrix(MAL_S4x4_MATRIX(&lWaistAbsPos, double)) const = 0;
+  // :264-267
+  virtual void setZMPInitialPoint(MAL_S3_VECTOR(&, double) lZMPInitialPoint) = 0;
+  virtual void getZMPInitialPoint(MAL_S3_VECTOR(&, double) lZMPInitialPoint) const = 0;
+  // :274
+  virtual int ParseCmd(std::istringstream &strm) = 0;
+  // :283  from the robot's forward kinematics of the current joint values (abstract robot), or the supplied start state
+  // (HumanoidModel); then ":comheight <CoM z>" like the reference (PatternGeneratorInterfacePrivate.cpp:588-617)
+  virtual void EvaluateStartingState(COMState &lStartingCOMState, MAL_S3_VECTOR_TYPE(double) & lStartingZMPPosition,
+                                     MAL_VECTOR_TYPE(double) & lStartingWaistPose, FootAbsolutePosition &InitLeftFootAbsPos,
+                                     FootAbsolutePosition &InitRightFootAbsPos) = 0;
+  // :298, :305
+  virtual void setVelocityReference(double x, double y, double yaw) = 0;
+  virtual void setCoMPerturbationForce(double x, double y) = 0;
 };
 
-// patterngeneratorinterface.hh:306; the caller owns the model and the returned object
+// patterngeneratorinterface.hh:306; the caller owns the robot and the returned object
+PatternGeneratorInterface *patternGeneratorInterfaceFactory(CjrlHumanoidDynamicRobot *aHDR);
+// the same generator on the plain numbers (start state supplied in the struct)
 PatternGeneratorInterface *patternGeneratorInterfaceFactory(const HumanoidModel *);
 
 }  // namespace PatternGeneratorJRL

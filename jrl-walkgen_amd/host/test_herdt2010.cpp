@@ -47,7 +47,7 @@ int main(int argc, char **argv) {
     ofstream aof(path);
     aof.precision(12);
     aof.setf(ios::scientific, ios::floatfield);
-    vector<double> q, dq, ddq, ZMPTarget(3, 0.0);
+    vectorN q, dq, ddq, ZMPTarget(3, 0.0);
     COMState c;
     FootAbsolutePosition L, R;
     unsigned long it = 0;

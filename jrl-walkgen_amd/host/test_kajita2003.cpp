@@ -53,7 +53,7 @@ int main(int argc, char **argv) {
 
     FILE *f = fopen(out.c_str(), "w");
     if (!f) throw std::runtime_error("cannot open " + out);
-    std::vector<double> q, dq, ddq, zmp;
+    vectorN q, dq, ddq, zmp;
     COMState com;
     FootAbsolutePosition lf, rf;
     unsigned long n = 0;

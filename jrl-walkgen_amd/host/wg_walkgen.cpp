@@ -46,6 +46,39 @@ HumanoidModel HumanoidModel::sampleRobot() {
   return h;
 }
 
+static const double kPi = 3.14159265358979323846;
+
+HumanoidModel HumanoidModelFromRobot(CjrlHumanoidDynamicRobot *aHDR) {
+  if (aHDR == 0) throw runtime_error("HumanoidModelFromRobot: null robot");
+  HumanoidModel h;
+  memset(&h, 0, sizeof h);
+  h.mass = aHDR->mass();                                   // ZMPVelocityReferencedQP.cpp:68
+  CjrlFoot *RightFoot = aHDR->rightFoot(), *LeftFoot = aHDR->leftFoot();
+  if (RightFoot == 0 || LeftFoot == 0) throw runtime_error("HumanoidModelFromRobot: the robot has no feet");
+  double WidthHalf = 0.0, HeightHalf = 0.0;                // relative-feet-inequalities.cpp:155-172: right, then left; the
+  RightFoot->getSoleSize(WidthHalf, HeightHalf);           // left foot's size ends up used for both feet
+  LeftFoot->getSoleSize(WidthHalf, HeightHalf);
+  h.soleWidth = WidthHalf; h.soleHeight = HeightHalf;
+  vector3d ankle;
+  LeftFoot->getAnklePositionInLocalFrame(ankle);           // rigid-body-system.cpp:38
+  for (int i = 0; i < 3; i++) h.anklePosition[i] = ankle[i];
+  // OrientationsPreview.cpp:42-68: hip-yaw joint = second joint on the chain waist -> ankle
+  CjrlJoint *waist = aHDR->waist();
+  const CjrlJoint *lAnkle = LeftFoot->associatedAnkle(), *rAnkle = RightFoot->associatedAnkle();
+  if (waist && lAnkle && rAnkle) {
+    vector<CjrlJoint *> lc = aHDR->jointsBetween(*waist, *lAnkle), rc = aHDR->jointsBetween(*waist, *rAnkle);
+    if (lc.size() > 1 && rc.size() > 1) {
+      h.hasHipYawLimits = true;
+      h.leftHipYawLower = lc[1]->lowerBound(0); h.leftHipYawUpper = lc[1]->upperBound(0);
+      h.rightHipYawLower = rc[1]->lowerBound(0); h.rightHipYawUpper = rc[1]->upperBound(0);
+      if (h.leftHipYawLower == h.leftHipYawUpper) { h.leftHipYawLower = -30.0 / 180.0 * kPi; h.leftHipYawUpper = 45.0 / 180.0 * kPi; }
+      if (h.rightHipYawLower == h.rightHipYawUpper) { h.rightHipYawLower = -30.0 / 180.0 * kPi; h.rightHipYawUpper = 45.0 / 180.0 * kPi; }
+      h.hipYawVelocityMax = fabs(lc[1]->upperVelocityBound(0));
+    }
+  }
+  return h;
+}
+
 // ---- SimplePluginManager / SimplePlugin (src/SimplePluginManager.cpp:40-163, src/SimplePlugin.cpp:35-50) -------------------
 SimplePluginManager::~SimplePluginManager() {
   for (auto it = m_SimplePlugins.begin(); it != m_SimplePlugins.end(); ++it) it->second->m_SimplePluginManager = 0;
@@ -145,8 +178,10 @@ ZMPVelocityReferencedQP::ZMPVelocityReferencedQP(SimplePluginManager *SPM, strin
   memset(&State_, 0, sizeof State_);
   Ctx_ = NewContext();
   if (wg_mpc_configure_ctx(Ctx_, &Model_) != WG_OK) { wg_ctx_destroy(Ctx_); Ctx_ = 0; wg_throw("wg_mpc_configure"); }
-  const unsigned int NbMethods = 3;
-  string aMethodName[NbMethods] = {":previewcontroltime", ":numberstepsbeforestop", ":stoppg"};
+  // ":setfeetconstraint" is RelativeFeetInequalities' command in the reference (relative-feet-inequalities.cpp:68-79: of its
+  // three names only this one is registered); that object's state is part of the device model here
+  const unsigned int NbMethods = 4;
+  string aMethodName[NbMethods] = {":previewcontroltime", ":numberstepsbeforestop", ":stoppg", ":setfeetconstraint"};
   for (unsigned int i = 0; i < NbMethods; i++)
     if (!RegisterMethod(aMethodName[i])) cerr << "Unable to register " << aMethodName[i] << endl;
 }
@@ -173,12 +208,29 @@ void ZMPVelocityReferencedQP::CallMethod(string &Method, istringstream &strm) { 
     State_.nb_steps_ssds = NbStepsSSDS_;
   }
   if (Method == ":stoppg") State_.ending_phase = 1;
+  if (Method == ":setfeetconstraint") {             // relative-feet-inequalities.cpp:322-342
+    string lCmd;
+    strm >> lCmd;
+    if (lCmd == "XY") {
+      double mx = Model_.margin_x, my = Model_.margin_y;
+      strm >> mx;
+      strm >> my;
+      SetFeetConstraint(mx, my);
+      cout << "Security margin On X: " << mx << " Security margin On Y: " << my << endl;
+    }
+  }
   ZMPRefTrajectoryGeneration::CallMethod(Method, strm);
   if (Model_.Tctrl != m_SamplingPeriod) {           // ":samplingperiod": the device copy of the model follows (or refuses)
     const double old = Model_.Tctrl;
     Model_.Tctrl = m_SamplingPeriod;
     if (wg_mpc_configure_ctx(Ctx_, &Model_) != WG_OK) { Model_.Tctrl = old; m_SamplingPeriod = old; wg_throw("wg_mpc_configure"); }
   }
+}
+
+void ZMPVelocityReferencedQP::SetFeetConstraint(double SecurityMarginX, double SecurityMarginY) {
+  const double ox = Model_.margin_x, oy = Model_.margin_y;
+  Model_.margin_x = SecurityMarginX; Model_.margin_y = SecurityMarginY;
+  if (wg_mpc_configure_ctx(Ctx_, &Model_) != WG_OK) { Model_.margin_x = ox; Model_.margin_y = oy; wg_throw("wg_mpc_configure"); }
 }
 
 void ZMPVelocityReferencedQP::LegacyGoldenReplay(bool on) {
@@ -588,6 +640,13 @@ void StepStackHandler::ReadStepSequenceAccordingToWalkMode(istringstream &strm) 
     m_KeepLastCorrectSupportFoot = aFootPosition.sy > 0 ? -1 : 1;
   }
 }
+void StepStackHandler::AddStepInTheStack(double sx, double sy, double theta, double sstime, double dstime) {   // :850-863
+  RelativeFootPosition aFootPosition;
+  memset(&aFootPosition, 0, sizeof aFootPosition);
+  aFootPosition.sx = sx; aFootPosition.sy = sy; aFootPosition.theta = theta;
+  aFootPosition.SStime = sstime; aFootPosition.DStime = dstime; aFootPosition.stepType = 0;
+  m_RelativeFootPositions.push_back(aFootPosition);
+}
 static void push_rel(deque<RelativeFootPosition> &q, double sx, double sy, double theta, double ss, double ds) {
   RelativeFootPosition a;
   memset(&a, 0, sizeof a);               // the reference leaves stepType uninitialised in the first two generators; 0 here
@@ -711,7 +770,10 @@ namespace {
 class PatternGeneratorInterfacePrivate : public virtual PatternGeneratorInterface, SimplePluginManager, SimplePlugin {
  public:
   PatternGeneratorInterfacePrivate(const HumanoidModel *aHDR)
-      : PatternGeneratorInterface(aHDR), SimplePlugin(this), m_Model(*aHDR) {
+      : PatternGeneratorInterface(aHDR), SimplePlugin(this), m_Model(*aHDR), m_Robot(0) { Construct(); }
+  PatternGeneratorInterfacePrivate(CjrlHumanoidDynamicRobot *aHDR)
+      : PatternGeneratorInterface(aHDR), SimplePlugin(this), m_Model(HumanoidModelFromRobot(aHDR)), m_Robot(aHDR) { Construct(); }
+  void Construct() {
     // PatternGeneratorInterfacePrivate.cpp:181-215: the commands this object handles itself
     string aMethodName[13] = {":samplingperiod", ":setVelReference", ":HerdtOnline", ":setCoMPerturbationForce",
                               ":SetAlgoForZmpTrajectory", ":wg_legacy_golden", ":stepseq", ":finish", ":supportfoot", ":arc",
@@ -728,6 +790,13 @@ class PatternGeneratorInterfacePrivate : public virtual PatternGeneratorInterfac
     m_Running = false;
     m_Herdt = false;
     m_NbOfHitBottom = 0;
+    // :147-174
+    m_count = 0; m_dt = 0.005; m_AbsTheta = 0; m_AbsMotionTheta = 0;
+    m_ZMPInitialPointSet = false;
+    m_NewStep = false; m_NewStepX = m_NewStepY = m_NewTheta = 0.0;
+    m_TSsupport = 0.78; m_TDsupport = 0.02;                 // :82-83 (":singlesupporttime", ":doublesupporttime")
+    for (int i = 0; i < 4; i++) { m_AbsLinearVelocity[i] = 0.0; m_AbsLinearAcc[i] = 0.0; m_AbsAngularVelocity[i] = 0.0; }
+    m_CurrentWaistState.reset();
   }
   ~PatternGeneratorInterfacePrivate() { delete m_ZMPVRQP; delete m_ZMPD; delete m_PC; }
 
@@ -764,6 +833,13 @@ class PatternGeneratorInterfacePrivate : public virtual PatternGeneratorInterfac
       FinishAndRealizeStepSequence();
     } else if (aCmd == ":supportfoot" || aCmd == ":arc" || aCmd == ":lastsupport" || aCmd == ":singlesupporttime" ||
                aCmd == ":doublesupporttime") {
+      if (aCmd == ":singlesupporttime" || aCmd == ":doublesupporttime") {   // :1085-1094: kept for AddStepInStack too
+        istringstream peek(strm.str());
+        string skip;
+        double v = 0.0;
+        peek >> skip >> v;
+        (aCmd == ":singlesupporttime" ? m_TSsupport : m_TDsupport) = v;
+      }
       m_SSH.CallMethod(aCmd, strm);                                  // StepStackHandler is a plugin of this manager there
     } else if (aCmd == ":wg_legacy_golden") {
       int on = 0;
@@ -772,33 +848,126 @@ class PatternGeneratorInterfacePrivate : public virtual PatternGeneratorInterfac
     }
   }
 
-  void EvaluateStartingState(COMState &lStartingCOMState, double lStartingZMPPosition[3], vector<double> &lStartingWaistPose,
-                             FootAbsolutePosition &InitLeftFootAbsPos, FootAbsolutePosition &InitRightFootAbsPos) {
-    lStartingCOMState.reset();
-    lStartingCOMState.x[0] = m_Model.startCoM[0]; lStartingCOMState.y[0] = m_Model.startCoM[1];
-    lStartingCOMState.z[0] = m_Model.startCoM[2]; lStartingCOMState.z[1] = lStartingCOMState.z[2] = 0.0;
-    for (int i = 0; i < 3; i++) lStartingZMPPosition[i] = m_Model.startZMP[i];
-    lStartingWaistPose.assign(6, 0.0);
+  // ComAndFootRealizationByGeometry::InitializationFoot, ComAndFootRealizationByGeometry.cpp:381-440: the foot frame is the
+  // ankle frame moved by minus the ankle's position in the foot frame; its rotation is taken relative to the ankle's rotation
+  // in the reference posture; the foot must be flat
+  static void InitializationFoot(const CjrlFoot *aFoot, FootAbsolutePosition &InitFootPosition) {
+    const CjrlJoint *AnkleJoint = aFoot->associatedAnkle();
+    if (AnkleJoint == 0) throw runtime_error("EvaluateStartingState: a foot without an ankle joint");
+    vector3d anklePosition;
+    aFoot->getAnklePositionInLocalFrame(anklePosition);
+    matrix4d lFootPose = AnkleJoint->currentTransformation();
+    for (int i = 0; i < 3; i++) {                       // lFootPose * translation(-anklePosition)
+      double t = lFootPose(i, 3);
+      for (int k = 0; k < 3; k++) t += lFootPose(i, k) * -anklePosition[k];
+      lFootPose(i, 3) = t;
+    }
+    InitFootPosition.x = lFootPose(0, 3); InitFootPosition.y = lFootPose(1, 3); InitFootPosition.z = lFootPose(2, 3);
+    const matrix4d &initialRot = AnkleJoint->initialPosition();
+    double invrot[3][3];
+    for (int i = 0; i < 3; i++)
+      for (int j = 0; j < 3; j++) {
+        invrot[i][j] = 0.0;
+        for (int k = 0; k < 3; k++) invrot[i][j] += lFootPose(i, k) * initialRot(j, k);
+      }
+    if (invrot[2][1] != 0.0) throw runtime_error("EvaluateStartingState: the initial foot position is not flat");   // assert there
+    InitFootPosition.omega = atan2(invrot[2][0], invrot[2][2]) * 180 / kPi;
+    InitFootPosition.theta = atan2(-invrot[0][1], invrot[1][1]) * 180 / kPi;
+  }
+
+  // the strategy-level evaluation (CoMAndFootOnlyStrategy::EvaluateStartingState, CoMAndFootOnlyStrategy.cpp:127-155 ->
+  // ComAndFootRealizationByGeometry::InitializationCoM, ComAndFootRealizationByGeometry.cpp:449-545), without the
+  // ":comheight" command the public method adds
+  void StrategyEvaluateStartingState(COMState &lStartingCOMState, vector3d &lStartingZMPPosition, vectorN &lStartingWaistPose,
+                                     FootAbsolutePosition &InitLeftFootAbsPos, FootAbsolutePosition &InitRightFootAbsPos) {
     memset(&InitLeftFootAbsPos, 0, sizeof InitLeftFootAbsPos);
     memset(&InitRightFootAbsPos, 0, sizeof InitRightFootAbsPos);
-    InitLeftFootAbsPos.x = m_Model.startLeftFoot[0]; InitLeftFootAbsPos.y = m_Model.startLeftFoot[1];
-    InitLeftFootAbsPos.theta = m_Model.startLeftFoot[2];
-    InitRightFootAbsPos.x = m_Model.startRightFoot[0]; InitRightFootAbsPos.y = m_Model.startRightFoot[1];
-    InitRightFootAbsPos.theta = m_Model.startRightFoot[2];
+    if (m_Robot == 0) {                                   // plain numbers: the start state is part of them
+      lStartingCOMState.reset();
+      lStartingCOMState.x[0] = m_Model.startCoM[0]; lStartingCOMState.y[0] = m_Model.startCoM[1];
+      lStartingCOMState.z[0] = m_Model.startCoM[2]; lStartingCOMState.z[1] = lStartingCOMState.z[2] = 0.0;
+      for (int i = 0; i < 3; i++) lStartingZMPPosition[i] = m_Model.startZMP[i];
+      lStartingWaistPose.assign(6, 0.0);
+      InitLeftFootAbsPos.x = m_Model.startLeftFoot[0]; InitLeftFootAbsPos.y = m_Model.startLeftFoot[1];
+      InitLeftFootAbsPos.theta = m_Model.startLeftFoot[2];
+      InitRightFootAbsPos.x = m_Model.startRightFoot[0]; InitRightFootAbsPos.y = m_Model.startRightFoot[1];
+      InitRightFootAbsPos.theta = m_Model.startRightFoot[2];
+      return;
+    }
+    // InitializationHumanoid :305-380: free flyer at the given waist pose (zero if none), joints after it
+    const unsigned int nDof = m_Robot->numberDof();
+    if (nDof < 6 + m_CurrentJointValues.size())
+      throw runtime_error("EvaluateStartingState: more joint values than the robot has degrees of freedom");
+    vectorN CurrentConfig(nDof, 0.0);
+    if (lStartingWaistPose.size() >= 6) for (int i = 0; i < 6; i++) CurrentConfig[i] = lStartingWaistPose[i];
+    else lStartingWaistPose.assign(6, 0.0);
+    for (size_t i = 0; i < m_CurrentJointValues.size(); i++) CurrentConfig[6 + i] = m_CurrentJointValues[i];
+    m_Robot->currentConfiguration(CurrentConfig);
+    {
+      string inProperty[2] = {"ComputeCoM", "ComputeZMP"};
+      string inValue[2] = {"true", "false"};
+      for (unsigned int i = 0; i < 2; i++) m_Robot->setProperty(inProperty[i], inValue[i]);
+    }
+    m_Robot->computeForwardKinematics();
+    CurrentConfig = m_Robot->currentConfiguration();
+    for (int i = 0; i < 6; i++) lStartingWaistPose[i] = CurrentConfig[i];
+    CjrlFoot *RightFoot = m_Robot->rightFoot(), *LeftFoot = m_Robot->leftFoot();
+    InitializationFoot(RightFoot, InitRightFootAbsPos);
+    InitializationFoot(LeftFoot, InitLeftFootAbsPos);
+    vector3d COGInitialAnkles(0.5 * (InitRightFootAbsPos.x + InitLeftFootAbsPos.x), 0.5 * (InitRightFootAbsPos.y + InitLeftFootAbsPos.y),
+                              0.5 * (InitRightFootAbsPos.z + InitLeftFootAbsPos.z));
+    lStartingWaistPose[2] -= InitRightFootAbsPos.z;
+    vector3d lStartingCOMPosition = m_Robot->positionCenterOfMass();
+    lStartingCOMPosition[2] -= InitRightFootAbsPos.z;
+    InitLeftFootAbsPos.z = 0.0;
+    InitRightFootAbsPos.z = 0.0;
+    lStartingCOMState.x[0] = lStartingCOMPosition[0]; lStartingCOMState.y[0] = lStartingCOMPosition[1];
+    lStartingCOMState.z[0] = lStartingCOMPosition[2];
+    lStartingCOMState.yaw[0] = lStartingWaistPose[5]; lStartingCOMState.pitch[0] = lStartingWaistPose[4];
+    lStartingCOMState.roll[0] = lStartingWaistPose[3];
+    lStartingZMPPosition = COGInitialAnkles;
+  }
+
+  void EvaluateStartingState(COMState &lStartingCOMState, vector3d &lStartingZMPPosition, vectorN &lStartingWaistPose,
+                             FootAbsolutePosition &InitLeftFootAbsPos, FootAbsolutePosition &InitRightFootAbsPos) {   // :588-617
+    StrategyEvaluateStartingState(lStartingCOMState, lStartingZMPPosition, lStartingWaistPose, InitLeftFootAbsPos,
+                                  InitRightFootAbsPos);
+    ostringstream osscomheightcmd;
+    osscomheightcmd.precision(17);
+    osscomheightcmd << ":comheight " << lStartingCOMState.z[0];
+    istringstream isscomheightcmd(osscomheightcmd.str());
+    ParseCmd(isscomheightcmd);
   }
 
   void initOnlineHerdt() {                                // :517-560
     COMState lStartingCOMState;
-    double lStartingZMPPosition[3];
-    vector<double> lStartingWaistPose;
+    vector3d lStartingZMPPosition;
+    vectorN lStartingWaistPose;
     FootAbsolutePosition InitLeftFootAbsPos, InitRightFootAbsPos;
     EvaluateStartingState(lStartingCOMState, lStartingZMPPosition, lStartingWaistPose, InitLeftFootAbsPos, InitRightFootAbsPos);
     deque<RelativeFootPosition> RelativeFootPositions;
     m_ZMPVRQP->SetCurrentTime(m_InternalClock);
     m_ZMPVRQP->InitOnLine(m_ZMPPositions, m_COMBuffer, m_LeftFootPositions, m_RightFootPositions, InitLeftFootAbsPos,
-                          InitRightFootAbsPos, RelativeFootPositions, lStartingCOMState, lStartingZMPPosition);
+                          InitRightFootAbsPos, RelativeFootPositions, lStartingCOMState, lStartingZMPPosition.v);
     m_NbOfHitBottom = 0;
     m_ShouldBeRunning = true;
+  }
+
+  // :688-776 (AutoFirstStep is off on this path, :62)
+  void CommonInitializationOfWalking(COMState &lStartingCOMState, vector3d &lStartingZMPPosition, vectorN &BodyAnglesIni,
+                                     FootAbsolutePosition &InitLeftFootAbsPos, FootAbsolutePosition &InitRightFootAbsPos,
+                                     deque<RelativeFootPosition> &lRelativeFootPositions, vector<double> &lCurrentJointValues,
+                                     bool ClearStepStackHandler) {
+    m_ZMPPositions.clear();
+    m_LeftFootPositions.clear();
+    m_RightFootPositions.clear();
+    lCurrentJointValues = m_CurrentJointValues;
+    BodyAnglesIni = vectorN(m_CurrentJointValues);
+    m_SSH.CopyRelativeFootPosition(lRelativeFootPositions, ClearStepStackHandler);
+    vectorN lStartingWaistPose;
+    StrategyEvaluateStartingState(lStartingCOMState, lStartingZMPPosition, lStartingWaistPose, InitLeftFootAbsPos,
+                                  InitRightFootAbsPos);
+    if (m_Robot) { string aProperty("ResetIteration"), aValue("any"); m_Robot->setProperty(aProperty, aValue); }
   }
 
   // :881-1005 in Kajita mode, stage 1 only: the step stack -> ZMPDiscretization (CreateZMPReferences :1870-1882) -> the
@@ -807,13 +976,16 @@ class PatternGeneratorInterfacePrivate : public virtual PatternGeneratorInterfac
   // CoM handed out is the cart-table one)
   void FinishAndRealizeStepSequence() {
     COMState lStartingCOMState;
-    double lStartingZMPPosition[3];
-    vector<double> lStartingWaistPose;
+    vector3d lStartingZMPPositionV;
+    vectorN BodyAnglesIni;
     FootAbsolutePosition InitLeftFootAbsPos, InitRightFootAbsPos;
     deque<RelativeFootPosition> lRelativeFootPositions;
-    m_SSH.CopyRelativeFootPosition(lRelativeFootPositions, true);
-    EvaluateStartingState(lStartingCOMState, lStartingZMPPosition, lStartingWaistPose, InitLeftFootAbsPos, InitRightFootAbsPos);
-    m_ZMPPositions.clear(); m_COMBuffer.clear(); m_LeftFootPositions.clear(); m_RightFootPositions.clear();
+    vector<double> lCurrentJointValues;
+    CommonInitializationOfWalking(lStartingCOMState, lStartingZMPPositionV, BodyAnglesIni, InitLeftFootAbsPos, InitRightFootAbsPos,
+                                  lRelativeFootPositions, lCurrentJointValues, true);                  // :895-904
+    if (m_ZMPInitialPointSet) lStartingZMPPositionV = m_ZMPInitialPoint;
+    double *lStartingZMPPosition = lStartingZMPPositionV.v;
+    m_COMBuffer.clear();
     m_ZMPD->SetCurrentTime(m_InternalClock);
     m_ZMPD->GetZMPDiscretization(m_ZMPPositions, m_COMBuffer, lRelativeFootPositions, m_LeftFootPositions,
                                  m_RightFootPositions, 0.0, lStartingCOMState, lStartingZMPPosition, InitLeftFootAbsPos,
@@ -842,9 +1014,30 @@ class PatternGeneratorInterfacePrivate : public virtual PatternGeneratorInterfac
   }
 
   // :1246-1514 (Herdt branch) + CoMAndFootOnlyStrategy::OneGlobalStepOfControl
-  bool RunOneStepOfTheControlLoop(vector<double> &, vector<double> &, vector<double> &, vector<double> &ZMPTarget,
-                                  COMState &finalCOMState, FootAbsolutePosition &LeftFootPosition,
+  bool RunOneStepOfTheControlLoop(vectorN &CurrentConfiguration, vectorN &CurrentVelocity, vectorN &CurrentAcceleration,
+                                  vectorN &ZMPTarget, COMState &finalCOMState, FootAbsolutePosition &LeftFootPosition,
                                   FootAbsolutePosition &RightFootPosition) {
+    const bool r = OneStep(ZMPTarget, finalCOMState, LeftFootPosition, RightFootPosition);
+    if (r) {
+      // :1360-1375: the waist state is read from the caller's configuration (this strategy does not write it)
+      m_count++;
+      if (CurrentConfiguration.size() >= 6) {
+        m_CurrentWaistState.x[0] = CurrentConfiguration[0]; m_CurrentWaistState.y[0] = CurrentConfiguration[1];
+        m_CurrentWaistState.z[0] = CurrentConfiguration[2]; m_CurrentWaistState.roll[0] = CurrentConfiguration[3];
+        m_CurrentWaistState.pitch[0] = CurrentConfiguration[4]; m_CurrentWaistState.yaw[0] = CurrentConfiguration[5];
+      }
+      if (CurrentVelocity.size() >= 3) {
+        m_CurrentWaistState.x[1] = CurrentVelocity[0]; m_CurrentWaistState.y[1] = CurrentVelocity[1];
+        m_CurrentWaistState.z[1] = CurrentVelocity[2];
+      }
+      (void)CurrentAcceleration;
+    }
+    // :1508-1510: the absolute motion frame moves on when a motion has finished
+    UpdateAbsolutePosition(!r || !m_ShouldBeRunning);
+    return r;
+  }
+  bool OneStep(vectorN &ZMPTarget, COMState &finalCOMState, FootAbsolutePosition &LeftFootPosition,
+               FootAbsolutePosition &RightFootPosition) {
     m_InternalClock += m_SamplingPeriod;
     if (!m_Herdt && m_ShouldBeRunning && m_ZMPPositions.size() <= 2 * (size_t)m_NL) {
       m_ShouldBeRunning = false;   // DoubleStagePreviewControlStrategy::EndOfMotion: two preview windows stay on the queue
@@ -869,33 +1062,115 @@ class PatternGeneratorInterfacePrivate : public virtual PatternGeneratorInterfac
     }
     return m_Running;
   }
-  bool RunOneStepOfTheControlLoop(vector<double> &q, vector<double> &dq, vector<double> &ddq, vector<double> &ZMPTarget,
-                                  COMPosition &finalCOMPosition, FootAbsolutePosition &L, FootAbsolutePosition &R) {
+  bool RunOneStepOfTheControlLoop(vectorN &q, vectorN &dq, vectorN &ddq, vectorN &ZMPTarget, COMPosition &finalCOMPosition,
+                                  FootAbsolutePosition &L, FootAbsolutePosition &R) {
     COMState aCOMState;
     m_Running = RunOneStepOfTheControlLoop(q, dq, ddq, ZMPTarget, aCOMState, L, R);
     finalCOMPosition = aCOMState;
     return m_Running;
   }
-  bool RunOneStepOfTheControlLoop(vector<double> &q, vector<double> &dq, vector<double> &ddq, vector<double> &ZMPTarget) {
+  bool RunOneStepOfTheControlLoop(vectorN &q, vectorN &dq, vectorN &ddq, vectorN &ZMPTarget) {
     FootAbsolutePosition L, R;
     COMState c;
     return RunOneStepOfTheControlLoop(q, dq, ddq, ZMPTarget, c, L, R);
   }
   bool RunOneStepOfTheControlLoop(FootAbsolutePosition &L, FootAbsolutePosition &R, ZMPPosition &ZMPRefPos,
                                   COMPosition &COMRefPos) {    // :1198-1229
-    vector<double> q, dq, ddq, ZMPTarget;
+    vectorN q, dq, ddq, ZMPTarget;
     COMState c;
     bool r = RunOneStepOfTheControlLoop(q, dq, ddq, ZMPTarget, c, L, R);
     if (ZMPTarget.size() >= 3) { ZMPRefPos.px = ZMPTarget[0]; ZMPRefPos.py = ZMPTarget[1]; ZMPRefPos.pz = ZMPTarget[2]; }
     COMRefPos = c;
     return r;
   }
-  void SetCurrentJointValues(vector<double> &v) { m_CurrentJointValues = v; }
+  void SetCurrentJointValues(vectorN &v) { m_CurrentJointValues = v; }                     // :1549-1558
+  void AddStepInStack(double dx, double dy, double theta) { m_SSH.AddStepInTheStack(dx, dy, theta, m_TSsupport, m_TDsupport); }   // :1906-1912
+  int GetWalkMode() const { return m_SSH.GetWalkMode(); }                                  // :1576-1579
+  void GetLegJointVelocity(vectorN &dqr, vectorN &dql) const { dqr.assign(6, 0.0); dql.assign(6, 0.0); }   // :1588-1600
+  void ReadSequenceOfSteps(istringstream &strm) {                                          // :461-515
+    if (m_SSH.GetWalkMode() != 0) throw NotOnThisPath("ReadSequenceOfSteps in walk mode " + to_string(m_SSH.GetWalkMode()));
+    m_SSH.ReadStepSequenceAccordingToWalkMode(strm);
+  }
+  void StartOnLineStepSequencing() { throw NotOnThisPath("StartOnLineStepSequencing (on-line step stack)"); }
+  void StopOnLineStepSequencing() {}                                                       // :876-879: a flag of the step stack
+  void AddOnLineStep(double X, double Y, double Theta) { m_NewStep = true; m_NewStepX = X; m_NewStepY = Y; m_NewTheta = Theta; }   // :1625-1631
+  int ChangeOnLineStep(double, FootAbsolutePosition &, double &) { return -1; }            // :1795-1816: Morisawa only
+  void ChangeOnLineStep(istringstream &, double &) {}                                      // m_ChangeNextStep -> the above
+  void setZMPInitialPoint(vector3d &lZMPInitialPoint) { m_ZMPInitialPoint = lZMPInitialPoint; m_ZMPInitialPointSet = true; }   // :1914-1918
+  void getZMPInitialPoint(vector3d &lZMPInitialPoint) const { lZMPInitialPoint = m_ZMPInitialPoint; }
+
+  // ---- odometry, :1632-1780 ----
+  static void mul4(matrix4d &C, const matrix4d &A, const matrix4d &B) {
+    matrix4d R;
+    for (int i = 0; i < 4; i++)
+      for (int j = 0; j < 4; j++) {
+        double t = 0.0;
+        for (int k = 0; k < 4; k++) t += A(i, k) * B(k, j);
+        R(i, j) = t;
+      }
+    C = R;
+  }
+  void UpdateAbsolutePosition(bool UpdateAbsMotionOrNot) {
+    const double thetarad = m_CurrentWaistState.yaw[0];
+    const double c = cos(thetarad), s = sin(thetarad);
+    m_WaistRelativePos = matrix4d();
+    m_WaistRelativePos(0, 0) = c; m_WaistRelativePos(0, 1) = -s;
+    m_WaistRelativePos(1, 0) = s; m_WaistRelativePos(1, 1) = c;
+    const double RelativeLinearVelocity[4] = {m_CurrentWaistState.x[1], m_CurrentWaistState.y[1], m_CurrentWaistState.z[0], 1.0};
+    const double RelativeLinearAcc[4] = {m_CurrentWaistState.x[2], m_CurrentWaistState.y[2], 0.0, 1.0};
+    for (int i = 0; i < 4; i++) {
+      double v = 0.0, a = 0.0;
+      for (int k = 0; k < 4; k++) { v += m_MotionAbsOrientation(i, k) * RelativeLinearVelocity[k]; a += m_MotionAbsOrientation(i, k) * RelativeLinearAcc[k]; }
+      m_AbsLinearVelocity[i] = v; m_AbsLinearAcc[i] = a;
+    }
+    m_WaistRelativePos(0, 3) = m_CurrentWaistState.x[0];
+    m_WaistRelativePos(1, 3) = m_CurrentWaistState.y[0];
+    m_WaistRelativePos(2, 3) = m_CurrentWaistState.z[0];
+    mul4(m_WaistAbsPos, m_MotionAbsPos, m_WaistRelativePos);
+    m_AbsAngularVelocity[0] = 0.0; m_AbsAngularVelocity[1] = 0.0;
+    if (m_count != 0) m_AbsAngularVelocity[2] = (m_AbsMotionTheta + thetarad - m_AbsTheta) / m_dt;
+    else m_AbsAngularVelocity[2] = 0.0;
+    m_AbsAngularVelocity[3] = 1.0;
+    m_AbsTheta = fmod(m_AbsMotionTheta + thetarad, 2 * kPi);
+    if (UpdateAbsMotionOrNot) {
+      m_MotionAbsPos = m_WaistAbsPos;
+      m_MotionAbsPos(2, 3) = 0.0;                     // the position is supposed at the ground level
+      m_AbsMotionTheta = m_AbsTheta;
+    }
+  }
+  void getWaistPositionMatrix(matrix4d &lWaistAbsPos) const { lWaistAbsPos = m_WaistAbsPos; }
+  void getWaistPositionAndOrientation(double aTQ[7], double &Orientation) const {
+    aTQ[0] = m_WaistAbsPos(0, 3); aTQ[1] = m_WaistAbsPos(1, 3); aTQ[2] = m_WaistAbsPos(2, 3);
+    aTQ[3] = 0; aTQ[4] = 0; aTQ[5] = sin(0.5 * m_AbsTheta); aTQ[6] = cos(0.5 * m_AbsTheta);   // a yaw-only quaternion (x y z w)
+    Orientation = m_AbsTheta;
+  }
+  void setWaistPositionAndOrientation(double aTQ[7]) {
+    m_WaistAbsPos(0, 3) = aTQ[0]; m_WaistAbsPos(1, 3) = aTQ[1]; m_WaistAbsPos(2, 3) = aTQ[2];
+    const double _x = aTQ[3], _y = aTQ[4], _z = aTQ[5], _r = aTQ[6];
+    const double x2 = _x * _x, y2 = _y * _y, z2 = _z * _z, r2 = _r * _r;
+    m_WaistAbsPos(0, 0) = r2 + x2 - y2 - z2; m_WaistAbsPos(1, 1) = r2 - x2 + y2 - z2; m_WaistAbsPos(2, 2) = r2 - x2 - y2 + z2;
+    const double xy = _x * _y, yz = _y * _z, zx = _z * _x, rx = _r * _x, ry = _r * _y, rz = _r * _z;
+    m_WaistAbsPos(0, 1) = 2 * (xy - rz); m_WaistAbsPos(0, 2) = 2 * (zx + ry); m_WaistAbsPos(1, 0) = 2 * (xy + rz);
+    m_WaistAbsPos(1, 2) = 2 * (yz - rx); m_WaistAbsPos(2, 0) = 2 * (zx - ry); m_WaistAbsPos(2, 1) = 2 * (yz + rx);
+  }
+  void getWaistVelocity(double &dx, double &dy, double &omega) const {
+    dx = m_AbsLinearVelocity[0]; dy = m_AbsLinearVelocity[1]; omega = m_AbsAngularVelocity[2];
+  }
   void setVelocityReference(double x, double y, double yaw) { m_ZMPVRQP->Reference(x, y, yaw); }
   void setCoMPerturbationForce(double x, double y) { m_ZMPVRQP->setCoMPerturbationForce(x, y); }
 
  private:
   HumanoidModel m_Model;
+  CjrlHumanoidDynamicRobot *m_Robot;          // the caller's robot (abstract-robot factory) or 0 (plain numbers)
+  // odometry (:1632-1780) and the small members of the reference the extra interface methods read or write
+  COMState m_CurrentWaistState;
+  matrix4d m_WaistRelativePos, m_WaistAbsPos, m_MotionAbsPos, m_MotionAbsOrientation;
+  double m_AbsLinearVelocity[4], m_AbsLinearAcc[4], m_AbsAngularVelocity[4];
+  double m_AbsTheta, m_AbsMotionTheta, m_dt;
+  unsigned long m_count;
+  vector3d m_ZMPInitialPoint;
+  bool m_ZMPInitialPointSet, m_NewStep;
+  double m_NewStepX, m_NewStepY, m_NewTheta, m_TSsupport, m_TDsupport;
   ZMPVelocityReferencedQP *m_ZMPVRQP;
   ZMPDiscretization *m_ZMPD;
   PreviewControl *m_PC;
@@ -914,6 +1189,10 @@ class PatternGeneratorInterfacePrivate : public virtual PatternGeneratorInterfac
 
 PatternGeneratorInterface *patternGeneratorInterfaceFactory(const HumanoidModel *aHDR) {
   if (aHDR == 0) throw runtime_error("patternGeneratorInterfaceFactory: a HumanoidModel is required");
+  return new PatternGeneratorInterfacePrivate(aHDR);
+}
+PatternGeneratorInterface *patternGeneratorInterfaceFactory(CjrlHumanoidDynamicRobot *aHDR) {   // patterngeneratorinterface.hh:306
+  if (aHDR == 0) throw runtime_error("patternGeneratorInterfaceFactory: a robot is required");
   return new PatternGeneratorInterfacePrivate(aHDR);
 }
 
