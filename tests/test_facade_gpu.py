@@ -192,6 +192,16 @@ def test_cpp_fleet_bench_rank_launcher_with_rccl():
     assert r.returncode != 0 and "FAILED" in r.stderr
 
 
+def test_two_facade_objects_of_a_kind_do_not_share_device_state():
+    """jrl-walkgen_amd/host/test_two_objects.cpp: two PreviewControl objects (different windows / CoM heights) and two
+    PatternGeneratorInterface objects (different robots), interleaved, each bit-identical to the same object run alone --
+    the reference keeps this state per object; here every such object owns a context of the C ABI"""
+    exe = os.path.join(ROOT, "jrl-walkgen_amd", "bin", "test_two_objects")
+    assert os.path.exists(exe)
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "two objects ok" in r.stdout, r.stdout + r.stderr
+
+
 def test_cpp_kajita_fleet_runs_through_the_c_abi():
     """jrl-walkgen_amd/host/kajita_fleet.cpp: step sequences -> wg_zmpdisc_batch_dev -> wg_preview_run_batch_dev from plain C++
     (hipMalloc'd buffers, one stream); the program itself compares gait 0 of the device chain with the host-pointer entry
