@@ -35,6 +35,10 @@ shard = importlib.import_module("jrl-walkgen_amd.shard")
 BATCH_PER_GPU = 4096
 REDRAW_TICKS = 50            # 5 s of walking
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+FP64_VECTOR_PEAK_TFLOPS = 78.6   # MI355X FP64 vector peak (spec): 256 CUs x 4 SIMDs x 16 lanes x 2 flop x 2.4 GHz
+CONFIG5_BATCH = 8192         # BASELINE configs[4]: N = 32 with foot-placement variables, batch = 8192
+# counters of the timed kernel measured by rocprofv3 --pmc passes of this very command (tools/prof_round.sh files them)
+PMC_SUMMARY = os.path.join(ROOT, "profiles", "current_tick_pmc.json")
 
 
 def velocity_table(lo, hi, n_seg):
@@ -93,11 +97,14 @@ def _cpu_run(args):
     s0.nb_steps_left = 2
     for g in range(ng):
         C.memmove(C.byref(states[g]), C.byref(s0), C.sizeof(wg.GaitState))
+    lib.wgo_solve_timer(1, None, None)
     t0 = time.perf_counter()
     rc = lib.wgo_mpc_run(C.byref(model), states, ng, n_ticks, tab.ctypes.data_as(C.c_void_p), REDRAW_TICKS)
     dt = time.perf_counter() - t0
+    sec, cnt = C.c_double(), C.c_long()
+    lib.wgo_solve_timer(0, C.byref(sec), C.byref(cnt))
     assert rc == 0
-    return ng * n_ticks, dt, kind
+    return ng * n_ticks, dt, kind, (sec.value if kind == "reference" else None), cnt.value
 
 
 def cpu_baseline(n_gaits, n_ticks):
@@ -106,10 +113,11 @@ def cpu_baseline(n_gaits, n_ticks):
     else the restated solver.  Timed on one core, then on every host core (one process per core, QLD keeps statics).
     Checker code timed as a baseline -- never part of the measured GPU path."""
     import multiprocessing as mp
-    ticks, dt, kind = _cpu_run((0, n_gaits, n_ticks, True))
-    one = dict(value=ticks / dt, seconds=dt, kind=kind)
+    ticks, dt, kind, solve_s, solves = _cpu_run((0, n_gaits, n_ticks, True))
+    one = dict(value=ticks / dt, seconds=dt, kind=kind,
+               solve_only=(solves / solve_s if solve_s else None))
     cores = os.cpu_count() or 1
-    per = max(8, n_gaits // 16)
+    per = max(8, n_gaits // 8)
     try:
         with mp.get_context("fork").Pool(cores) as pool:
             t0 = time.perf_counter()
@@ -117,6 +125,9 @@ def cpu_baseline(n_gaits, n_ticks):
             wall = time.perf_counter() - t0
         allc = dict(value=sum(r[0] for r in res) / max(r[1] for r in res), cores=cores, wall_seconds=wall,
                     sample="%d gaits x %d ticks per core" % (per, n_ticks))
+        if all(r[3] for r in res):
+            # every core's solves at that core's own solve-only rate
+            allc["solve_only"] = sum(r[4] / r[3] for r in res)
     except Exception as e:                                        # noqa: BLE001 -- a baseline, never fatal
         allc = dict(value=None, cores=cores, error=str(e))
     return one, allc
@@ -137,10 +148,14 @@ def golden_parity():
     s.nb_steps_left = 2; s.nb_steps_ssds = 2; s.sup_y = 0.1
     wg.mpc_configure(m)
 
+    lat = []
+
     def tick(model, state, want_dump):
         arr = (wg.GaitState * 1)()
         C.memmove(C.byref(arr[0]), C.byref(state), C.sizeof(wg.GaitState))
+        t0 = time.perf_counter()
         outs, _, _, _ = wg.mpc_tick_batch(arr, want_out=True)
+        lat.append(time.perf_counter() - t0)
         C.memmove(C.byref(state), C.byref(arr[0]), C.sizeof(wg.GaitState))
         out = wg.TickOut()
         C.memmove(C.byref(out), C.byref(outs[0]), C.sizeof(wg.TickOut))
@@ -152,8 +167,66 @@ def golden_parity():
     d = rows - datref
     return {"com_rmse_m": float(np.sqrt((d[:, 1:3] ** 2).mean())), "max_abs_err": float(np.abs(d).max()),
             "rows": int(datref.shape[0]), "columns": int(datref.shape[1]), "tolerance": 1e-6,
+            # what a drop-in user with ONE robot sees per MPC tick (every 0.1 s of walking): wg_mpc_tick_batch(B = 1) with
+            # host pointers = copy in, launch, synchronise, copy out
+            "b1_tick_latency_us": {"median": float(np.median(lat) * 1e6), "p90": float(np.quantile(lat, 0.9) * 1e6),
+                                   "ticks": len(lat)},
             "reference": "TestHerdt2010EmergencyStopTestFGPI.datref (the reference's golden file, printed to 1e-7), "
                          "every MPC tick on the GPU, B = 1"}
+
+
+def config5_leg(dev, flags, ticks=40, warm=10):
+    """BASELINE configs[4] at its stated size on this GPU: N = 32 with foot-placement variables, batch = 8192, in its own
+    context (the N = 16 context of the main measurement stays configured).  flags = 0: Q_b from the reference-order host loop
+    (bit-exact tick); flags = WG_FLAG_GRAMIAN_MFMA_F32: Q_b from the fp32 matrix-core Gramian (tolerance mode).  The QL
+    solve is fp64 either way.  Same workload recipe as the main measurement (seeds 20100 + gait, redraw every 50 ticks)."""
+    model = wg.model_defaults()
+    model.N = 32
+    model.flags = flags
+    B = CONFIG5_BATCH
+    with wg.Context(dev.index or 0) as ctx:
+        ctx.mpc_configure(model)
+        n_seg = (warm + ticks + REDRAW_TICKS - 1) // REDRAW_TICKS
+        vtab = torch.from_numpy(velocity_table(0, B, n_seg)).to(dev)
+        states = start_states(model, B).to(dev)
+        diag = torch.zeros(warm + ticks, B, 6, dtype=torch.int32, device=dev)
+        stream = torch.cuda.Stream(device=dev)
+        sh, sp, dp, dstride = stream.cuda_stream, states.data_ptr(), diag.data_ptr(), B * 6 * 4
+
+        def run(t0, t1, evs=None):
+            for t, n in launch_plan(t0, t1):
+                if t % REDRAW_TICKS == 0:
+                    ctx.mpc_set_velref_dev(B, sp, vtab[t // REDRAW_TICKS].data_ptr(), sh)
+                adv = 1 if t == 0 else (19 if t == 1 else 20)
+                if evs is not None:
+                    evs.append((torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True), n))
+                    evs[-1][0].record(stream)
+                if n == 1:
+                    ctx.mpc_tick_batch_dev(B, sp, None, dp + t * dstride, adv, stream=sh)
+                else:
+                    ctx.mpc_run_batch_dev(B, sp, n, adv, None, dp + t * dstride, stream=sh)
+                if evs is not None:
+                    evs[-1][1].record(stream)
+        with torch.cuda.stream(stream):
+            run(0, warm)
+        torch.cuda.synchronize(dev)
+        evs = []
+        t0 = time.perf_counter()
+        with torch.cuda.stream(stream):
+            run(warm, warm + ticks, evs)
+        torch.cuda.synchronize(dev)
+        wall = time.perf_counter() - t0
+        d = diag[warm:].cpu().numpy().reshape(-1, 6)
+    kern_s = sum(a.elapsed_time(b) for a, b, _ in evs) * 1e-3
+    alg = float(algorithmic_bytes(d[:, 3].astype(np.float64), d[:, 4].astype(np.float64)).sum())
+    return {"value": B * ticks / wall, "unit": "ticks/s", "batch": B, "horizon_N": 32, "steps": ticks, "warmup": warm,
+            "ms_per_step": 1e3 * wall / ticks, "kernel_ms_per_step": 1e3 * kern_s / ticks,
+            "hessian_source": "fp32 matrix-core Gramian (WG_FLAG_GRAMIAN_MFMA_F32)" if flags & 4 else "reference-order host loop (bit-exact)",
+            "solve_dtype": "f64", "failed_qps": int((d[:, 0] != 0).sum()),
+            "mean_iterations": float(d[:, 1].mean()), "max_iterations": int(d[:, 1].max()),
+            "n_hist": {str(int(k)): int(v) for k, v in zip(*np.unique(d[:, 3], return_counts=True))},
+            "roofline": {"bound": "hbm", "achieved": alg / kern_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": alg / kern_s / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes_per_step": alg / ticks}}
 
 
 def main():
@@ -167,12 +240,13 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true", help="skip the golden-file replay (CoM RMSE) after the timed run")
     ap.add_argument("--no-per-tick-leg", action="store_true", help="skip the secondary one-launch-per-tick measurement")
+    ap.add_argument("--no-config5", action="store_true", help="skip the N = 32, batch = 8192 leg (BASELINE configs[4])")
     args = ap.parse_args()
 
     # CPU baseline first: it forks one worker per host core, which must happen before this process touches the GPU
     cpu_line = None
     if int(os.environ.get("WORLD_SIZE", "1")) == 1 and not args.no_cpu_baseline:
-        ng, nt = 256, 200
+        ng, nt = 1024, 200                                   # ~13 s on one core
         one, allc = cpu_baseline(ng, nt)
         solver = ("QP solve by the reference's qld.cpp compiled -O3 -DNDEBUG (oracle/_ref)" if one["kind"] == "reference"
                   else "QP solve by the restated QL (oracle/ql_oracle.c)")
@@ -180,6 +254,8 @@ def main():
                     "sample": f"first {ng} gaits x {nt} ticks of the same workload ({ng * nt} ticks, "
                               f"{one['seconds']:.1f} s); tick assembly by the oracle/ C restatement, {solver}; "
                               f"1 core of {os.cpu_count()} host cores",
+                    "value_is": "assemble + solve (the whole tick)",
+                    "solve_only": one["solve_only"],          # ticks/s counting only the time inside ql0001_ (qp-problem.cpp:275-279)
                     "all_cores": allc}
 
     # rehearsal knobs (tools/rehearse_ranks.sh): several ranks on ONE card with the gloo backend exercise the multi-rank
@@ -280,13 +356,23 @@ def main():
 
     if rank == 0:
         achieved = alg_bytes_total / (kern_ms_total * 1e-3) / 1e9          # = bytes per launch / average launch duration
+        # HBM traffic and issue-slot counters come from rocprofv3 --pmc passes of this same command (they cannot be read
+        # from inside the process): measured per gait-tick there, scaled here to THIS run's launch so that `traffic` and
+        # `algorithmic_bytes_per_launch` describe the same launch
         traffic = None
-        pmc = os.path.join(ROOT, "profiles", "round1_pmc_summary.json")
-        if os.path.exists(pmc):
+        pmc = None
+        if os.path.exists(PMC_SUMMARY):
             try:
-                traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
+                pmc = json.load(open(PMC_SUMMARY))
+                kname = "per_tick_kernel" if args.per_tick_launch else "run_kernel"
+                traffic = pmc[kname]["hbm_bytes_per_gait_tick"] * (B * K / len(timed))
+            except Exception:                                              # noqa: BLE001 -- a missing profile is not fatal
+                traffic, pmc = None, None
+        iters = d[:, 1].astype(np.float64)
+        # flops per tick = (2/3) n^3 + 2 m n + 4 n^2 + it (2 m n + 10 n^2), here with each tick's own n, m, it
+        nn, mm = d[:, 3].astype(np.float64), d[:, 4].astype(np.float64)
+        flops_total = float(((2.0 / 3.0) * nn ** 3 + 2 * mm * nn + 4 * nn ** 2 + iters * (2 * mm * nn + 10 * nn ** 2)).sum())
+        useful_tflops = flops_total / (kern_ms_total * 1e-3) / 1e12
         line = {
             "metric": "QP-MPC ticks/sec (batch=4096, N=16)",
             "value": value, "unit": "ticks/s", "n_gpus": world, "steps": K, "warmup": W,
@@ -303,17 +389,44 @@ def main():
                                   "queue): %d launches, up to %d ticks each" % (len(timed), ticks_per_launch))},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "wg_mpc_tick_kernel" if args.per_tick_launch else "wg_mpc_run_kernel",
+                         "kernel": "wg_mpc_tick_kernel" if args.per_tick_launch else "wg_mpc_run_xcd_kernel",
                          "kernel_ms": kern_ms, "launches": len(timed), "ticks_per_launch": ticks_per_launch,
-                         "algorithmic_bytes_per_launch": alg_bytes_per_launch},
+                         "algorithmic_bytes_per_launch": alg_bytes_per_launch,
+                         "traffic_source": None if pmc is None else
+                         "%s: %.0f B per gait-tick measured by rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over launches of %s ticks, "
+                         "scaled to this run's %.1f ticks per launch" % (os.path.relpath(PMC_SUMMARY, ROOT),
+                                                                        pmc[kname]["hbm_bytes_per_gait_tick"],
+                                                                        pmc[kname]["ticks_per_launch"], K / len(timed)),
+                         # second axis: HBM is the formal roof but not what binds -- the vector ALUs are
+                         "second_axis": {"useful_fp64_tflops": useful_tflops, "fp64_vector_peak_tflops": FP64_VECTOR_PEAK_TFLOPS,
+                                         "useful_flop_frac": useful_tflops / FP64_VECTOR_PEAK_TFLOPS,
+                                         "flops_per_tick": flops_total / len(d),
+                                         "valu_busy": None if pmc is None else pmc[kname].get("valu_busy"),
+                                         "valu_insts_per_tick": None if pmc is None else pmc[kname].get("valu_insts_per_gait_tick"),
+                                         "note": "useful flops = SURVEY 8(d)'s operation count of the reference algorithm for each "
+                                                 "tick's own n, m and iteration count; valu_busy = SQ_ACTIVE_INST_VALU x 4 / "
+                                                 "(SQ_BUSY_CU_CYCLES-equivalent) from the same rocprofv3 passes (issue slots of the "
+                                                 "vector ALUs in use)"}},
             "solver": {"mean_iterations": float(d[:, 1].mean()), "max_iterations": int(d[:, 1].max()),
                        "mean_active": float(d[:, 2].mean()), "failed_qps": n_fail,
-                       "n_hist": {str(int(k)): int(v) for k, v in zip(*np.unique(d[:, 3], return_counts=True))}},
+                       "n_hist": {str(int(k)): int(v) for k, v in zip(*np.unique(d[:, 3], return_counts=True))},
+                       "iteration_histogram": {str(int(k)): int(v) for k, v in zip(*np.unique(d[:, 1], return_counts=True))},
+                       "active_histogram": {str(int(k)): int(v) for k, v in zip(*np.unique(d[:, 2], return_counts=True))}},
         }
         if alt is not None:
             line["per_tick_launch"] = alt
+        if world == 1 and not args.no_config5:
+            try:
+                line["config5"] = {"default": config5_leg(dev, 0), "gramian_mfma_f32": config5_leg(dev, 4),
+                                   "note": "BASELINE configs[4]: Herdt2010 N = 32 with foot-placement variables, batch = 8192; "
+                                           "fp64 solve in both (DESIGN 7), the fp32 part is the matrix-core Gramian as Hessian source"}
+            except Exception as e:                                         # noqa: BLE001 -- the main figure stands without it
+                line["config5"] = {"error": str(e)}
+            wg.mpc_configure(model)
         if world == 1 and not args.no_parity:
             line["parity"] = golden_parity()
+            if cpu_line is not None and "b1_tick_latency_us" in line["parity"]:
+                line["parity"]["b1_tick_latency_us"]["cpu_reference_us_per_tick_one_core"] = 1e6 / cpu_line["value"]
         if cpu_line is not None:
             line["cpu_baseline"] = cpu_line
         print(json.dumps(line), flush=True)

@@ -173,10 +173,12 @@ struct DenseProb {
 // ---- optional in-kernel phase timers (diagnostic build only: -DWG_PROFILE) ----
 #ifdef WG_PROFILE
 __device__ unsigned long long g_prof[32];
-#define PT_DECL unsigned long long pt_acc[28] = {0}; unsigned long long pt_last = clock64();
+#define PT_DECL unsigned long long pt_acc[28] = {0}; unsigned long long pt_cnt[4] = {0}; unsigned long long pt_last = clock64();
 #define PT(k) do { unsigned long long t_ = clock64(); pt_acc[k] += t_ - pt_last; pt_last = t_; } while (0)
-#define PT_FLUSH do { if ((threadIdx.x & 63) == 0) for (int k_ = 0; k_ < 28; ++k_) if (k_ < 21 || k_ > 23) atomicAdd(&g_prof[k_], pt_acc[k_]); } while (0)
-#define PT_COUNT(k) do { if ((threadIdx.x & 63) == 0) atomicAdd(&g_prof[k], 1ull); } while (0)
+#define PT_FLUSH do { if ((threadIdx.x & 63) == 0) { for (int k_ = 0; k_ < 28; ++k_) if (k_ < 21 || k_ > 23) atomicAdd(&g_prof[k_], pt_acc[k_]); \
+                                                      for (int k_ = 0; k_ < 4; ++k_) atomicAdd(&g_prof[28 + k_], pt_cnt[k_]); } } while (0)
+// event counters 28..31: kept in registers and flushed once (a global atomic per event would show up in the phase it sits in)
+#define PT_COUNT(k) do { pt_cnt[(k) - 28]++; } while (0)
 #else
 #define PT_COUNT(k) do {} while (0)
 #define PT_DECL

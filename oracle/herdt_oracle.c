@@ -27,6 +27,7 @@
 #endif
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 
 #include "../include/wg_mpc.h"
 #include "wg_oracle.h"
@@ -443,6 +444,16 @@ typedef int (*wgo_ql0001_fn)(int *m, int *me, int *mmax, int *n, int *nmax, int 
                              double *b, double *xl, double *xu, double *x, double *u, int *iout, int *ifail, int *iprint,
                              double *war, int *lwar, int *iwar, int *liwar, double *eps1);
 static wgo_ql0001_fn g_ref_ql = 0;
+/* bench.py's "solve-only" CPU figure: wall time spent inside the reference's ql0001_ alone, next to the
+ * assemble + solve time of the whole tick */
+static int g_solve_timer = 0;
+static double g_solve_seconds = 0.0;
+static long g_solve_count = 0;
+void wgo_solve_timer(int enable, double *seconds, long *count) {
+  if (seconds) *seconds = g_solve_seconds;
+  if (count) *count = g_solve_count;
+  g_solve_timer = enable; g_solve_seconds = 0.0; g_solve_count = 0;
+}
 /* route the tick's QP through the reference's own compiled solver (NULL = this directory's restatement) */
 void wgo_set_reference_ql(void *ql0001_entry) { g_ref_ql = (wgo_ql0001_fn)ql0001_entry; }
 
@@ -660,8 +671,15 @@ int wgo_mpc_tick(const wg_model_t *m, wg_gait_state_t *s, wg_tick_out_t *out, wg
     double eps_ = 1e-8;
     double *war = (double *)calloc((size_t)lwar_, sizeof(double));
     iact[0] = 1;
+    struct timespec t0_, t1_;
+    if (g_solve_timer) clock_gettime(CLOCK_MONOTONIC, &t0_);
     g_ref_ql(&m_, &me_, &mmax_, &n_, &nmax_, &mnn_, C, d, A, b, xl, xu, x, u, &iout_, &ifail, &iprint_, war, &lwar_, iact,
              &liwar_, &eps_);
+    if (g_solve_timer) {
+      clock_gettime(CLOCK_MONOTONIC, &t1_);
+      g_solve_seconds += (double)(t1_.tv_sec - t0_.tv_sec) + 1e-9 * (double)(t1_.tv_nsec - t0_.tv_nsec);
+      g_solve_count++;
+    }
     free(war);
     for (int i = 0; i < mq + 2 * n; i++) nact += (u[i] != 0.0);
   } else

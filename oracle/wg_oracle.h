@@ -54,6 +54,8 @@ int wgo_invariant_hessian(const wg_model_t *model, double *Qb);
 /* NULL (default): the tick solves with wgo_ql_solve; otherwise with the given ql0001_ entry point (the reference's own
  * compiled qld.cpp from oracle/_ref/libqld_ref.so) */
 void wgo_set_reference_ql(void *ql0001_entry);
+/* enable / disable and read-and-reset the wall time spent inside the reference's ql0001_ (solve only) */
+void wgo_solve_timer(int enable, double *seconds, long *count);
 /* the benchmark workload on the CPU, loop in C (see herdt_oracle.c) */
 int wgo_mpc_run(const wg_model_t *model, wg_gait_state_t *states, int n_gaits, int n_ticks, const double *vel, int redraw);
 

@@ -1,0 +1,90 @@
+"""Files the summaries of the last tools/prof_round.sh run (merged back under gpurun_out/) into profiles/ as <tag>_*, writes
+profiles/current_tick_pmc.json (what bench.py scales roofline.traffic and the second roofline axis from) and
+profiles/README.md (which set describes HEAD).     python tools/save_round_profiles.py round2"""
+import glob
+import json
+import os
+import shutil
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+tag = sys.argv[1] if len(sys.argv) > 1 else "round2"
+
+B, W, K, REDRAW = 4096, 50, 200, 50
+
+
+def launch_plan(t0, t1, per_tick=False, redraw=REDRAW):            # bench.launch_plan (kept in step by tests/test_bench_plan.py)
+    out, t = [], t0
+    while t < t1:
+        n = 1 if (t < 2 or per_tick) else min(t1, (t // redraw + 1) * redraw) - t
+        out.append((t, n)); t += n
+    return out
+
+
+names = ["tick", "tickg", "pertick", "config5", "gramian", "dimitrov", "pldp", "preview", "zmpdisc"]
+summ = {}
+for k in names:
+    d = os.path.join(ROOT, "gpurun_out", "prof_" + k)
+    if not os.path.isdir(d):
+        print("missing", d); continue
+    txt = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "prof_summary.py"), d], capture_output=True, text=True).stdout
+    open(os.path.join(d, "summary.txt"), "w").write(txt)
+    shutil.copy(os.path.join(d, "summary.txt"), os.path.join(ROOT, "profiles", f"{tag}_{k}_rocprofv3_summary.txt"))
+    shutil.copy(os.path.join(d, "summary.json"), os.path.join(ROOT, "profiles", f"{tag}_{k}_rocprofv3_summary.json"))
+    stats = sorted(glob.glob(os.path.join(d, "trace", "**", "*_kernel_stats.csv"), recursive=True), key=os.path.getmtime)
+    if stats:
+        shutil.copy(stats[-1], os.path.join(ROOT, "profiles", f"{tag}_{k}_kernel_stats.csv"))
+    summ[k] = json.load(open(os.path.join(d, "summary.json")))
+    log = os.path.join(d, "trace.log")
+    if k in ("gramian", "config5") and os.path.exists(log):
+        keep = [ln for ln in open(log) if ("TFLOP" in ln or "ticks/s" in ln or "same" in ln or "run" in ln) and "amdgpu.ids" not in ln]
+        open(os.path.join(ROOT, "profiles", f"{tag}_{k}_probe_output.txt"), "w").writelines(keep)
+
+
+def per_gait_tick(s, kernel, gait_ticks):
+    c = s["counters"][kernel]
+    tot = lambda n: c[n]["mean_per_launch"] * c[n]["launches"]       # noqa: E731
+    rd = tot("FETCH_SIZE") * 1024 * 2                               # MI355X_MICROARCH.md: KiB units; gfx950 reports half the read bytes
+    wr = tot("WRITE_SIZE") * 1024
+    waves_per_simd = 2
+    r = {"kernel": kernel, "launches": int(c["FETCH_SIZE"]["launches"]), "gait_ticks": gait_ticks,
+         "hbm_read_bytes_per_gait_tick": rd / gait_ticks, "hbm_write_bytes_per_gait_tick": wr / gait_ticks,
+         "hbm_bytes_per_gait_tick": (rd + wr) / gait_ticks,
+         "valu_insts_per_gait_tick": tot("SQ_INSTS_VALU") / gait_ticks, "salu_insts_per_gait_tick": tot("SQ_INSTS_SALU") / gait_ticks,
+         "lds_insts_per_gait_tick": tot("SQ_INSTS_LDS") / gait_ticks, "vmem_insts_per_gait_tick": tot("SQ_INSTS_VMEM") / gait_ticks,
+         "valu_active_frac_per_wave": tot("SQ_ACTIVE_INST_VALU") / tot("SQ_WAVE_CYCLES"),
+         "valu_busy": waves_per_simd * tot("SQ_ACTIVE_INST_VALU") / tot("SQ_WAVE_CYCLES"),
+         "wait_any_frac_per_wave": tot("SQ_WAIT_ANY") / tot("SQ_WAVE_CYCLES"),
+         "wait_inst_any_frac_per_wave": tot("SQ_WAIT_INST_ANY") / tot("SQ_WAVE_CYCLES"),
+         "mfma_f64_mops": tot("SQ_INSTS_VALU_MFMA_MOPS_F64"),
+         "avg_kernel_ns_rocprofv3": s["kernels"][kernel]["avg_ns"], "kernel_calls_rocprofv3": s["kernels"][kernel]["calls"]}
+    return r
+
+
+out = {"tag": tag,
+       "how": "rocprofv3 passes of `python3 bench.py --steps 200 --warmup 50 --no-cpu-baseline --no-parity --no-per-tick-leg "
+              "--no-config5` (tools/prof_round.sh): kernel trace + stats, then the counters in separate --pmc passes (FETCH_SIZE and "
+              "WRITE_SIZE each in its own).  Units and gfx950 correction per MI355X_MICROARCH.md (HBM / rocprofv3): KiB x 1024, "
+              "FETCH_SIZE doubled.  Totals over ALL launches of the kernel divided by the gait-ticks those launches ran "
+              "(B = 4096; multi-tick: one 48-tick and four 50-tick launches = 248 ticks; per-tick: 250 launches).  valu_busy = "
+              "2 waves per SIMD x SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES."}
+run_ticks = sum(n for _, n in launch_plan(0, W + K) if n > 1)
+n_run = sum(1 for _, n in launch_plan(0, W + K) if n > 1)
+if "tick" in summ:
+    out["run_kernel"] = per_gait_tick(summ["tick"], "wg_mpc_run_xcd_kernel<16>", B * run_ticks)
+    out["run_kernel"]["ticks_per_launch"] = "48, 50, 50, 50, 50"
+    assert out["run_kernel"]["launches"] == n_run, (out["run_kernel"]["launches"], n_run)
+if "tickg" in summ:
+    out["run_kernel_device_wide_queue"] = per_gait_tick(summ["tickg"], "wg_mpc_run_kernel<16>", B * run_ticks)
+    out["run_kernel_device_wide_queue"]["ticks_per_launch"] = "48, 50, 50, 50, 50"
+if "pertick" in summ:
+    out["per_tick_kernel"] = per_gait_tick(summ["pertick"], "wg_mpc_tick_kernel<16>", B * (W + K))
+    out["per_tick_kernel"]["ticks_per_launch"] = "1"
+json.dump(out, open(os.path.join(ROOT, "profiles", "current_tick_pmc.json"), "w"), indent=1)
+for k in ("run_kernel", "run_kernel_device_wide_queue", "per_tick_kernel"):
+    if k in out:
+        r = out[k]
+        print("%-30s %7.0f B read + %7.0f B written per gait-tick, %6.0f VALU, valu_busy %.2f, avg %.3f ms"
+              % (k, r["hbm_read_bytes_per_gait_tick"], r["hbm_write_bytes_per_gait_tick"], r["valu_insts_per_gait_tick"], r["valu_busy"],
+                 r["avg_kernel_ns_rocprofv3"] / 1e6))
