@@ -370,31 +370,67 @@ struct HerdtProb {
     }
     for (int e = lane; e < (n - M2) * M2; e += 64) { const int i = M2 + e % (n - M2), j = e / (n - M2); Zm(i, j) = 0.0; }
     WG_WSYNC();
-    // rows of R, columns >= 2N only (lane <-> column)
-    const int j = M2 + lane;
-    const bool col = j < n;
-    bool ok = true;
-    for (int i = 0; i < n; ++i) {
-      double temp = 0.0;
-      if (col && j >= i) {
-        temp = G(q, i, j);
-        // R(k,i) == 0 for k in the other diagonal block: those products are exact zeros
-        const int k0 = (i >= NH && i < M2) ? NH : 0;
-        WG_UNROLL
-        for (int k = k0; k < i; ++k) temp -= Rp(k, j) * Rp(k, i);
+    // Rows of R, columns >= 2N only (:859-890 restricted to the border columns).  R(i,j) = (G(i,j) - sum_{k<i} R(k,j) R(k,i)) / R(i,i)
+    // is a forward substitution per border column: serial in i, and in the row-serial form each row's sum is itself a chain
+    // of i dependent multiply-subtracts carried by the few lanes that own a border column (630 of them per tick).  Here one
+    // ROW per lane instead: lane i keeps the running value of its entry in each border column; step k finalises row k
+    // (lane k divides), broadcasts R(k, border) and every lane below subtracts its product -- the same products in the same
+    // order k = 0, 1, ... for every entry, so the same bits, but n short steps instead of n growing chains.
+    const int nb = n - M2;                                  // border columns: 2 ns <= 4
+    if (nb > 0) {
+      const int i = lane;
+      const bool row = i < n;
+      const int ib = i - M2;                                // >= 0: a border row, whose column of R is being computed too
+      double acc[kGvLd];
+#pragma unroll
+      for (int jb = 0; jb < kGvLd; ++jb) {
+        const int j = M2 + jb;
+        acc[jb] = (row && jb < nb && j >= i) ? ((i == j) ? gd[i] : Gv[i * kGvLd + jb]) : 0.0;
       }
-      if (i >= M2) {
-        if (col && j == i) {
-          if (temp < vsmall) q.slot[0] = 1.0; else { q.slot[0] = 0.0; Rp(i, i) = sqrt(temp); }
+      const double dreg = (row && i < M2) ? Rp(i, i) : 1.0;
+      const int colbase = row ? i * (i + 1) / 2 : 0;        // R(k, i) = q.R[colbase + k], k <= i
+      // R(k,i) == 0 for k in the other diagonal block: those products are exact zeros and are skipped, as in the row-serial form
+      const int klo = (i >= NH && i < M2) ? NH : 0;
+      auto rcol = [&](int k) -> double { return (row && i < M2 && k < i && k >= klo) ? q.R[colbase + k] : 0.0; };
+      double rnext = rcol(0);
+      for (int k = 0; k < n; ++k) {
+        const double rki_lds = rnext;                       // R(k, i) of a constant column, fetched one step ahead
+        rnext = rcol(k + 1);
+        double rk[kGvLd];
+        if (k < M2) {
+#pragma unroll
+          for (int jb = 0; jb < kGvLd; ++jb) rk[jb] = (jb < nb) ? acc[jb] / dreg : 0.0;
+        } else {
+          const int kb = k - M2;
+          double t = acc[0];
+#pragma unroll
+          for (int jb = 1; jb < kGvLd; ++jb) t = (jb == kb) ? acc[jb] : t;
+          const bool bad = t < vsmall;
+          if (WG_UBOOL(__builtin_amdgcn_readlane((int)bad, k))) return false;   // pivot too small: nothing usable, generic path
+          const double rt = sqrt(t);
+#pragma unroll
+          for (int jb = 0; jb < kGvLd; ++jb) rk[jb] = (jb == kb) ? rt : ((jb > kb && jb < nb) ? acc[jb] / rt : 0.0);
         }
-        WG_WSYNC();
-        if (WG_UBOOL(q.slot[0] != 0.0)) { ok = false; break; }
+        double bk[kGvLd];
+#pragma unroll
+        for (int jb = 0; jb < kGvLd; ++jb) bk[jb] = rl(rk[jb], k);
+        if (lane == k) {
+#pragma unroll
+          for (int jb = 0; jb < kGvLd; ++jb)
+            if (jb < nb && M2 + jb >= k) Rp(k, M2 + jb) = rk[jb];
+        }
+        double rki = rki_lds;
+#pragma unroll
+        for (int jb = 0; jb < kGvLd; ++jb) rki = (ib == jb) ? bk[jb] : rki;
+        const bool upd = row && i > k && k >= klo;
+#pragma unroll
+        for (int jb = 0; jb < kGvLd; ++jb) {
+          const double nv = acc[jb] - bk[jb] * rki;
+          acc[jb] = (upd && jb < nb && M2 + jb >= i) ? nv : acc[jb];
+        }
       }
-      const double rii = Rp(i, i);
-      if (col && j > i) Rp(i, j) = temp / rii;
       WG_WSYNC();
     }
-    if (!ok) return false;
     // columns >= 2N of Z: lane <-> row
     for (int c = M2; c < n; ++c) {
       const int i = lane;
