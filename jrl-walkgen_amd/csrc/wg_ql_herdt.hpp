@@ -328,12 +328,97 @@ struct HerdtProb {
     return wave_max(dl);
   }
 
+  // ------------------------------------------------------------------ border columns of R, one row per lane
+  // NB = number of border columns handled (compile time); nbr = how many of them exist (== NB except in the generic case)
+  template <int NB>
+  __device__ __forceinline__ bool border_rows(const QlView &q, double vsmall, int lane, int nbr = NB) const {
+    const int n = q.n;
+    constexpr int M2 = 2 * NH;
+    const int i = lane;
+    const bool row = i < n;
+    const int ib = i - M2;                                  // >= 0: a border row, whose column of R is being computed too
+    double acc[NB];
+#pragma unroll
+    for (int jb = 0; jb < NB; ++jb) {
+      const int j = M2 + jb;
+      acc[jb] = (row && jb < nbr && j >= i) ? ((i == j) ? gd[i] : Gv[i * kGvLd + jb]) : 0.0;
+    }
+    const double dreg = (row && i < M2) ? Rp(i, i) : 1.0;
+    const int colbase = (row && i < M2) ? i * (i + 1) / 2 : 0;   // R(k, i) = q.R[colbase + k], k <= i
+    // R(k,i) == 0 for k in the other diagonal block: those products are exact zeros and are skipped, as in the row-serial form
+    const int klo = (i >= NH && i < M2) ? NH : 0;
+    const int khi = (row && i < M2) ? i : 0;                // constant column of lane i: rows klo <= k < khi take part
+    // ---- steps k < 2N: the divisor is the constant diagonal ----
+    double rnext = (0 >= klo && 0 < khi) ? q.R[colbase] : 0.0;
+    for (int k = 0; k < M2; ++k) {
+      const double rki_lds = rnext;                         // R(k, i), fetched one step ahead (clamped address, selected value)
+      {
+        const int kn = k + 1;
+        const double v = q.R[colbase + (kn < khi ? kn : 0)];
+        rnext = (kn >= klo && kn < khi) ? v : 0.0;
+      }
+      double bk[NB];
+#pragma unroll
+      for (int jb = 0; jb < NB; ++jb) {
+        const double rk = acc[jb] / dreg;                   // lane k's is R(k, 2N + jb)
+        bk[jb] = rl(rk, k);
+        if (lane == k && jb < nbr) Rp(k, M2 + jb) = rk;
+      }
+      double rki = rki_lds;
+#pragma unroll
+      for (int jb = 0; jb < NB; ++jb) rki = (ib == jb) ? bk[jb] : rki;   // a border row's own column entry R(k, i)
+      const bool upd = row && i > k && k >= klo;
+#pragma unroll
+      for (int jb = 0; jb < NB; ++jb) {
+        const double nv = acc[jb] - bk[jb] * rki;
+        acc[jb] = (upd && jb < nbr && M2 + jb >= i) ? nv : acc[jb];
+      }
+    }
+    // ---- steps k >= 2N: the border's own diagonal block (pivot test :868-872, square root, the entries to its right) ----
+    bool ok = true;
+#pragma unroll
+    for (int kb = 0; kb < NB; ++kb) {
+      if (kb < nbr) {
+        const int k = M2 + kb;
+        const double t = rl(acc[kb], k);                    // the pivot, wave-uniform
+        ok = ok && !(t < vsmall);                           // a failed pivot: the rest is computed and discarded (caller: generic path)
+        const double rt = sqrt(t);
+        if (lane == k) Rp(k, k) = rt;
+        double bk[NB];
+#pragma unroll
+        for (int jb = 0; jb < NB; ++jb) {
+          bk[jb] = 0.0;
+          if (jb > kb) {
+            const double rk = acc[jb] / rt;
+            bk[jb] = rl(rk, k);
+            if (lane == k && jb < nbr) Rp(k, M2 + jb) = rk;
+          }
+        }
+        double rki = 0.0;
+#pragma unroll
+        for (int jb = 0; jb < NB; ++jb) rki = (ib == jb) ? bk[jb] : rki;
+        const bool upd = row && i > k;
+#pragma unroll
+        for (int jb = 0; jb < NB; ++jb) {
+          if (jb > kb) {
+            const double nv = acc[jb] - bk[jb] * rki;
+            acc[jb] = (upd && jb < nbr && M2 + jb >= i) ? nv : acc[jb];
+          }
+        }
+      }
+    }
+    return ok;
+  }
+
   // ------------------------------------------------------------------ R and Z = R^-1 (:859-975)
   // Leading 2N columns: copied.  Remaining columns: the reference recurrences, restricted to them.
   // Returns false (nothing usable written) if a pivot fails -> caller falls back to the generic path.
   __device__ __forceinline__ bool factor(const QlView &q, double vsmall, int lane) const {
     const int n = q.n;
     constexpr int M2 = 2 * NH;
+#ifdef WG_PROFILE
+    const unsigned long long fp0 = clock64();
+#endif
     // C = blockdiag(Qb, Qb) + border: the constant factor blocks are blockdiag(Rb, Rb) and blockdiag(Zb, Zb) with exact
     // zeros in between (the cross-block products of the recurrences are x * 0), so only the first diagonal block is
     // fetched from global memory -- 392 doubles instead of 1552 -- all loads issued before the first LDS store.
@@ -377,60 +462,19 @@ struct HerdtProb {
     // (lane k divides), broadcasts R(k, border) and every lane below subtracts its product -- the same products in the same
     // order k = 0, 1, ... for every entry, so the same bits, but n short steps instead of n growing chains.
     const int nb = n - M2;                                  // border columns: 2 ns <= 4
-    if (nb > 0) {
-      const int i = lane;
-      const bool row = i < n;
-      const int ib = i - M2;                                // >= 0: a border row, whose column of R is being computed too
-      double acc[kGvLd];
-#pragma unroll
-      for (int jb = 0; jb < kGvLd; ++jb) {
-        const int j = M2 + jb;
-        acc[jb] = (row && jb < nb && j >= i) ? ((i == j) ? gd[i] : Gv[i * kGvLd + jb]) : 0.0;
-      }
-      const double dreg = (row && i < M2) ? Rp(i, i) : 1.0;
-      const int colbase = row ? i * (i + 1) / 2 : 0;        // R(k, i) = q.R[colbase + k], k <= i
-      // R(k,i) == 0 for k in the other diagonal block: those products are exact zeros and are skipped, as in the row-serial form
-      const int klo = (i >= NH && i < M2) ? NH : 0;
-      auto rcol = [&](int k) -> double { return (row && i < M2 && k < i && k >= klo) ? q.R[colbase + k] : 0.0; };
-      double rnext = rcol(0);
-      for (int k = 0; k < n; ++k) {
-        const double rki_lds = rnext;                       // R(k, i) of a constant column, fetched one step ahead
-        rnext = rcol(k + 1);
-        double rk[kGvLd];
-        if (k < M2) {
-#pragma unroll
-          for (int jb = 0; jb < kGvLd; ++jb) rk[jb] = (jb < nb) ? acc[jb] / dreg : 0.0;
-        } else {
-          const int kb = k - M2;
-          double t = acc[0];
-#pragma unroll
-          for (int jb = 1; jb < kGvLd; ++jb) t = (jb == kb) ? acc[jb] : t;
-          const bool bad = t < vsmall;
-          if (WG_UBOOL(__builtin_amdgcn_readlane((int)bad, k))) return false;   // pivot too small: nothing usable, generic path
-          const double rt = sqrt(t);
-#pragma unroll
-          for (int jb = 0; jb < kGvLd; ++jb) rk[jb] = (jb == kb) ? rt : ((jb > kb && jb < nb) ? acc[jb] / rt : 0.0);
-        }
-        double bk[kGvLd];
-#pragma unroll
-        for (int jb = 0; jb < kGvLd; ++jb) bk[jb] = rl(rk[jb], k);
-        if (lane == k) {
-#pragma unroll
-          for (int jb = 0; jb < kGvLd; ++jb)
-            if (jb < nb && M2 + jb >= k) Rp(k, M2 + jb) = rk[jb];
-        }
-        double rki = rki_lds;
-#pragma unroll
-        for (int jb = 0; jb < kGvLd; ++jb) rki = (ib == jb) ? bk[jb] : rki;
-        const bool upd = row && i > k && k >= klo;
-#pragma unroll
-        for (int jb = 0; jb < kGvLd; ++jb) {
-          const double nv = acc[jb] - bk[jb] * rki;
-          acc[jb] = (upd && jb < nb && M2 + jb >= i) ? nv : acc[jb];
-        }
-      }
-      WG_WSYNC();
-    }
+#ifdef WG_PROFILE
+    const unsigned long long fp1 = clock64();
+    if (lane == 0) atomicAdd(&g_prof[2], fp1 - fp0);       // slot "chol" (unused by the compact view): constant blocks into LDS
+#endif
+    // straight-line per column count (a wave-uniform switch): the loop bodies carry no per-column branches
+    bool ok = true;
+    if (nb == 2) ok = border_rows<2>(q, vsmall, lane);                       // nb = 2 ns, ns in {1, 2}
+    else if (nb > 0) ok = border_rows<kGvLd>(q, vsmall, lane, nb);
+    if (!WG_UBOOL(ok)) return false;
+    WG_WSYNC();
+#ifdef WG_PROFILE
+    if (lane == 0) atomicAdd(&g_prof[31], clock64() - fp1);   // border rows of R
+#endif
     // columns >= 2N of Z: lane <-> row
     for (int c = M2; c < n; ++c) {
       const int i = lane;

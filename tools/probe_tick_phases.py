@@ -32,5 +32,6 @@ names = ["norms", "diagchk", "chol", "inverse", "resid/reset+shift", "ZT*ww(resi
          "xmag(add)", "tail", "TICK pre (lane0)", "TICK assembly", "TICK post", "(reset body)", "(resid: gradient+s)", "(resid: forward subst)", "(resid: d + G x)"]
 tot = v[:28].sum()
 print(f"gait-ticks={n} mean QL iters={its/n:.1f} cycles/tick={tot/n:.0f}  route decisions/tick={v[28]/n:.1f} of which coordinate checks {v[29]/n:.2f}, dependent routes {v[30]/n:.2f}")
+print(f"   of 'inverse' (factor): constant blocks into LDS {v[2]/n:.0f} cyc/tick, border rows of R {v[31]/n:.0f} cyc/tick")
 for k, nme in enumerate(names):
     print(f"{k:2d} {nme:22s} {v[k]/n:12.0f} cyc/tick  {100*v[k]/tot:5.1f}%")
