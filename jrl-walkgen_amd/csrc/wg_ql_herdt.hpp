@@ -329,81 +329,97 @@ struct HerdtProb {
   }
 
   // ------------------------------------------------------------------ border columns of R, one row per lane
-  // NB = number of border columns handled (compile time); nbr = how many of them exist (== NB except in the generic case)
-  template <int NB>
-  __device__ __forceinline__ bool border_rows(const QlView &q, double vsmall, int lane, int nbr = NB) const {
-    const int n = q.n;
+  // R(i,j) = (G(i,j) - sum_{k<i} R(k,j) R(k,i)) / R(i,i) for the 2 ns border columns j (:859-890 restricted to them) is a
+  // forward substitution per column: serial in i, and in the row-serial form each row's sum is itself a chain of i dependent
+  // multiply-subtracts carried by the few lanes that own a border column.  Here one ROW per lane: lane i keeps the running
+  // value of its entries; step k finalises row k (lane k divides), broadcasts it, and every row below subtracts its product --
+  // the same products in the same order k = 0, 1, ... for every entry, so the same bits, in n short steps.
+  //
+  // Structure used on top of that (C = blockdiag(Qb, Qb) + border, generator-vel-ref.cpp:617-674):
+  //   * the x half (jerk-x rows, x-foot rows / columns) and the y half never mix: every entry that pairs a row of one half
+  //     with a border column of the other is G = +0.0 minus products that each have a +0.0 factor, i.e. +0.0 - (+-0.0) = +0.0,
+  //     divided by a positive diagonal: exactly +0.0.  Those entries are written, not computed; where such a product enters
+  //     the sum of a non-cross entry it is (+0.0)(+0.0) = +0.0 and x - (+0.0) == x for every x;
+  //   * the two halves are the same numbers: the assembly writes the same -gamma Uz'V and gamma V'V into both (mpc_tick), and
+  //     the constant factor blocks are blockdiag(Rb, Rb).  The x half is computed (N + ns rows, ns columns), the y half copied.
+  // NS = previewed steps (compile time: 1 or 2).
+  template <int NS>
+  __device__ __forceinline__ bool border_rows(const QlView &q, double vsmall, int lane) const {
     constexpr int M2 = 2 * NH;
-    const int i = lane;
-    const bool row = i < n;
-    const int ib = i - M2;                                  // >= 0: a border row, whose column of R is being computed too
-    double acc[NB];
+    const int i = lane;                                     // x half: rows 0..N-1 jerk-x, N..N+NS-1 the x-foot rows
+    const bool jerk = i < NH, foot = i >= NH && i < NH + NS, row = jerk || foot;
+    const int fi = i - NH;                                  // foot row index
+    const int gi = jerk ? i : M2 + (foot ? fi : 0);         // the row's index in the QP
+    double acc[NS];
 #pragma unroll
-    for (int jb = 0; jb < NB; ++jb) {
-      const int j = M2 + jb;
-      acc[jb] = (row && jb < nbr && j >= i) ? ((i == j) ? gd[i] : Gv[i * kGvLd + jb]) : 0.0;
-    }
-    const double dreg = (row && i < M2) ? Rp(i, i) : 1.0;
-    const int colbase = (row && i < M2) ? i * (i + 1) / 2 : 0;   // R(k, i) = q.R[colbase + k], k <= i
-    // R(k,i) == 0 for k in the other diagonal block: those products are exact zeros and are skipped, as in the row-serial form
-    const int klo = (i >= NH && i < M2) ? NH : 0;
-    const int khi = (row && i < M2) ? i : 0;                // constant column of lane i: rows klo <= k < khi take part
-    // ---- steps k < 2N: the divisor is the constant diagonal ----
-    double rnext = (0 >= klo && 0 < khi) ? q.R[colbase] : 0.0;
-    for (int k = 0; k < M2; ++k) {
+    for (int f = 0; f < NS; ++f)
+      acc[f] = (jerk || (foot && f >= fi)) ? ((foot && f == fi) ? gd[gi] : Gv[gi * kGvLd + f]) : 0.0;
+    const double dreg = jerk ? Rp(i, i) : 1.0;
+    const int colbase = jerk ? i * (i + 1) / 2 : 0;         // R(k, i) = q.R[colbase + k], k <= i (first diagonal block)
+    const int khi = jerk ? i : 0;
+    // ---- steps k < N: the divisor is the constant diagonal ----
+    double rnext = (0 < khi) ? q.R[colbase] : 0.0;
+    for (int k = 0; k < NH; ++k) {
       const double rki_lds = rnext;                         // R(k, i), fetched one step ahead (clamped address, selected value)
       {
         const int kn = k + 1;
         const double v = q.R[colbase + (kn < khi ? kn : 0)];
-        rnext = (kn >= klo && kn < khi) ? v : 0.0;
+        rnext = (kn < khi) ? v : 0.0;
       }
-      double bk[NB];
+      double bk[NS];
 #pragma unroll
-      for (int jb = 0; jb < NB; ++jb) {
-        const double rk = acc[jb] / dreg;                   // lane k's is R(k, 2N + jb)
-        bk[jb] = rl(rk, k);
-        if (lane == k && jb < nbr) Rp(k, M2 + jb) = rk;
+      for (int f = 0; f < NS; ++f) {
+        const double rk = acc[f] / dreg;                    // lane k's is R(k, 2N + f)
+        bk[f] = rl(rk, k);
+      }
+      if (lane == k) {
+#pragma unroll
+        for (int f = 0; f < NS; ++f) {
+          Rp(k, M2 + f) = bk[f]; Rp(NH + k, M2 + NS + f) = bk[f];     // x entry and its y twin
+          Rp(k, M2 + NS + f) = 0.0; Rp(NH + k, M2 + f) = 0.0;         // the two cross entries
+        }
       }
       double rki = rki_lds;
 #pragma unroll
-      for (int jb = 0; jb < NB; ++jb) rki = (ib == jb) ? bk[jb] : rki;   // a border row's own column entry R(k, i)
-      const bool upd = row && i > k && k >= klo;
+      for (int f = 0; f < NS; ++f) rki = (fi == f) ? bk[f] : rki;     // a foot row's own column entry R(k, i)
+      const bool upd = row && i > k;
 #pragma unroll
-      for (int jb = 0; jb < NB; ++jb) {
-        const double nv = acc[jb] - bk[jb] * rki;
-        acc[jb] = (upd && jb < nbr && M2 + jb >= i) ? nv : acc[jb];
+      for (int f = 0; f < NS; ++f) {
+        const double nv = acc[f] - bk[f] * rki;
+        acc[f] = (upd && (jerk || f >= fi)) ? nv : acc[f];
       }
     }
-    // ---- steps k >= 2N: the border's own diagonal block (pivot test :868-872, square root, the entries to its right) ----
+    // ---- the foot rows: pivot test (:868-872), square root, the entries to its right ----
     bool ok = true;
 #pragma unroll
-    for (int kb = 0; kb < NB; ++kb) {
-      if (kb < nbr) {
-        const int k = M2 + kb;
-        const double t = rl(acc[kb], k);                    // the pivot, wave-uniform
-        ok = ok && !(t < vsmall);                           // a failed pivot: the rest is computed and discarded (caller: generic path)
-        const double rt = sqrt(t);
-        if (lane == k) Rp(k, k) = rt;
-        double bk[NB];
+    for (int kb = 0; kb < NS; ++kb) {
+      const int k = NH + kb;                                // lane that holds the row
+      const double t = rl(acc[kb], k);                      // the pivot, wave-uniform
+      ok = ok && !(t < vsmall);                             // a failed pivot: the rest is computed and discarded (caller: generic path)
+      const double rt = sqrt(t);
+      double bk[NS];
 #pragma unroll
-        for (int jb = 0; jb < NB; ++jb) {
-          bk[jb] = 0.0;
-          if (jb > kb) {
-            const double rk = acc[jb] / rt;
-            bk[jb] = rl(rk, k);
-            if (lane == k && jb < nbr) Rp(k, M2 + jb) = rk;
-          }
+      for (int f = 0; f < NS; ++f) {
+        bk[f] = 0.0;
+        if (f > kb) bk[f] = rl(acc[f] / rt, k);
+      }
+      if (lane == k) {
+        Rp(M2 + kb, M2 + kb) = rt; Rp(M2 + NS + kb, M2 + NS + kb) = rt;
+#pragma unroll
+        for (int f = 0; f < NS; ++f) {
+          if (f > kb) { Rp(M2 + kb, M2 + f) = bk[f]; Rp(M2 + NS + kb, M2 + NS + f) = bk[f]; }
+          Rp(M2 + kb, M2 + NS + f) = 0.0;                   // x-foot row, y-foot column: cross (its mirror lies below the diagonal)
         }
-        double rki = 0.0;
+      }
+      double rki = 0.0;
 #pragma unroll
-        for (int jb = 0; jb < NB; ++jb) rki = (ib == jb) ? bk[jb] : rki;
-        const bool upd = row && i > k;
+      for (int f = 0; f < NS; ++f) rki = (fi == f) ? bk[f] : rki;
+      const bool upd = foot && i > k;
 #pragma unroll
-        for (int jb = 0; jb < NB; ++jb) {
-          if (jb > kb) {
-            const double nv = acc[jb] - bk[jb] * rki;
-            acc[jb] = (upd && jb < nbr && M2 + jb >= i) ? nv : acc[jb];
-          }
+      for (int f = 0; f < NS; ++f) {
+        if (f > kb) {
+          const double nv = acc[f] - bk[f] * rki;
+          acc[f] = (upd && f >= fi) ? nv : acc[f];
         }
       }
     }
@@ -455,21 +471,15 @@ struct HerdtProb {
     }
     for (int e = lane; e < (n - M2) * M2; e += 64) { const int i = M2 + e % (n - M2), j = e / (n - M2); Zm(i, j) = 0.0; }
     WG_WSYNC();
-    // Rows of R, columns >= 2N only (:859-890 restricted to the border columns).  R(i,j) = (G(i,j) - sum_{k<i} R(k,j) R(k,i)) / R(i,i)
-    // is a forward substitution per border column: serial in i, and in the row-serial form each row's sum is itself a chain
-    // of i dependent multiply-subtracts carried by the few lanes that own a border column (630 of them per tick).  Here one
-    // ROW per lane instead: lane i keeps the running value of its entry in each border column; step k finalises row k
-    // (lane k divides), broadcasts R(k, border) and every lane below subtracts its product -- the same products in the same
-    // order k = 0, 1, ... for every entry, so the same bits, but n short steps instead of n growing chains.
     const int nb = n - M2;                                  // border columns: 2 ns <= 4
 #ifdef WG_PROFILE
     const unsigned long long fp1 = clock64();
     if (lane == 0) atomicAdd(&g_prof[2], fp1 - fp0);       // slot "chol" (unused by the compact view): constant blocks into LDS
 #endif
-    // straight-line per column count (a wave-uniform switch): the loop bodies carry no per-column branches
+    // rows of R, columns >= 2N only (border_rows above); straight-line per step count (a wave-uniform switch)
     bool ok = true;
-    if (nb == 2) ok = border_rows<2>(q, vsmall, lane);                       // nb = 2 ns, ns in {1, 2}
-    else if (nb > 0) ok = border_rows<kGvLd>(q, vsmall, lane, nb);
+    if (nb == 2) ok = border_rows<1>(q, vsmall, lane);
+    else if (nb == 4) ok = border_rows<2>(q, vsmall, lane);
     if (!WG_UBOOL(ok)) return false;
     WG_WSYNC();
 #ifdef WG_PROFILE
