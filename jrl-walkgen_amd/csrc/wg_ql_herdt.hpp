@@ -426,6 +426,54 @@ struct HerdtProb {
     return ok;
   }
 
+  // ------------------------------------------------------------------ border columns of Z = R^-1 (:937-975), same structure
+  // Z(i,c) = -(sum_{k=i}^{c-1} Z(i,k) R(k,c)) / R(c,c) for the border columns c.  The sums start from +0.0, so terms that are
+  // exact zeros -- everything that pairs the x half with the y half, and the zeros below the diagonal of the constant block --
+  // change nothing wherever they stand; what is left of a cross entry is -(+0.0) / R(c,c) = -0.0 above the diagonal (and the
+  // +0.0 the reference stores below it).  The x half is computed, the y half is the same numbers.
+  template <int NS>
+  __device__ __forceinline__ void border_z(const QlView &q, int lane) const {
+    constexpr int M2 = 2 * NH;
+    const int i = lane;
+    const bool jerk = i < NH, foot = i >= NH && i < NH + NS, row = jerk || foot;
+    const int fi = i - NH;
+    const int gi = jerk ? i : M2 + (foot ? fi : 0);         // the row's index in the QP, and its twin in the y half
+    const int gy = jerk ? NH + i : M2 + NS + (foot ? fi : 0);
+    const int zi = jerk ? i : 0;
+    double sum[NS];
+#pragma unroll
+    for (int f = 0; f < NS; ++f) sum[f] = 0.0;
+#pragma unroll 4
+    for (int k = 0; k < NH; ++k) {                          // k < i: Z(i,k) = +0.0, the products are exact zeros
+      const double zk = Zm(zi, k);
+#pragma unroll
+      for (int f = 0; f < NS; ++f) sum[f] += zk * Rp(k, M2 + f);
+    }
+    double zl[NS];
+#pragma unroll
+    for (int f = 0; f < NS; ++f) {
+      const int c = M2 + f;
+      const double rcc = Rp(c, c);
+      double sj = sum[f], sf = 0.0;
+#pragma unroll
+      for (int g = 0; g < NS; ++g) {
+        if (g < f) {
+          const double t = zl[g] * Rp(M2 + g, c);
+          sj += t;                                          // jerk rows: every earlier foot row takes part
+          sf = (g >= fi) ? sf + t : sf;                     // foot row fi: rows fi .. f-1
+        }
+      }
+      double z = -sj / rcc;
+      if (!jerk) z = (fi < f) ? -sf / rcc : ((fi == f) ? 1.0 / rcc : 0.0);
+      zl[f] = z;
+      if (row) {
+        Zm(gi, c) = z; Zm(gy, M2 + NS + f) = z;             // the entry and its y twin
+        Zm(gi, M2 + NS + f) = -0.0;                         // x row, y-foot column: cross, above the diagonal
+        Zm(gy, c) = jerk ? -0.0 : 0.0;                      // y row, x-foot column: above (jerk-y rows) / below (y-foot rows) it
+      }
+    }
+  }
+
   // ------------------------------------------------------------------ R and Z = R^-1 (:859-975)
   // Leading 2N columns: copied.  Remaining columns: the reference recurrences, restricted to them.
   // Returns false (nothing usable written) if a pivot fails -> caller falls back to the generic path.
@@ -485,20 +533,9 @@ struct HerdtProb {
 #ifdef WG_PROFILE
     if (lane == 0) atomicAdd(&g_prof[31], clock64() - fp1);   // border rows of R
 #endif
-    // columns >= 2N of Z: lane <-> row
-    for (int c = M2; c < n; ++c) {
-      const int i = lane;
-      double sum = 0.0;
-      if (i < c) {
-        // Z(i,k) == -+0 for k in the other block (i < N <= k < 2N): exact zeros again
-        WG_UNROLL
-        for (int k = i; k < c; ++k) sum += Zm(i, k) * Rp(k, c);
-      }
-      const double rcc = Rp(c, c);
-      if (i < c) Zm(i, c) = -sum / rcc;
-      else if (i == c) Zm(i, c) = 1.0 / rcc;
-      else if (i < n) Zm(i, c) = 0.0;
-    }
+    // columns >= 2N of Z (border_z above)
+    if (nb == 2) border_z<1>(q, lane);
+    else if (nb == 4) border_z<2>(q, lane);
     WG_WSYNC();
     return true;
   }
