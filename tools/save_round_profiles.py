@@ -82,6 +82,29 @@ if "pertick" in summ:
     out["per_tick_kernel"] = per_gait_tick(summ["pertick"], "wg_mpc_tick_kernel<16>", B * (W + K))
     out["per_tick_kernel"]["ticks_per_launch"] = "1"
 json.dump(out, open(os.path.join(ROOT, "profiles", "current_tick_pmc.json"), "w"), indent=1)
+ph = os.path.join(ROOT, "gpurun_out", "phases_tick.txt")
+if os.path.exists(ph):
+    shutil.copy(ph, os.path.join(ROOT, "profiles", f"{tag}_tick_phase_timers.txt"))
+readme = f"""# profiles/ -- one set, describing HEAD
+
+Everything named `{tag}_*` was produced by ONE run of `tools/prof_round.sh` on an MI355X (gpurun) and filed by
+`tools/save_round_profiles.py {tag}`; older sets are in the git history only.
+
+| files | command profiled | what to read there |
+|---|---|---|
+| `{tag}_tick_*` | `python3 bench.py --steps 200 --warmup 50 --no-cpu-baseline --no-parity --no-per-tick-leg --no-config5` | the benchmarked kernel `wg_mpc_run_xcd_kernel<16>` alone: B = 4096, launches of 48, 50, 50, 50, 50 ticks (plus the two single-tick launches of the control loop's first ticks under their own kernel name); kernel-trace stats and the PMC passes |
+| `{tag}_tickg_*` | the same with `WG_RUN_QUEUE=global` | the device-wide queue of round 1 (`wg_mpc_run_kernel<16>`): the L2 write-back traffic the XCD-local hand-over removed |
+| `{tag}_pertick_*` | the same with `--per-tick-launch` | `wg_mpc_tick_kernel<16>`, 250 launches of one tick |
+| `{tag}_config5_*` | `PN=32 PB=8192 PT=50 python3 tools/probe_run.py` | BASELINE configs[4]'s size: N = 32, B = 8192 (element view), per-tick and multi-tick launches |
+| `{tag}_gramian_*` | `python3 tools/probe_gramian.py` | `wg_gramian_kernel`: SQ_INSTS_VALU_MFMA_MOPS_F64 / _F32, SQ_VALU_MFMA_BUSY_CYCLES, duration against the dense MFMA peak (`*_probe_output.txt`) |
+| `{tag}_dimitrov_*`, `{tag}_pldp_*`, `{tag}_preview_*`, `{tag}_zmpdisc_*` | `tools/probe_<name>.py` | the other kernels of the path |
+| `{tag}_tick_phase_timers.txt` | `PB=4096 python3 tools/probe_tick_phases.py` (diagnostic build `lib/libwg_mpc_prof.so`) | in-kernel phase timers of the tick (shader cycles per gait-tick, one launch per tick) |
+| `current_tick_pmc.json` | derived from `{tag}_tick_*`, `{tag}_tickg_*`, `{tag}_pertick_*` | per gait-tick: HBM bytes read / written (FETCH_SIZE x 2 and WRITE_SIZE, KiB units, separate passes), VALU / SALU / LDS / VMEM instructions, VALU busy; `bench.py` scales `roofline.traffic` and its second axis from this file |
+
+Each `*_rocprofv3_summary.txt/json` = per-kernel averages of the trace (`kernels`) and per-launch means of every counter
+(`counters`); `*_kernel_stats.csv` = rocprofv3's own `--stats` table of the same run.
+"""
+open(os.path.join(ROOT, "profiles", "README.md"), "w").write(readme)
 for k in ("run_kernel", "run_kernel_device_wide_queue", "per_tick_kernel"):
     if k in out:
         r = out[k]
