@@ -117,7 +117,7 @@ def cpu_baseline(n_gaits, n_ticks):
     one = dict(value=ticks / dt, seconds=dt, kind=kind,
                solve_only=(solves / solve_s if solve_s else None))
     cores = os.cpu_count() or 1
-    per = max(8, n_gaits // 8)
+    per = max(8, n_gaits // 32)
     try:
         with mp.get_context("fork").Pool(cores) as pool:
             t0 = time.perf_counter()
@@ -404,9 +404,9 @@ def main():
                                          "valu_busy": None if pmc is None else pmc[kname].get("valu_busy"),
                                          "valu_insts_per_tick": None if pmc is None else pmc[kname].get("valu_insts_per_gait_tick"),
                                          "note": "useful flops = SURVEY 8(d)'s operation count of the reference algorithm for each "
-                                                 "tick's own n, m and iteration count; valu_busy = SQ_ACTIVE_INST_VALU x 4 / "
-                                                 "(SQ_BUSY_CU_CYCLES-equivalent) from the same rocprofv3 passes (issue slots of the "
-                                                 "vector ALUs in use)"}},
+                                                 "tick's own n, m and iteration count; valu_busy = 2 waves per SIMD x "
+                                                 "SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES from the same rocprofv3 passes (share of the "
+                                                 "vector ALUs' issue time in use)"}},
             "solver": {"mean_iterations": float(d[:, 1].mean()), "max_iterations": int(d[:, 1].max()),
                        "mean_active": float(d[:, 2].mean()), "failed_qps": n_fail,
                        "n_hist": {str(int(k)): int(v) for k, v in zip(*np.unique(d[:, 3], return_counts=True))},
