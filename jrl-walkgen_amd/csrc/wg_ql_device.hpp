@@ -296,6 +296,27 @@ __device__ __forceinline__ bool significant(double base, double delta_abs) {
 // s[i] = sum_j Z(j,i) * ww[j]   (qld.cpp:2071-2085); lane i owns s[i]
 __device__ __forceinline__ void zt_times_ww(const QlView &q, double *s, int lane) {
   const int n = q.n;
+  if (n > 64 && n <= 128) {
+    // two columns per lane in ONE pass (the second pass of the strided form has n - 64 useful lanes), loads in groups of
+    // eight ahead of the two add chains: at this size Z may live in global memory (L2), where every exposed round trip
+    // costs hundreds of cycles
+    const int i0 = lane, i1 = lane + 64 < n ? lane + 64 : lane;      // surplus lanes shadow their first column
+    const double *z0 = q.Z + (size_t)i0 * q.ldz, *z1 = q.Z + (size_t)i1 * q.ldz;
+    double a0 = 0.0, a1 = 0.0;
+    int j = 0;
+    for (; j + 8 <= n; j += 8) {
+      double u0[8], u1[8], w[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { u0[e] = z0[j + e]; u1[e] = z1[j + e]; w[e] = q.ww[j + e]; }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { a0 += u0[e] * w[e]; a1 += u1[e] * w[e]; }
+    }
+    for (; j < n; ++j) { const double w = q.ww[j]; a0 += z0[j] * w; a1 += z1[j] * w; }
+    s[i0] = a0;
+    if (lane + 64 < n) s[i1] = a1;
+    WG_WSYNC();
+    return;
+  }
   for (int i = lane; i < n; i += 64) {
     double acc = 0.0;
     WG_UNROLL
@@ -661,6 +682,49 @@ __device__ __forceinline__ void sweep(const QlView &q, double *s, int nu, int na
     }
   }
   WG_WSYNC();
+  if (n <= 128) {
+    // phase 3 for 64 < n <= 128: two rows per lane in one pass, the row entries of the coming rotations fetched kSwD
+    // rotations ahead (each entry is read before the rotation that rewrites it, so fetching earlier reads the same value):
+    // with Z in global memory an un-prefetched entry is an L2 round trip per rotation on the carry chain
+    constexpr int kSwD = 6;
+    const int i0 = lane;
+    const bool two = lane + 64 < n;
+    const int i1 = two ? lane + 64 : lane;                    // surplus lanes shadow their first row (loads only)
+    const int ldz = q.ldz;
+    double carry0 = Zm(i0, nu - 1), carry1 = Zm(i1, nu - 1);
+    double p0[kSwD], p1[kSwD];
+#pragma unroll
+    for (int k = 0; k < kSwD; ++k) {
+      const int cc = (nu - 2 - k) > nact ? (nu - 2 - k) : nact;
+      p0[k] = q.Z[i0 + cc * ldz]; p1[k] = q.Z[i1 + cc * ldz];
+    }
+    int c = nu - 1;
+    while (c > nact) {
+#pragma unroll
+      for (int k = 0; k < kSwD; ++k) {
+        if (c > nact) {
+          const double zl0 = p0[k], zl1 = p1[k];
+          {
+            const int cc = (c - 1 - kSwD) > nact ? (c - 1 - kSwD) : nact;      // clamped: unused past the end
+            p0[k] = q.Z[i0 + cc * ldz]; p1[k] = q.Z[i1 + cc * ldz];
+          }
+          const double nrm = q.sc2[c], ga = q.sc0[c], gb = q.sc1[c];
+          const bool skip = (nrm == 0.0);
+          const double t0 = ga * zl0 + gb * carry0, w0 = ga * carry0 - gb * zl0;
+          const double t1 = ga * zl1 + gb * carry1, w1 = ga * carry1 - gb * zl1;
+          q.Z[i0 + c * ldz] = skip ? carry0 : w0;
+          if (two) q.Z[i1 + c * ldz] = skip ? carry1 : w1;
+          carry0 = skip ? zl0 : t0;
+          carry1 = skip ? zl1 : t1;
+          --c;
+        }
+      }
+    }
+    q.Z[i0 + nact * ldz] = carry0;
+    if (two) q.Z[i1 + nact * ldz] = carry1;
+    WG_WSYNC();
+    return;
+  }
   for (int i = lane; i < n; i += 64) {
     double carry = Zm(i, nu - 1);
     for (int c = nu - 1; c > nact; --c) {
