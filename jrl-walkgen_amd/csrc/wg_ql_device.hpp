@@ -660,25 +660,37 @@ __device__ __forceinline__ void sweep(const QlView &q, double *s, int nu, int na
     WG_WSYNC();
     return;
   }
-  // phase 1: sc0[c] = p (s[c-1] before), sc1[c] = q (s[c] current), sc2[c] = norm; sc2[c] = 0 marks "skipped"
+  // phase 1: the chain of norms, as in sweep_flat: ONE value per rotation is recorded (`cur` as it leaves rotation c, in
+  // chain[c - 1]); p = s[c - 1] is fetched one rotation ahead, off the chain.  Phase 2 rebuilds each rotation from it:
+  // sc0[c] = ga, sc1[c] = gb, sc2[c] = norm (0 marks "skipped").
+  double *chain = q.sc3;
   {
     double cur = s[nu - 1];
+    double p = s[nu - 2];
     for (int c = nu - 1; c > nact; --c) {
-      double p = s[c - 1];
-      double nrm;
-      if (cur == 0.0) { nrm = 0.0; cur = p; }
-      else { nrm = givens_norm(p, cur); if (lane == 0) { q.sc0[c] = p; q.sc1[c] = cur; } cur = nrm; }
-      if (lane == 0) q.sc2[c] = nrm;
+      const double p_next = s[(c - 2 >= 0) ? c - 2 : 0];
+      const double nrmc = givens_norm(p, cur);
+      cur = (cur == 0.0) ? p : nrmc;
+      chain[c - 1] = cur;
+      p = p_next;
     }
     WG_WSYNC();
   }
-  for (int c = nact + 1 + lane; c < nu; c += 64) {
-    double nrm = q.sc2[c];
-    if (nrm != 0.0) {
-      double p = q.sc0[c], qq = q.sc1[c];
-      q.sc0[c] = p / nrm;   // ga
-      q.sc1[c] = qq / nrm;  // gb
-      s[c - 1] = nrm;
+  for (int c0 = nact + 1; c0 < nu; c0 += 64) {
+    const int c = c0 + lane;
+    const bool mine = c < nu;
+    const int cc = mine ? c : nu - 1;
+    const double P = s[cc - 1];
+    const double Q = (cc == nu - 1) ? s[nu - 1] : chain[cc];
+    const double Nn = (Q == 0.0) ? 0.0 : chain[cc - 1];
+    WG_WSYNC();                                             // every lane has read s[] before any lane rewrites it
+    if (mine) {
+      q.sc2[c] = Nn;
+      if (Nn != 0.0) {
+        q.sc0[c] = P / Nn;   // ga
+        q.sc1[c] = Q / Nn;   // gb
+        s[c - 1] = Nn;
+      }
     }
   }
   WG_WSYNC();
