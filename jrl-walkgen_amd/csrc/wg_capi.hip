@@ -420,6 +420,8 @@ inline size_t tick_ql_bytes(const wg_model_t &m) {
 // gaits fit a CU (SIMDs hold 2,2,1,1 waves); the second wave of a SIMD hides the first one's dependent fp64 chains
 // (measured: 4 -> 6 resident gaits per CU = 1.78 -> 2.23 M ticks/s).  -DWG_TICK_WPE_MIN=1 -DWG_TICK_WPE_MAX=1 gives the
 // 512-register build (lib/libwg_mpc_w1.so, tools/bench_variants.sh).
+// The element view (NH == -1, N = 32) is held to ONE wave per SIMD by its LDS footprint (four gaits per CU): its kernels
+// are compiled for that, i.e. with the whole register file of a SIMD lane (512) -- no spills.
 #ifndef WG_TICK_WPE_MIN
 #define WG_TICK_WPE_MIN 2
 #endif
@@ -427,7 +429,7 @@ inline size_t tick_ql_bytes(const wg_model_t &m) {
 #define WG_TICK_WPE_MAX 2
 #endif
 template <int NH>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WG_TICK_WPE_MIN, WG_TICK_WPE_MAX))) void wg_mpc_tick_kernel(int B, wg_model_t model, const wg::TickTables *__restrict__ tb,
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NH == -1 ? 1 : WG_TICK_WPE_MIN, NH == -1 ? 1 : WG_TICK_WPE_MAX))) void wg_mpc_tick_kernel(int B, wg_model_t model, const wg::TickTables *__restrict__ tb,
                                                          wg_gait_state_t *__restrict__ states,
                                                          wg_tick_out_t *__restrict__ outs, int *__restrict__ diag,
                                                          int advance_calls, int *__restrict__ hist, int hist_cap,
@@ -480,7 +482,7 @@ __global__ void wg_run_queue_init_kernel(int B, int total, wg_run_queue *q, int 
 }
 
 template <int NH>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WG_TICK_WPE_MIN, WG_TICK_WPE_MAX))) void wg_mpc_run_kernel(
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NH == -1 ? 1 : WG_TICK_WPE_MIN, NH == -1 ? 1 : WG_TICK_WPE_MAX))) void wg_mpc_run_kernel(
     int B, int n_ticks, const wg_model_t *__restrict__ model_p, const wg::TickTables *__restrict__ tb_p,
     wg_gait_state_t *__restrict__ states_p, wg_tick_out_t *__restrict__ outs_p, int *__restrict__ diag_p, int advance_calls,
     wg_run_queue *__restrict__ q, int *__restrict__ ring, int *__restrict__ done, unsigned ql_bytes, double *zscratch,
@@ -579,7 +581,7 @@ __device__ __forceinline__ int xrun_take_fresh(wg_xrun_ctl *ctl, int y) {
 __device__ __forceinline__ void xrun_stores_done() { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); }
 
 template <int NH>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WG_TICK_WPE_MIN, WG_TICK_WPE_MAX))) void wg_mpc_run_xcd_kernel(
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NH == -1 ? 1 : WG_TICK_WPE_MIN, NH == -1 ? 1 : WG_TICK_WPE_MAX))) void wg_mpc_run_xcd_kernel(
     int B, int n_ticks, const wg_model_t *__restrict__ model_p, const wg::TickTables *__restrict__ tb_p,
     wg_gait_state_t *__restrict__ states_p, wg_tick_out_t *__restrict__ outs_p, int *__restrict__ diag_p, int advance_calls,
     wg_xrun_ctl *__restrict__ ctl_p, unsigned long long *__restrict__ rings_p, int cap, int *__restrict__ done_p,

@@ -114,7 +114,7 @@ struct QlView {
   double *x, *d, *ww, *wd, *wx, *lam, *xl, *xu, *wa, *b;
   double *sc0, *sc1, *sc2, *sc3, *slot;
   int *iact;
-  __device__ void carve(double *base, const QlDims &D, int me_) {
+  __device__ __forceinline__ void carve(double *base, const QlDims &D, int me_) {
     n = D.n; m = D.m; me = me_; mn = D.m + D.n; ldg = D.ldg; ldz = D.ldz; lda = D.lda;
     double *p = base;
     G = nullptr; A = nullptr;
@@ -159,6 +159,7 @@ struct QlView {
 struct QlView;
 struct DenseProb {
   static constexpr bool kCompact = false;
+  static constexpr bool kHasFactor = false;    // no structure to exploit: ql0002's own Cholesky and inverse
   static constexpr bool kRowOps = false;   // no structured row products: rows are read element by element
   static constexpr int kNM = 0;        // no compile-time bound on n
   __device__ __forceinline__ double G(const QlView &q, int i, int j) const;
@@ -294,9 +295,10 @@ __device__ __forceinline__ bool significant(double base, double delta_abs) {
 }
 
 // s[i] = sum_j Z(j,i) * ww[j]   (qld.cpp:2071-2085); lane i owns s[i]
+template <int NM = 0>                                     // NM > 0: n <= NM known at compile time (the wide form is left out)
 __device__ __forceinline__ void zt_times_ww(const QlView &q, double *s, int lane) {
   const int n = q.n;
-  if (n > 64 && n <= 128) {
+  if ((NM == 0 || NM > 64) && n > 64 && n <= 128) {
     // two columns per lane in ONE pass (the second pass of the strided form has n - 64 useful lanes), loads in groups of
     // eight ahead of the two add chains: at this size Z may live in global memory (L2), where every exposed round trip
     // costs hundreds of cycles
@@ -912,7 +914,7 @@ __device__ __forceinline__ QlResult ql_solve(const QlView &q, P &prob, double vs
     bool need_shift = diag > 0.0;
     PT(1);
     bool factored = false;
-    if constexpr (P::kCompact) {
+    if constexpr (P::kHasFactor) {
       if (!need_shift && prob.blocks_ok) factored = WG_UBOOL(prob.factor(q, vsmall, lane));
     }
     if (!factored) {
@@ -1096,7 +1098,7 @@ __device__ __forceinline__ QlResult ql_solve(const QlView &q, P &prob, double vs
         WG_WSYNC();
       }
       PT(4);
-      zt_times_ww(q, s, lane);                              // :1175-1177
+      zt_times_ww<P::kNM>(q, s, lane);                      // :1175-1177
       PT(5);
       if (nact != n) {                                      // :1186-1201
         for (int i = lane; i < n; i += 64) {
@@ -1276,7 +1278,7 @@ __device__ __forceinline__ QlResult ql_solve(const QlView &q, P &prob, double vs
         for (int i = lane; i < n; i += 64) q.ww[i] = Am(knext - 1, i);
         WG_WSYNC();
         if constexpr (P::kCompact) prob.zt_row(q, s, knext - 1, lane);
-        else zt_times_ww(q, s, lane);
+        else zt_times_ww<P::kNM>(q, s, lane);
       } else {
         int k1 = knext - m;
         double sg = 1.0;

@@ -23,9 +23,220 @@ constexpr int kSMaxQ = 4;   // == kSMax of the tick
 constexpr int kGvLd = 4;    // row stride of the border block Gv: 2*ns <= 4 columns (at most two previewed steps)
 constexpr int kQbLd = 32;   // row stride of TickTables::Qb (== kNMaxH)
 
+// ------------------------------------------------------------------ border columns of R, one row per lane
+// R(i,j) = (G(i,j) - sum_{k<i} R(k,j) R(k,i)) / R(i,i) for the 2 ns border columns j (:859-890 restricted to them) is a
+// forward substitution per column: serial in i, and in the row-serial form each row's sum is itself a chain of i dependent
+// multiply-subtracts carried by the few lanes that own a border column.  Here one ROW per lane: lane i keeps the running
+// value of its entries; step k finalises row k (lane k divides), broadcasts it, and every row below subtracts its product --
+// the same products in the same order k = 0, 1, ... for every entry, so the same bits, in n short steps.
+//
+// Structure used on top of that (C = blockdiag(Qb, Qb) + border, generator-vel-ref.cpp:617-674):
+//   * the x half (jerk-x rows, x-foot rows / columns) and the y half never mix: every entry that pairs a row of one half
+//     with a border column of the other is G = +0.0 minus products that each have a +0.0 factor, i.e. +0.0 - (+-0.0) = +0.0,
+//     divided by a positive diagonal: exactly +0.0.  Those entries are written, not computed; where such a product enters
+//     the sum of a non-cross entry it is (+0.0)(+0.0) = +0.0 and x - (+0.0) == x for every x;
+//   * the two halves are the same numbers: the assembly writes the same -gamma Uz'V and gamma V'V into both (mpc_tick), and
+//     the constant factor blocks are blockdiag(Rb, Rb).  The x half is computed (N + ns rows, ns columns), the y half copied.
+// NH = horizon, NS = previewed steps (compile time); Gv rows are kGvLd wide with the row's own group first (both table views).
+template <int NH, int NS>
+__device__ __forceinline__ bool herdt_border_rows(const QlView &q, const double *gd, const double *Gv, double vsmall, int lane) {
+  constexpr int M2 = 2 * NH;
+  const int i = lane;                                     // x half: rows 0..N-1 jerk-x, N..N+NS-1 the x-foot rows
+  const bool jerk = i < NH, foot = i >= NH && i < NH + NS, row = jerk || foot;
+  const int fi = i - NH;                                  // foot row index
+  const int gi = jerk ? i : M2 + (foot ? fi : 0);         // the row's index in the QP
+  double acc[NS];
+#pragma unroll
+  for (int f = 0; f < NS; ++f)
+    acc[f] = (jerk || (foot && f >= fi)) ? ((foot && f == fi) ? gd[gi] : Gv[gi * kGvLd + f]) : 0.0;
+  const double dreg = jerk ? Rp(i, i) : 1.0;
+  const int colbase = jerk ? i * (i + 1) / 2 : 0;         // R(k, i) = q.R[colbase + k], k <= i (first diagonal block)
+  const int khi = jerk ? i : 0;
+  // ---- steps k < N: the divisor is the constant diagonal ----
+  double rnext = (0 < khi) ? q.R[colbase] : 0.0;
+  for (int k = 0; k < NH; ++k) {
+    const double rki_lds = rnext;                         // R(k, i), fetched one step ahead (clamped address, selected value)
+    {
+      const int kn = k + 1;
+      const double v = q.R[colbase + (kn < khi ? kn : 0)];
+      rnext = (kn < khi) ? v : 0.0;
+    }
+    double bk[NS];
+#pragma unroll
+    for (int f = 0; f < NS; ++f) {
+      const double rk = acc[f] / dreg;                    // lane k's is R(k, 2N + f)
+      bk[f] = rl(rk, k);
+    }
+    if (lane == k) {
+#pragma unroll
+      for (int f = 0; f < NS; ++f) {
+        Rp(k, M2 + f) = bk[f]; Rp(NH + k, M2 + NS + f) = bk[f];     // x entry and its y twin
+        Rp(k, M2 + NS + f) = 0.0; Rp(NH + k, M2 + f) = 0.0;         // the two cross entries
+      }
+    }
+    double rki = rki_lds;
+#pragma unroll
+    for (int f = 0; f < NS; ++f) rki = (fi == f) ? bk[f] : rki;     // a foot row's own column entry R(k, i)
+    const bool upd = row && i > k;
+#pragma unroll
+    for (int f = 0; f < NS; ++f) {
+      const double nv = acc[f] - bk[f] * rki;
+      acc[f] = (upd && (jerk || f >= fi)) ? nv : acc[f];
+    }
+  }
+  // ---- the foot rows: pivot test (:868-872), square root, the entries to its right ----
+  bool ok = true;
+#pragma unroll
+  for (int kb = 0; kb < NS; ++kb) {
+    const int k = NH + kb;                                // lane that holds the row
+    const double t = rl(acc[kb], k);                      // the pivot, wave-uniform
+    ok = ok && !(t < vsmall);                             // a failed pivot: the rest is computed and discarded (caller: generic path)
+    const double rt = sqrt(t);
+    double bk[NS];
+#pragma unroll
+    for (int f = 0; f < NS; ++f) {
+      bk[f] = 0.0;
+      if (f > kb) bk[f] = rl(acc[f] / rt, k);
+    }
+    if (lane == k) {
+      Rp(M2 + kb, M2 + kb) = rt; Rp(M2 + NS + kb, M2 + NS + kb) = rt;
+#pragma unroll
+      for (int f = 0; f < NS; ++f) {
+        if (f > kb) { Rp(M2 + kb, M2 + f) = bk[f]; Rp(M2 + NS + kb, M2 + NS + f) = bk[f]; }
+        Rp(M2 + kb, M2 + NS + f) = 0.0;                   // x-foot row, y-foot column: cross (its mirror lies below the diagonal)
+      }
+    }
+    double rki = 0.0;
+#pragma unroll
+    for (int f = 0; f < NS; ++f) rki = (fi == f) ? bk[f] : rki;
+    const bool upd = foot && i > k;
+#pragma unroll
+    for (int f = 0; f < NS; ++f) {
+      if (f > kb) {
+        const double nv = acc[f] - bk[f] * rki;
+        acc[f] = (upd && f >= fi) ? nv : acc[f];
+      }
+    }
+  }
+  return ok;
+}
+
+// ------------------------------------------------------------------ border columns of Z = R^-1 (:937-975), same structure
+// Z(i,c) = -(sum_{k=i}^{c-1} Z(i,k) R(k,c)) / R(c,c) for the border columns c.  The sums start from +0.0, so terms that are
+// exact zeros -- everything that pairs the x half with the y half, and the zeros below the diagonal of the constant block --
+// change nothing wherever they stand; what is left of a cross entry is -(+0.0) / R(c,c) = -0.0 above the diagonal (and the
+// +0.0 the reference stores below it).  The x half is computed, the y half is the same numbers.
+template <int NH, int NS>
+__device__ __forceinline__ void herdt_border_z(const QlView &q, int lane) {
+  constexpr int M2 = 2 * NH;
+  const int i = lane;
+  const bool jerk = i < NH, foot = i >= NH && i < NH + NS, row = jerk || foot;
+  const int fi = i - NH;
+  const int gi = jerk ? i : M2 + (foot ? fi : 0);         // the row's index in the QP, and its twin in the y half
+  const int gy = jerk ? NH + i : M2 + NS + (foot ? fi : 0);
+  const int zi = jerk ? i : 0;
+  double sum[NS];
+#pragma unroll
+  for (int f = 0; f < NS; ++f) sum[f] = 0.0;
+#pragma unroll 4
+  for (int k = 0; k < NH; ++k) {                          // k < i: Z(i,k) = +0.0, the products are exact zeros
+    const double zk = Zm(zi, k);
+#pragma unroll
+    for (int f = 0; f < NS; ++f) sum[f] += zk * Rp(k, M2 + f);
+  }
+  double zl[NS];
+#pragma unroll
+  for (int f = 0; f < NS; ++f) {
+    const int c = M2 + f;
+    const double rcc = Rp(c, c);
+    double sj = sum[f], sf = 0.0;
+#pragma unroll
+    for (int g = 0; g < NS; ++g) {
+      if (g < f) {
+        const double t = zl[g] * Rp(M2 + g, c);
+        sj += t;                                          // jerk rows: every earlier foot row takes part
+        sf = (g >= fi) ? sf + t : sf;                     // foot row fi: rows fi .. f-1
+      }
+    }
+    double z = -sj / rcc;
+    if (!jerk) z = (fi < f) ? -sf / rcc : ((fi == f) ? 1.0 / rcc : 0.0);
+    zl[f] = z;
+    if (row) {
+      Zm(gi, c) = z; Zm(gy, M2 + NS + f) = z;             // the entry and its y twin
+      Zm(gi, M2 + NS + f) = -0.0;                         // x row, y-foot column: cross, above the diagonal
+      Zm(gy, c) = jerk ? -0.0 : 0.0;                      // y row, x-foot column: above (jerk-y rows) / below (y-foot rows) it
+    }
+  }
+}
+
+
+// Constant factor blocks of C = blockdiag(Qb, Qb) + border into the solver's R and Z: blockdiag(Rb, Rb) and blockdiag(Zb, Zb)
+// with exact zeros in between (the cross-block products of the recurrences are x * 0), so only the first diagonal block is
+// fetched from global memory; the zeros of Z's upper-right block are SIGNED (-(x * 0) / r), their signs come from a bit
+// mask.  n = 2 NH + border columns; also clears the border rows of Z below the constant block.
+template <int NH>
+__device__ __forceinline__ void herdt_constant_blocks(const QlView &q, const double *R2, const double *Z2, const unsigned long long *z2sign,
+                                                      int lane) {
+  const int n = q.n;
+  constexpr int M2 = 2 * NH;
+  constexpr int NR = NH * (NH + 1) / 2, TR = (NR + 63) / 64, TZ = (NH * NH + 63) / 64;
+  if constexpr (NH > 16) {
+    // large horizon: one element at a time (the staged form below would keep 25 doubles per lane in flight; at this size the
+    // copy is a per-mille of the tick)
+    for (int e = lane; e < NR; e += 64) {
+      int j = 0;
+      while ((j + 1) * (j + 2) / 2 <= e) ++j;
+      const int i = e - j * (j + 1) / 2;
+      const double v = R2[e];
+      q.R[e] = v;
+      Rp(NH + i, NH + j) = v;
+    }
+    for (int e = lane; e < NH * NH; e += 64) { const int i = e % NH, j = NH + e / NH; Rp(i, j) = 0.0; }   // cross block of R
+    for (int e = lane; e < NH * NH; e += 64) {
+      const int i = e % NH, j = e / NH;
+      const double v = Z2[i + j * M2];
+      Zm(i, j) = v; Zm(NH + i, NH + j) = v;
+      Zm(NH + i, j) = 0.0;
+      Zm(i, NH + j) = ((z2sign[e >> 6] >> (e & 63)) & 1ull) ? -0.0 : 0.0;
+    }
+    for (int e = lane; e < (n - M2) * M2; e += 64) { const int i = M2 + e % (n - M2), j = e / (n - M2); Zm(i, j) = 0.0; }
+    return;
+  }
+  double rv[TR], zv[TZ];
+#pragma unroll
+  for (int t = 0; t < TR; ++t) { const int e = lane + 64 * t; rv[t] = e < NR ? R2[e] : 0.0; }
+#pragma unroll
+  for (int t = 0; t < TZ; ++t) { const int e = lane + 64 * t; zv[t] = e < NH * NH ? Z2[(e % NH) + (e / NH) * M2] : 0.0; }
+#pragma unroll
+  for (int t = 0; t < TR; ++t) {
+    const int e = lane + 64 * t;
+    if (e < NR) {
+      // e = j(j+1)/2 + i, i <= j < NH: column j is the largest with j(j+1)/2 <= e
+      int j = 0;
+      while ((j + 1) * (j + 2) / 2 <= e) ++j;
+      const int i = e - j * (j + 1) / 2;
+      q.R[e] = rv[t];
+      Rp(NH + i, NH + j) = rv[t];
+    }
+  }
+  for (int e = lane; e < NH * NH; e += 64) { const int i = e % NH, j = NH + e / NH; Rp(i, j) = 0.0; }   // cross block of R
+#pragma unroll
+  for (int t = 0; t < TZ; ++t) {
+    const int e = lane + 64 * t;
+    if (e < NH * NH) {
+      const int i = e % NH, j = e / NH;
+      Zm(i, j) = zv[t]; Zm(NH + i, NH + j) = zv[t];
+      Zm(NH + i, j) = 0.0;
+      Zm(i, NH + j) = ((z2sign[e >> 6] >> (e & 63)) & 1ull) ? -0.0 : 0.0;
+    }
+  }
+  for (int e = lane; e < (n - M2) * M2; e += 64) { const int i = M2 + e % (n - M2), j = e / (n - M2); Zm(i, j) = 0.0; }
+}
+
 template <int NH>
 struct HerdtProb {
   static constexpr bool kCompact = true;
+  static constexpr bool kHasFactor = true;
   static constexpr bool kRowOps = false;       // the compact view has its own register-row paths
   static constexpr int kNM = 2 * NH + 2 * 2;   // n <= 2N + 2*2: at most two previewed steps (checked by wg_mpc_configure)
   static_assert(4 * NH == 64, "one CoP row per lane needs 4N == 64");
@@ -328,152 +539,6 @@ struct HerdtProb {
     return wave_max(dl);
   }
 
-  // ------------------------------------------------------------------ border columns of R, one row per lane
-  // R(i,j) = (G(i,j) - sum_{k<i} R(k,j) R(k,i)) / R(i,i) for the 2 ns border columns j (:859-890 restricted to them) is a
-  // forward substitution per column: serial in i, and in the row-serial form each row's sum is itself a chain of i dependent
-  // multiply-subtracts carried by the few lanes that own a border column.  Here one ROW per lane: lane i keeps the running
-  // value of its entries; step k finalises row k (lane k divides), broadcasts it, and every row below subtracts its product --
-  // the same products in the same order k = 0, 1, ... for every entry, so the same bits, in n short steps.
-  //
-  // Structure used on top of that (C = blockdiag(Qb, Qb) + border, generator-vel-ref.cpp:617-674):
-  //   * the x half (jerk-x rows, x-foot rows / columns) and the y half never mix: every entry that pairs a row of one half
-  //     with a border column of the other is G = +0.0 minus products that each have a +0.0 factor, i.e. +0.0 - (+-0.0) = +0.0,
-  //     divided by a positive diagonal: exactly +0.0.  Those entries are written, not computed; where such a product enters
-  //     the sum of a non-cross entry it is (+0.0)(+0.0) = +0.0 and x - (+0.0) == x for every x;
-  //   * the two halves are the same numbers: the assembly writes the same -gamma Uz'V and gamma V'V into both (mpc_tick), and
-  //     the constant factor blocks are blockdiag(Rb, Rb).  The x half is computed (N + ns rows, ns columns), the y half copied.
-  // NS = previewed steps (compile time: 1 or 2).
-  template <int NS>
-  __device__ __forceinline__ bool border_rows(const QlView &q, double vsmall, int lane) const {
-    constexpr int M2 = 2 * NH;
-    const int i = lane;                                     // x half: rows 0..N-1 jerk-x, N..N+NS-1 the x-foot rows
-    const bool jerk = i < NH, foot = i >= NH && i < NH + NS, row = jerk || foot;
-    const int fi = i - NH;                                  // foot row index
-    const int gi = jerk ? i : M2 + (foot ? fi : 0);         // the row's index in the QP
-    double acc[NS];
-#pragma unroll
-    for (int f = 0; f < NS; ++f)
-      acc[f] = (jerk || (foot && f >= fi)) ? ((foot && f == fi) ? gd[gi] : Gv[gi * kGvLd + f]) : 0.0;
-    const double dreg = jerk ? Rp(i, i) : 1.0;
-    const int colbase = jerk ? i * (i + 1) / 2 : 0;         // R(k, i) = q.R[colbase + k], k <= i (first diagonal block)
-    const int khi = jerk ? i : 0;
-    // ---- steps k < N: the divisor is the constant diagonal ----
-    double rnext = (0 < khi) ? q.R[colbase] : 0.0;
-    for (int k = 0; k < NH; ++k) {
-      const double rki_lds = rnext;                         // R(k, i), fetched one step ahead (clamped address, selected value)
-      {
-        const int kn = k + 1;
-        const double v = q.R[colbase + (kn < khi ? kn : 0)];
-        rnext = (kn < khi) ? v : 0.0;
-      }
-      double bk[NS];
-#pragma unroll
-      for (int f = 0; f < NS; ++f) {
-        const double rk = acc[f] / dreg;                    // lane k's is R(k, 2N + f)
-        bk[f] = rl(rk, k);
-      }
-      if (lane == k) {
-#pragma unroll
-        for (int f = 0; f < NS; ++f) {
-          Rp(k, M2 + f) = bk[f]; Rp(NH + k, M2 + NS + f) = bk[f];     // x entry and its y twin
-          Rp(k, M2 + NS + f) = 0.0; Rp(NH + k, M2 + f) = 0.0;         // the two cross entries
-        }
-      }
-      double rki = rki_lds;
-#pragma unroll
-      for (int f = 0; f < NS; ++f) rki = (fi == f) ? bk[f] : rki;     // a foot row's own column entry R(k, i)
-      const bool upd = row && i > k;
-#pragma unroll
-      for (int f = 0; f < NS; ++f) {
-        const double nv = acc[f] - bk[f] * rki;
-        acc[f] = (upd && (jerk || f >= fi)) ? nv : acc[f];
-      }
-    }
-    // ---- the foot rows: pivot test (:868-872), square root, the entries to its right ----
-    bool ok = true;
-#pragma unroll
-    for (int kb = 0; kb < NS; ++kb) {
-      const int k = NH + kb;                                // lane that holds the row
-      const double t = rl(acc[kb], k);                      // the pivot, wave-uniform
-      ok = ok && !(t < vsmall);                             // a failed pivot: the rest is computed and discarded (caller: generic path)
-      const double rt = sqrt(t);
-      double bk[NS];
-#pragma unroll
-      for (int f = 0; f < NS; ++f) {
-        bk[f] = 0.0;
-        if (f > kb) bk[f] = rl(acc[f] / rt, k);
-      }
-      if (lane == k) {
-        Rp(M2 + kb, M2 + kb) = rt; Rp(M2 + NS + kb, M2 + NS + kb) = rt;
-#pragma unroll
-        for (int f = 0; f < NS; ++f) {
-          if (f > kb) { Rp(M2 + kb, M2 + f) = bk[f]; Rp(M2 + NS + kb, M2 + NS + f) = bk[f]; }
-          Rp(M2 + kb, M2 + NS + f) = 0.0;                   // x-foot row, y-foot column: cross (its mirror lies below the diagonal)
-        }
-      }
-      double rki = 0.0;
-#pragma unroll
-      for (int f = 0; f < NS; ++f) rki = (fi == f) ? bk[f] : rki;
-      const bool upd = foot && i > k;
-#pragma unroll
-      for (int f = 0; f < NS; ++f) {
-        if (f > kb) {
-          const double nv = acc[f] - bk[f] * rki;
-          acc[f] = (upd && f >= fi) ? nv : acc[f];
-        }
-      }
-    }
-    return ok;
-  }
-
-  // ------------------------------------------------------------------ border columns of Z = R^-1 (:937-975), same structure
-  // Z(i,c) = -(sum_{k=i}^{c-1} Z(i,k) R(k,c)) / R(c,c) for the border columns c.  The sums start from +0.0, so terms that are
-  // exact zeros -- everything that pairs the x half with the y half, and the zeros below the diagonal of the constant block --
-  // change nothing wherever they stand; what is left of a cross entry is -(+0.0) / R(c,c) = -0.0 above the diagonal (and the
-  // +0.0 the reference stores below it).  The x half is computed, the y half is the same numbers.
-  template <int NS>
-  __device__ __forceinline__ void border_z(const QlView &q, int lane) const {
-    constexpr int M2 = 2 * NH;
-    const int i = lane;
-    const bool jerk = i < NH, foot = i >= NH && i < NH + NS, row = jerk || foot;
-    const int fi = i - NH;
-    const int gi = jerk ? i : M2 + (foot ? fi : 0);         // the row's index in the QP, and its twin in the y half
-    const int gy = jerk ? NH + i : M2 + NS + (foot ? fi : 0);
-    const int zi = jerk ? i : 0;
-    double sum[NS];
-#pragma unroll
-    for (int f = 0; f < NS; ++f) sum[f] = 0.0;
-#pragma unroll 4
-    for (int k = 0; k < NH; ++k) {                          // k < i: Z(i,k) = +0.0, the products are exact zeros
-      const double zk = Zm(zi, k);
-#pragma unroll
-      for (int f = 0; f < NS; ++f) sum[f] += zk * Rp(k, M2 + f);
-    }
-    double zl[NS];
-#pragma unroll
-    for (int f = 0; f < NS; ++f) {
-      const int c = M2 + f;
-      const double rcc = Rp(c, c);
-      double sj = sum[f], sf = 0.0;
-#pragma unroll
-      for (int g = 0; g < NS; ++g) {
-        if (g < f) {
-          const double t = zl[g] * Rp(M2 + g, c);
-          sj += t;                                          // jerk rows: every earlier foot row takes part
-          sf = (g >= fi) ? sf + t : sf;                     // foot row fi: rows fi .. f-1
-        }
-      }
-      double z = -sj / rcc;
-      if (!jerk) z = (fi < f) ? -sf / rcc : ((fi == f) ? 1.0 / rcc : 0.0);
-      zl[f] = z;
-      if (row) {
-        Zm(gi, c) = z; Zm(gy, M2 + NS + f) = z;             // the entry and its y twin
-        Zm(gi, M2 + NS + f) = -0.0;                         // x row, y-foot column: cross, above the diagonal
-        Zm(gy, c) = jerk ? -0.0 : 0.0;                      // y row, x-foot column: above (jerk-y rows) / below (y-foot rows) it
-      }
-    }
-  }
-
   // ------------------------------------------------------------------ R and Z = R^-1 (:859-975)
   // Leading 2N columns: copied.  Remaining columns: the reference recurrences, restricted to them.
   // Returns false (nothing usable written) if a pivot fails -> caller falls back to the generic path.
@@ -483,59 +548,24 @@ struct HerdtProb {
 #ifdef WG_PROFILE
     const unsigned long long fp0 = clock64();
 #endif
-    // C = blockdiag(Qb, Qb) + border: the constant factor blocks are blockdiag(Rb, Rb) and blockdiag(Zb, Zb) with exact
-    // zeros in between (the cross-block products of the recurrences are x * 0), so only the first diagonal block is
-    // fetched from global memory -- 392 doubles instead of 1552 -- all loads issued before the first LDS store.
-    {
-      constexpr int NR = NH * (NH + 1) / 2, TR = (NR + 63) / 64, TZ = (NH * NH + 63) / 64;
-      double rv[TR], zv[TZ];
-#pragma unroll
-      for (int t = 0; t < TR; ++t) { const int e = lane + 64 * t; rv[t] = e < NR ? R2[e] : 0.0; }
-#pragma unroll
-      for (int t = 0; t < TZ; ++t) { const int e = lane + 64 * t; zv[t] = e < NH * NH ? Z2[(e % NH) + (e / NH) * M2] : 0.0; }
-#pragma unroll
-      for (int t = 0; t < TR; ++t) {
-        const int e = lane + 64 * t;
-        if (e < NR) {
-          // e = j(j+1)/2 + i, i <= j < NH: column j is the largest with j(j+1)/2 <= e
-          int j = 0;
-          while ((j + 1) * (j + 2) / 2 <= e) ++j;
-          const int i = e - j * (j + 1) / 2;
-          q.R[e] = rv[t];
-          Rp(NH + i, NH + j) = rv[t];
-        }
-      }
-      for (int e = lane; e < NH * NH; e += 64) { const int i = e % NH, j = NH + e / NH; Rp(i, j) = 0.0; }   // cross block of R
-#pragma unroll
-      for (int t = 0; t < TZ; ++t) {
-        const int e = lane + 64 * t;
-        if (e < NH * NH) {
-          const int i = e % NH, j = e / NH;
-          Zm(i, j) = zv[t]; Zm(NH + i, NH + j) = zv[t];
-          Zm(NH + i, j) = 0.0;
-          Zm(i, NH + j) = ((z2sign[e >> 6] >> (e & 63)) & 1ull) ? -0.0 : 0.0;
-        }
-      }
-    }
-    for (int e = lane; e < (n - M2) * M2; e += 64) { const int i = M2 + e % (n - M2), j = e / (n - M2); Zm(i, j) = 0.0; }
+    herdt_constant_blocks<NH>(q, R2, Z2, z2sign, lane);
     WG_WSYNC();
     const int nb = n - M2;                                  // border columns: 2 ns <= 4
 #ifdef WG_PROFILE
     const unsigned long long fp1 = clock64();
     if (lane == 0) atomicAdd(&g_prof[2], fp1 - fp0);       // slot "chol" (unused by the compact view): constant blocks into LDS
 #endif
-    // rows of R, columns >= 2N only (border_rows above); straight-line per step count (a wave-uniform switch)
+    // rows of R, columns >= 2N only; straight-line per step count (a wave-uniform switch)
     bool ok = true;
-    if (nb == 2) ok = border_rows<1>(q, vsmall, lane);
-    else if (nb == 4) ok = border_rows<2>(q, vsmall, lane);
+    if (nb == 2) ok = herdt_border_rows<NH, 1>(q, gd, Gv, vsmall, lane);
+    else if (nb == 4) ok = herdt_border_rows<NH, 2>(q, gd, Gv, vsmall, lane);
     if (!WG_UBOOL(ok)) return false;
     WG_WSYNC();
 #ifdef WG_PROFILE
     if (lane == 0) atomicAdd(&g_prof[31], clock64() - fp1);   // border rows of R
 #endif
-    // columns >= 2N of Z (border_z above)
-    if (nb == 2) border_z<1>(q, lane);
-    else if (nb == 4) border_z<2>(q, lane);
+    if (nb == 2) herdt_border_z<NH, 1>(q, lane);
+    else if (nb == 4) herdt_border_z<NH, 2>(q, lane);
     WG_WSYNC();
     return true;
   }
@@ -577,6 +607,7 @@ struct HerdtProb {
 constexpr int kGvLdElem = kSMaxQ;
 struct HerdtElemProb {
   static constexpr bool kCompact = false;
+  static constexpr bool kHasFactor = true;     // constant factor blocks + structured border (N == 32 only, see factor())
   static constexpr bool kRowOps = true;        // row products walk the row's structure instead of calling A() per element
   static constexpr int kNM = 0;
   int N, ns;
@@ -587,6 +618,35 @@ struct HerdtElemProb {
   const double *rowA, *rowB;
   const int *rowK, *stepidx;
   const double *V_f;
+  const double *R2, *Z2;  // global: constant 2N x 2N factor blocks (TickTables)
+  const unsigned long long *z2sign;
+  int blocks_ok;
+  // R and Z = R^-1 (:859-975) from the constant blocks + the structured border, exactly as the compact view does it
+  // (herdt_constant_blocks, herdt_border_rows, herdt_border_z): instantiated for BASELINE config 5's horizon, N = 32, with
+  // 1..4 previewed steps; other horizons of this view take the solver's generic factorisation (return false).
+  __device__ __forceinline__ bool factor(const QlView &q, double vsmall, int lane) const {
+    if (N != 32 || ns < 1 || ns > 4) return false;
+    constexpr int NHc = 32;
+    herdt_constant_blocks<NHc>(q, R2, Z2, z2sign, lane);
+    WG_WSYNC();
+    bool ok = true;
+    switch (ns) {
+      case 1: ok = herdt_border_rows<NHc, 1>(q, gd, Gv, vsmall, lane); break;
+      case 2: ok = herdt_border_rows<NHc, 2>(q, gd, Gv, vsmall, lane); break;
+      case 3: ok = herdt_border_rows<NHc, 3>(q, gd, Gv, vsmall, lane); break;
+      default: ok = herdt_border_rows<NHc, 4>(q, gd, Gv, vsmall, lane); break;
+    }
+    if (!WG_UBOOL(ok)) return false;
+    WG_WSYNC();
+    switch (ns) {
+      case 1: herdt_border_z<NHc, 1>(q, lane); break;
+      case 2: herdt_border_z<NHc, 2>(q, lane); break;
+      case 3: herdt_border_z<NHc, 3>(q, lane); break;
+      default: herdt_border_z<NHc, 4>(q, lane); break;
+    }
+    WG_WSYNC();
+    return true;
+  }
   __device__ __forceinline__ double G(const QlView &q, int i, int j) const {
     if (i == j) return gd[i];
     if (j < i) { const int t = i; i = j; j = t; }

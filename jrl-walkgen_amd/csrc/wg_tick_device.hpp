@@ -186,7 +186,7 @@ struct TickLds {
     if (!compact) b += pre_bytes(N, smax);
     return (b + 15) & ~(size_t)15;
   }
-  __device__ void carve(char *base, int N, int smax, int gvld, char *overlay, bool rows_presolve, double *ext_gv = nullptr) {
+  __device__ __forceinline__ void carve(char *base, int N, int smax, int gvld, char *overlay, bool rows_presolve, double *ext_gv = nullptr) {
     const bool compact = gvld > 0;
     const int m = 1 + 4 * N + 5 * smax;
     char *p = base;
@@ -835,6 +835,7 @@ __device__ __forceinline__ TickDiag mpc_tick(const wg_model_t &m, const TickTabl
     HerdtElemProb prob;
     prob.N = N; prob.ns = ns; prob.Qb = &tb->Qb[0][0]; prob.u = L.uvec; prob.Gv = L.Gv; prob.gd = L.gd;
     prob.rowA = L.rowA; prob.rowB = L.rowB; prob.rowK = L.rowK; prob.stepidx = L.stepidx; prob.V_f = L.V_f;
+    prob.R2 = tb->R2; prob.Z2 = tb->Z2; prob.z2sign = tb->z2_cross_sign; prob.blocks_ok = tb->blocks_ok;
     qr = ql_solve(q, prob, 1e-8, hist, hist_cap);
   } else {
     if (lane == 0 && fabs(GmL(n - 1, n - 1)) == 0.0) GmL(n - 1, n - 1) = 1e-8;   // qld.cpp:442-444 (nmax == n)
