@@ -1178,8 +1178,21 @@ __device__ __forceinline__ QlResult ql_solve(const QlView &q, P &prob, double vs
         if (wak <= 0.0) continue;
         double bk = q.b[k];
         double sum = -bk;
-        if constexpr (P::kRowOps) sum = prob.template row_dot<false>(q, k, q.x, sum);
-        else {
+        if constexpr (P::kRowOps) {
+          // structured rows: both sums in one walk (see row_dot_both); the tests below are the reference's, in its order
+          double temp = fabs(bk);
+          prob.row_dot_both(q, k, q.x, sum, temp);
+          double sumx = -sum * wak;
+          if (k + 1 <= me) sumx = fabs(sumx);
+          if (sumx <= 0.0) continue;
+          if (bidx >= 0 && sumx <= bestv) continue;
+          double tempa = temp + fabs(sum);
+          if (tempa <= temp) continue;
+          temp += onha * fabs(sum);
+          if (temp <= tempa) continue;
+          bestv = sumx; bestres = sum; bidx = k + 1;
+          continue;
+        } else {
           WG_UNROLL
           for (int i = 0; i < n; ++i) sum += q.x[i] * Am(k, i);
         }

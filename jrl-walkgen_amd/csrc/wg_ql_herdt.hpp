@@ -706,6 +706,28 @@ struct HerdtElemProb {
     for (int j = 0; j < ns; ++j) { const double t = v[2 * N + ns + j] * (0.0 + (0.0 + b * V_f[kk * kSMaxQ + j]) * -1.0); acc += ABS ? fabs(t) : t; }
     return acc;
   }
+  // both sums of the violation scan in ONE walk of the row: sum += v[i] A(k,i) and asum += |v[i] A(k,i)|, i ascending (two
+  // independent chains over the same products).  The scan needs asum only for rows that turn out violated, but a wave walks
+  // again as soon as one lane does: one fused walk costs an add per term more and never a second walk.
+  __device__ __forceinline__ void row_dot_both(const QlView &, int k, const double *v, double &sum, double &asum) const {
+    if (k == 0) return;
+    const double a = rowA[k], b = rowB[k];
+    const int kk = rowK[k];
+    if (k <= 4 * N) {
+      const int r = kk;
+      for (int c = 0; c <= r; ++c) { const double t = v[c] * (0.0 + (0.0 + a * u[r - c]) * -1.0); sum += t; asum += fabs(t); }
+      for (int c = 0; c <= r; ++c) { const double t = v[N + c] * (0.0 + (0.0 + b * u[r - c]) * -1.0); sum += t; asum += fabs(t); }
+      const int j = stepidx[r] - 1;
+      if (j >= 0 && j < ns) {
+        { const double t = v[2 * N + j] * (0.0 + (0.0 + a * 1.0) * 1.0); sum += t; asum += fabs(t); }
+        { const double t = v[2 * N + ns + j] * (0.0 + (0.0 + b * 1.0) * 1.0); sum += t; asum += fabs(t); }
+      }
+      return;
+    }
+    if (kk < 0) return;
+    for (int j = 0; j < ns; ++j) { const double t = v[2 * N + j] * (0.0 + (0.0 + a * V_f[kk * kSMaxQ + j]) * -1.0); sum += t; asum += fabs(t); }
+    for (int j = 0; j < ns; ++j) { const double t = v[2 * N + ns + j] * (0.0 + (0.0 + b * V_f[kk * kSMaxQ + j]) * -1.0); sum += t; asum += fabs(t); }
+  }
   __device__ __forceinline__ double row_sqnorm(const QlView &, int k) const {
     double sum = 0.0;
     if (k == 0) return sum;
