@@ -1173,15 +1173,17 @@ __device__ __forceinline__ QlResult ql_solve(const QlView &q, P &prob, double vs
           }
         }
       } else {
-      for (int k = lane; k < m; k += 64) {
-        double wak = q.wa[k];
-        if (wak <= 0.0) continue;
-        double bk = q.b[k];
-        double sum = -bk;
-        if constexpr (P::kRowOps) {
-          // structured rows: both sums in one walk (see row_dot_both); the tests below are the reference's, in its order
-          double temp = fabs(bk);
-          prob.row_dot_both(q, k, q.x, sum, temp);
+      if constexpr (P::kRowOps) {
+        // structured rows: every lane of a pass walks its row the same number of steps, both sums at once (row_dot_both);
+        // the tests below are the reference's, in its order
+        for (int k0 = 1; k0 < m; k0 += 64) {                 // row 0 is the all-zero dummy row: never a candidate, not walked
+          const int k = k0 + lane;
+          const bool in = k < m;
+          const int kc = in ? k : 0;                          // surplus lanes walk the all-zero dummy row
+          const double wak = in ? q.wa[kc] : 0.0, bk = q.b[kc];
+          double sum = -bk, temp = fabs(bk);
+          prob.row_dot_both(q, kc, k0, q.x, sum, temp);
+          if (wak <= 0.0) continue;
           double sumx = -sum * wak;
           if (k + 1 <= me) sumx = fabs(sumx);
           if (sumx <= 0.0) continue;
@@ -1191,7 +1193,14 @@ __device__ __forceinline__ QlResult ql_solve(const QlView &q, P &prob, double vs
           temp += onha * fabs(sum);
           if (temp <= tempa) continue;
           bestv = sumx; bestres = sum; bidx = k + 1;
-          continue;
+        }
+      } else
+      for (int k = lane; k < m; k += 64) {
+        double wak = q.wa[k];
+        if (wak <= 0.0) continue;
+        double bk = q.b[k];
+        double sum = -bk;
+        if constexpr (P::kRowOps) {
         } else {
           WG_UNROLL
           for (int i = 0; i < n; ++i) sum += q.x[i] * Am(k, i);

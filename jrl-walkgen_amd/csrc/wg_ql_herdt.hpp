@@ -706,27 +706,47 @@ struct HerdtElemProb {
     for (int j = 0; j < ns; ++j) { const double t = v[2 * N + ns + j] * (0.0 + (0.0 + b * V_f[kk * kSMaxQ + j]) * -1.0); acc += ABS ? fabs(t) : t; }
     return acc;
   }
-  // both sums of the violation scan in ONE walk of the row: sum += v[i] A(k,i) and asum += |v[i] A(k,i)|, i ascending (two
-  // independent chains over the same products).  The scan needs asum only for rows that turn out violated, but a wave walks
-  // again as soon as one lane does: one fused walk costs an add per term more and never a second walk.
-  __device__ __forceinline__ void row_dot_both(const QlView &, int k, const double *v, double &sum, double &asum) const {
-    if (k == 0) return;
+  // Both sums of the violation scan -- sum += v[i] A(k,i) and asum += |v[i] A(k,i)|, i ascending -- in ONE walk of the row, the
+  // same for every lane of the pass (k = k0 + lane): trip counts depend on k0 only, the operands of four terms are fetched
+  // ahead of the two add chains, and a lane whose row ends earlier (or is no CoP / foot row at all) walks on over exact-zero
+  // coefficients (u[-1] = 0.0 in LDS, or a zeroed edge coefficient): its extra terms are +-0.0, which change neither a
+  // non-zero sum nor any decision taken on a zero one (sumx = -(+-0) wak is not > 0 either way).
+  __device__ __forceinline__ void row_dot_both(const QlView &, int k, int k0, const double *v, double &sum, double &asum) const {
     const double a = rowA[k], b = rowB[k];
     const int kk = rowK[k];
-    if (k <= 4 * N) {
-      const int r = kk;
-      for (int c = 0; c <= r; ++c) { const double t = v[c] * (0.0 + (0.0 + a * u[r - c]) * -1.0); sum += t; asum += fabs(t); }
-      for (int c = 0; c <= r; ++c) { const double t = v[N + c] * (0.0 + (0.0 + b * u[r - c]) * -1.0); sum += t; asum += fabs(t); }
-      const int j = stepidx[r] - 1;
-      if (j >= 0 && j < ns) {
-        { const double t = v[2 * N + j] * (0.0 + (0.0 + a * 1.0) * 1.0); sum += t; asum += fabs(t); }
-        { const double t = v[2 * N + ns + j] * (0.0 + (0.0 + b * 1.0) * 1.0); sum += t; asum += fabs(t); }
+    if (k0 <= 4 * N) {                                      // the pass holds CoP rows (wave-uniform)
+      const bool cop = k >= 1 && k <= 4 * N;
+      const int r = cop ? kk : -1;
+      const int klast = (k0 + 63 < 4 * N) ? k0 + 63 : 4 * N;
+      const int rmax = (klast - 1) >> 2;                    // instant of the pass's last CoP row
+      const double ac = cop ? a : 0.0, bc = cop ? b : 0.0;
+      for (int c0 = 0; c0 <= rmax; c0 += 4) {
+        double vv[4], uu[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { const int d = r - c0 - e, ci = c0 + e < N ? c0 + e : N - 1; vv[e] = v[ci]; uu[e] = u[d > -1 ? d : -1]; }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { const double t = vv[e] * (0.0 + (0.0 + ac * uu[e]) * -1.0); sum += t; asum += fabs(t); }
       }
-      return;
+      for (int c0 = 0; c0 <= rmax; c0 += 4) {
+        double vv[4], uu[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { const int d = r - c0 - e, ci = c0 + e < N ? c0 + e : N - 1; vv[e] = v[N + ci]; uu[e] = u[d > -1 ? d : -1]; }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { const double t = vv[e] * (0.0 + (0.0 + bc * uu[e]) * -1.0); sum += t; asum += fabs(t); }
+      }
+      const int j = (r >= 0) ? stepidx[r] - 1 : -1;
+      const bool st = j >= 0 && j < ns;
+      const int jc = st ? j : 0;
+      { const double t = v[2 * N + jc] * (0.0 + (0.0 + (st ? a : 0.0) * 1.0) * 1.0); sum += t; asum += fabs(t); }
+      { const double t = v[2 * N + ns + jc] * (0.0 + (0.0 + (st ? b : 0.0) * 1.0) * 1.0); sum += t; asum += fabs(t); }
     }
-    if (kk < 0) return;
-    for (int j = 0; j < ns; ++j) { const double t = v[2 * N + j] * (0.0 + (0.0 + a * V_f[kk * kSMaxQ + j]) * -1.0); sum += t; asum += fabs(t); }
-    for (int j = 0; j < ns; ++j) { const double t = v[2 * N + ns + j] * (0.0 + (0.0 + b * V_f[kk * kSMaxQ + j]) * -1.0); sum += t; asum += fabs(t); }
+    if (k0 + 63 > 4 * N) {                                  // the pass holds foot-placement rows (wave-uniform)
+      const bool ft = k > 4 * N && kk >= 0;
+      const int kf = ft ? kk : 0;
+      const double af = ft ? a : 0.0, bf = ft ? b : 0.0;
+      for (int j = 0; j < ns; ++j) { const double t = v[2 * N + j] * (0.0 + (0.0 + af * V_f[kf * kSMaxQ + j]) * -1.0); sum += t; asum += fabs(t); }
+      for (int j = 0; j < ns; ++j) { const double t = v[2 * N + ns + j] * (0.0 + (0.0 + bf * V_f[kf * kSMaxQ + j]) * -1.0); sum += t; asum += fabs(t); }
+    }
   }
   __device__ __forceinline__ double row_sqnorm(const QlView &, int k) const {
     double sum = 0.0;

@@ -180,7 +180,7 @@ struct TickLds {
     const int m = 1 + 4 * N + 5 * smax;
     const int nmax = 2 * N + 2 * smax;
     const bool compact = gvld > 0;
-    size_t b = sizeof(Sup) + 8 * (size_t)(kSMax * kSMax + 8 + (rows_presolve ? 0 : 2 * m) + 16 + (compact ? N + (gv_lds ? nmax * gvld : 0) + nmax : 0)) +
+    size_t b = sizeof(Sup) + 8 * (size_t)(kSMax * kSMax + 8 + (rows_presolve ? 0 : 2 * m) + 16 + (compact ? (N + 2) + (gv_lds ? nmax * gvld : 0) + nmax : 0)) +
                4 * (size_t)(((N + 1) & ~1) + (rows_presolve ? 0 : ((m + 1) & ~1))) +
                (rows_presolve ? 0 : ((sizeof(wg_gait_state_t) + 15) & ~(size_t)15));
     if (!compact) b += pre_bytes(N, smax);
@@ -199,7 +199,7 @@ struct TickLds {
     uvec = Gv = gd = nullptr;
     if (compact) {
       const int nmax = 2 * N + 2 * smax;
-      uvec = d; d += N;
+      uvec = d + 2; d += N + 2;          // uvec[-1] = uvec[-2] = 0.0: a row walked past its instant reads an exact-zero coefficient
       if (ext_gv) Gv = ext_gv; else { Gv = d; d += nmax * gvld; }
       gd = d; d += nmax;
     }
@@ -695,6 +695,7 @@ __device__ __forceinline__ TickDiag mpc_tick(const wg_model_t &m, const TickTabl
   if constexpr (kTableView) {
     // table views: Qb and u as small LDS tables, the 2ns border columns (symmetric) and the diagonal
     for (int d = lane; d < N; d += 64) L.uvec[d] = tb->Uz[d][0];                 // Uz[r][c] = u[r-c]
+    if (lane < 2) L.uvec[-1 - lane] = 0.0;
     for (int e = lane; e < n * kGvStride; e += 64) L.Gv[e] = 0.0;
     for (int i = lane; i < 2 * N; i += 64) L.gd[i] = tb->Qb[i % N][i % N];
     WG_WSYNC();
