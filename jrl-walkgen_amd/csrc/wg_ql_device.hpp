@@ -371,10 +371,10 @@ __device__ __forceinline__ void backsub(const QlView &q, const double *s, int na
 //     ahead, the first term formed in registers from R(j,j+1) and the w just computed.
 // The v_readlane form above costs ~40 cycles per term (two readlanes + add, serialised); this one ~8.
 // buf: 2 * kBsLen doubles of LDS (the four scratch vectors are contiguous).
-constexpr int kBsLen = 48;
 // one row of backsub_lds: P = {terms k = j+2 .. j+9, R(j, j+1)} prefetched by the previous row, Nx receives the same for
 // row j-1.  Two copies of this body with P / Nx swapped make the hand-over a renaming instead of nine register moves.
 struct BsState { double w, wprev, rr, sreg, dreg; int col, nact, lane; bool mine; };
+template <int kBsLen>                                       // length of each of the two product buffers (>= nact + 12)
 __device__ __forceinline__ void bs_row(const QlView &q, double *buf, int j, BsState &S, const double (&P)[9], double (&Nx)[9]) {
   const double *bj = buf + (j & 1) * kBsLen;
   double *bn = buf + ((j & 1) ^ 1) * kBsLen;
@@ -413,19 +413,21 @@ __device__ __forceinline__ void bs_row(const QlView &q, double *buf, int j, BsSt
   if (lane == j) S.w = v;
   S.wprev = v;
 }
+template <int kBsLen = 48>                                  // nact <= 64 (one multiplier per lane) and nact + 12 <= kBsLen
 __device__ __forceinline__ void backsub_lds(const QlView &q, const double *s, int nact, int lane, double *buf) {
   BsState S;
   S.mine = lane < nact; S.nact = nact; S.lane = lane;
   S.sreg = S.mine ? s[lane] : 0.0;
   S.dreg = S.mine ? Rp(lane, lane) : 1.0;
-  if (lane < kBsLen) { buf[lane] = 0.0; buf[kBsLen + lane] = 0.0; }
+  if constexpr (kBsLen <= 64) { if (lane < kBsLen) { buf[lane] = 0.0; buf[kBsLen + lane] = 0.0; } }
+  else { for (int e = lane; e < kBsLen; e += 64) { buf[e] = 0.0; buf[kBsLen + e] = 0.0; } }
   S.col = S.mine ? lane : 0;
   S.w = 0.0; S.wprev = 0.0;
   S.rr = Rp(nact >= 2 ? nact - 2 : 0, S.col);               // R(j-1, lane) of the row whose products are formed next
   double A9[9] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0}, B9[9];
   int j = nact - 1;
-  for (; j >= 1; j -= 2) { bs_row(q, buf, j, S, A9, B9); bs_row(q, buf, j - 1, S, B9, A9); }
-  if (j == 0) bs_row(q, buf, 0, S, A9, B9);
+  for (; j >= 1; j -= 2) { bs_row<kBsLen>(q, buf, j, S, A9, B9); bs_row<kBsLen>(q, buf, j - 1, S, B9, A9); }
+  if (j == 0) bs_row<kBsLen>(q, buf, 0, S, A9, B9);
   if (S.mine) q.ww[lane] = S.w;
   WG_WSYNC();
 }
@@ -833,8 +835,14 @@ __device__ __forceinline__ bool independent_coordinate(const QlView &q, const P 
 #ifdef WG_BACKSUB_READLANE
 #define WG_BACKSUB(q, s, nact, lane) backsub(q, s, nact, lane)
 #else
-#define WG_BACKSUB(q, s, nact, lane) \
-  do { if constexpr (P::kNM > 0 && P::kNM + 12 <= kBsLen) backsub_lds(q, s, nact, lane, q.sc0); else backsub(q, s, nact, lane); } while (0)
+// compact view (n <= 36): the LDS-pipelined form with two 48-entry buffers; other views whose four scratch vectors hold two
+// 96-entry buffers (n >= 48) take it too while every multiplier has a lane of its own (nact <= 60), the generic forms otherwise
+#define WG_BACKSUB(q, s, nact, lane)                                                                   \
+  do {                                                                                                 \
+    if constexpr (P::kNM > 0 && P::kNM + 12 <= 48) backsub_lds<48>(q, s, nact, lane, q.sc0);          \
+    else if (P::kNM == 0 && q.n >= 48 && (nact) <= 60) backsub_lds<96>(q, s, nact, lane, q.sc0);     \
+    else backsub(q, s, nact, lane);                                                                    \
+  } while (0)
 #endif
 #define WG_SWEEP(q, s, nu, nact, lane) \
   do { if constexpr (P::kNM > 0) sweep_flat(q, s, nu, nact, lane); else sweep(q, s, nu, nact, lane); } while (0)
