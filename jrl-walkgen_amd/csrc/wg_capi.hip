@@ -143,13 +143,14 @@ int use_ctx(wg_ctx *ctx) {
 // Dense batched QP kernel: one wavefront (= one workgroup) per QP.
 // Replaces ql0001_ (qld.hh:27-31) for B problems at once.
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void wg_ql_dense_kernel(
+template <bool kALds>                                      // where A lives is known at compile time: ds_ or global_ accesses,
+__global__ __launch_bounds__(64) void wg_ql_dense_kernel(   // never flat_ (those also count on lgkmcnt and stall the LDS waits)
     int B, int nmax, int mmax, const int *__restrict__ n_arr, const int *__restrict__ m_arr,
     const int *__restrict__ me_arr, const double *__restrict__ C, const double *__restrict__ dvec,
     const double *__restrict__ A, const double *__restrict__ bvec, const double *__restrict__ xl,
     const double *__restrict__ xu, double eps, double *__restrict__ x, double *__restrict__ u,
     int *__restrict__ ifail, int *__restrict__ n_iter, int *__restrict__ iact, int *__restrict__ nact,
-    int *__restrict__ hist, int hist_cap, int *__restrict__ hist_len, int a_in_lds) {
+    int *__restrict__ hist, int hist_cap, int *__restrict__ hist_len) {
   extern __shared__ __attribute__((aligned(16))) double wg_lds[];
   const int lane = threadIdx.x & 63;
   const int qp = blockIdx.x;                     // one QP per block (grid == B): nothing lane-dependent lives across QPs
@@ -157,7 +158,7 @@ __global__ __launch_bounds__(64) void wg_ql_dense_kernel(
     const int n = n_arr ? n_arr[qp] : nmax;
     const int m = m_arr ? m_arr[qp] : mmax - 1;
     const int me = me_arr ? me_arr[qp] : 0;
-    wg::QlDims D(n, m, m, true, a_in_lds != 0);
+    wg::QlDims D(n, m, m, true, kALds);
     wg::QlView q;
     q.carve(wg_lds, D, me);
 
@@ -166,7 +167,7 @@ __global__ __launch_bounds__(64) void wg_ql_dense_kernel(
     const double *Ag = A + (size_t)qp * mmax * nmax;
     for (int j = 0; j < n; ++j)
       for (int i = lane; i < n; i += 64) q.G[i + j * q.ldg] = Cg[i + (size_t)j * nmax];
-    if (a_in_lds) {
+    if constexpr (kALds) {
       for (int i = 0; i < n; ++i)
         for (int k = lane; k < m; k += 64) q.A[k + i * q.lda] = Ag[k + (size_t)i * mmax];
     } else {                                   // too large for LDS next to G, Z, R: the solver only reads A -> in place (L2)
@@ -298,12 +299,17 @@ int wg_qp_solve_batch_dev_ctx(wg_ctx_t *ctx, int B, int nmax, int mmax, const in
   if (lds > 160 * 1024 || !a_in_lds) { a_in_lds = 0; lds = lds_noa; }
   if (lds > 160 * 1024) return fail(WG_ERR_TOO_LARGE, "QP (n=%d, m=%d) needs %zu B of LDS > 160 KiB", nmax, m_cap, lds);
   if (lds > 64 * 1024)
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(wg_ql_dense_kernel),
+    HIP_TRY(hipFuncSetAttribute(a_in_lds ? reinterpret_cast<const void *>(wg_ql_dense_kernel<true>)
+                                         : reinterpret_cast<const void *>(wg_ql_dense_kernel<false>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   const int grid = B;
   hipStream_t st = reinterpret_cast<hipStream_t>(hip_stream);
-  hipLaunchKernelGGL(wg_ql_dense_kernel, dim3(grid), dim3(64), lds, st, B, nmax, mmax, n, m, me, C, d, A, b,
-                     xl, xu, eps, x, u, ifail, n_iter, iact, nact, hist, hist_cap, hist_len, a_in_lds);
+  if (a_in_lds)
+    hipLaunchKernelGGL(wg_ql_dense_kernel<true>, dim3(grid), dim3(64), lds, st, B, nmax, mmax, n, m, me, C, d, A, b,
+                       xl, xu, eps, x, u, ifail, n_iter, iact, nact, hist, hist_cap, hist_len);
+  else
+    hipLaunchKernelGGL(wg_ql_dense_kernel<false>, dim3(grid), dim3(64), lds, st, B, nmax, mmax, n, m, me, C, d, A, b,
+                       xl, xu, eps, x, u, ifail, n_iter, iact, nact, hist, hist_cap, hist_len);
   HIP_TRY(hipGetLastError());
   return WG_OK;
 }
@@ -378,18 +384,10 @@ inline bool tick_compact(const wg_model_t &m) {
   const char *v = getenv("WG_TICK_VIEW");
   return m.N == 16 && m.N * m.T <= 2.0 * m.step_period + 1e-12 && !(e && atoi(e) != 0) && !(v && *v);
 }
-// element view: Z in a per-block slot of global memory instead of LDS (WG_TICK_Z_GLOBAL=0 keeps it in LDS: A/B tests)
-inline bool tick_z_global(int view) {
-  if (view != -1) return false;
-  const char *e = getenv("WG_TICK_Z_GLOBAL");
-  return !(e && atoi(e) == 0);
-}
-// compact view (N = 16): wa, b and the border block Gv in a per-block slot of global memory (WG_TICK16_EXT=0: all in LDS)
-inline bool tick16_ext(int view) {
-  if (view != 16) return false;
-  const char *e = getenv("WG_TICK16_EXT");
-  return !(e && atoi(e) == 0);
-}
+// element view: Z in a per-block slot of global memory instead of LDS (decided at compile time: mpc_tick<-1>)
+inline bool tick_z_global(int view) { return view == -1; }
+// compact view (N = 16): wa, b and the border block Gv in a per-block slot of global memory (decided at compile time: mpc_tick<16>)
+inline bool tick16_ext(int view) { return view == 16; }
 inline size_t tick_z_slot_doubles(const wg_model_t &m, int view) {
   if (view == 16) return (size_t)(tick_max_n(m) + 2 * tick_max_m(m)) + (size_t)tick_max_n(m) * wg::kGvLd;   // wa | b | Gv
   return (size_t)tick_max_n(m) * (tick_max_n(m) | 1);
@@ -422,6 +420,22 @@ inline size_t tick_ql_bytes(const wg_model_t &m) {
 // 512-register build (lib/libwg_mpc_w1.so, tools/bench_variants.sh).
 // The element view (NH == -1, N = 32) is held to ONE wave per SIMD by its LDS footprint (four gaits per CU): its kernels
 // are compiled for that, i.e. with the whole register file of a SIMD lane (512) -- no spills.
+// The run kernels pin their pointer arguments in scalar registers with an opaque asm once per tick (so that nothing derived
+// from them stays alive across the tick).  Pinned as GENERIC pointers they would come back with no address space and every
+// access through them would be a flat_ instruction: those count on both vmcnt and lgkmcnt and may return out of order with
+// LDS reads, so each LDS wait behind one turns into lgkmcnt(0) -- a global round trip.  Pinned as address-space-1 pointers
+// they stay global_ accesses (kernel arguments are global memory).
+#ifdef WG_PIN_GENERIC
+#define WG_PIN_GLOBAL(p) asm volatile("" : "+s"(p))
+#else
+#define WG_PIN_GLOBAL(p)                                                                          \
+  do {                                                                                            \
+    auto gp_ = (__attribute__((address_space(1))) std::remove_pointer_t<decltype(p)> *)(p);       \
+    asm volatile("" : "+s"(gp_));                                                                 \
+    (p) = (decltype(p))gp_;                                                                       \
+  } while (0)
+#endif
+
 #ifndef WG_TICK_WPE_MIN
 #define WG_TICK_WPE_MIN 2
 #endif
@@ -497,7 +511,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NH == -1 ? 1
     asm volatile("" : "+v"(lane));
     const wg_model_t *mp = model_p; const wg::TickTables *tb = tb_p; wg_gait_state_t *states = states_p;
     wg_tick_out_t *outs = outs_p; int *diag = diag_p;
-    asm volatile("" : "+s"(mp), "+s"(tb), "+s"(states), "+s"(outs), "+s"(diag));
+    WG_PIN_GLOBAL(mp); WG_PIN_GLOBAL(tb); WG_PIN_GLOBAL(states); WG_PIN_GLOBAL(outs); WG_PIN_GLOBAL(diag);
     const wg_model_t &model = *mp;
     int idx = 0, g = 0, t = 0;
     if (lane == 0) idx = atomicAdd(&q->head, 1);
@@ -570,7 +584,14 @@ __global__ void wg_xrun_init_kernel(int B, wg_xrun_ctl *ctl, unsigned long long 
   if (i < B) done[i] = 0;
 }
 
-__device__ __forceinline__ int xrun_rmw_load(int *p) { return __hip_atomic_fetch_add(p, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// reads of the counters and ring entries are read-modify-writes with an operand the compiler cannot see through (a literal 0
+// is folded into an atomic LOAD, which the vector L1 may serve: a stale tail reads as "ring empty" and the wave leaves early --
+// measured: 59 % average wave residency and a third of the throughput once these became global_ instead of flat_ loads)
+__device__ __forceinline__ int xrun_opaque_zero() { int z = 0; asm volatile("" : "+v"(z)); return z; }
+__device__ __forceinline__ int xrun_rmw_load(int *p) { return __hip_atomic_fetch_add(p, xrun_opaque_zero(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ unsigned long long xrun_rmw_load(unsigned long long *p) {
+  return __hip_atomic_fetch_or(p, (unsigned long long)(unsigned)xrun_opaque_zero(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 __device__ __forceinline__ int xrun_take_fresh(wg_xrun_ctl *ctl, int y) {
   const int end = ctl->x[y].fresh_end;                     // written before the launch, never changed
   if (xrun_rmw_load(&ctl->x[y].fresh) >= end) return -1;
@@ -587,19 +608,25 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NH == -1 ? 1
     wg_xrun_ctl *__restrict__ ctl_p, unsigned long long *__restrict__ rings_p, int cap, int *__restrict__ done_p,
     unsigned ql_bytes, double *zscratch, unsigned zslot) {
   extern __shared__ __attribute__((aligned(16))) double wg_lds[];
+  unsigned fresh_gone = 0;                                 // bit y: range y was seen exhausted (the counters only grow)
   for (;;) {
     int lane = threadIdx.x & 63;
     asm volatile("" : "+v"(lane));
     const wg_model_t *mp = model_p; const wg::TickTables *tb = tb_p; wg_gait_state_t *states = states_p;
     wg_tick_out_t *outs = outs_p; int *diag = diag_p; wg_xrun_ctl *ctl = ctl_p; unsigned long long *rings = rings_p; int *done = done_p;
-    asm volatile("" : "+s"(mp), "+s"(tb), "+s"(states), "+s"(outs), "+s"(diag), "+s"(ctl), "+s"(rings), "+s"(done));
+    // data pointers come back as global-memory pointers; the queue's stay generic (measured: 2.5 % faster than global_ atomics)
+    WG_PIN_GLOBAL(mp); WG_PIN_GLOBAL(tb); WG_PIN_GLOBAL(states); WG_PIN_GLOBAL(outs); WG_PIN_GLOBAL(diag);
+    asm volatile("" : "+s"(ctl), "+s"(rings), "+s"(done));
     const wg_model_t &model = *mp;
     int xcc;
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID, 0, 4)" : "=s"(xcc));
     xcc &= kXcds - 1;
     int g = -1, t = 0;
     if (lane == 0) {
-      g = xrun_take_fresh(ctl, xcc);
+      if (!((fresh_gone >> xcc) & 1u)) {
+        g = xrun_take_fresh(ctl, xcc);
+        if (g < 0) fresh_gone |= 1u << xcc;
+      }
       if (g < 0) {
         for (;;) {
           const int h = xrun_rmw_load(&ctl->x[xcc].head), tl = xrun_rmw_load(&ctl->x[xcc].tail);
@@ -611,16 +638,21 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NH == -1 ? 1
           unsigned long long *slot = rings + (size_t)xcc * cap + (h & (cap - 1));
           unsigned long long e;
           // the pusher reserved position h (tail) before writing the entry: a short wait at most
-          while ((unsigned)((e = __hip_atomic_fetch_or(slot, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >> 32) != (unsigned)(h + 1))
+          while ((unsigned)((e = xrun_rmw_load(slot)) >> 32) != (unsigned)(h + 1))
             __builtin_amdgcn_s_sleep(4);
           g = (int)(e & 0xffffffffull);
-          t = __hip_atomic_load(done + g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // written (L2) before the entry was
+          t = xrun_rmw_load(done + g);                       // written (L2) before the entry was
           break;
         }
       }
-      for (int y = 1; g < 0 && y < kXcds; ++y) g = xrun_take_fresh(ctl, (xcc + y) & (kXcds - 1));
+      for (int y = 1; g < 0 && y < kXcds; ++y) {
+        const int z = (xcc + y) & (kXcds - 1);
+        if ((fresh_gone >> z) & 1u) continue;
+        g = xrun_take_fresh(ctl, z);
+        if (g < 0) fresh_gone |= 1u << z;
+      }
     }
-    g = wg::uni(g); t = wg::uni(t);
+    g = wg::uni(g); t = wg::uni(t); fresh_gone = (unsigned)wg::uni((int)fresh_gone);
     if (g < 0) break;
     if (advance_calls > 0) {
       if (lane == 0) {
@@ -893,12 +925,13 @@ int wg_mpc_set_velref_dev_ctx(wg_ctx_t *ctx, int B, wg_gait_state_t *states, con
 
 // ---- PLDP / OptCholesky back-end -----------------------------------------------------------------------------------
 
+template <bool kALds>                                      // A's place known at compile time (see wg_ql_dense_kernel)
 __global__ void __launch_bounds__(64)
 wg_pldp_kernel(int B, int mcap, const wg::PldpModel *__restrict__ model, const int *__restrict__ m,
                const double *__restrict__ D, const double *__restrict__ A, const double *__restrict__ b,
                const double *__restrict__ zmpref, const double *__restrict__ xkyk, const int *__restrict__ similar,
                const int *__restrict__ n_removed, const int *__restrict__ starting, int max_iter,
-               wg_pldp_state_t *states, double *X, int *ret, int *n_iter, int *active, int *n_active, int a_in_lds) {
+               wg_pldp_state_t *states, double *X, int *ret, int *n_iter, int *active, int *n_active) {
   extern __shared__ __attribute__((aligned(16))) unsigned char pldp_lds[];
   const wg::PldpModel &M = *model;
   const int n = 2 * M.N;
@@ -910,10 +943,10 @@ wg_pldp_kernel(int B, int mcap, const wg::PldpModel *__restrict__ model, const i
       if (threadIdx.x == 0) { ret[p] = WG_PLDP_BAD_INPUT; if (n_iter) n_iter[p] = 0; if (n_active) n_active[p] = 0; }
       return;
     }
-    wg::pldp_problem(M, pldp_lds, mcap, mp, D + (size_t)p * n, A + p * aslot, b + (size_t)p * mcap,
+    wg::pldp_problem<kALds>(M, pldp_lds, mcap, mp, D + (size_t)p * n, A + p * aslot, b + (size_t)p * mcap,
                      zmpref + (size_t)p * n, xkyk + (size_t)p * 6, similar + (size_t)p * mcap, n_removed[p], starting[p],
                      max_iter, states + p, X + (size_t)p * n, ret + p, n_iter ? n_iter + p : nullptr,
-                     active ? active + (size_t)p * mcap : nullptr, n_active ? n_active + p : nullptr, a_in_lds != 0);
+                     active ? active + (size_t)p * mcap : nullptr, n_active ? n_active + p : nullptr);
   }
 }
 
@@ -961,12 +994,18 @@ int wg_pldp_solve_batch_dev_ctx(wg_ctx_t *ctx, int B, int mcap, const int *m, co
   if (const char *e = getenv("WG_PLDP_A_IN_LDS")) a_in_lds = atoi(e) != 0;   // tests force either path
   if (!a_in_lds) lds = lds_noa;
   if (lds > 64 * 1024)
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(wg_pldp_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)lds));
+    HIP_TRY(hipFuncSetAttribute(a_in_lds ? reinterpret_cast<const void *>(wg_pldp_kernel<true>)
+                                         : reinterpret_cast<const void *>(wg_pldp_kernel<false>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   const int grid = B;
-  hipLaunchKernelGGL(wg_pldp_kernel, dim3(grid), dim3(64), lds, reinterpret_cast<hipStream_t>(hip_stream), B, mcap,
-                     ctx->pldp_dev, m, D, A, b, zmpref, xkyk, similar, n_removed, starting, max_iter, states, X, ret, n_iter,
-                     active, n_active, a_in_lds);
+  if (a_in_lds)
+    hipLaunchKernelGGL(wg_pldp_kernel<true>, dim3(grid), dim3(64), lds, reinterpret_cast<hipStream_t>(hip_stream), B, mcap,
+                       ctx->pldp_dev, m, D, A, b, zmpref, xkyk, similar, n_removed, starting, max_iter, states, X, ret, n_iter,
+                       active, n_active);
+  else
+    hipLaunchKernelGGL(wg_pldp_kernel<false>, dim3(grid), dim3(64), lds, reinterpret_cast<hipStream_t>(hip_stream), B, mcap,
+                       ctx->pldp_dev, m, D, A, b, zmpref, xkyk, similar, n_removed, starting, max_iter, states, X, ret, n_iter,
+                       active, n_active);
   HIP_TRY(hipGetLastError());
   return WG_OK;
 }

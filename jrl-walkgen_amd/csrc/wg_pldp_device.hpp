@@ -303,16 +303,16 @@ __device__ int pldp_solve(const PldpModel &M, const PldpLds &W, int m, const dou
 
 
 // kernel body: stage problem `b` into LDS, solve, write the outputs
-__device__ void pldp_problem(const PldpModel &M, unsigned char *lds, int mcap, int m, const double *__restrict__ D,
+template <bool kALds = true>                               // A staged in LDS, or read in place from global memory (L2)
+__device__ __forceinline__ void pldp_problem(const PldpModel &M, unsigned char *lds, int mcap, int m, const double *__restrict__ D,
                              const double *__restrict__ A, const double *__restrict__ bvec,
                              const double *__restrict__ zmpref, const double *__restrict__ xkyk,
                              const int *__restrict__ similar, int n_removed, int starting, int max_iter,
-                             wg_pldp_state_t *st, double *X, int *ret, int *n_iter, int *active, int *n_active,
-                             bool a_lds = true) {
+                             wg_pldp_state_t *st, double *X, int *ret, int *n_iter, int *active, int *n_active) {
   const int lane = threadIdx.x;
   const int n = 2 * M.N;
   PldpLds W;
-  W.carve(lds, mcap, WG_PLDP_ACTIVE_CAP, false, WG_PLDP_N, a_lds);
+  W.carve(lds, mcap, WG_PLDP_ACTIVE_CAP, false, WG_PLDP_N, kALds);
   bool bad = false;
   for (int li = lane; li < m; li += 64) {
     const int sim = similar[li];
@@ -322,7 +322,7 @@ __device__ void pldp_problem(const PldpModel &M, unsigned char *lds, int mcap, i
     if (sim > 0 || li + sim < 0) bad = true;
   }
   const int ldg = m + 1;
-  if (a_lds) {
+  if constexpr (kALds) {
     for (int col = 0; col < n; col++)
       for (int row = lane; row < m; row += 64) W.A[row + col * W.lda] = A[row + col * ldg];
   } else {                                         // the solver only reads A: in place, the reference's own layout

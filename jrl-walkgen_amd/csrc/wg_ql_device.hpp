@@ -134,7 +134,7 @@ struct QlView {
   // Same partition laid out for the compile-time maxima (NMAX, MMAX), whatever the actual n, m: every array then sits at
   // a constant offset from the wave's LDS base (immediate offsets in the ds instructions, no address registers), and Z's
   // leading dimension is the constant NMAX|1.  No G / A matrices (compact views only).
-  template <int NMAX, int MMAX, int NSC>
+  template <int NMAX, int MMAX, int NSC, bool kExt = false>   // kExt: wa / b live in ext_wab (global memory), known at compile time
   __device__ void carve_fixed(double *base, int n_, int m_, int me_, double *ext_wab = nullptr) {
     n = n_; m = m_; me = me_; mn = m_ + n_; ldg = NMAX | 1; ldz = NMAX | 1; lda = MMAX | 1;
     double *p = base;
@@ -143,7 +143,7 @@ struct QlView {
     R = p; p += NMAX * (NMAX + 1) / 2 + NMAX;
     x = p; p += NMAX;  d = p; p += NMAX;  ww = p; p += NMAX;  wd = p; p += NMAX;
     wx = p; p += NMAX; lam = p; p += NMAX; xl = nullptr; xu = nullptr;     // bounds come from the problem view
-    if (ext_wab) { wa = ext_wab; b = ext_wab + (MMAX + NMAX); }
+    if constexpr (kExt) { wa = ext_wab; b = ext_wab + (MMAX + NMAX); }
     else { wa = p; p += MMAX + NMAX; b = p; p += MMAX; }
     sc0 = p; p += NSC; sc1 = p; p += NSC; sc2 = p; p += NSC; sc3 = p; p += NSC;
     slot = p; p += 8;

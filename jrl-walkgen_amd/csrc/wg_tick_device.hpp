@@ -186,7 +186,8 @@ struct TickLds {
     if (!compact) b += pre_bytes(N, smax);
     return (b + 15) & ~(size_t)15;
   }
-  __device__ __forceinline__ void carve(char *base, int N, int smax, int gvld, char *overlay, bool rows_presolve, double *ext_gv = nullptr) {
+  template <bool kExtGv = false>                          // kExtGv: Gv is ext_gv (global memory), decided at compile time so that
+  __device__ __forceinline__ void carve(char *base, int N, int smax, int gvld, char *overlay, bool rows_presolve, double *ext_gv = nullptr) {   // its accesses are global_ instructions, not flat_
     const bool compact = gvld > 0;
     const int m = 1 + 4 * N + 5 * smax;
     char *p = base;
@@ -200,7 +201,7 @@ struct TickLds {
     if (compact) {
       const int nmax = 2 * N + 2 * smax;
       uvec = d + 2; d += N + 2;          // uvec[-1] = uvec[-2] = 0.0: a row walked past its instant reads an exact-zero coefficient
-      if (ext_gv) Gv = ext_gv; else { Gv = d; d += nmax * gvld; }
+      if constexpr (kExtGv) Gv = ext_gv; else { Gv = d; d += nmax * gvld; }
       gd = d; d += nmax;
     }
     int *ip = reinterpret_cast<int *>(d);
@@ -218,7 +219,8 @@ struct TickLds {
       // the working copy of the state also lives on Z: it is written back before the solver starts and fetched again
       // after it (mpc_tick), so that it costs no LDS while the solve is resident
       char *q = reinterpret_cast<char *>(rowK + ((m + 1) & ~1));
-      q = reinterpret_cast<char *>((reinterpret_cast<size_t>(q) + 15) & ~(size_t)15);
+      q += (0 - reinterpret_cast<size_t>(q)) & 15;           // up to 16 bytes, as pointer arithmetic (an integer round trip would
+                                                              // make `st` a generic pointer: flat_ instead of ds_ accesses)
       st = reinterpret_cast<wg_gait_state_t *>(q);
     }
   }
@@ -495,9 +497,9 @@ __device__ __forceinline__ TickDiag mpc_tick(const wg_model_t &m, const TickTabl
   // compact view with a global slot: [wa (kMmax + kNmax) | b (kMmax) | Gv (kNmax x kGvLd)] leave the LDS -- 2.6 KB, the
   // difference between seven and eight gaits per CU.  All three are read lane-parallel, early in their phases.
   constexpr int kExtWab = (2 * 16 + 4) + 2 * (1 + 4 * 16 + 10);
-  double *ext16 = (NH == 16) ? zglobal : nullptr;
-  L.carve(lds_tick, N, (NH == 16) ? 2 : kSMax, kGvStride, reinterpret_cast<char *>(lds_ql), NH == 16,
-          ext16 ? ext16 + kExtWab : nullptr);
+  double *ext16 = (NH == 16) ? zglobal : nullptr;         // never null for the compact view (the host reserves the slot)
+  L.template carve<NH == 16>(lds_tick, N, (NH == 16) ? 2 : kSMax, kGvStride, reinterpret_cast<char *>(lds_ql), NH == 16,
+                             (NH == 16) ? ext16 + kExtWab : nullptr);
   wg_gait_state_t *s = L.st;
 #ifdef WG_PROFILE
   unsigned long long tk0 = clock64(), tk1 = 0, tk2 = 0, tk3 = 0;
@@ -641,16 +643,16 @@ __device__ __forceinline__ TickDiag mpc_tick(const wg_model_t &m, const TickTabl
   constexpr bool kCompactView = (NH == 16);
   constexpr bool kTableView = (NH == 16) || (NH == -1);   // Hessian / constraints kept as compact tables
   // element view with a Z slot in global memory: Z leaves the LDS (it is the operand that caps the residency at N = 32)
-  const bool z_in_lds = !(NH == -1 && zglobal != nullptr);
+  constexpr bool z_in_lds = (NH != -1);
   QlDims D(n, mq, mq, !kTableView, true, kCompactView ? 2 * NH + 4 : 0, !kCompactView, z_in_lds);   // ordered sums run the static length
   QlView q;
   if constexpr (kCompactView) {
     constexpr int kNmax = 2 * NH + 4, kMmax = 1 + 4 * NH + 10;     // two previewed steps at most (wg_mpc_configure)
     // same footprint as QlDims(kNmax, kMmax, kMmax, dense = false, nsc = kNmax, bounds = false), which sized the LDS on the host
-    q.template carve_fixed<kNmax, kMmax, kNmax>(lds_ql, n, mq, 0, ext16);
+    q.template carve_fixed<kNmax, kMmax, kNmax, true>(lds_ql, n, mq, 0, ext16);
   } else {
     q.carve(lds_ql, D, 0);
-    if (!z_in_lds) q.Z = zglobal;
+    if constexpr (!z_in_lds) q.Z = zglobal;
   }
 
   // ---- S*c products (MV2_ = prod(S, CoM), generator-vel-ref.cpp:780-787) ----

@@ -169,12 +169,10 @@ def test_other_horizons_run_through_the_dense_policy_bit_exact(N, T, step):
     assert max(sizes) > 2 * N                                      # foot-placement variables did appear
 
 
-@pytest.mark.parametrize("z_global", ["1", "0"])
-def test_config5_horizon_32_runs_through_the_element_view_bit_exact(z_global, monkeypatch):
+def test_config5_horizon_32_runs_through_the_element_view_bit_exact():
     """BASELINE config 5's problem size (N = 32, foot-placement variables kept: n up to 72, m up to 149), in fp64: its
     dense matrices do not fit a CU's LDS, so the tick regenerates G / A per element from the compact tables.  Z (42 KB) sits
-    in a per-block slot of global memory by default (four gaits per CU instead of two); WG_TICK_Z_GLOBAL=0 keeps it in LDS."""
-    monkeypatch.setenv("WG_TICK_Z_GLOBAL", z_global)
+    in a per-block slot of global memory (four gaits per CU instead of two)."""
     wg.init(0)
     sizes = _horizon_vs_oracle(32, 0.1, 0.8, B=5, ticks=36, redraw=12)
     assert max(sizes) == 72 and min(sizes) >= 64                   # all four previewed steps appeared
