@@ -668,6 +668,9 @@ __device__ __forceinline__ void sweep(const QlView &q, double *s, int nu, int na
   // chain[c - 1]); p = s[c - 1] is fetched one rotation ahead, off the chain.  Phase 2 rebuilds each rotation from it:
   // sc0[c] = ga, sc1[c] = gb, sc2[c] = norm (0 marks "skipped").
   double *chain = q.sc3;
+#ifdef WG_PROFILE_SWEEP
+  unsigned long long sw0 = clock64();
+#endif
   {
     double cur = s[nu - 1];
     double p = s[nu - 2];
@@ -698,46 +701,84 @@ __device__ __forceinline__ void sweep(const QlView &q, double *s, int nu, int na
     }
   }
   WG_WSYNC();
+#ifdef WG_PROFILE_SWEEP
+  unsigned long long sw2 = clock64();
+  if ((threadIdx.x & 63) == 0) { atomicAdd(&g_prof[30], sw2 - sw0); }
+#endif
   if (n <= 128) {
-    // phase 3 for 64 < n <= 128: two rows per lane in one pass, the row entries of the coming rotations fetched kSwD
-    // rotations ahead (each entry is read before the rotation that rewrites it, so fetching earlier reads the same value):
-    // with Z in global memory an un-prefetched entry is an L2 round trip per rotation on the carry chain
-    constexpr int kSwD = 6;
+    // phase 3 for 64 < n <= 128: two rows per lane in one pass.  Rotation c reads Z(i, c-1) BEFORE any rotation rewrites it,
+    // so the row entries are independent of the carry chain: they are fetched a chunk of kSwC columns at a time, the next
+    // chunk while the current one is rotated (two register sets, loop unrolled by two so that handing a set on is a renaming).
+    // Everything inside a chunk is straight-line code -- no early exit between a load and its use, which is what lets the
+    // compiler wait for exactly the loads it needs (with Z in global memory an exposed entry is an L2 round trip on the
+    // carry chain; an earlier form with an exit test per rotation waited for ALL outstanding accesses at every step).
+    // The first chunk takes the cnt % kSwC odd rotations; past-the-end addresses are clamped to column nact (loaded, unused).
+    // Surplus lanes shadow their first row completely: same loads, same arithmetic, the same value stored to the same place.
+    constexpr int kSwC = 8;
     const int i0 = lane;
-    const bool two = lane + 64 < n;
-    const int i1 = two ? lane + 64 : lane;                    // surplus lanes shadow their first row (loads only)
+    const int i1 = lane + 64 < n ? lane + 64 : lane;
     const int ldz = q.ldz;
-    double carry0 = Zm(i0, nu - 1), carry1 = Zm(i1, nu - 1);
-    double p0[kSwD], p1[kSwD];
+    double *z0 = q.Z + i0, *z1 = q.Z + i1;
+    double carry0 = z0[(nu - 1) * ldz], carry1 = z1[(nu - 1) * ldz];
+    auto step = [&](int c, double zl0, double zl1) {
+      const double nrm = q.sc2[c], ga = q.sc0[c], gb = q.sc1[c];
+      const bool skip = (nrm == 0.0);
+      const double t0 = ga * zl0 + gb * carry0, w0 = ga * carry0 - gb * zl0;
+      const double t1 = ga * zl1 + gb * carry1, w1 = ga * carry1 - gb * zl1;
+      z0[c * ldz] = skip ? carry0 : w0;
+      z1[c * ldz] = skip ? carry1 : w1;
+      carry0 = skip ? zl0 : t0;
+      carry1 = skip ? zl1 : t1;
+    };
+    int c = nu - 1;                                          // the next rotation
+    {
+      const int rem = (nu - 1 - nact) % kSwC;
+      if (rem) {
+        double h0[kSwC - 1], h1[kSwC - 1];
 #pragma unroll
-    for (int k = 0; k < kSwD; ++k) {
-      const int cc = (nu - 2 - k) > nact ? (nu - 2 - k) : nact;
-      p0[k] = q.Z[i0 + cc * ldz]; p1[k] = q.Z[i1 + cc * ldz];
-    }
-    int c = nu - 1;
-    while (c > nact) {
-#pragma unroll
-      for (int k = 0; k < kSwD; ++k) {
-        if (c > nact) {
-          const double zl0 = p0[k], zl1 = p1[k];
-          {
-            const int cc = (c - 1 - kSwD) > nact ? (c - 1 - kSwD) : nact;      // clamped: unused past the end
-            p0[k] = q.Z[i0 + cc * ldz]; p1[k] = q.Z[i1 + cc * ldz];
-          }
-          const double nrm = q.sc2[c], ga = q.sc0[c], gb = q.sc1[c];
-          const bool skip = (nrm == 0.0);
-          const double t0 = ga * zl0 + gb * carry0, w0 = ga * carry0 - gb * zl0;
-          const double t1 = ga * zl1 + gb * carry1, w1 = ga * carry1 - gb * zl1;
-          q.Z[i0 + c * ldz] = skip ? carry0 : w0;
-          if (two) q.Z[i1 + c * ldz] = skip ? carry1 : w1;
-          carry0 = skip ? zl0 : t0;
-          carry1 = skip ? zl1 : t1;
-          --c;
+        for (int k = 0; k < kSwC - 1; ++k) {
+          const int cc = (c - 1 - k) > nact ? (c - 1 - k) : nact;
+          h0[k] = z0[cc * ldz]; h1[k] = z1[cc * ldz];
         }
+#pragma unroll
+        for (int k = 0; k < kSwC - 1; ++k)
+          if (k < rem) step(c - k, h0[k], h1[k]);
+        c -= rem;
       }
     }
-    q.Z[i0 + nact * ldz] = carry0;
-    if (two) q.Z[i1 + nact * ldz] = carry1;
+    if (c > nact) {                                          // a whole number of chunks is left
+      double a0[kSwC], a1[kSwC], b0[kSwC], b1[kSwC];
+#pragma unroll
+      for (int k = 0; k < kSwC; ++k) { a0[k] = z0[(c - 1 - k) * ldz]; a1[k] = z1[(c - 1 - k) * ldz]; }
+      for (;;) {
+        {
+          const int cn = c - kSwC;                           // first rotation of the next chunk (if any)
+#pragma unroll
+          for (int k = 0; k < kSwC; ++k) {
+            const int cc = (cn - 1 - k) > nact ? (cn - 1 - k) : nact;
+            b0[k] = z0[cc * ldz]; b1[k] = z1[cc * ldz];
+          }
+#pragma unroll
+          for (int k = 0; k < kSwC; ++k) step(c - k, a0[k], a1[k]);
+          c = cn;
+        }
+        if (c <= nact) break;
+        {
+          const int cn = c - kSwC;
+#pragma unroll
+          for (int k = 0; k < kSwC; ++k) {
+            const int cc = (cn - 1 - k) > nact ? (cn - 1 - k) : nact;
+            a0[k] = z0[cc * ldz]; a1[k] = z1[cc * ldz];
+          }
+#pragma unroll
+          for (int k = 0; k < kSwC; ++k) step(c - k, b0[k], b1[k]);
+          c = cn;
+        }
+        if (c <= nact) break;
+      }
+    }
+    z0[nact * ldz] = carry0;
+    z1[nact * ldz] = carry1;
     WG_WSYNC();
     return;
   }
