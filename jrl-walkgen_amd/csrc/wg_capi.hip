@@ -389,14 +389,17 @@ inline bool tick_z_global(int view) { return view == -1; }
 // compact view (N = 16): wa, b and the border block Gv in a per-block slot of global memory (decided at compile time: mpc_tick<16>)
 inline bool tick16_ext(int view) { return view == 16; }
 inline size_t tick_z_slot_doubles(const wg_model_t &m, int view) {
-  if (view == 16) return (size_t)(tick_max_n(m) + 2 * tick_max_m(m)) + (size_t)tick_max_n(m) * wg::kGvLd;   // wa | b | Gv
-  return (size_t)tick_max_n(m) * (tick_max_n(m) | 1);
+  const size_t n = (size_t)tick_max_n(m), mm = (size_t)tick_max_m(m);
+  if (view == 16) return (n + 2 * mm) + n * wg::kGvLd;       // wa | b | Gv
+  // element view: Z | wa | b | Gv | rowA | rowB | rowK (mpc_tick<-1>)
+  return n * (n | 1) + (n + 2 * mm) + n * wg::kGvLdElem + 2 * mm + (mm + 1) / 2 + 2;
 }
 inline size_t tick_lds_for(const wg_model_t &m, int view) {
-  const size_t ql = (wg::QlDims(tick_max_n(m), tick_max_m(m), tick_max_m(m), view == 0, true, 0, view != 16, !tick_z_global(view),
-                                !tick16_ext(view)).bytes() + 15) & ~(size_t)15;
+  const bool ext = tick16_ext(view) || tick_z_global(view);        // wa, b, Gv (element view: the rows too) in the global slot
+  const size_t ql = (wg::QlDims(tick_max_n(m), tick_max_m(m), tick_max_m(m), view == 0, true, 0, view == 0, !tick_z_global(view),
+                                !ext).bytes() + 15) & ~(size_t)15;
   const int gvld = view == 16 ? wg::kGvLd : (view == -1 ? wg::kGvLdElem : 0);
-  return ql + wg::TickLds::bytes(m.N, tick_smax(m), gvld, view == 16, !tick16_ext(view));
+  return ql + wg::TickLds::bytes(m.N, tick_smax(m), gvld, view == 16, !ext, view != -1);
 }
 inline int tick_view(const wg_model_t &m) {
   if (tick_compact(m)) return 16;
@@ -408,8 +411,8 @@ inline int tick_view(const wg_model_t &m) {
   return (tick_lds_for(m, 0) <= 160 * 1024 || !overlay_fits) ? 0 : -1;
 }
 inline size_t tick_ql_bytes(const wg_model_t &m) {
-  size_t b = wg::QlDims(tick_max_n(m), tick_max_m(m), tick_max_m(m), tick_view(m) == 0, true, 0, tick_view(m) != 16,
-                        !tick_z_global(tick_view(m)), !tick16_ext(tick_view(m))).bytes();
+  size_t b = wg::QlDims(tick_max_n(m), tick_max_m(m), tick_max_m(m), tick_view(m) == 0, true, 0, tick_view(m) == 0,
+                        !tick_z_global(tick_view(m)), !(tick16_ext(tick_view(m)) || tick_z_global(tick_view(m)))).bytes();
   return (b + 15) & ~(size_t)15;
 }
 }  // namespace
@@ -436,6 +439,9 @@ inline size_t tick_ql_bytes(const wg_model_t &m) {
   } while (0)
 #endif
 
+#ifndef WG_TICK32_WPE
+#define WG_TICK32_WPE 2                                    // element view (N = 32): 256 registers, so that a fifth gait of a CU can share a SIMD
+#endif
 #ifndef WG_TICK_WPE_MIN
 #define WG_TICK_WPE_MIN 2
 #endif
@@ -443,7 +449,7 @@ inline size_t tick_ql_bytes(const wg_model_t &m) {
 #define WG_TICK_WPE_MAX 2
 #endif
 template <int NH>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NH == -1 ? 1 : WG_TICK_WPE_MIN, NH == -1 ? 1 : WG_TICK_WPE_MAX))) void wg_mpc_tick_kernel(int B, wg_model_t model, const wg::TickTables *__restrict__ tb,
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NH == -1 ? WG_TICK32_WPE : WG_TICK_WPE_MIN, NH == -1 ? WG_TICK32_WPE : WG_TICK_WPE_MAX))) void wg_mpc_tick_kernel(int B, wg_model_t model, const wg::TickTables *__restrict__ tb,
                                                          wg_gait_state_t *__restrict__ states,
                                                          wg_tick_out_t *__restrict__ outs, int *__restrict__ diag,
                                                          int advance_calls, int *__restrict__ hist, int hist_cap,
@@ -496,7 +502,7 @@ __global__ void wg_run_queue_init_kernel(int B, int total, wg_run_queue *q, int 
 }
 
 template <int NH>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NH == -1 ? 1 : WG_TICK_WPE_MIN, NH == -1 ? 1 : WG_TICK_WPE_MAX))) void wg_mpc_run_kernel(
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NH == -1 ? WG_TICK32_WPE : WG_TICK_WPE_MIN, NH == -1 ? WG_TICK32_WPE : WG_TICK_WPE_MAX))) void wg_mpc_run_kernel(
     int B, int n_ticks, const wg_model_t *__restrict__ model_p, const wg::TickTables *__restrict__ tb_p,
     wg_gait_state_t *__restrict__ states_p, wg_tick_out_t *__restrict__ outs_p, int *__restrict__ diag_p, int advance_calls,
     wg_run_queue *__restrict__ q, int *__restrict__ ring, int *__restrict__ done, unsigned ql_bytes, double *zscratch,
@@ -602,7 +608,7 @@ __device__ __forceinline__ int xrun_take_fresh(wg_xrun_ctl *ctl, int y) {
 __device__ __forceinline__ void xrun_stores_done() { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); }
 
 template <int NH>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NH == -1 ? 1 : WG_TICK_WPE_MIN, NH == -1 ? 1 : WG_TICK_WPE_MAX))) void wg_mpc_run_xcd_kernel(
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NH == -1 ? WG_TICK32_WPE : WG_TICK_WPE_MIN, NH == -1 ? WG_TICK32_WPE : WG_TICK_WPE_MAX))) void wg_mpc_run_xcd_kernel(
     int B, int n_ticks, const wg_model_t *__restrict__ model_p, const wg::TickTables *__restrict__ tb_p,
     wg_gait_state_t *__restrict__ states_p, wg_tick_out_t *__restrict__ outs_p, int *__restrict__ diag_p, int advance_calls,
     wg_xrun_ctl *__restrict__ ctl_p, unsigned long long *__restrict__ rings_p, int cap, int *__restrict__ done_p,

@@ -114,7 +114,10 @@ struct QlView {
   double *x, *d, *ww, *wd, *wx, *lam, *xl, *xu, *wa, *b;
   double *sc0, *sc1, *sc2, *sc3, *slot;
   int *iact;
-  __device__ __forceinline__ void carve(double *base, const QlDims &D, int me_) {
+  // kBounds / kWabLds mirror QlDims::bounds / wab_lds at compile time (a run-time choice between an LDS and a global array
+  // would make the pointer generic and every access through it a flat_ instruction); ext_wab: [wa (mmax + nmax) | b (mmax)]
+  template <bool kBounds = true, bool kWabLds = true>
+  __device__ __forceinline__ void carve(double *base, const QlDims &D, int me_, double *ext_wab = nullptr, int ext_b_off = 0) {
     n = D.n; m = D.m; me = me_; mn = D.m + D.n; ldg = D.ldg; ldz = D.ldz; lda = D.lda;
     double *p = base;
     G = nullptr; A = nullptr;
@@ -124,9 +127,9 @@ struct QlView {
     R = p; p += D.r_len();
     if (D.dense && D.a_lds) { A = p; p += n * lda; }
     x = p; p += n;  d = p; p += n;  ww = p; p += n;  wd = p; p += n;
-    wx = p; p += n; lam = p; p += n; xl = p; p += n; xu = p; p += n;
-    wa = p; p += m + n;
-    b = p; p += m;
+    wx = p; p += n; lam = p; p += n;
+    if constexpr (kBounds) { xl = p; p += n; xu = p; p += n; } else { xl = nullptr; xu = nullptr; }
+    if constexpr (kWabLds) { wa = p; p += m + n; b = p; p += m; } else { wa = ext_wab; b = ext_wab + ext_b_off; }
     sc0 = p; p += D.nsc; sc1 = p; p += D.nsc; sc2 = p; p += D.nsc; sc3 = p; p += D.nsc;
     slot = p; p += 8;
     iact = reinterpret_cast<int *>(p);

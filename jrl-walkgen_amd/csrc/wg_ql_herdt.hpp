@@ -662,8 +662,9 @@ struct HerdtElemProb {
   }
   __device__ __forceinline__ double Gd(const QlView &, int i) const { return gd[i]; }
   __device__ __forceinline__ void setGd(const QlView &, int i, double v) const { gd[i] = v; }
-  __device__ __forceinline__ double xl(const QlView &q, int i) const { return q.xl[i]; }
-  __device__ __forceinline__ double xu(const QlView &q, int i) const { return q.xu[i]; }
+  // QPProblem's bounds are the constants of qp-problem.cpp:118-121: no LDS copy
+  __device__ __forceinline__ double xl(const QlView &, int) const { return -1e8; }
+  __device__ __forceinline__ double xu(const QlView &, int) const { return 1e8; }
   __device__ __forceinline__ double A(const QlView &, int k, int i) const {
     if (k == 0) return 0.0;
     const double a = rowA[k], b = rowB[k];

@@ -176,18 +176,24 @@ struct TickLds {
   // rows_presolve: rowA / rowB / rowK are only read while the QP is assembled and the register rows are loaded (the compact
   // view keeps every row's coefficients in registers afterwards) -- they join the pre-solve group
   // gv_lds = false: the border block Gv lives in a per-block slot of global memory (see mpc_tick)
-  __host__ __device__ static size_t bytes(int N, int smax = kSMax, int gvld = 0, bool rows_presolve = false, bool gv_lds = true) {
+  // rows_lds = false (with rows_presolve = false): rowA / rowB / rowK live in the per-block slot of global memory too
+  __host__ __device__ static size_t bytes(int N, int smax = kSMax, int gvld = 0, bool rows_presolve = false, bool gv_lds = true,
+                                          bool rows_lds = true) {
     const int m = 1 + 4 * N + 5 * smax;
     const int nmax = 2 * N + 2 * smax;
     const bool compact = gvld > 0;
-    size_t b = sizeof(Sup) + 8 * (size_t)(kSMax * kSMax + 8 + (rows_presolve ? 0 : 2 * m) + 16 + (compact ? (N + 2) + (gv_lds ? nmax * gvld : 0) + nmax : 0)) +
-               4 * (size_t)(((N + 1) & ~1) + (rows_presolve ? 0 : ((m + 1) & ~1))) +
+    const bool rows_here = !rows_presolve && rows_lds;
+    size_t b = sizeof(Sup) + 8 * (size_t)(kSMax * kSMax + 8 + (rows_here ? 2 * m : 0) + 16 + (compact ? (N + 2) + (gv_lds ? nmax * gvld : 0) + nmax : 0)) +
+               4 * (size_t)(((N + 1) & ~1) + (rows_here ? ((m + 1) & ~1) : 0)) +
                (rows_presolve ? 0 : ((sizeof(wg_gait_state_t) + 15) & ~(size_t)15));
     if (!compact) b += pre_bytes(N, smax);
     return (b + 15) & ~(size_t)15;
   }
-  template <bool kExtGv = false>                          // kExtGv: Gv is ext_gv (global memory), decided at compile time so that
-  __device__ __forceinline__ void carve(char *base, int N, int smax, int gvld, char *overlay, bool rows_presolve, double *ext_gv = nullptr) {   // its accesses are global_ instructions, not flat_
+  // kExtGv: Gv is ext_gv (global memory); kExtRows: rowA | rowB | rowK are ext_rows (global memory, m doubles each, then m
+  // ints) -- decided at compile time so that their accesses are global_ instructions, not flat_
+  template <bool kExtGv = false, bool kExtRows = false>
+  __device__ __forceinline__ void carve(char *base, int N, int smax, int gvld, char *overlay, bool rows_presolve, double *ext_gv = nullptr,
+                                        double *ext_rows = nullptr) {
     const bool compact = gvld > 0;
     const int m = 1 + 4 * N + 5 * smax;
     char *p = base;
@@ -195,7 +201,8 @@ struct TickLds {
     sup0 = reinterpret_cast<Sup *>(p); p += sizeof(Sup);
     double *d = reinterpret_cast<double *>(p);
     V_f = d; d += kSMax * kSMax; sup_angles = d; d += 8;
-    if (!rows_presolve) { rowA = d; d += m; rowB = d; d += m; }
+    if constexpr (kExtRows) { rowA = ext_rows; rowB = ext_rows + m; rowK = reinterpret_cast<int *>(ext_rows + 2 * m); }
+    else if (!rows_presolve) { rowA = d; d += m; rowB = d; d += m; }
     misc = d; d += 16;
     uvec = Gv = gd = nullptr;
     if (compact) {
@@ -206,7 +213,7 @@ struct TickLds {
     }
     int *ip = reinterpret_cast<int *>(d);
     stepidx = ip; ip += (N + 1) & ~1;
-    if (!rows_presolve) { rowK = ip; ip += (m + 1) & ~1; }
+    if constexpr (!kExtRows) { if (!rows_presolve) { rowK = ip; ip += (m + 1) & ~1; } }
     char *o = compact ? overlay : reinterpret_cast<char *>(ip);
     sup = reinterpret_cast<Sup *>(o); o += sizeof(Sup) * (N + 1);
     double *e = reinterpret_cast<double *>(o);
@@ -498,8 +505,17 @@ __device__ __forceinline__ TickDiag mpc_tick(const wg_model_t &m, const TickTabl
   // difference between seven and eight gaits per CU.  All three are read lane-parallel, early in their phases.
   constexpr int kExtWab = (2 * 16 + 4) + 2 * (1 + 4 * 16 + 10);
   double *ext16 = (NH == 16) ? zglobal : nullptr;         // never null for the compact view (the host reserves the slot)
-  L.template carve<NH == 16>(lds_tick, N, (NH == 16) ? 2 : kSMax, kGvStride, reinterpret_cast<char *>(lds_ql), NH == 16,
-                             (NH == 16) ? ext16 + kExtWab : nullptr);
+  // element view: the slot holds [Z (nmax x (nmax|1)) | wa (mmax + nmax) | b (mmax) | Gv (nmax x kGvLdElem) | rowA | rowB | rowK]
+  // for the largest problem of the model -- with them in LDS a CU holds four gaits at N = 32, without them five
+  const int eNmax = 2 * N + 2 * kSMax, eMmax = 1 + 4 * N + 5 * kSMax;
+  double *extE = (NH == -1) ? zglobal + (size_t)eNmax * (eNmax | 1) : nullptr;
+  const int eWab = (eMmax + eNmax) + eMmax;
+  if constexpr (NH == -1)
+    L.template carve<true, true>(lds_tick, N, kSMax, kGvStride, reinterpret_cast<char *>(lds_ql), false, extE + eWab,
+                                 extE + eWab + (size_t)eNmax * kGvStride);
+  else
+    L.template carve<NH == 16>(lds_tick, N, (NH == 16) ? 2 : kSMax, kGvStride, reinterpret_cast<char *>(lds_ql), NH == 16,
+                               (NH == 16) ? ext16 + kExtWab : nullptr);
   wg_gait_state_t *s = L.st;
 #ifdef WG_PROFILE
   unsigned long long tk0 = clock64(), tk1 = 0, tk2 = 0, tk3 = 0;
@@ -644,15 +660,16 @@ __device__ __forceinline__ TickDiag mpc_tick(const wg_model_t &m, const TickTabl
   constexpr bool kTableView = (NH == 16) || (NH == -1);   // Hessian / constraints kept as compact tables
   // element view with a Z slot in global memory: Z leaves the LDS (it is the operand that caps the residency at N = 32)
   constexpr bool z_in_lds = (NH != -1);
-  QlDims D(n, mq, mq, !kTableView, true, kCompactView ? 2 * NH + 4 : 0, !kCompactView, z_in_lds);   // ordered sums run the static length
+  constexpr bool kElemView = (NH == -1);
+  QlDims D(n, mq, mq, !kTableView, true, kCompactView ? 2 * NH + 4 : 0, !kTableView, z_in_lds, !kElemView);   // ordered sums run the static length
   QlView q;
   if constexpr (kCompactView) {
     constexpr int kNmax = 2 * NH + 4, kMmax = 1 + 4 * NH + 10;     // two previewed steps at most (wg_mpc_configure)
     // same footprint as QlDims(kNmax, kMmax, kMmax, dense = false, nsc = kNmax, bounds = false), which sized the LDS on the host
     q.template carve_fixed<kNmax, kMmax, kNmax, true>(lds_ql, n, mq, 0, ext16);
   } else {
-    q.carve(lds_ql, D, 0);
-    if constexpr (!z_in_lds) q.Z = zglobal;
+    if constexpr (kElemView) { q.template carve<false, false>(lds_ql, D, 0, extE, eMmax + eNmax); q.Z = zglobal; }
+    else q.carve(lds_ql, D, 0);
   }
 
   // ---- S*c products (MV2_ = prod(S, CoM), generator-vel-ref.cpp:780-787) ----
@@ -691,7 +708,7 @@ __device__ __forceinline__ TickDiag mpc_tick(const wg_model_t &m, const TickTabl
     dx += qx * m.gamma; dy += qy * m.gamma;
     q.d[2 * N + j] = dx; q.d[2 * N + ns + j] = dy;
   }
-  if constexpr (!kCompactView) { for (int i = lane; i < n; i += 64) { q.xl[i] = -1e8; q.xu[i] = 1e8; } }   // qp-problem.cpp:118-121
+  if constexpr (!kTableView) { for (int i = lane; i < n; i += 64) { q.xl[i] = -1e8; q.xu[i] = 1e8; } }   // qp-problem.cpp:118-121 (table views: constants)
 
   // ---- Hessian ----
   if constexpr (kTableView) {
