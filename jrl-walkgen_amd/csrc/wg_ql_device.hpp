@@ -1407,13 +1407,26 @@ __device__ __forceinline__ QlResult ql_solve(const QlView &q, P &prob, double vs
               suma += rl(ta, i + 3); sumb += rl(tb, i + 3); sumc += rl(tc, i + 3);
             }
           } else {
-            WG_UNROLL
-            for (int i = 0; i < n; ++i) {
-              double zi = Zm(i, nact), wi = q.ww[i];
-              suma += wi * zi;
-              sumb += fabs(wi * zi);
-              sumc += zi * zi;
+            // column nact of Z is read once, lane-parallel (with Z in global memory: two coalesced loads instead of n
+            // broadcast ones in a row); the three ordered sums then run from LDS, one per lane, as in the compact view
+            for (int i = lane; i < n; i += 64) {
+              const double zi = Zm(i, nact), wi = q.ww[i];
+              q.sc0[i] = wi * zi; q.sc1[i] = fabs(wi * zi); q.sc2[i] = zi * zi;
             }
+            WG_WSYNC();
+            const double *src = q.sc0 + (lane < 3 ? lane : 0) * (int)(q.sc1 - q.sc0);
+            double acc = 0.0;
+            int i = 0;
+            for (; i + 8 <= n; i += 8) {
+              double t[8];
+#pragma unroll
+              for (int e = 0; e < 8; ++e) t[e] = src[i + e];
+#pragma unroll
+              for (int e = 0; e < 8; ++e) acc += t[e];
+            }
+            for (; i < n; ++i) acc += src[i];
+            suma = rl(acc, 0); sumb = rl(acc, 1); sumc = rl(acc, 2);
+            WG_WSYNC();
           }
 #ifdef WG_DEBUG_ROUTE
           if (lane == 0 && blockIdx.x == 2 && iterc == 3) { for (int i = 0; i < n; i++) printf("GPUW %d %.17g %.17g\n", i, q.ww[i], Zm(i, nact)); }
