@@ -686,6 +686,7 @@ __device__ __forceinline__ void sweep(const QlView &q, double *s, int nu, int na
     }
     WG_WSYNC();
   }
+  bool any_skip = false;                                    // a skipped rotation (q == 0) is rare: phase 3 has a select-free form
   for (int c0 = nact + 1; c0 < nu; c0 += 64) {
     const int c = c0 + lane;
     const bool mine = c < nu;
@@ -693,6 +694,7 @@ __device__ __forceinline__ void sweep(const QlView &q, double *s, int nu, int na
     const double P = s[cc - 1];
     const double Q = (cc == nu - 1) ? s[nu - 1] : chain[cc];
     const double Nn = (Q == 0.0) ? 0.0 : chain[cc - 1];
+    any_skip = any_skip || (__ballot(mine && Nn == 0.0) != 0ull);
     WG_WSYNC();                                             // every lane has read s[] before any lane rewrites it
     if (mine) {
       q.sc2[c] = Nn;
@@ -717,69 +719,77 @@ __device__ __forceinline__ void sweep(const QlView &q, double *s, int nu, int na
     // carry chain; an earlier form with an exit test per rotation waited for ALL outstanding accesses at every step).
     // The first chunk takes the cnt % kSwC odd rotations; past-the-end addresses are clamped to column nact (loaded, unused).
     // Surplus lanes shadow their first row completely: same loads, same arithmetic, the same value stored to the same place.
+    // The rotation coefficients of a chunk (LDS, broadcast reads) are fetched at the head of the chunk as well, so that no
+    // step waits for an LDS round trip; when no rotation of the sweep is skipped (one ballot in phase 2) the steps run
+    // without the selects.
     constexpr int kSwC = 8;
     const int i0 = lane;
     const int i1 = lane + 64 < n ? lane + 64 : lane;
     const int ldz = q.ldz;
     double *z0 = q.Z + i0, *z1 = q.Z + i1;
     double carry0 = z0[(nu - 1) * ldz], carry1 = z1[(nu - 1) * ldz];
-    auto step = [&](int c, double zl0, double zl1) {
-      const double nrm = q.sc2[c], ga = q.sc0[c], gb = q.sc1[c];
-      const bool skip = (nrm == 0.0);
+    struct Co { double ga[kSwC], gb[kSwC], nr[kSwC]; };
+    auto coef = [&](Co &o, int c) {                          // coefficients of rotations c, c-1, .. (clamped: unused past the end)
+#pragma unroll
+      for (int k = 0; k < kSwC; ++k) {
+        const int cc = (c - k) > nact ? (c - k) : nact + 1;
+        o.ga[k] = q.sc0[cc]; o.gb[k] = q.sc1[cc]; o.nr[k] = q.sc2[cc];
+      }
+    };
+    auto rows = [&](double (&p0)[kSwC], double (&p1)[kSwC], int c) {   // Z(i, c-1-k): the entries rotations c, c-1, .. read
+#pragma unroll
+      for (int k = 0; k < kSwC; ++k) {
+        const int cc = (c - 1 - k) > nact ? (c - 1 - k) : nact;
+        p0[k] = z0[cc * ldz]; p1[k] = z1[cc * ldz];
+      }
+    };
+    auto step = [&](auto may_skip, int c, double zl0, double zl1, double ga, double gb, double nrm) {
       const double t0 = ga * zl0 + gb * carry0, w0 = ga * carry0 - gb * zl0;
       const double t1 = ga * zl1 + gb * carry1, w1 = ga * carry1 - gb * zl1;
-      z0[c * ldz] = skip ? carry0 : w0;
-      z1[c * ldz] = skip ? carry1 : w1;
-      carry0 = skip ? zl0 : t0;
-      carry1 = skip ? zl1 : t1;
+      if constexpr (decltype(may_skip)::value) {
+        const bool skip = (nrm == 0.0);
+        z0[c * ldz] = skip ? carry0 : w0;
+        z1[c * ldz] = skip ? carry1 : w1;
+        carry0 = skip ? zl0 : t0;
+        carry1 = skip ? zl1 : t1;
+      } else {
+        z0[c * ldz] = w0; z1[c * ldz] = w1;
+        carry0 = t0; carry1 = t1;
+      }
     };
-    int c = nu - 1;                                          // the next rotation
-    {
-      const int rem = (nu - 1 - nact) % kSwC;
-      if (rem) {
-        double h0[kSwC - 1], h1[kSwC - 1];
+    auto run = [&](auto may_skip) {
+      int c = nu - 1;                                        // the next rotation
+      {
+        const int rem = (nu - 1 - nact) % kSwC;
+        if (rem) {
+          double h0[kSwC], h1[kSwC];
+          Co hc;
+          rows(h0, h1, c); coef(hc, c);
 #pragma unroll
-        for (int k = 0; k < kSwC - 1; ++k) {
-          const int cc = (c - 1 - k) > nact ? (c - 1 - k) : nact;
-          h0[k] = z0[cc * ldz]; h1[k] = z1[cc * ldz];
+          for (int k = 0; k < kSwC - 1; ++k)
+            if (k < rem) step(may_skip, c - k, h0[k], h1[k], hc.ga[k], hc.gb[k], hc.nr[k]);
+          c -= rem;
         }
-#pragma unroll
-        for (int k = 0; k < kSwC - 1; ++k)
-          if (k < rem) step(c - k, h0[k], h1[k]);
-        c -= rem;
       }
-    }
-    if (c > nact) {                                          // a whole number of chunks is left
-      double a0[kSwC], a1[kSwC], b0[kSwC], b1[kSwC];
+      if (c > nact) {                                        // a whole number of chunks is left
+        double a0[kSwC], a1[kSwC], b0[kSwC], b1[kSwC];
+        Co cc;                                               // one set: read at the head of its chunk (one LDS wait per chunk)
+        rows(a0, a1, c);
+        for (;;) {
+          rows(b0, b1, c - kSwC); coef(cc, c);
 #pragma unroll
-      for (int k = 0; k < kSwC; ++k) { a0[k] = z0[(c - 1 - k) * ldz]; a1[k] = z1[(c - 1 - k) * ldz]; }
-      for (;;) {
-        {
-          const int cn = c - kSwC;                           // first rotation of the next chunk (if any)
+          for (int k = 0; k < kSwC; ++k) step(may_skip, c - k, a0[k], a1[k], cc.ga[k], cc.gb[k], cc.nr[k]);
+          c -= kSwC;
+          if (c <= nact) break;
+          rows(a0, a1, c - kSwC); coef(cc, c);
 #pragma unroll
-          for (int k = 0; k < kSwC; ++k) {
-            const int cc = (cn - 1 - k) > nact ? (cn - 1 - k) : nact;
-            b0[k] = z0[cc * ldz]; b1[k] = z1[cc * ldz];
-          }
-#pragma unroll
-          for (int k = 0; k < kSwC; ++k) step(c - k, a0[k], a1[k]);
-          c = cn;
+          for (int k = 0; k < kSwC; ++k) step(may_skip, c - k, b0[k], b1[k], cc.ga[k], cc.gb[k], cc.nr[k]);
+          c -= kSwC;
+          if (c <= nact) break;
         }
-        if (c <= nact) break;
-        {
-          const int cn = c - kSwC;
-#pragma unroll
-          for (int k = 0; k < kSwC; ++k) {
-            const int cc = (cn - 1 - k) > nact ? (cn - 1 - k) : nact;
-            a0[k] = z0[cc * ldz]; a1[k] = z1[cc * ldz];
-          }
-#pragma unroll
-          for (int k = 0; k < kSwC; ++k) step(c - k, b0[k], b1[k]);
-          c = cn;
-        }
-        if (c <= nact) break;
       }
-    }
+    };
+    if (any_skip) run(std::true_type{}); else run(std::false_type{});
     z0[nact * ldz] = carry0;
     z1[nact * ldz] = carry1;
     WG_WSYNC();

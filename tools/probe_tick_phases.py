@@ -2,7 +2,7 @@
 import ctypes as C, importlib, os, sys, numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-os.environ["WG_LIB_PATH"] = os.path.join(ROOT, "jrl-walkgen_amd", "lib", "libwg_mpc_prof.so")
+os.environ["WG_LIB_PATH"] = os.environ.get("WG_PROF_LIB", os.path.join(ROOT, "jrl-walkgen_amd", "lib", "libwg_mpc_prof.so"))
 wg = importlib.import_module("jrl-walkgen_amd"); wg.init(0)
 B = int(os.environ.get("PB", "1024")); WARM = 60; MEAS = 20
 model = wg.model_defaults()
