@@ -282,6 +282,38 @@ __device__ __forceinline__ double givens_norm(double p, double qq) {
   return t * sqrt_1to2(x);                         // x is in [1, 2], or NaN (which stays NaN)
 #endif
 }
+// The same norm for operands whose non-zero magnitudes lie in [2^-400, 2^404] (sweep_range_ok), five instructions shorter:
+//   * min / max of the magnitudes in one instruction each: the quotient enters only through its square, and
+//     (|x| / |y|)^2 == (x / y)^2 bit for bit;
+//   * the division is the compiler's own f64 expansion (v_rcp_f64, two Newton steps, quotient, residual, correction) without
+//     v_div_scale_f64 / v_div_fixup_f64: with 0 <= a <= t and t in that range both scalings are the identity and the fix-up
+//     passes the quotient through whenever it is >= 2^-27; below that d * d < 2^-54 and 1 + d * d is exactly 1 whatever the
+//     last bits of d.  t == 0 (both operands zero) gives NaN here as 0/0 does there: the caller discards it.
+__device__ __forceinline__ double givens_norm_fast(double p, double qq) {
+  double t, a;
+  asm("v_max_f64 %0, |%1|, |%2|" : "=v"(t) : "v"(p), "v"(qq));
+  asm("v_min_f64 %0, |%1|, |%2|" : "=v"(a) : "v"(p), "v"(qq));
+  double r = __builtin_amdgcn_rcp(t);
+  double e = __builtin_fma(-t, r, 1.0);
+  r = __builtin_fma(r, e, r);
+  e = __builtin_fma(-t, r, 1.0);
+  r = __builtin_fma(r, e, r);
+  const double q0 = a * r;
+  const double rem = __builtin_fma(-t, q0, a);
+  const double d = __builtin_fma(rem, r, q0);
+  const double x = 1.0 + d * d;
+  return t * sqrt_1to2(x);
+}
+// every entry of s[lo, hi) is zero or has its magnitude in [2^-400, 2^400] (then every norm of a sweep over them, being at
+// least its larger operand and at most sqrt(n) times the largest entry, is zero or in [2^-400, 2^404]); wave-uniform
+__device__ __forceinline__ bool sweep_range_ok(const double *s, int lo, int hi, int lane) {
+  bool bad = false;
+  for (int j = lo + lane; j < hi; j += 64) {
+    const double v = fabs(s[j]);
+    bad = bad || !(v == 0.0 || (v >= 0x1p-400 && v <= 0x1p400));
+  }
+  return __ballot(bad) == 0ull;
+}
 // qld.cpp:1921-1930 / 2005-2014
 __device__ __forceinline__ void givens(double p, double qq, double &ga, double &gb, double &nrm) {
   const double sum = givens_norm(p, qq);
@@ -480,7 +512,20 @@ __device__ __forceinline__ void sweep_flat(const QlView &q, double *s, int nu, i
   // (untouched until phase 2), norm = chain[c-1] when q != 0 (then cur = norm), skipped when q == 0 (then cur = p).
   // givens_norm runs unguarded on q == 0: its result (|p|, or NaN for 0/0) is discarded by the select.
   double *chain = q.sc2;                                    // nu <= n entries
-  {
+  if (sweep_range_ok(s, nact, nu, lane)) {
+    // the usual case: the shorter norm; unrolled by two so that handing the prefetched operand on is a renaming
+    double cur = s[nu - 1];
+    double pa = s[nu - 2], pb;
+    int c = nu - 1;
+    for (;;) {
+      pb = s[(c - 2 >= 0) ? c - 2 : 0];                     // operand of the next rotation, off the chain
+      { const double nrmc = givens_norm_fast(pa, cur); cur = (cur == 0.0) ? pa : nrmc; chain[c - 1] = cur; }
+      if (--c <= nact) break;
+      pa = s[(c - 2 >= 0) ? c - 2 : 0];
+      { const double nrmc = givens_norm_fast(pb, cur); cur = (cur == 0.0) ? pb : nrmc; chain[c - 1] = cur; }
+      if (--c <= nact) break;
+    }
+  } else {
     double cur = s[nu - 1];
     double p = s[nu - 2];
     for (int c = nu - 1; c > nact; --c) {
@@ -671,10 +716,20 @@ __device__ __forceinline__ void sweep(const QlView &q, double *s, int nu, int na
   // chain[c - 1]); p = s[c - 1] is fetched one rotation ahead, off the chain.  Phase 2 rebuilds each rotation from it:
   // sc0[c] = ga, sc1[c] = gb, sc2[c] = norm (0 marks "skipped").
   double *chain = q.sc3;
-#ifdef WG_PROFILE_SWEEP
-  unsigned long long sw0 = clock64();
-#endif
-  {
+  if (sweep_range_ok(s, nact, nu, lane)) {                  // the usual case: the shorter norm, as in sweep_flat
+    double cur = s[nu - 1];
+    double pa = s[nu - 2], pb;
+    int c = nu - 1;
+    for (;;) {
+      pb = s[(c - 2 >= 0) ? c - 2 : 0];
+      { const double nrmc = givens_norm_fast(pa, cur); cur = (cur == 0.0) ? pa : nrmc; chain[c - 1] = cur; }
+      if (--c <= nact) break;
+      pa = s[(c - 2 >= 0) ? c - 2 : 0];
+      { const double nrmc = givens_norm_fast(pb, cur); cur = (cur == 0.0) ? pb : nrmc; chain[c - 1] = cur; }
+      if (--c <= nact) break;
+    }
+    WG_WSYNC();
+  } else {
     double cur = s[nu - 1];
     double p = s[nu - 2];
     for (int c = nu - 1; c > nact; --c) {
@@ -706,10 +761,6 @@ __device__ __forceinline__ void sweep(const QlView &q, double *s, int nu, int na
     }
   }
   WG_WSYNC();
-#ifdef WG_PROFILE_SWEEP
-  unsigned long long sw2 = clock64();
-  if ((threadIdx.x & 63) == 0) { atomicAdd(&g_prof[30], sw2 - sw0); }
-#endif
   if (n <= 128) {
     // phase 3 for 64 < n <= 128: two rows per lane in one pass.  Rotation c reads Z(i, c-1) BEFORE any rotation rewrites it,
     // so the row entries are independent of the carry chain: they are fetched a chunk of kSwC columns at a time, the next
