@@ -88,6 +88,25 @@ def test_constraint_matrix_in_lds_or_read_in_place(a_in_lds, monkeypatch):
     assert not bad, bad[:5]
 
 
+@pytest.mark.parametrize("log2_scale", [0, 380, 450, -380, -450])
+def test_sweep_norm_range_guard(log2_scale):
+    """The sweep's norm chain takes a shorter instruction sequence when every operand is zero or within [2^-400, 2^400]
+    (wg_ql_device.hpp, givens_norm_fast / sweep_range_ok) and the reference-shaped one otherwise.  Constraint rows scaled by
+    2^k put the operands (Z^T a) on either side of the guard, close to it and far from it; n > 64 takes the generic sweep."""
+    wg = _wg()
+    qps = []
+    for s_ in range(24):
+        q = qpgen.random_pd(np.random.default_rng(8800 + s_), 70, 48)
+        f = float(2.0 ** log2_scale)                       # exact scaling: the same feasible set
+        q["A"] = np.asfortranarray(q["A"] * f); q["b"] = q["b"] * f
+        qps.append(q)
+    pk = wg.pack_qps(qps)
+    res = wg.qp_solve_batch(pk, hist_cap=512)
+    bad = _compare(qps, res, "scale=2^%d" % log2_scale, pk)
+    assert not bad, bad[:5]
+    assert int(np.max(res["n_iter"])) > 3                  # the solves did add constraints (sweeps ran)
+
+
 def test_empty_batch_and_errors():
     wg = _wg()
     q = qpgen.random_pd(np.random.default_rng(1), 4, 3)
