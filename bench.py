@@ -59,13 +59,20 @@ def start_states(model, B):
     return torch.frombuffer(bytearray(one * B), dtype=torch.uint8)
 
 
-def launch_plan(t0, t1, per_tick=False, redraw=REDRAW_TICKS):
+def launch_plan(t0, t1, per_tick=False, redraw=REDRAW_TICKS, staged=True):
     """[(first tick, number of ticks)] covering ticks [t0, t1): the control loop's first two ticks advance the clock by 1
-    and 19 control periods and go alone; otherwise one launch per stretch of constant references (or per tick)."""
+    and 19 control periods and go alone (or every tick does, per_tick); a launch that starts where the velocity references
+    change runs to t1 with the references of all its stretches staged on the device (wg_mpc_run_sched_dev), any other
+    launch ends where they change next (staged = False: every launch does -- round 1's plan)."""
     out = []
     t = t0
     while t < t1:
-        n = 1 if (t < 2 or per_tick) else min(t1, (t // redraw + 1) * redraw) - t
+        if t < 2 or per_tick:
+            n = 1
+        elif staged and t % redraw == 0:
+            n = t1 - t
+        else:
+            n = min(t1, (t // redraw + 1) * redraw) - t
         out.append((t, n))
         t += n
     return out
@@ -195,7 +202,8 @@ def config5_leg(dev, flags, ticks=40, warm=10):
 
         def run(t0, t1, evs=None):
             for t, n in launch_plan(t0, t1):
-                if t % REDRAW_TICKS == 0:
+                staged = n > 1 and t % REDRAW_TICKS == 0
+                if t % REDRAW_TICKS == 0 and not staged:
                     ctx.mpc_set_velref_dev(B, sp, vtab[t // REDRAW_TICKS].data_ptr(), sh)
                 adv = 1 if t == 0 else (19 if t == 1 else 20)
                 if evs is not None:
@@ -203,6 +211,8 @@ def config5_leg(dev, flags, ticks=40, warm=10):
                     evs[-1][0].record(stream)
                 if n == 1:
                     ctx.mpc_tick_batch_dev(B, sp, None, dp + t * dstride, adv, stream=sh)
+                elif staged:
+                    ctx.mpc_run_sched_dev(B, sp, n, vtab[t // REDRAW_TICKS].data_ptr(), REDRAW_TICKS, adv, None, dp + t * dstride, stream=sh)
                 else:
                     ctx.mpc_run_batch_dev(B, sp, n, adv, None, dp + t * dstride, stream=sh)
                 if evs is not None:
@@ -241,6 +251,9 @@ def main():
     ap.add_argument("--no-parity", action="store_true", help="skip the golden-file replay (CoM RMSE) after the timed run")
     ap.add_argument("--no-per-tick-leg", action="store_true", help="skip the secondary one-launch-per-tick measurement")
     ap.add_argument("--no-config5", action="store_true", help="skip the N = 32, batch = 8192 leg (BASELINE configs[4])")
+    ap.add_argument("--no-staged-refs", action="store_true", help="one launch per stretch of constant velocity references "
+                    "(wg_mpc_set_velref_dev + wg_mpc_run_batch_dev, round 1's plan) instead of one launch with the references "
+                    "of every stretch staged on the device (wg_mpc_run_sched_dev)")
     args = ap.parse_args()
 
     # CPU baseline first: it forks one worker per host core, which must happen before this process touches the GPU
@@ -291,22 +304,27 @@ def main():
     dstride = B * 6 * 4
 
     def launches(t0, t1):
-        return launch_plan(t0, t1, args.per_tick_launch)
+        return launch_plan(t0, t1, args.per_tick_launch, staged=not args.no_staged_refs)
 
-    def redraw(t):
-        if t % REDRAW_TICKS == 0:
+    def is_staged(t, n):
+        return n > 1 and t % REDRAW_TICKS == 0 and not args.no_staged_refs
+
+    def redraw(t, n=1):
+        if t % REDRAW_TICKS == 0 and not is_staged(t, n):
             wg.mpc_set_velref_dev(B, sp, vtab[t // REDRAW_TICKS].data_ptr(), sh)
 
     def fire(t, n):
         adv = 1 if t == 0 else (19 if t == 1 else 20)
         if n == 1 and (t < 2 or args.per_tick_launch):
             wg.mpc_tick_batch_dev(B, sp, None, dp + t * dstride, adv, stream=sh)
+        elif is_staged(t, n):                                 # the references of every stretch of the launch wait on the device
+            wg.mpc_run_sched_dev(B, sp, n, vtab[t // REDRAW_TICKS].data_ptr(), REDRAW_TICKS, adv, None, dp + t * dstride, stream=sh)
         else:
             wg.mpc_run_batch_dev(B, sp, n, adv, None, dp + t * dstride, stream=sh)
 
     with torch.cuda.stream(stream):
         for t, n in launches(0, W):
-            redraw(t)
+            redraw(t, n)
             fire(t, n)
     torch.cuda.synchronize(dev)
     timed = launches(W, W + K)
@@ -317,7 +335,7 @@ def main():
     t0 = time.perf_counter()
     with torch.cuda.stream(stream):
         for k, (t, n) in enumerate(timed):
-            redraw(t)
+            redraw(t, n)
             ev[k][0].record(stream)
             fire(t, n)
             ev[k][1].record(stream)
@@ -385,8 +403,10 @@ def main():
                                         "MT19937-64 seed 20100+gait",
                        "sharding": "gaits by contiguous index range, one RCCL broadcast of the model block",
                        "launch": ("one launch per tick (wg_mpc_tick_batch_dev)" if args.per_tick_launch else
-                                  "one launch per stretch of constant references (wg_mpc_run_batch_dev, device-side work "
-                                  "queue): %d launches, up to %d ticks each" % (len(timed), ticks_per_launch))},
+                                  ("one launch per stretch of constant references (wg_mpc_run_batch_dev, device-side work "
+                                   "queue): %d launches, up to %d ticks each" if args.no_staged_refs else
+                                   "velocity references of every stretch staged on the device (wg_mpc_run_sched_dev, device-side "
+                                   "work queue): %d launch(es), up to %d ticks each") % (len(timed), ticks_per_launch))},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": "wg_mpc_tick_kernel" if args.per_tick_launch else "wg_mpc_run_xcd_kernel",

@@ -280,6 +280,14 @@ int wg_mpc_tick_batch_dev(int B, wg_gait_state_t *states, wg_tick_out_t *outs, i
  * a time (launches on one stream are fine -- they run one after the other). */
 int wg_mpc_run_batch_dev(int B, wg_gait_state_t *states, int n_ticks, int advance_calls, wg_tick_out_t *outs, int *diag,
                          void *hip_stream);
+/* The same with the velocity references staged ahead: before tick t = 0, period, 2 period, ... of the launch, gait g's
+ * reference becomes vref_sched[(t / period) * 3 B + 3 g + {0, 1, 2}] (DEVICE pointer, ceil(n_ticks / period) x B x 3
+ * doubles) -- exactly what a loop of { wg_mpc_set_velref_dev; wg_mpc_run_batch_dev(period ticks) } does, bit for bit, in one
+ * launch: the batch does not drain at every change of the references.  The batched form of a caller that issues
+ * ":setVelReference" / setVelocityReference (patterngeneratorinterface.hh:291-293, ZMPVelocityReferencedQP.hh:103-114)
+ * every `period` ticks of the control loop.  period >= 1; vref_sched == NULL: wg_mpc_run_batch_dev. */
+int wg_mpc_run_sched_dev(int B, wg_gait_state_t *states, int n_ticks, int advance_calls, const double *vref_sched,
+                         int period, wg_tick_out_t *outs, int *diag, void *hip_stream);
 /* NewVelRef_ <- (vx, vy, vyaw) for every gait (":setVelReference", ZMPVelocityReferencedQP.hh:103-114);
  * vref = B x 3 doubles, DEVICE pointers. */
 int wg_mpc_set_velref_dev(int B, wg_gait_state_t *states, const double *vref, void *hip_stream);
@@ -565,6 +573,8 @@ int wg_mpc_tick_batch_dev_ctx(wg_ctx_t *ctx, int B, wg_gait_state_t *states, wg_
                               int advance_calls, int *hist, int hist_cap, int *hist_len, void *hip_stream);
 int wg_mpc_run_batch_dev_ctx(wg_ctx_t *ctx, int B, wg_gait_state_t *states, int n_ticks, int advance_calls,
                              wg_tick_out_t *outs, int *diag, void *hip_stream);
+int wg_mpc_run_sched_dev_ctx(wg_ctx_t *ctx, int B, wg_gait_state_t *states, int n_ticks, int advance_calls,
+                             const double *vref_sched, int period, wg_tick_out_t *outs, int *diag, void *hip_stream);
 int wg_mpc_tick_batch_ctx(wg_ctx_t *ctx, int B, wg_gait_state_t *states, wg_tick_out_t *outs, int *diag,
                           int advance_calls, int *hist, int hist_cap, int *hist_len);
 int wg_mpc_set_velref_dev_ctx(wg_ctx_t *ctx, int B, wg_gait_state_t *states, const double *vref, void *hip_stream);

@@ -612,7 +612,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NH == -1 ? W
     int B, int n_ticks, const wg_model_t *__restrict__ model_p, const wg::TickTables *__restrict__ tb_p,
     wg_gait_state_t *__restrict__ states_p, wg_tick_out_t *__restrict__ outs_p, int *__restrict__ diag_p, int advance_calls,
     wg_xrun_ctl *__restrict__ ctl_p, unsigned long long *__restrict__ rings_p, int cap, int *__restrict__ done_p,
-    unsigned ql_bytes, double *zscratch, unsigned zslot) {
+    unsigned ql_bytes, double *zscratch, unsigned zslot, const double *__restrict__ vsched, int vperiod) {
   extern __shared__ __attribute__((aligned(16))) double wg_lds[];
   unsigned fresh_gone = 0;                                 // bit y: range y was seen exhausted (the counters only grow)
   for (;;) {
@@ -660,6 +660,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NH == -1 ? W
     }
     g = wg::uni(g); t = wg::uni(t); fresh_gone = (unsigned)wg::uni((int)fresh_gone);
     if (g < 0) break;
+    if (vsched && t % vperiod == 0) {                      // staged references: what wg_set_velref_kernel writes between launches
+      if (lane < 3) states[g].vref[lane] = vsched[((size_t)(t / vperiod) * B + g) * 3 + lane];
+      xrun_stores_done();                                  // mpc_tick reads the state back from L2
+      WG_WSYNC();
+    }
     if (advance_calls > 0) {
       if (lane == 0) {
         double c = __hip_atomic_load(&states[g].clock, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -809,10 +814,28 @@ int wg_mpc_tick_batch_dev_ctx(wg_ctx_t *ctx, int B, wg_gait_state_t *states, wg_
 }
 
 int wg_mpc_run_batch_dev_ctx(wg_ctx_t *ctx, int B, wg_gait_state_t *states, int n_ticks, int advance_calls, wg_tick_out_t *outs, int *diag, void *hip_stream) {
+  return wg_mpc_run_sched_dev_ctx(ctx, B, states, n_ticks, advance_calls, nullptr, 1, outs, diag, hip_stream);
+}
+
+int wg_mpc_run_sched_dev_ctx(wg_ctx_t *ctx, int B, wg_gait_state_t *states, int n_ticks, int advance_calls, const double *vref_sched, int period, wg_tick_out_t *outs, int *diag, void *hip_stream) {
   if (int rc = use_ctx(ctx)) return rc;
   if (!ctx->model_set) return fail(WG_ERR_BAD_ARG, "wg_mpc_configure() has not been called on this context");
-  if (B < 0 || n_ticks < 0 || !states) return fail(WG_ERR_BAD_ARG, "bad arguments");
+  if (B < 0 || n_ticks < 0 || !states || period < 1) return fail(WG_ERR_BAD_ARG, "bad arguments");
   if (B == 0 || n_ticks == 0) return WG_OK;
+  if (vref_sched) {
+    bool xcd = true;
+    if (const char *e = getenv("WG_RUN_QUEUE")) xcd = e[0] != 'g';
+    if (!xcd) {                                      // the device-wide queue of round 1 has no staged form: one launch per stretch
+      for (int t = 0; t < n_ticks; t += period) {
+        const int n = n_ticks - t < period ? n_ticks - t : period;
+        if (int rc = wg_mpc_set_velref_dev_ctx(ctx, B, states, vref_sched + (size_t)(t / period) * B * 3, hip_stream)) return rc;
+        if (int rc = wg_mpc_run_sched_dev_ctx(ctx, B, states, n, advance_calls, nullptr, 1, outs ? outs + (size_t)t * B : nullptr,
+                                              diag ? diag + (size_t)t * B * 6 : nullptr, hip_stream))
+          return rc;
+      }
+      return WG_OK;
+    }
+  }
   if ((long long)B * n_ticks > 0x3fffffffLL) return fail(WG_ERR_TOO_LARGE, "B * n_ticks = %lld work items", (long long)B * n_ticks);
   const int total = B * n_ticks;
   hipStream_t st = reinterpret_cast<hipStream_t>(hip_stream);
@@ -866,13 +889,13 @@ int wg_mpc_run_batch_dev_ctx(wg_ctx_t *ctx, int B, wg_gait_state_t *states, int 
   if (xcd_mode) {
     if (view == 16)
       hipLaunchKernelGGL(wg_mpc_run_xcd_kernel<16>, dim3(grid), dim3(64), lds, st, B, n_ticks, ctx->model_dev, ctx->tables_dev, states,
-                         outs, diag, advance_calls, xctl, xrings, cap, xdone, (unsigned)qlb, zs, (unsigned)zslot);
+                         outs, diag, advance_calls, xctl, xrings, cap, xdone, (unsigned)qlb, zs, (unsigned)zslot, vref_sched, period);
     else if (view == 0)
       hipLaunchKernelGGL(wg_mpc_run_xcd_kernel<0>, dim3(grid), dim3(64), lds, st, B, n_ticks, ctx->model_dev, ctx->tables_dev, states,
-                         outs, diag, advance_calls, xctl, xrings, cap, xdone, (unsigned)qlb, zs, (unsigned)zslot);
+                         outs, diag, advance_calls, xctl, xrings, cap, xdone, (unsigned)qlb, zs, (unsigned)zslot, vref_sched, period);
     else
       hipLaunchKernelGGL(wg_mpc_run_xcd_kernel<-1>, dim3(grid), dim3(64), lds, st, B, n_ticks, ctx->model_dev, ctx->tables_dev, states,
-                         outs, diag, advance_calls, xctl, xrings, cap, xdone, (unsigned)qlb, zs, (unsigned)zslot);
+                         outs, diag, advance_calls, xctl, xrings, cap, xdone, (unsigned)qlb, zs, (unsigned)zslot, vref_sched, period);
   } else if (view == 16)
     hipLaunchKernelGGL(wg_mpc_run_kernel<16>, dim3(grid), dim3(64), lds, st, B, n_ticks, ctx->model_dev, ctx->tables_dev, states, outs,
                        diag, advance_calls, q, ring, done, (unsigned)qlb, zs, (unsigned)zslot);
@@ -1509,6 +1532,12 @@ int wg_mpc_tick_batch_dev(int B, wg_gait_state_t *states, wg_tick_out_t *outs, i
   wg_ctx *c = nullptr;
   if (int rc = default_ctx(&c)) return rc;
   return wg_mpc_tick_batch_dev_ctx(c, B, states, outs, diag, advance_calls, hist, hist_cap, hist_len, hip_stream);
+}
+
+int wg_mpc_run_sched_dev(int B, wg_gait_state_t *states, int n_ticks, int advance_calls, const double *vref_sched, int period, wg_tick_out_t *outs, int *diag, void *hip_stream) {
+  wg_ctx *c = nullptr;
+  if (int rc = default_ctx(&c)) return rc;
+  return wg_mpc_run_sched_dev_ctx(c, B, states, n_ticks, advance_calls, vref_sched, period, outs, diag, hip_stream);
 }
 
 int wg_mpc_run_batch_dev(int B, wg_gait_state_t *states, int n_ticks, int advance_calls, wg_tick_out_t *outs, int *diag, void *hip_stream) {

@@ -1,5 +1,5 @@
 // fleet_bench.cpp -- the fleet path from plain C++ through the C ABI (no Python, no PyTorch): B gaits per GPU resident in
-// device memory, velocity references redrawn every 50 ticks, ticks advanced with wg_mpc_run_batch_dev (device-side work
+// device memory, velocity references redrawn every 50 ticks and staged on the device, ticks advanced with wg_mpc_run_sched_dev (device-side work
 // queue) or, with --per-tick, one wg_mpc_tick_batch_dev launch per tick.  Same workload as bench.py (std::mt19937_64
 // seeded 20100 + GLOBAL gait index; bench.py draws the same distribution through numpy).
 //
@@ -162,17 +162,23 @@ int main(int argc, char **argv) {
   wg_gait_state_t *d_states = nullptr; double *d_vref = nullptr; int *d_diag = nullptr;
   CHECK_HIP(hipMalloc((void **)&d_states, sizeof(wg_gait_state_t) * Bl));
   CHECK_HIP(hipMalloc((void **)&d_vref, sizeof(double) * vref.size()));
-  CHECK_HIP(hipMalloc((void **)&d_diag, sizeof(int) * 6 * (size_t)Bl * REDRAW));
+  CHECK_HIP(hipMalloc((void **)&d_diag, sizeof(int) * 6 * (size_t)Bl * (size_t)(W > K ? W : K)));   // tick-major, one launch
   CHECK_HIP(hipMemcpy(d_states, host.data(), sizeof(wg_gait_state_t) * Bl, hipMemcpyHostToDevice));
   CHECK_HIP(hipMemcpy(d_vref, vref.data(), sizeof(double) * vref.size(), hipMemcpyHostToDevice));
 
   auto advance = [&](int t0, int t1) -> int {           // ticks [t0, t1)
     for (int t = t0; t < t1;) {
-      if (t % REDRAW == 0) CHECK_WG(wg_mpc_set_velref_dev_ctx(ctx, Bl, d_states, d_vref + (size_t)(t / REDRAW) * Bl * 3, st));
       const int adv = t == 0 ? 1 : (t == 1 ? 19 : 20);
+      const double *refs = d_vref + (size_t)(t / REDRAW) * Bl * 3;
+      // a launch that starts where the references change runs to t1 with the references of all its stretches staged
+      // (wg_mpc_run_sched_dev); any other ends where they change next
+      const bool staged = t >= 2 && !per_tick && t % REDRAW == 0 && t1 - t > 1;
+      if (t % REDRAW == 0 && !staged) CHECK_WG(wg_mpc_set_velref_dev_ctx(ctx, Bl, d_states, refs, st));
       int n = 1;
-      if (t >= 2 && !per_tick) { n = (t / REDRAW + 1) * REDRAW - t; if (t + n > t1) n = t1 - t; }
-      if (n == 1) CHECK_WG(wg_mpc_tick_batch_dev_ctx(ctx, Bl, d_states, nullptr, d_diag, adv, nullptr, 0, nullptr, st));
+      if (staged) n = t1 - t;
+      else if (t >= 2 && !per_tick) { n = (t / REDRAW + 1) * REDRAW - t; if (t + n > t1) n = t1 - t; }
+      if (staged) CHECK_WG(wg_mpc_run_sched_dev_ctx(ctx, Bl, d_states, n, adv, refs, REDRAW, nullptr, d_diag, st));
+      else if (n == 1) CHECK_WG(wg_mpc_tick_batch_dev_ctx(ctx, Bl, d_states, nullptr, d_diag, adv, nullptr, 0, nullptr, st));
       else CHECK_WG(wg_mpc_run_batch_dev_ctx(ctx, Bl, d_states, n, adv, nullptr, d_diag, st));
       t += n;
     }

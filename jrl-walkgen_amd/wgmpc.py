@@ -89,6 +89,8 @@ def lib():
         _lib.wg_mpc_tick_batch_dev.argtypes = _lib.wg_mpc_tick_batch.argtypes + [C.c_void_p]
         _lib.wg_mpc_set_velref_dev.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
         _lib.wg_mpc_run_batch_dev.argtypes = [C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        _lib.wg_mpc_run_sched_dev.argtypes = [C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
+                                              C.c_void_p]
         _lib.wg_pldp_lds_bytes.restype = C.c_size_t
         _lib.wg_pldp_configure.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
         _lib.wg_pldp_solve_batch.argtypes = [C.c_int, C.c_int] + [C.c_void_p] * 9 + [C.c_int] + [C.c_void_p] * 6
@@ -127,7 +129,7 @@ def lib():
 
 
 CTX_ENTRY_POINTS = ("wg_qp_solve_batch", "wg_qp_solve_batch_dev", "wg_mpc_configure", "wg_mpc_tick_lds_bytes", "wg_mpc_tick_batch",
-                    "wg_mpc_tick_batch_dev", "wg_mpc_run_batch_dev", "wg_mpc_set_velref_dev", "wg_pldp_configure",
+                    "wg_mpc_tick_batch_dev", "wg_mpc_run_batch_dev", "wg_mpc_run_sched_dev", "wg_mpc_set_velref_dev", "wg_pldp_configure",
                     "wg_pldp_solve_batch", "wg_pldp_solve_batch_dev", "wg_dimitrov_configure", "wg_dimitrov_get_constants",
                     "wg_dimitrov_tick_batch", "wg_dimitrov_tick_batch_dev", "wg_preview_configure", "wg_preview_window",
                     "wg_preview_run_batch", "wg_preview_run_batch_dev", "wg_gramian_batch", "wg_gramian_batch_dev",
@@ -192,6 +194,11 @@ class Context:
 
     def mpc_run_batch_dev(self, B, states_ptr, n_ticks, advance_calls=20, outs_ptr=None, diag_ptr=None, stream=None):
         _check(self.call("wg_mpc_run_batch_dev", B, states_ptr, int(n_ticks), int(advance_calls), outs_ptr, diag_ptr, stream))
+
+    def mpc_run_sched_dev(self, B, states_ptr, n_ticks, vref_sched_ptr, period, advance_calls=20, outs_ptr=None, diag_ptr=None,
+                          stream=None):
+        _check(self.call("wg_mpc_run_sched_dev", B, states_ptr, int(n_ticks), int(advance_calls), vref_sched_ptr, int(period),
+                         outs_ptr, diag_ptr, stream))
 
     def mpc_set_velref_dev(self, B, states_ptr, vref_ptr, stream=None):
         v = lambda p: C.c_void_p(p) if p else None
@@ -316,6 +323,13 @@ def mpc_tick_batch_dev(B, states_ptr, outs_ptr=None, diag_ptr=None, advance_call
 def mpc_run_batch_dev(B, states_ptr, n_ticks, advance_calls=20, outs_ptr=None, diag_ptr=None, stream=None):
     """n_ticks ticks of every gait in one launch (device-side work queue); device pointers as integers."""
     _check(lib().wg_mpc_run_batch_dev(B, states_ptr, int(n_ticks), int(advance_calls), outs_ptr, diag_ptr, stream))
+
+
+def mpc_run_sched_dev(B, states_ptr, n_ticks, vref_sched_ptr, period, advance_calls=20, outs_ptr=None, diag_ptr=None, stream=None):
+    """mpc_run_batch_dev with the velocity references staged ahead: block t // period of vref_sched (ceil(n_ticks / period)
+    x B x 3 doubles on the device) takes effect before tick t = 0, period, 2 period, ... of the launch."""
+    _check(lib().wg_mpc_run_sched_dev(B, states_ptr, int(n_ticks), int(advance_calls), vref_sched_ptr, int(period), outs_ptr,
+                                      diag_ptr, stream))
 
 
 def mpc_set_velref_dev(B, states_ptr, vref_ptr, stream=None):

@@ -22,13 +22,18 @@ def test_launch_plan_covers_ticks_and_respects_redraws():
     b = _bench()
     for t0, t1 in ((0, 50), (50, 250), (20, 220), (0, 3), (7, 8), (49, 51), (100, 100)):
         for per_tick in (False, True):
-            plan = b.launch_plan(t0, t1, per_tick)
-            ticks = [t for s, n in plan for t in range(s, s + n)]
-            assert ticks == list(range(t0, t1))
-            for s, n in plan:
-                assert n >= 1 and s // b.REDRAW_TICKS == (s + n - 1) // b.REDRAW_TICKS      # one reference segment
-                assert n == 1 or (s >= 2 and not per_tick)
-    assert b.launch_plan(50, 250) == [(50, 50), (100, 50), (150, 50), (200, 50)]
+            for staged in (False, True):
+                plan = b.launch_plan(t0, t1, per_tick, staged=staged)
+                ticks = [t for s, n in plan for t in range(s, s + n)]
+                assert ticks == list(range(t0, t1))
+                for s, n in plan:
+                    one_segment = s // b.REDRAW_TICKS == (s + n - 1) // b.REDRAW_TICKS
+                    # a launch crosses a change of the references only if it starts on one (then they are staged on the device)
+                    assert n >= 1 and (one_segment or (staged and s % b.REDRAW_TICKS == 0))
+                    assert n == 1 or (s >= 2 and not per_tick)
+    assert b.launch_plan(50, 250, staged=False) == [(50, 50), (100, 50), (150, 50), (200, 50)]
+    assert b.launch_plan(50, 250) == [(50, 200)]
+    assert b.launch_plan(20, 220) == [(20, 30), (50, 170)]
     assert b.launch_plan(0, 50)[:3] == [(0, 1), (1, 1), (2, 48)]
 
 

@@ -97,3 +97,47 @@ def test_run_batch_dense_view_and_arguments():
         assert lib.wg_mpc_run_batch_dev(B, b.data_ptr(), 0, adv, None, None, None) == 0     # nothing to do
     finally:
         wg.mpc_configure(wg.model_defaults())
+
+
+@pytest.mark.parametrize("N,B,T,period,queue", [(16, 700, 37, 10, "xcd"), (16, 2500, 23, 23, "xcd"), (16, 64, 9, 4, "global"),
+                                              (32, 96, 11, 5, "xcd")])
+def test_staged_references_equal_a_loop_of_set_velref_and_run(N, B, T, period, queue, monkeypatch):
+    """wg_mpc_run_sched_dev: the velocity references of every stretch staged on the device, ONE launch for all the ticks --
+    the same bytes (states, diagnostics, outputs) as wg_mpc_set_velref_dev + wg_mpc_run_batch_dev per stretch.  Also through
+    the device-wide queue (which takes the per-stretch path inside the library) and the element view (N = 32)."""
+    wg.init(0)
+    if queue == "global":
+        monkeypatch.setenv("WG_RUN_QUEUE", "global")
+    model = wg.model_defaults(); model.N = N
+    wg.mpc_configure(model)
+    try:
+        rng = np.random.default_rng(N * 1000 + B + T)
+        host = _start(model, B, rng)
+        adv = int(round(model.T / model.Tctrl))
+        a = _dev(host); b = _dev(host)
+        for st in (a, b):
+            wg.mpc_tick_batch_dev(B, st.data_ptr(), None, None, 1)
+            wg.mpc_tick_batch_dev(B, st.data_ptr(), None, None, adv - 1)
+        nblk = (T + period - 1) // period
+        sched = torch.from_numpy(np.stack([rng.uniform(-0.1, 0.3, (nblk, B)), rng.uniform(-0.1, 0.1, (nblk, B)),
+                                           rng.uniform(-0.2, 0.2, (nblk, B))], axis=2)).cuda().contiguous()
+        osz = C.sizeof(wg.TickOut)
+        da = torch.zeros(T, B, 6, dtype=torch.int32, device="cuda"); db = torch.zeros_like(da)
+        oa = torch.zeros(T, B, osz, dtype=torch.uint8, device="cuda"); ob = torch.zeros_like(oa)
+        for k in range(nblk):
+            t0 = k * period; n = min(period, T - t0)
+            wg.mpc_set_velref_dev(B, a.data_ptr(), sched[k].data_ptr())
+            wg.mpc_run_batch_dev(B, a.data_ptr(), n, adv, oa[t0].data_ptr(), da[t0].data_ptr())
+        wg.mpc_run_sched_dev(B, b.data_ptr(), T, sched.data_ptr(), period, adv, ob.data_ptr(), db.data_ptr())
+        torch.cuda.synchronize()
+        assert torch.equal(da, db) and torch.equal(oa, ob) and torch.equal(a, b)
+        assert int(da[:, :, 0].abs().sum()) == 0                               # every QP solved
+        # the references did change: the last block's values are in the states
+        st = np.frombuffer(b.cpu().numpy().tobytes(), dtype=np.uint8).reshape(B, -1)
+        off = wg.GaitState.vref.offset
+        got = np.frombuffer(st[:, off:off + 24].tobytes(), dtype=np.float64).reshape(B, 3)
+        assert np.array_equal(got, sched[nblk - 1].cpu().numpy())
+        lib = wg.lib()
+        assert lib.wg_mpc_run_sched_dev(B, b.data_ptr(), 1, adv, sched.data_ptr(), 0, None, None, None) == -2   # period < 1
+    finally:
+        wg.mpc_configure(wg.model_defaults())

@@ -14,10 +14,10 @@ tag = sys.argv[1] if len(sys.argv) > 1 else "round2"
 B, W, K, REDRAW = 4096, 50, 200, 50
 
 
-def launch_plan(t0, t1, per_tick=False, redraw=REDRAW):            # bench.launch_plan (kept in step by tests/test_bench_plan.py)
+def launch_plan(t0, t1, per_tick=False, redraw=REDRAW):            # bench.launch_plan (staged references), kept in step by hand
     out, t = [], t0
     while t < t1:
-        n = 1 if (t < 2 or per_tick) else min(t1, (t // redraw + 1) * redraw) - t
+        n = 1 if (t < 2 or per_tick) else (t1 - t if t % redraw == 0 else min(t1, (t // redraw + 1) * redraw) - t)
         out.append((t, n)); t += n
     return out
 
@@ -67,13 +67,15 @@ out = {"tag": tag,
               "--no-config5` (tools/prof_round.sh): kernel trace + stats, then the counters in separate --pmc passes (FETCH_SIZE and "
               "WRITE_SIZE each in its own).  Units and gfx950 correction per MI355X_MICROARCH.md (HBM / rocprofv3): KiB x 1024, "
               "FETCH_SIZE doubled.  Totals over ALL launches of the kernel divided by the gait-ticks those launches ran "
-              "(B = 4096; multi-tick: one 48-tick and four 50-tick launches = 248 ticks; per-tick: 250 launches).  valu_busy = "
+              "(B = 4096; multi-tick: one 48-tick launch and one 200-tick launch with the references staged = 248 ticks; the "
+              "device-wide queue takes one launch per stretch: 48 + 4 x 50; per-tick: 250 launches).  valu_busy = "
               "2 waves per SIMD x SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES."}
 run_ticks = sum(n for _, n in launch_plan(0, W + K) if n > 1)
 n_run = sum(1 for _, n in launch_plan(0, W + K) if n > 1)
+plan_txt = ", ".join(str(n) for _, n in launch_plan(0, W + K) if n > 1)
 if "tick" in summ:
     out["run_kernel"] = per_gait_tick(summ["tick"], "wg_mpc_run_xcd_kernel<16>", B * run_ticks)
-    out["run_kernel"]["ticks_per_launch"] = "48, 50, 50, 50, 50"
+    out["run_kernel"]["ticks_per_launch"] = plan_txt
     assert out["run_kernel"]["launches"] == n_run, (out["run_kernel"]["launches"], n_run)
 if "tickg" in summ:
     out["run_kernel_device_wide_queue"] = per_gait_tick(summ["tickg"], "wg_mpc_run_kernel<16>", B * run_ticks)
@@ -92,7 +94,7 @@ Everything named `{tag}_*` was produced by ONE run of `tools/prof_round.sh` on a
 
 | files | command profiled | what to read there |
 |---|---|---|
-| `{tag}_tick_*` | `python3 bench.py --steps 200 --warmup 50 --no-cpu-baseline --no-parity --no-per-tick-leg --no-config5` | the benchmarked kernel `wg_mpc_run_xcd_kernel<16>` alone: B = 4096, launches of 48, 50, 50, 50, 50 ticks (plus the two single-tick launches of the control loop's first ticks under their own kernel name); kernel-trace stats and the PMC passes |
+| `{tag}_tick_*` | `python3 bench.py --steps 200 --warmup 50 --no-cpu-baseline --no-parity --no-per-tick-leg --no-config5` | the benchmarked kernel `wg_mpc_run_xcd_kernel<16>` alone: B = 4096, one launch of 48 ticks (warm-up) and one of 200 ticks with the velocity references of its four stretches staged on the device (plus the two single-tick launches of the control loop's first ticks under their own kernel name); kernel-trace stats and the PMC passes |
 | `{tag}_tickg_*` | the same with `WG_RUN_QUEUE=global` | the device-wide queue of round 1 (`wg_mpc_run_kernel<16>`): the L2 write-back traffic the XCD-local hand-over removed |
 | `{tag}_pertick_*` | the same with `--per-tick-launch` | `wg_mpc_tick_kernel<16>`, 250 launches of one tick |
 | `{tag}_config5_*` | `PN=32 PB=8192 PT=50 python3 tools/probe_run.py` | BASELINE configs[4]'s size: N = 32, B = 8192 (element view), per-tick and multi-tick launches |
