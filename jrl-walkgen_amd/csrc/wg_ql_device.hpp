@@ -1289,13 +1289,28 @@ __device__ __forceinline__ QlResult ql_solve(const QlView &q, P &prob, double vs
       if constexpr (P::kRowOps) {
         // structured rows: every lane of a pass walks its row the same number of steps, both sums at once (row_dot_both);
         // the tests below are the reference's, in its order
-        for (int k0 = 1; k0 < m; k0 += 64) {                 // row 0 is the all-zero dummy row: never a candidate, not walked
-          const int k = k0 + lane;
+        // wa, b and the row tables may live in global memory (L2): the operands of every pass are requested before the first
+        // pass starts (m <= 1 + 64 kScanPasses rows, checked where the view is chosen)
+        constexpr int kScanPasses = 3;
+        double wak_p[kScanPasses], bk_p[kScanPasses], ra_p[kScanPasses], rb_p[kScanPasses];
+        int rk_p[kScanPasses];
+#pragma unroll
+        for (int pp = 0; pp < kScanPasses; ++pp) {
+          const int k = 1 + 64 * pp + lane;
           const bool in = k < m;
           const int kc = in ? k : 0;                          // surplus lanes walk the all-zero dummy row
-          const double wak = in ? q.wa[kc] : 0.0, bk = q.b[kc];
+          wak_p[pp] = in ? q.wa[kc] : 0.0; bk_p[pp] = q.b[kc];
+          ra_p[pp] = prob.rowA[kc]; rb_p[pp] = prob.rowB[kc]; rk_p[pp] = prob.rowK[kc];
+        }
+#pragma unroll
+        for (int pp = 0; pp < kScanPasses; ++pp) {            // row 0 is the all-zero dummy row: never a candidate, not walked
+          const int k0 = 1 + 64 * pp;
+          if (k0 >= m) break;
+          const int k = k0 + lane;
+          const int kc = k < m ? k : 0;
+          const double wak = wak_p[pp], bk = bk_p[pp];
           double sum = -bk, temp = fabs(bk);
-          prob.row_dot_both(q, kc, k0, q.x, sum, temp);
+          prob.row_dot_both(q, kc, k0, ra_p[pp], rb_p[pp], rk_p[pp], q.x, sum, temp);
           if (wak <= 0.0) continue;
           double sumx = -sum * wak;
           if (k + 1 <= me) sumx = fabs(sumx);

@@ -712,9 +712,13 @@ struct HerdtElemProb {
   // ahead of the two add chains, and a lane whose row ends earlier (or is no CoP / foot row at all) walks on over exact-zero
   // coefficients (u[-1] = 0.0 in LDS, or a zeroed edge coefficient): its extra terms are +-0.0, which change neither a
   // non-zero sum nor any decision taken on a zero one (sumx = -(+-0) wak is not > 0 either way).
-  __device__ __forceinline__ void row_dot_both(const QlView &, int k, int k0, const double *v, double &sum, double &asum) const {
-    const double a = rowA[k], b = rowB[k];
-    const int kk = rowK[k];
+  __device__ __forceinline__ void row_dot_both(const QlView &q, int k, int k0, const double *v, double &sum, double &asum) const {
+    row_dot_both(q, k, k0, rowA[k], rowB[k], rowK[k], v, sum, asum);
+  }
+  // the same with the row's (a, b, instant) already in registers: the row tables live in global memory (L2), and the scan
+  // fetches the parameters of all its passes before the first one
+  __device__ __forceinline__ void row_dot_both(const QlView &, int k, int k0, double a, double b, int kk, const double *v, double &sum,
+                                               double &asum) const {
     if (k0 <= 4 * N) {                                      // the pass holds CoP rows (wave-uniform)
       const bool cop = k >= 1 && k <= 4 * N;
       const int r = cop ? kk : -1;
