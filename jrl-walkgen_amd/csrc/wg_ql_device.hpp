@@ -363,6 +363,35 @@ __device__ __forceinline__ void zt_times_ww(const QlView &q, double *s, int lane
   WG_WSYNC();
 }
 
+// r0 = sum_{j0 <= j < j1} Z(i0, j) * s[j], r1 the same for row i1 (j ascending, from +0.0): rows i0 = lane and i1 = lane + 64
+// of a matrix of 64 < n <= 128 rows in ONE pass, the entries of eight columns requested together ahead of the two add chains
+// (with Z in global memory an exposed entry is an L2 round trip; one register set only: this sits where many values are live).
+// Surplus lanes shadow a real row.
+__device__ __forceinline__ void z_rows_times(const QlView &q, const double *s, int j0, int j1, int lane, double &r0, double &r1) {
+  const int n = q.n, ldz = q.ldz;
+  const int i0 = lane < n ? lane : n - 1, i1 = lane + 64 < n ? lane + 64 : i0;
+  const double *z0 = q.Z + i0, *z1 = q.Z + i1;
+  constexpr int kG = 8;
+  double a0 = 0.0, a1 = 0.0;
+  int j = j0;
+  for (; j + kG <= j1; j += kG) {
+    double u0[kG], u1[kG], w[kG];
+#pragma unroll
+    for (int e = 0; e < kG; ++e) { u0[e] = z0[(j + e) * ldz]; u1[e] = z1[(j + e) * ldz]; w[e] = s[j + e]; }
+#pragma unroll
+    for (int e = 0; e < kG; ++e) { a0 += u0[e] * w[e]; a1 += u1[e] * w[e]; }
+  }
+  if (j < j1) {                                             // the odd columns: requested together (clamped), added in order
+    double u0[kG - 1], u1[kG - 1];
+#pragma unroll
+    for (int e = 0; e < kG - 1; ++e) { const int jj = j + e < j1 ? j + e : j1 - 1; u0[e] = z0[jj * ldz]; u1[e] = z1[jj * ldz]; }
+#pragma unroll
+    for (int e = 0; e < kG - 1; ++e)
+      if (j + e < j1) { const double w = s[j + e]; a0 += u0[e] * w; a1 += u1[e] * w; }
+  }
+  r0 = a0; r1 = a1;
+}
+
 // ww[0..nact) = R^-1 s[0..nact)   (qld.cpp:1824-1851): rows from the bottom up, inner sums ascending in j.
 // nact <= 64: lane j keeps ww[j] in a register; row i's products R(i,j)*ww[j] are formed lane-parallel and
 // summed in index order through v_readlane (no LDS round trip on the dependent chain).
@@ -659,8 +688,15 @@ __device__ __forceinline__ double xmag_sum(const QlView &q, const P &prob, doubl
   }
   WG_WSYNC();
   double sum = 0.0;
-  WG_UNROLL
-  for (int i = 0; i < n; ++i) sum += q.sc3[i];
+  int i = 0;
+  for (; i + 8 <= n; i += 8) {                              // loads in groups of eight ahead of the add chain
+    double t[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) t[e] = q.sc3[i + e];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) sum += t[e];
+  }
+  for (; i < n; ++i) sum += q.sc3[i];
   return sum;
 }
 
@@ -1191,6 +1227,12 @@ __device__ __forceinline__ QlResult ql_solve(const QlView &q, P &prob, double vs
           }
         }
         PT(26);
+        if (P::kNM == 0 && n > 64 && n <= 128) {
+          double r0, r1;
+          z_rows_times(q, s, 0, nact, lane, r0, r1);
+          q.x[lane] += r0; q.sc0[lane] = r0;
+          if (lane + 64 < n) { q.x[lane + 64] += r1; q.sc0[lane + 64] = r1; }
+        } else
         for (int i = lane; i < n; i += 64) {
           double sum = 0.0;
           WG_UNROLL
@@ -1214,6 +1256,12 @@ __device__ __forceinline__ QlResult ql_solve(const QlView &q, P &prob, double vs
       zt_times_ww<P::kNM>(q, s, lane);                      // :1175-1177
       PT(5);
       if (nact != n) {                                      // :1186-1201
+        if (P::kNM == 0 && n > 64 && n <= 128) {
+          double r0, r1;
+          z_rows_times(q, s, nact, n, lane, r0, r1);
+          q.x[lane] -= r0;
+          if (lane + 64 < n) q.x[lane + 64] -= r1;
+        } else
         for (int i = lane; i < n; i += 64) {
           double sum = 0.0;
           WG_UNROLL
