@@ -391,28 +391,31 @@ inline bool tick16_ext(int view) { return view == 16; }
 inline size_t tick_z_slot_doubles(const wg_model_t &m, int view) {
   const size_t n = (size_t)tick_max_n(m), mm = (size_t)tick_max_m(m);
   if (view == 16) return (n + 2 * mm) + n * wg::kGvLd;       // wa | b | Gv
-  // element view: Z | wa | b | Gv | rowA | rowB | rowK (mpc_tick<-1>)
-  return n * (n | 1) + (n + 2 * mm) + n * wg::kGvLdElem + 2 * mm + (mm + 1) / 2 + 2;
+  // element view: Z | wa | b | Gv | rowA | rowB | rowK | gd | d | wd | wx (mpc_tick<-1>)
+  return n * (n | 1) + (n + 2 * mm) + n * wg::kGvLdElem + 2 * mm + (mm + 1) / 2 + 2 + 4 * n;
 }
 inline size_t tick_lds_for(const wg_model_t &m, int view) {
   const bool ext = tick16_ext(view) || tick_z_global(view);        // wa, b, Gv (element view: the rows too) in the global slot
   const size_t ql = (wg::QlDims(tick_max_n(m), tick_max_m(m), tick_max_m(m), view == 0, true, 0, view == 0, !tick_z_global(view),
-                                !ext).bytes() + 15) & ~(size_t)15;
+                                !ext, view != -1).bytes() + 15) & ~(size_t)15;
   const int gvld = view == 16 ? wg::kGvLd : (view == -1 ? wg::kGvLdElem : 0);
-  return ql + wg::TickLds::bytes(m.N, tick_smax(m), gvld, view == 16, !ext, view != -1);
+  return ql + wg::TickLds::bytes(m.N, tick_smax(m), gvld, view == 16, !ext, view != -1, view == -1);
 }
 inline int tick_view(const wg_model_t &m) {
   if (tick_compact(m)) return 16;
   // the element view parks the pre-solve scratch on Z (n >= 2N): tiny horizons whose Z is smaller than that stay dense
   // (with Z in global memory the first array of the solver area is R: (2N)(2N+1)/2 + 2N doubles at the least)
-  const bool overlay_fits = wg::TickLds::pre_bytes(m.N, tick_smax(m)) <= (size_t)8 * ((size_t)(2 * m.N) * (2 * m.N + 1) / 2 + 2 * m.N);
+  // (the element view also parks its copy of the state there)
+  const bool overlay_fits = wg::TickLds::pre_bytes(m.N, tick_smax(m)) + sizeof(wg_gait_state_t) + 32 <=
+                            (size_t)8 * ((size_t)(2 * m.N) * (2 * m.N + 1) / 2 + 2 * m.N);
   const char *v = getenv("WG_TICK_VIEW");
   if (v && v[0] == 'e' && overlay_fits) return -1;
   return (tick_lds_for(m, 0) <= 160 * 1024 || !overlay_fits) ? 0 : -1;
 }
 inline size_t tick_ql_bytes(const wg_model_t &m) {
   size_t b = wg::QlDims(tick_max_n(m), tick_max_m(m), tick_max_m(m), tick_view(m) == 0, true, 0, tick_view(m) == 0,
-                        !tick_z_global(tick_view(m)), !(tick16_ext(tick_view(m)) || tick_z_global(tick_view(m)))).bytes();
+                        !tick_z_global(tick_view(m)), !(tick16_ext(tick_view(m)) || tick_z_global(tick_view(m))),
+                        tick_view(m) != -1).bytes();
   return (b + 15) & ~(size_t)15;
 }
 }  // namespace

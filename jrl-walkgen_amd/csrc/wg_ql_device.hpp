@@ -92,14 +92,16 @@ struct QlDims {
                 // Z is the operand that caps the residency; it is streamed lane-parallel, never on a serial chain)
   bool wab_lds; // wa and b held in LDS (false: in a per-block slot of global memory -- they are read lane-parallel once per
                 // iteration, early enough for an L2 round trip to hide; freeing them is what lets an eighth gait onto the CU)
+  bool cold_lds; // d, wd, wx held in LDS (false: in the global slot too -- the gradient, the saved diagonal and the saved
+                 // iterate are read lane-parallel, d once per iteration, the others a few times per solve)
   __host__ __device__ QlDims(int n_, int m_, int mmax_, bool dense_ = true, bool a_lds_ = true, int nsc_ = 0,
-                             bool bounds_ = true, bool z_lds_ = true, bool wab_lds_ = true)
+                             bool bounds_ = true, bool z_lds_ = true, bool wab_lds_ = true, bool cold_lds_ = true)
       : n(n_), m(m_), mmax(mmax_), ldg(n_ | 1), ldz(n_ | 1), lda(mmax_ | 1), dense(dense_), a_lds(a_lds_),
-        nsc(nsc_ > n_ ? nsc_ : n_), bounds(bounds_), z_lds(z_lds_), wab_lds(wab_lds_) {}
+        nsc(nsc_ > n_ ? nsc_ : n_), bounds(bounds_), z_lds(z_lds_), wab_lds(wab_lds_), cold_lds(cold_lds_) {}
   __host__ __device__ int r_len() const { return n * (n + 1) / 2 + n; }
   __host__ __device__ int n_doubles() const {
     return (dense ? n * ldg + (a_lds ? n * lda : 0) : 0) + (z_lds ? n * ldz : 0) + r_len()   // [G, A,] [Z,] R
-           + (bounds ? 8 : 6) * n                   // x d ww wd wx lam [xl xu]
+           + ((bounds ? 8 : 6) - (cold_lds ? 0 : 3)) * n   // x [d] ww [wd wx] lam [xl xu]
            + (wab_lds ? (m + n) + m : 0)            // wa, b (inner)
            + 4 * nsc + 8;                           // scratch + scalar slots
   }
@@ -116,8 +118,10 @@ struct QlView {
   int *iact;
   // kBounds / kWabLds mirror QlDims::bounds / wab_lds at compile time (a run-time choice between an LDS and a global array
   // would make the pointer generic and every access through it a flat_ instruction); ext_wab: [wa (mmax + nmax) | b (mmax)]
-  template <bool kBounds = true, bool kWabLds = true>
-  __device__ __forceinline__ void carve(double *base, const QlDims &D, int me_, double *ext_wab = nullptr, int ext_b_off = 0) {
+  // kColdLds mirrors QlDims::cold_lds: false puts d | wd | wx at ext_cold, ext_cold_ld doubles apart
+  template <bool kBounds = true, bool kWabLds = true, bool kColdLds = true>
+  __device__ __forceinline__ void carve(double *base, const QlDims &D, int me_, double *ext_wab = nullptr, int ext_b_off = 0,
+                                        double *ext_cold = nullptr, int ext_cold_ld = 0) {
     n = D.n; m = D.m; me = me_; mn = D.m + D.n; ldg = D.ldg; ldz = D.ldz; lda = D.lda;
     double *p = base;
     G = nullptr; A = nullptr;
@@ -126,8 +130,8 @@ struct QlView {
     if (D.z_lds) { Z = p; p += n * ldz; }
     R = p; p += D.r_len();
     if (D.dense && D.a_lds) { A = p; p += n * lda; }
-    x = p; p += n;  d = p; p += n;  ww = p; p += n;  wd = p; p += n;
-    wx = p; p += n; lam = p; p += n;
+    if constexpr (kColdLds) { x = p; p += n;  d = p; p += n;  ww = p; p += n;  wd = p; p += n;  wx = p; p += n; lam = p; p += n; }
+    else { x = p; p += n; ww = p; p += n; lam = p; p += n; d = ext_cold; wd = ext_cold + ext_cold_ld; wx = ext_cold + 2 * ext_cold_ld; }
     if constexpr (kBounds) { xl = p; p += n; xu = p; p += n; } else { xl = nullptr; xu = nullptr; }
     if constexpr (kWabLds) { wa = p; p += m + n; b = p; p += m; } else { wa = ext_wab; b = ext_wab + ext_b_off; }
     sc0 = p; p += D.nsc; sc1 = p; p += D.nsc; sc2 = p; p += D.nsc; sc3 = p; p += D.nsc;

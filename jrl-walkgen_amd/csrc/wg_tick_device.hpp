@@ -177,27 +177,30 @@ struct TickLds {
   // view keeps every row's coefficients in registers afterwards) -- they join the pre-solve group
   // gv_lds = false: the border block Gv lives in a per-block slot of global memory (see mpc_tick)
   // rows_lds = false (with rows_presolve = false): rowA / rowB / rowK live in the per-block slot of global memory too
+  // lean = true (element view): the Hessian diagonal gd joins Gv in the global slot and the state copy is parked on the overlay
   __host__ __device__ static size_t bytes(int N, int smax = kSMax, int gvld = 0, bool rows_presolve = false, bool gv_lds = true,
-                                          bool rows_lds = true) {
+                                          bool rows_lds = true, bool lean = false) {
     const int m = 1 + 4 * N + 5 * smax;
     const int nmax = 2 * N + 2 * smax;
     const bool compact = gvld > 0;
     const bool rows_here = !rows_presolve && rows_lds;
-    size_t b = sizeof(Sup) + 8 * (size_t)(kSMax * kSMax + 8 + (rows_here ? 2 * m : 0) + 16 + (compact ? (N + 2) + (gv_lds ? nmax * gvld : 0) + nmax : 0)) +
+    size_t b = sizeof(Sup) + 8 * (size_t)(kSMax * kSMax + 8 + (rows_here ? 2 * m : 0) + 16 +
+                                          (compact ? (N + 2) + (gv_lds ? nmax * gvld : 0) + (lean ? 0 : nmax) : 0)) +
                4 * (size_t)(((N + 1) & ~1) + (rows_here ? ((m + 1) & ~1) : 0)) +
-               (rows_presolve ? 0 : ((sizeof(wg_gait_state_t) + 15) & ~(size_t)15));
+               ((rows_presolve || lean) ? 0 : ((sizeof(wg_gait_state_t) + 15) & ~(size_t)15));
     if (!compact) b += pre_bytes(N, smax);
     return (b + 15) & ~(size_t)15;
   }
   // kExtGv: Gv is ext_gv (global memory); kExtRows: rowA | rowB | rowK are ext_rows (global memory, m doubles each, then m
   // ints) -- decided at compile time so that their accesses are global_ instructions, not flat_
-  template <bool kExtGv = false, bool kExtRows = false>
+  // kLean (element view): gd is ext_gd (global memory) and the state copy sits on the overlay (parked during the solve)
+  template <bool kExtGv = false, bool kExtRows = false, bool kLean = false>
   __device__ __forceinline__ void carve(char *base, int N, int smax, int gvld, char *overlay, bool rows_presolve, double *ext_gv = nullptr,
-                                        double *ext_rows = nullptr) {
+                                        double *ext_rows = nullptr, double *ext_gd = nullptr) {
     const bool compact = gvld > 0;
     const int m = 1 + 4 * N + 5 * smax;
     char *p = base;
-    if (!rows_presolve) { st = reinterpret_cast<wg_gait_state_t *>(p); p += (sizeof(wg_gait_state_t) + 15) & ~(size_t)15; }
+    if constexpr (!kLean) { if (!rows_presolve) { st = reinterpret_cast<wg_gait_state_t *>(p); p += (sizeof(wg_gait_state_t) + 15) & ~(size_t)15; } }
     sup0 = reinterpret_cast<Sup *>(p); p += sizeof(Sup);
     double *d = reinterpret_cast<double *>(p);
     V_f = d; d += kSMax * kSMax; sup_angles = d; d += 8;
@@ -209,7 +212,7 @@ struct TickLds {
       const int nmax = 2 * N + 2 * smax;
       uvec = d + 2; d += N + 2;          // uvec[-1] = uvec[-2] = 0.0: a row walked past its instant reads an exact-zero coefficient
       if constexpr (kExtGv) Gv = ext_gv; else { Gv = d; d += nmax * gvld; }
-      gd = d; d += nmax;
+      if constexpr (kLean) gd = ext_gd; else { gd = d; d += nmax; }
     }
     int *ip = reinterpret_cast<int *>(d);
     stepidx = ip; ip += (N + 1) & ~1;
@@ -221,6 +224,11 @@ struct TickLds {
     trunk = e; e += N + 1; refx = e; e += N; refy = e; e += N;
     svx = e; e += N; svy = e; e += N; szx = e; e += N; szy = e; e += N;
     rowD = e; e += m;
+    if constexpr (kLean) {
+      char *q = reinterpret_cast<char *>(e);
+      q += (0 - reinterpret_cast<size_t>(q)) & 15;
+      st = reinterpret_cast<wg_gait_state_t *>(q);           // parked in its HBM slot during the solve (mpc_tick)
+    }
     if (rows_presolve) {
       rowA = e; e += m; rowB = e; e += m; rowK = reinterpret_cast<int *>(e);
       // the working copy of the state also lives on Z: it is written back before the solver starts and fetched again
@@ -505,14 +513,17 @@ __device__ __forceinline__ TickDiag mpc_tick(const wg_model_t &m, const TickTabl
   // difference between seven and eight gaits per CU.  All three are read lane-parallel, early in their phases.
   constexpr int kExtWab = (2 * 16 + 4) + 2 * (1 + 4 * 16 + 10);
   double *ext16 = (NH == 16) ? zglobal : nullptr;         // never null for the compact view (the host reserves the slot)
-  // element view: the slot holds [Z (nmax x (nmax|1)) | wa (mmax + nmax) | b (mmax) | Gv (nmax x kGvLdElem) | rowA | rowB | rowK]
-  // for the largest problem of the model -- with them in LDS a CU holds four gaits at N = 32, without them five
+  // element view: the slot holds [Z (nmax x (nmax|1)) | wa (mmax + nmax) | b (mmax) | Gv (nmax x kGvLdElem) | rowA | rowB | rowK
+  // (2 mmax + (mmax + 1) / 2 + 2 doubles) | gd | d | wd | wx (nmax each)] for the largest problem of the model -- with all of
+  // them in LDS a CU holds four gaits at N = 32, without them six
   const int eNmax = 2 * N + 2 * kSMax, eMmax = 1 + 4 * N + 5 * kSMax;
   double *extE = (NH == -1) ? zglobal + (size_t)eNmax * (eNmax | 1) : nullptr;
   const int eWab = (eMmax + eNmax) + eMmax;
+  const int eRows = eWab + eNmax * kGvStride;               // offset of the row tables, then of gd | d | wd | wx
+  const int eCold = eRows + 2 * eMmax + (eMmax + 1) / 2 + 2;
   if constexpr (NH == -1)
-    L.template carve<true, true>(lds_tick, N, kSMax, kGvStride, reinterpret_cast<char *>(lds_ql), false, extE + eWab,
-                                 extE + eWab + (size_t)eNmax * kGvStride);
+    L.template carve<true, true, true>(lds_tick, N, kSMax, kGvStride, reinterpret_cast<char *>(lds_ql), false, extE + eWab,
+                                       extE + eRows, extE + eCold);
   else
     L.template carve<NH == 16>(lds_tick, N, (NH == 16) ? 2 : kSMax, kGvStride, reinterpret_cast<char *>(lds_ql), NH == 16,
                                (NH == 16) ? ext16 + kExtWab : nullptr);
@@ -661,14 +672,17 @@ __device__ __forceinline__ TickDiag mpc_tick(const wg_model_t &m, const TickTabl
   // element view with a Z slot in global memory: Z leaves the LDS (it is the operand that caps the residency at N = 32)
   constexpr bool z_in_lds = (NH != -1);
   constexpr bool kElemView = (NH == -1);
-  QlDims D(n, mq, mq, !kTableView, true, kCompactView ? 2 * NH + 4 : 0, !kTableView, z_in_lds, !kElemView);   // ordered sums run the static length
+  QlDims D(n, mq, mq, !kTableView, true, kCompactView ? 2 * NH + 4 : 0, !kTableView, z_in_lds, !kElemView, !kElemView);   // ordered sums run the static length
   QlView q;
   if constexpr (kCompactView) {
     constexpr int kNmax = 2 * NH + 4, kMmax = 1 + 4 * NH + 10;     // two previewed steps at most (wg_mpc_configure)
     // same footprint as QlDims(kNmax, kMmax, kMmax, dense = false, nsc = kNmax, bounds = false), which sized the LDS on the host
     q.template carve_fixed<kNmax, kMmax, kNmax, true>(lds_ql, n, mq, 0, ext16);
   } else {
-    if constexpr (kElemView) { q.template carve<false, false>(lds_ql, D, 0, extE, eMmax + eNmax); q.Z = zglobal; }
+    if constexpr (kElemView) {
+      q.template carve<false, false, false>(lds_ql, D, 0, extE, eMmax + eNmax, extE + eCold + eNmax, eNmax);
+      q.Z = zglobal;
+    }
     else q.carve(lds_ql, D, 0);
   }
 
@@ -852,11 +866,27 @@ __device__ __forceinline__ TickDiag mpc_tick(const wg_model_t &m, const TickTabl
   } else if constexpr (NH == -1) {
     if (lane == 0 && fabs(L.gd[n - 1]) == 0.0) L.gd[n - 1] = 1e-8;               // qld.cpp:442-444 (nmax == n)
     WG_WSYNC();
+    {
+      // the state's LDS copy sits on the solver's area: park it in its HBM slot (L2) for the duration of the solve
+      double *dst = reinterpret_cast<double *>(gstate);
+      const double *src = reinterpret_cast<const double *>(s);
+      for (int i = lane; i < (int)(sizeof(wg_gait_state_t) / 8); i += 64) dst[i] = src[i];
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // gd / d (global slot) written above are read by other lanes below
+    }
     HerdtElemProb prob;
     prob.N = N; prob.ns = ns; prob.Qb = &tb->Qb[0][0]; prob.u = L.uvec; prob.Gv = L.Gv; prob.gd = L.gd;
     prob.rowA = L.rowA; prob.rowB = L.rowB; prob.rowK = L.rowK; prob.stepidx = L.stepidx; prob.V_f = L.V_f;
     prob.R2 = tb->R2; prob.Z2 = tb->Z2; prob.z2sign = tb->z2_cross_sign; prob.blocks_ok = tb->blocks_ok;
     qr = ql_solve(q, prob, 1e-8, hist, hist_cap);
+    {
+      WG_WSYNC();
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      const double *src = reinterpret_cast<const double *>(gstate);
+      double *dst = reinterpret_cast<double *>(s);
+      for (int i = lane; i < (int)(sizeof(wg_gait_state_t) / 8); i += 64)
+        dst[i] = __hip_atomic_load(src + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      WG_WSYNC();
+    }
   } else {
     if (lane == 0 && fabs(GmL(n - 1, n - 1)) == 0.0) GmL(n - 1, n - 1) = 1e-8;   // qld.cpp:442-444 (nmax == n)
     WG_WSYNC();
