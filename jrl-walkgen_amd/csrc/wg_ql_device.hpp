@@ -1308,9 +1308,13 @@ __device__ __forceinline__ QlResult ql_solve(const QlView &q, P &prob, double vs
         double xs[2 * NH];
 #pragma unroll
         for (int c = 0; c < 2 * NH; ++c) xs[c] = q.x[c];
+        // the foot-placement row's operands are requested here as well: they arrive while the CoP row is summed
+        const bool has_foot = lane < 5 * prob.ns;
+        const int kf = has_foot ? 1 + 4 * NH + lane : 0;
+        const double wakf = q.wa[kf], bkf = q.b[kf];
         {
           const int k = lane + 1;                     // the lane's CoP row
-          const double wak = q.wa[k], bk = q.b[k];
+          const double wak = q.wa[k], bk = prob.bcop;
           double sum = -bk, asum = fabs(bk);
           prob.cop_row_dot(xs, sum, asum);
           if (prob.fj >= 0) {
@@ -1324,9 +1328,9 @@ __device__ __forceinline__ QlResult ql_solve(const QlView &q, P &prob, double vs
             if (!(tempa <= asum) && !(temp2 <= tempa)) { bestv = sumx; bestres = sum; bidx = k + 1; }
           }
         }
-        if (lane < 5 * prob.ns) {
-          const int k = 1 + 4 * NH + lane;            // the lane's foot-placement row
-          const double wak = q.wa[k], bk = q.b[k];
+        if (has_foot) {
+          const int k = kf;                           // the lane's foot-placement row
+          const double wak = wakf, bk = bkf;
           double sum = -bk, asum = fabs(bk);
 #pragma unroll
           for (int e = 0; e < 4; ++e) { const double t = q.x[prob.f2c[e]] * prob.f2v[e]; sum += t; asum += fabs(t); }

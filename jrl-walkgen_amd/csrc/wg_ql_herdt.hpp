@@ -260,6 +260,8 @@ struct HerdtProb {
   // raw edge coefficients of the lane's two rows (rowA / rowB / rowK live in LDS only until the solver starts: their
   // storage is part of the pre-solve overlay): any row's (a, b, k) is one v_readlane away
   double ra, rb;          // CoP row lane+1
+  double bcop;            // b of the CoP row lane+1 (constant during the solve; b itself lives in global memory, and the scan's
+                          // first operation on a row is sum = -b: from a register it does not wait for an L2 round trip)
   double ga, gb; int gk;  // foot-placement row 1+4N+lane (gk < 0: unused row)
 
   // ------------------------------------------------------------------ element access (rare paths)
@@ -304,7 +306,8 @@ struct HerdtProb {
   }
 
   // ------------------------------------------------------------------ per-lane rows into registers
-  __device__ __forceinline__ void load_rows(int lane) {
+  __device__ __forceinline__ void load_rows(int lane, const double *bvec) {
+    bcop = bvec[lane + 1];
     {
       const int k = lane + 1;
       const double a = rowA[k], b = rowB[k];

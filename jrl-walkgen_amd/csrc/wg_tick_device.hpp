@@ -849,7 +849,7 @@ __device__ __forceinline__ TickDiag mpc_tick(const wg_model_t &m, const TickTabl
     prob.Qb = &tb->Qb[0][0]; prob.u = L.uvec; prob.Gv = L.Gv; prob.gd = L.gd;
     prob.rowA = L.rowA; prob.rowB = L.rowB; prob.rowK = L.rowK; prob.stepidx = L.stepidx; prob.V_f = L.V_f;
     prob.R2 = tb->R2; prob.Z2 = tb->Z2; prob.z2sign = tb->z2_cross_sign; prob.diag_b = tb->diag_b; prob.blocks_ok = tb->blocks_ok; prob.ns = ns;
-    prob.load_rows(lane);
+    prob.load_rows(lane, q.b);
     qr = ql_solve(q, prob, 1e-8, hist, hist_cap);
     {
       WG_WSYNC();
