@@ -424,26 +424,22 @@ inline size_t tick_ql_bytes(const wg_model_t &m) {
 // gaits fit a CU (SIMDs hold 2,2,1,1 waves); the second wave of a SIMD hides the first one's dependent fp64 chains
 // (measured: 4 -> 6 resident gaits per CU = 1.78 -> 2.23 M ticks/s).  -DWG_TICK_WPE_MIN=1 -DWG_TICK_WPE_MAX=1 gives the
 // 512-register build (lib/libwg_mpc_w1.so, tools/bench_variants.sh).
-// The element view (NH == -1, N = 32) is held to ONE wave per SIMD by its LDS footprint (four gaits per CU): its kernels
-// are compiled for that, i.e. with the whole register file of a SIMD lane (512) -- no spills.
+// The element view (NH == -1, N = 32) keeps 26.8 KB of LDS per gait: six gaits per CU, two SIMDs of a CU hold two of them, so
+// its kernels are compiled for 256 registers as well (WG_TICK32_WPE = 2; = 1 gives the 512-register build, four per CU).
 // The run kernels pin their pointer arguments in scalar registers with an opaque asm once per tick (so that nothing derived
 // from them stays alive across the tick).  Pinned as GENERIC pointers they would come back with no address space and every
 // access through them would be a flat_ instruction: those count on both vmcnt and lgkmcnt and may return out of order with
 // LDS reads, so each LDS wait behind one turns into lgkmcnt(0) -- a global round trip.  Pinned as address-space-1 pointers
 // they stay global_ accesses (kernel arguments are global memory).
-#ifdef WG_PIN_GENERIC
-#define WG_PIN_GLOBAL(p) asm volatile("" : "+s"(p))
-#else
 #define WG_PIN_GLOBAL(p)                                                                          \
   do {                                                                                            \
     auto gp_ = (__attribute__((address_space(1))) std::remove_pointer_t<decltype(p)> *)(p);       \
     asm volatile("" : "+s"(gp_));                                                                 \
     (p) = (decltype(p))gp_;                                                                       \
   } while (0)
-#endif
 
 #ifndef WG_TICK32_WPE
-#define WG_TICK32_WPE 2                                    // element view (N = 32): 256 registers, so that a fifth gait of a CU can share a SIMD
+#define WG_TICK32_WPE 2                                    // element view (N = 32): 256 registers (two gaits on a SIMD)
 #endif
 #ifndef WG_TICK_WPE_MIN
 #define WG_TICK_WPE_MIN 2
