@@ -722,6 +722,9 @@ struct HerdtElemProb {
   // fetches the parameters of all its passes before the first one
   __device__ __forceinline__ void row_dot_both(const QlView &, int k, int k0, double a, double b, int kk, const double *v, double &sum,
                                                double &asum) const {
+    // The coefficients are the assembly's expressions 0.0 + (0.0 + p) * -1.0 and 0.0 + (0.0 + p) * 1.0 of a product p, written as
+    // 0.0 - p and p + 0.0: the same value for every p (a zero product of either sign gives +0.0 both ways), two operations
+    // instead of four per element.
     if (k0 <= 4 * N) {                                      // the pass holds CoP rows (wave-uniform)
       const bool cop = k >= 1 && k <= 4 * N;
       const int r = cop ? kk : -1;
@@ -733,27 +736,27 @@ struct HerdtElemProb {
 #pragma unroll
         for (int e = 0; e < 4; ++e) { const int d = r - c0 - e, ci = c0 + e < N ? c0 + e : N - 1; vv[e] = v[ci]; uu[e] = u[d > -1 ? d : -1]; }
 #pragma unroll
-        for (int e = 0; e < 4; ++e) { const double t = vv[e] * (0.0 + (0.0 + ac * uu[e]) * -1.0); sum += t; asum += fabs(t); }
+        for (int e = 0; e < 4; ++e) { const double t = vv[e] * (0.0 - ac * uu[e]); sum += t; asum += fabs(t); }
       }
       for (int c0 = 0; c0 <= rmax; c0 += 4) {
         double vv[4], uu[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) { const int d = r - c0 - e, ci = c0 + e < N ? c0 + e : N - 1; vv[e] = v[N + ci]; uu[e] = u[d > -1 ? d : -1]; }
 #pragma unroll
-        for (int e = 0; e < 4; ++e) { const double t = vv[e] * (0.0 + (0.0 + bc * uu[e]) * -1.0); sum += t; asum += fabs(t); }
+        for (int e = 0; e < 4; ++e) { const double t = vv[e] * (0.0 - bc * uu[e]); sum += t; asum += fabs(t); }
       }
       const int j = (r >= 0) ? stepidx[r] - 1 : -1;
       const bool st = j >= 0 && j < ns;
       const int jc = st ? j : 0;
-      { const double t = v[2 * N + jc] * (0.0 + (0.0 + (st ? a : 0.0) * 1.0) * 1.0); sum += t; asum += fabs(t); }
-      { const double t = v[2 * N + ns + jc] * (0.0 + (0.0 + (st ? b : 0.0) * 1.0) * 1.0); sum += t; asum += fabs(t); }
+      { const double t = v[2 * N + jc] * ((st ? a : 0.0) * 1.0 + 0.0); sum += t; asum += fabs(t); }
+      { const double t = v[2 * N + ns + jc] * ((st ? b : 0.0) * 1.0 + 0.0); sum += t; asum += fabs(t); }
     }
     if (k0 + 63 > 4 * N) {                                  // the pass holds foot-placement rows (wave-uniform)
       const bool ft = k > 4 * N && kk >= 0;
       const int kf = ft ? kk : 0;
       const double af = ft ? a : 0.0, bf = ft ? b : 0.0;
-      for (int j = 0; j < ns; ++j) { const double t = v[2 * N + j] * (0.0 + (0.0 + af * V_f[kf * kSMaxQ + j]) * -1.0); sum += t; asum += fabs(t); }
-      for (int j = 0; j < ns; ++j) { const double t = v[2 * N + ns + j] * (0.0 + (0.0 + bf * V_f[kf * kSMaxQ + j]) * -1.0); sum += t; asum += fabs(t); }
+      for (int j = 0; j < ns; ++j) { const double t = v[2 * N + j] * (0.0 - af * V_f[kf * kSMaxQ + j]); sum += t; asum += fabs(t); }
+      for (int j = 0; j < ns; ++j) { const double t = v[2 * N + ns + j] * (0.0 - bf * V_f[kf * kSMaxQ + j]); sum += t; asum += fabs(t); }
     }
   }
   __device__ __forceinline__ double row_sqnorm(const QlView &, int k) const {
