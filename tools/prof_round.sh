@@ -39,5 +39,6 @@ for spec in "dimitrov tools/probe_dimitrov.py" "pldp tools/probe_pldp.py" "previ
 done
 # in-kernel phase timers of the tick (diagnostic build lib/libwg_mpc_prof.so, one launch per tick)
 PB=4096 python3 $R/tools/probe_tick_phases.py 2>&1 | grep -v amdgpu.ids > $R/gpurun_out/phases_tick.txt
+PN=32 PB=3072 python3 $R/tools/probe_tick_phases.py 2>&1 | grep -v amdgpu.ids > $R/gpurun_out/phases_tick32.txt
 echo "phases done"
 tail -25 $R/gpurun_out/prof_tick.log

@@ -84,9 +84,10 @@ if "pertick" in summ:
     out["per_tick_kernel"] = per_gait_tick(summ["pertick"], "wg_mpc_tick_kernel<16>", B * (W + K))
     out["per_tick_kernel"]["ticks_per_launch"] = "1"
 json.dump(out, open(os.path.join(ROOT, "profiles", "current_tick_pmc.json"), "w"), indent=1)
-ph = os.path.join(ROOT, "gpurun_out", "phases_tick.txt")
-if os.path.exists(ph):
-    shutil.copy(ph, os.path.join(ROOT, "profiles", f"{tag}_tick_phase_timers.txt"))
+for src, dst in (("phases_tick.txt", "tick_phase_timers.txt"), ("phases_tick32.txt", "tick32_phase_timers.txt")):
+    ph = os.path.join(ROOT, "gpurun_out", src)
+    if os.path.exists(ph):
+        shutil.copy(ph, os.path.join(ROOT, "profiles", f"{tag}_{dst}"))
 readme = f"""# profiles/ -- one set, describing HEAD
 
 Everything named `{tag}_*` was produced by ONE run of `tools/prof_round.sh` on an MI355X (gpurun) and filed by
@@ -100,7 +101,7 @@ Everything named `{tag}_*` was produced by ONE run of `tools/prof_round.sh` on a
 | `{tag}_config5_*` | `PN=32 PB=8192 PT=50 python3 tools/probe_run.py` | BASELINE configs[4]'s size: N = 32, B = 8192 (element view), per-tick and multi-tick launches |
 | `{tag}_gramian_*` | `python3 tools/probe_gramian.py` | `wg_gramian_kernel`: SQ_INSTS_VALU_MFMA_MOPS_F64 / _F32, SQ_VALU_MFMA_BUSY_CYCLES, duration against the dense MFMA peak (`*_probe_output.txt`) |
 | `{tag}_dimitrov_*`, `{tag}_pldp_*`, `{tag}_preview_*`, `{tag}_zmpdisc_*` | `tools/probe_<name>.py` | the other kernels of the path |
-| `{tag}_tick_phase_timers.txt` | `PB=4096 python3 tools/probe_tick_phases.py` (diagnostic build `lib/libwg_mpc_prof.so`) | in-kernel phase timers of the tick (shader cycles per gait-tick, one launch per tick) |
+| `{tag}_tick_phase_timers.txt`, `{tag}_tick32_phase_timers.txt` | `PB=4096 python3 tools/probe_tick_phases.py`, `PN=32 PB=3072 ...` (diagnostic build `lib/libwg_mpc_prof.so`) | in-kernel phase timers of the tick at N = 16 and N = 32 (shader cycles per gait-tick, one launch per tick) |
 | `current_tick_pmc.json` | derived from `{tag}_tick_*`, `{tag}_tickg_*`, `{tag}_pertick_*` | per gait-tick: HBM bytes read / written (FETCH_SIZE x 2 and WRITE_SIZE, KiB units, separate passes), VALU / SALU / LDS / VMEM instructions, VALU busy; `bench.py` scales `roofline.traffic` and its second axis from this file |
 
 Each `*_rocprofv3_summary.txt/json` = per-kernel averages of the trace (`kernels`) and per-launch means of every counter
