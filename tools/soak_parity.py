@@ -1,0 +1,95 @@
+"""Whole-batch parity soak (evidence, not a test): EVERY gait of the benchmark workload, advanced on the GPU exactly as bench.py
+does it (two single ticks, then multi-tick launches with the velocity references staged on the device), against the CPU checker
+(oracle/ with the portable trigonometry, the bit-exact partner of the kernels) run on the host cores -- final gait states compared
+byte for byte.  N = 16: 4096 gaits x 250 ticks; N = 32: 8192 gaits x 50 ticks.   python tools/soak_parity.py > profiles/<tag>_soak_parity.txt
+The checker runs beside the product path here, as in tests/: nothing of it is measured or shipped."""
+import ctypes as C
+import importlib
+import importlib.util
+import multiprocessing as mp
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+wg = importlib.import_module("jrl-walkgen_amd")
+spec = importlib.util.spec_from_file_location("wg_bench", os.path.join(ROOT, "bench.py"))
+bench = importlib.util.module_from_spec(spec); sys.modules["wg_bench"] = bench; spec.loader.exec_module(bench)
+import oraclelib as ol  # noqa: E402
+
+
+def cpu_chunk(args):
+    N, g0, ng, n_ticks = args
+    ol.build_oracle()
+    lib = C.CDLL(os.path.join(ol.ORACLE_DIR, "libwg_oracle_ptrig.so"))
+    model = wg.Model(); lib.wgo_model_defaults(C.byref(model)); model.N = N
+    tab = np.ascontiguousarray(bench.velocity_table(g0, g0 + ng, (n_ticks + bench.REDRAW_TICKS - 1) // bench.REDRAW_TICKS))
+    states = (wg.GaitState * ng)()
+    s0 = wg.gait_init(model, [0.0316055, 0.0, 0.7116911], [0.0, 0.09, 0.0], [0.0, -0.09, 0.0]); s0.nb_steps_left = 2
+    for g in range(ng):
+        C.memmove(C.byref(states[g]), C.byref(s0), C.sizeof(wg.GaitState))
+    rc = lib.wgo_mpc_run(C.byref(model), states, ng, n_ticks, tab.ctypes.data_as(C.c_void_p), bench.REDRAW_TICKS)
+    assert rc == 0
+    return g0, bytes(memoryview(states).cast("B"))
+
+
+def gpu_run(N, B, n_ticks):
+    dev = torch.device("cuda:0")
+    model = wg.model_defaults(); model.N = N
+    with wg.Context(0) as ctx:
+        ctx.mpc_configure(model)
+        vtab = torch.from_numpy(bench.velocity_table(0, B, (n_ticks + bench.REDRAW_TICKS - 1) // bench.REDRAW_TICKS)).to(dev)
+        states = bench.start_states(model, B).to(dev)
+        diag = torch.zeros(n_ticks, B, 6, dtype=torch.int32, device=dev)
+        sp, dp, ds = states.data_ptr(), diag.data_ptr(), B * 6 * 4
+        t0 = time.perf_counter()
+        for t, n in bench.launch_plan(0, n_ticks):
+            adv = 1 if t == 0 else (19 if t == 1 else 20)
+            staged = n > 1 and t % bench.REDRAW_TICKS == 0
+            if t % bench.REDRAW_TICKS == 0 and not staged:
+                ctx.mpc_set_velref_dev(B, sp, vtab[t // bench.REDRAW_TICKS].data_ptr())
+            if n == 1:
+                ctx.mpc_tick_batch_dev(B, sp, None, dp + t * ds, adv)
+            elif staged:
+                ctx.mpc_run_sched_dev(B, sp, n, vtab[t // bench.REDRAW_TICKS].data_ptr(), bench.REDRAW_TICKS, adv, None, dp + t * ds)
+            else:
+                ctx.mpc_run_batch_dev(B, sp, n, adv, None, dp + t * ds)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        d = diag.cpu().numpy()
+        return states.cpu().numpy().tobytes(), dt, d
+
+
+def soak(N, B, n_ticks, workers):
+    per = (B + workers - 1) // workers
+    jobs = [(N, g0, min(per, B - g0), n_ticks) for g0 in range(0, B, per)]
+    t0 = time.perf_counter()
+    with mp.get_context("spawn").Pool(min(workers, len(jobs))) as pool:
+        cpu = dict(pool.map(cpu_chunk, jobs))
+    t_cpu = time.perf_counter() - t0
+    got, t_gpu, d = gpu_run(N, B, n_ticks)
+    sz = C.sizeof(wg.GaitState)
+    bad = 0
+    for g0, blob in cpu.items():
+        ng = len(blob) // sz
+        for g in range(ng):
+            if blob[g * sz:(g + 1) * sz] != got[(g0 + g) * sz:(g0 + g + 1) * sz]:
+                bad += 1
+    print("N = %d: %d gaits x %d ticks = %d MPC ticks; gaits whose final state differs from the CPU checker's: %d; "
+          "failed QPs %d; QL iterations mean %.1f max %d; n in %s; GPU %.2f s (launch plan %s), CPU checker %.1f s on %d processes"
+          % (N, B, n_ticks, B * n_ticks, bad, int((d[..., 0] != 0).sum()), float(d[..., 1].mean()), int(d[..., 1].max()),
+             sorted(set(int(v) for v in np.unique(d[..., 3]))), t_gpu, bench.launch_plan(0, n_ticks), t_cpu, min(workers, len(jobs))), flush=True)
+    return bad
+
+
+if __name__ == "__main__":
+    wg.init(0)
+    workers = min(os.cpu_count() or 8, 64)
+    bad = soak(16, 4096, 250, workers)
+    bad += soak(32, 8192, 50, workers)
+    print("soak parity: %s" % ("PASS (bit-identical)" if bad == 0 else "FAIL"))
+    sys.exit(1 if bad else 0)
