@@ -88,6 +88,15 @@ for src, dst in (("phases_tick.txt", "tick_phase_timers.txt"), ("phases_tick32.t
     ph = os.path.join(ROOT, "gpurun_out", src)
     if os.path.exists(ph):
         shutil.copy(ph, os.path.join(ROOT, "profiles", f"{tag}_{dst}"))
+agree = ""
+if "run_kernel" in out:
+    r = out["run_kernel"]
+    tot_ms = r["avg_kernel_ns_rocprofv3"] * r["kernel_calls_rocprofv3"] / 1e6
+    agree = (f"How the run kernel's table lines up with `bench.py`: rocprofv3 saw {r['kernel_calls_rocprofv3']} launches of "
+             f"`wg_mpc_run_xcd_kernel<16>` ({r['ticks_per_launch']} ticks: the warm-up stretch and the timed launch), {tot_ms:.1f} ms in "
+             f"all = {tot_ms / run_ticks:.4f} ms per tick of the batch; the table's average ({r['avg_kernel_ns_rocprofv3'] / 1e6:.1f} ms) is "
+             f"over launches of different lengths, its MaxNs is the timed launch that `bench.py` brackets with HIP events "
+             f"(`roofline.kernel_ms` in `{tag}_bench.json`, / `ticks_per_launch` = ms per tick).")
 readme = f"""# profiles/ -- one set, describing HEAD
 
 Everything named `{tag}_*` was produced by ONE run of `tools/prof_round.sh` on an MI355X (gpurun) and filed by
@@ -104,6 +113,8 @@ Everything named `{tag}_*` was produced by ONE run of `tools/prof_round.sh` on a
 | `{tag}_tick_phase_timers.txt`, `{tag}_tick32_phase_timers.txt` | `PB=4096 python3 tools/probe_tick_phases.py`, `PN=32 PB=3072 ...` (diagnostic build `lib/libwg_mpc_prof.so`) | in-kernel phase timers of the tick at N = 16 and N = 32 (shader cycles per gait-tick, one launch per tick) |
 | `{tag}_soak_parity.txt` | `python tools/soak_parity.py` | every gait of the benchmark workload (4096 x 250 ticks at N = 16, 8192 x 50 at N = 32) advanced as `bench.py` does it, final states byte for byte against the CPU checker on the host cores |
 | `current_tick_pmc.json` | derived from `{tag}_tick_*`, `{tag}_tickg_*`, `{tag}_pertick_*` | per gait-tick: HBM bytes read / written (FETCH_SIZE x 2 and WRITE_SIZE, KiB units, separate passes), VALU / SALU / LDS / VMEM instructions, VALU busy; `bench.py` scales `roofline.traffic` and its second axis from this file |
+
+{agree}
 
 Each `*_rocprofv3_summary.txt/json` = per-kernel averages of the trace (`kernels`) and per-launch means of every counter
 (`counters`); `*_kernel_stats.csv` = rocprofv3's own `--stats` table of the same run.
