@@ -986,11 +986,13 @@ __device__ __forceinline__ bool independent_coordinate(const QlView &q, const P 
   do {                                                                                                 \
     if constexpr (P::kNM > 0 && P::kNM + 12 <= 48) backsub_lds<48>(q, s, nact, lane, q.sc0);          \
     else if (P::kNM == 0 && q.n >= 48 && (nact) <= 60) backsub_lds<96>(q, s, nact, lane, q.sc0);     \
+    else if (P::kNM == 0 && q.n >= 24 && (nact) <= 36) backsub_lds<48>(q, s, nact, lane, q.sc0);      \
     else backsub(q, s, nact, lane);                                                                    \
   } while (0)
 #endif
+// one row of Z per lane (n <= 64): the branch-free, prefetching form, whatever the view
 #define WG_SWEEP(q, s, nu, nact, lane) \
-  do { if constexpr (P::kNM > 0) sweep_flat(q, s, nu, nact, lane); else sweep(q, s, nu, nact, lane); } while (0)
+  do { if (P::kNM > 0 || q.n <= 64) sweep_flat(q, s, nu, nact, lane); else sweep(q, s, nu, nact, lane); } while (0)
 
 template <class P>
 __device__ __forceinline__ QlResult ql_solve(const QlView &q, P &prob, double vsmall, int *hist, int hist_cap) {
