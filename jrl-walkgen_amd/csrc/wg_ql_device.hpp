@@ -1381,26 +1381,59 @@ __device__ __forceinline__ QlResult ql_solve(const QlView &q, P &prob, double vs
           bestv = sumx; bestres = sum; bidx = k + 1;
         }
       } else
-      for (int k = lane; k < m; k += 64) {
-        double wak = q.wa[k];
-        if (wak <= 0.0) continue;
-        double bk = q.b[k];
-        double sum = -bk;
-        if constexpr (P::kRowOps) {
-        } else {
-          WG_UNROLL
-          for (int i = 0; i < n; ++i) sum += q.x[i] * Am(k, i);
+      // dense rows: ONE walk of the row for both sums (sum += x_i a_ki, temp += |x_i a_ki|, i ascending: the same values the
+      // serial code forms in two walks, the second only for candidates), the row's entries of eight columns requested while the
+      // previous eight are added -- with A read in place (L2) the 4-at-a-time walk exposed a round trip every four terms.
+      // Every lane of a pass walks (surplus lanes a valid row); the tests below are the reference's, in its order.
+      for (int k0 = 0; k0 < m; k0 += 64) {
+        const int k = k0 + lane;
+        const bool in = k < m;
+        const int kc = in ? k : m - 1;
+        const double wak = in ? q.wa[kc] : 0.0, bk = q.b[kc];
+        double sum = -bk, temp = fabs(bk);
+        {
+          constexpr int kG = 8;
+          double ua[kG], ub[kG];
+          auto fetch = [&](double (&u)[kG], int i) {
+#pragma unroll
+            for (int e = 0; e < kG; ++e) u[e] = Am(kc, i + e < n ? i + e : n - 1);   // past the end: clamped (loaded, unused)
+          };
+          auto add = [&](const double (&u)[kG], int i) {
+            double xs[kG];
+#pragma unroll
+            for (int e = 0; e < kG; ++e) xs[e] = q.x[i + e];
+#pragma unroll
+            for (int e = 0; e < kG; ++e) { const double t = xs[e] * u[e]; sum += t; temp += fabs(t); }
+          };
+          int i = 0;
+          const int whole = n / kG * kG;
+          if (whole > 0) {
+            fetch(ua, 0);
+            for (;;) {
+              fetch(ub, i + kG);
+              add(ua, i); i += kG;
+              if (i >= whole) break;
+              fetch(ua, i + kG);
+              add(ub, i); i += kG;
+              if (i >= whole) { 
+#pragma unroll
+                for (int e = 0; e < kG; ++e) ub[e] = ua[e];
+                break;
+              }
+            }
+            // ub holds columns i .. i + kG - 1 (clamped): the odd ones
+#pragma unroll
+            for (int e = 0; e < kG - 1; ++e)
+              if (i + e < n) { const double t = q.x[i + e] * ub[e]; sum += t; temp += fabs(t); }
+          } else {
+            for (; i < n; ++i) { const double t = q.x[i] * Am(kc, i); sum += t; temp += fabs(t); }
+          }
         }
+        if (wak <= 0.0) continue;
         double sumx = -sum * wak;
         if (k + 1 <= me) sumx = fabs(sumx);
         if (sumx <= 0.0) continue;              // cvmax starts at 0 (:1256)
         if (bidx >= 0 && sumx <= bestv) continue;
-        double temp = fabs(bk);
-        if constexpr (P::kRowOps) temp = prob.template row_dot<true>(q, k, q.x, temp);
-        else {
-          WG_UNROLL
-          for (int i = 0; i < n; ++i) temp += fabs(q.x[i] * Am(k, i));
-        }
         double tempa = temp + fabs(sum);
         if (tempa <= temp) continue;
         temp += onha * fabs(sum);
