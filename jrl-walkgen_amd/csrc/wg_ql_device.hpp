@@ -1564,15 +1564,6 @@ __device__ __forceinline__ QlResult ql_solve(const QlView &q, P &prob, double vs
             }
             suma = rl(acc, 0); sumb = rl(acc, 1); sumc = rl(acc, 2);
             WG_WSYNC();
-          } else if (n <= 60) {
-            double ta = 0.0, tb = 0.0, tc = 0.0;
-            if (lane < n) { const double zi = Zm(lane, nact), wi = q.ww[lane]; ta = wi * zi; tb = fabs(wi * zi); tc = zi * zi; }
-            for (int i = 0; i < n; i += 4) {
-              suma += rl(ta, i); sumb += rl(tb, i); sumc += rl(tc, i);
-              suma += rl(ta, i + 1); sumb += rl(tb, i + 1); sumc += rl(tc, i + 1);
-              suma += rl(ta, i + 2); sumb += rl(tb, i + 2); sumc += rl(tc, i + 2);
-              suma += rl(ta, i + 3); sumb += rl(tb, i + 3); sumc += rl(tc, i + 3);
-            }
           } else {
             // column nact of Z is read once, lane-parallel (with Z in global memory: two coalesced loads instead of n
             // broadcast ones in a row); the three ordered sums then run from LDS, one per lane, as in the compact view
