@@ -681,11 +681,6 @@ __device__ __forceinline__ double xmag_sum(const QlView &q, const P &prob, doubl
     if (lane < n) { const double xi = q.x[lane]; term = fabs(xi) * vfact * (fabs(q.d[lane]) + fabs(prob.Gd(q, lane) * xi)); }
     return ordered_sum_lds<P::kNM>(term, q.sc3, n, lane);
   }
-  if (n <= 60) {
-    double term = 0.0;
-    if (lane < n) { const double xi = q.x[lane]; term = fabs(xi) * vfact * (fabs(q.d[lane]) + fabs(prob.Gd(q, lane) * xi)); }
-    return lane_sum_ordered(term, 0, n);
-  }
   for (int i = lane; i < n; i += 64) {
     double xi = q.x[i];
     q.sc3[i] = fabs(xi) * vfact * (fabs(q.d[i]) + fabs(prob.Gd(q, i) * xi));
