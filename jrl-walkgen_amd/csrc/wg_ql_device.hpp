@@ -550,8 +550,20 @@ __device__ __forceinline__ void sweep_flat(const QlView &q, double *s, int nu, i
     double cur = s[nu - 1];
     double pa = s[nu - 2], pb;
     int c = nu - 1;
+    if (WG_UBOOL(cur != 0.0)) {
+      // a norm is at least its larger operand: once cur is non-zero it stays non-zero, no rotation is skipped and the
+      // "cur == 0 ? p : norm" select of the general form below always takes the norm
+      for (;;) {
+        pb = s[(c - 2 >= 0) ? c - 2 : 0];                   // operand of the next rotation, off the chain
+        cur = givens_norm_fast(pa, cur); chain[c - 1] = cur;
+        if (--c <= nact) break;
+        pa = s[(c - 2 >= 0) ? c - 2 : 0];
+        cur = givens_norm_fast(pb, cur); chain[c - 1] = cur;
+        if (--c <= nact) break;
+      }
+    } else
     for (;;) {
-      pb = s[(c - 2 >= 0) ? c - 2 : 0];                     // operand of the next rotation, off the chain
+      pb = s[(c - 2 >= 0) ? c - 2 : 0];
       { const double nrmc = givens_norm_fast(pa, cur); cur = (cur == 0.0) ? pa : nrmc; chain[c - 1] = cur; }
       if (--c <= nact) break;
       pa = s[(c - 2 >= 0) ? c - 2 : 0];
@@ -755,6 +767,16 @@ __device__ __forceinline__ void sweep(const QlView &q, double *s, int nu, int na
     double cur = s[nu - 1];
     double pa = s[nu - 2], pb;
     int c = nu - 1;
+    if (WG_UBOOL(cur != 0.0)) {                             // cur stays non-zero: no select (see sweep_flat)
+      for (;;) {
+        pb = s[(c - 2 >= 0) ? c - 2 : 0];
+        cur = givens_norm_fast(pa, cur); chain[c - 1] = cur;
+        if (--c <= nact) break;
+        pa = s[(c - 2 >= 0) ? c - 2 : 0];
+        cur = givens_norm_fast(pb, cur); chain[c - 1] = cur;
+        if (--c <= nact) break;
+      }
+    } else
     for (;;) {
       pb = s[(c - 2 >= 0) ? c - 2 : 0];
       { const double nrmc = givens_norm_fast(pa, cur); cur = (cur == 0.0) ? pa : nrmc; chain[c - 1] = cur; }
@@ -981,13 +1003,14 @@ __device__ __forceinline__ bool independent_coordinate(const QlView &q, const P 
   do {                                                                                                 \
     if constexpr (P::kNM > 0 && P::kNM + 12 <= 48) backsub_lds<48>(q, s, nact, lane, q.sc0);          \
     else if (P::kNM == 0 && q.n >= 48 && (nact) <= 60) backsub_lds<96>(q, s, nact, lane, q.sc0);     \
-    else if (P::kNM == 0 && q.n >= 24 && (nact) <= 36) backsub_lds<48>(q, s, nact, lane, q.sc0);      \
+    else if (P::kNM == 0 && !P::kRowOps && q.n >= 24 && (nact) <= 36) backsub_lds<48>(q, s, nact, lane, q.sc0); \
     else backsub(q, s, nact, lane);                                                                    \
   } while (0)
 #endif
-// one row of Z per lane (n <= 64): the branch-free, prefetching form, whatever the view
+// one row of Z per lane (n <= 64): the branch-free, prefetching form -- the compact view always, the dense view by size (the
+// element view is built for n > 64: it keeps the one form it needs, its kernel is large enough as it is)
 #define WG_SWEEP(q, s, nu, nact, lane) \
-  do { if (P::kNM > 0 || q.n <= 64) sweep_flat(q, s, nu, nact, lane); else sweep(q, s, nu, nact, lane); } while (0)
+  do { if (P::kNM > 0 || (!P::kRowOps && q.n <= 64)) sweep_flat(q, s, nu, nact, lane); else sweep(q, s, nu, nact, lane); } while (0)
 
 template <class P>
 __device__ __forceinline__ QlResult ql_solve(const QlView &q, P &prob, double vsmall, int *hist, int hist_cap) {
