@@ -388,19 +388,57 @@ inline bool tick_compact(const wg_model_t &m) {
 inline bool tick_z_global(int view) { return view == -1; }
 // compact view (N = 16): wa, b and the border block Gv in a per-block slot of global memory (decided at compile time: mpc_tick<16>)
 inline bool tick16_ext(int view) { return view == 16; }
-inline size_t tick_z_slot_doubles(const wg_model_t &m, int view) {
-  const size_t n = (size_t)tick_max_n(m), mm = (size_t)tick_max_m(m);
-  if (view == 16) return (n + 2 * mm) + n * wg::kGvLd;       // wa | b | Gv
-  // element view: Z | wa | b | Gv | rowA | rowB | rowK | gd | d | wd | wx (mpc_tick<-1>)
-  return n * (n | 1) + (n + 2 * mm) + n * wg::kGvLdElem + 2 * mm + (mm + 1) / 2 + 2 + 4 * n;
-}
-inline size_t tick_lds_for(const wg_model_t &m, int view) {
+inline size_t tick_lds_with_cap(const wg_model_t &m, int view, int r_cols) {
   const bool ext = tick16_ext(view) || tick_z_global(view);        // wa, b, Gv (element view: the rows too) in the global slot
   const size_t ql = (wg::QlDims(tick_max_n(m), tick_max_m(m), tick_max_m(m), view == 0, true, 0, view == 0, !tick_z_global(view),
-                                !ext, view != -1).bytes() + 15) & ~(size_t)15;
+                                !ext, view != -1, r_cols).bytes() + 15) & ~(size_t)15;
   const int gvld = view == 16 ? wg::kGvLd : (view == -1 ? wg::kGvLdElem : 0);
   return ql + wg::TickLds::bytes(m.N, tick_smax(m), gvld, view == 16, !ext, view != -1, view == -1);
 }
+// Element view: how many columns of R the LDS holds (0: all of them).  R is the operand that decides the residency at N = 32
+// (21.6 KB of the 26.8); with its first 60 columns and one working column the gait takes 20 384 B -- eight gaits per CU, two on
+// every SIMD -- and a solve whose active set outgrows them is repeated with R in global memory (mpc_tick<-1>).  The cap is
+// the largest one that reaches the next residency step and leaves the usual active sets alone (>= 3/4 of n); WG_ELEM_NACT_CAP
+// forces a value (tests run with tiny caps so that every solve takes the second route).
+inline int tick_elem_cap(const wg_model_t &m, int view) {
+  if (view != -1) return 0;
+  const int n = tick_max_n(m);
+  const size_t overlay = wg::TickLds::pre_bytes(m.N, tick_smax(m)) + sizeof(wg_gait_state_t) + 32;
+  // the pre-solve overlay -- the parked state copy at its end is fetched back right after the solve, while x still holds the
+  // solution -- must lie within R alone; sized for the smallest problem of the model (no previewed step: n = 2N)
+  auto fits = [&](int c) { return (size_t)8 * ((size_t)c * (c + 1) / 2 + (size_t)(2 * m.N)) >= overlay; };
+  if (const char *e = getenv("WG_ELEM_NACT_CAP")) {
+    int c = atoi(e);
+    if (c <= 0 || c >= n) return 0;
+    while (c < n - 1 && !fits(c)) ++c;
+    return (c < n && fits(c)) ? c : 0;
+  }
+  auto per_cu = [&](int c) { const size_t g = (tick_lds_with_cap(m, view, c) + 1279) / 1280; size_t k = 128 / g; return k > 8 ? (size_t)8 : k; };
+  const size_t full = per_cu(0);
+  for (int c = n - 1; c >= (3 * n) / 4; --c)
+    if (fits(c) && per_cu(c) > full) {
+      int best = c;                                      // keep lowering only while the residency keeps growing
+      for (int d = c - 1; d >= (3 * n) / 4; --d) if (fits(d) && per_cu(d) > per_cu(best)) best = d;
+      return best;
+    }
+  return 0;
+}
+// what the kernels receive: the column cap in the low 16 bits; tests may ask the solver to give up EARLIER than the layout
+// requires (WG_ELEM_ABORT_AT: active-set size at which the first attempt stops), so that the second route is taken often
+inline int tick_elem_cap_arg(const wg_model_t &m, int view) {
+  const int c = tick_elem_cap(m, view);
+  if (!c) return 0;
+  int a = c;
+  if (const char *e = getenv("WG_ELEM_ABORT_AT")) { const int v = atoi(e); if (v >= 1 && v < c) a = v; }
+  return c | (a << 16);
+}
+inline size_t tick_z_slot_doubles(const wg_model_t &m, int view) {
+  const size_t n = (size_t)tick_max_n(m), mm = (size_t)tick_max_m(m);
+  if (view == 16) return (n + 2 * mm) + n * wg::kGvLd;       // wa | b | Gv
+  // element view: Z | wa | b | Gv | rowA | rowB | rowK | gd | d | wd | wx | R in full (mpc_tick<-1>)
+  return n * (n | 1) + (n + 2 * mm) + n * wg::kGvLdElem + 2 * mm + (mm + 1) / 2 + 2 + 4 * n + (n * (n + 1) / 2 + n);
+}
+inline size_t tick_lds_for(const wg_model_t &m, int view) { return tick_lds_with_cap(m, view, tick_elem_cap(m, view)); }
 inline int tick_view(const wg_model_t &m) {
   if (tick_compact(m)) return 16;
   // the element view parks the pre-solve scratch on Z (n >= 2N): tiny horizons whose Z is smaller than that stay dense
@@ -415,7 +453,7 @@ inline int tick_view(const wg_model_t &m) {
 inline size_t tick_ql_bytes(const wg_model_t &m) {
   size_t b = wg::QlDims(tick_max_n(m), tick_max_m(m), tick_max_m(m), tick_view(m) == 0, true, 0, tick_view(m) == 0,
                         !tick_z_global(tick_view(m)), !(tick16_ext(tick_view(m)) || tick_z_global(tick_view(m))),
-                        tick_view(m) != -1).bytes();
+                        tick_view(m) != -1, tick_elem_cap(m, tick_view(m))).bytes();
   return (b + 15) & ~(size_t)15;
 }
 }  // namespace
@@ -453,7 +491,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NH == -1 ? W
                                                          wg_tick_out_t *__restrict__ outs, int *__restrict__ diag,
                                                          int advance_calls, int *__restrict__ hist, int hist_cap,
                                                          int *__restrict__ hist_len, unsigned ql_bytes, double *zscratch,
-                                                         unsigned zslot) {
+                                                         unsigned zslot, int elem_cap) {
   extern __shared__ __attribute__((aligned(16))) double wg_lds[];
   const int lane = threadIdx.x & 63;
   // one block = one gait (grid == B): no grid-stride loop, so nothing lane-dependent is hoisted out of it and kept
@@ -472,7 +510,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NH == -1 ? W
     wg::TickDiag dg = wg::mpc_tick<NH>(model, tb, states + g, outs ? outs + g : nullptr, wg_lds,
                                    reinterpret_cast<char *>(wg_lds) + ql_bytes, hist ? hist + (size_t)g * hist_cap : nullptr,
                                    hist_cap, hist_len ? hist_len + g : nullptr,
-                                   zscratch ? zscratch + (size_t)blockIdx.x * zslot : nullptr);
+                                   zscratch ? zscratch + (size_t)blockIdx.x * zslot : nullptr, elem_cap);
     if (diag && lane == 0) {
       int *dq = diag + (size_t)g * 6;
       dq[0] = dg.ifail; dq[1] = dg.n_iter; dq[2] = dg.nact; dq[3] = dg.n; dq[4] = dg.m; dq[5] = dg.ns;
@@ -505,7 +543,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NH == -1 ? W
     int B, int n_ticks, const wg_model_t *__restrict__ model_p, const wg::TickTables *__restrict__ tb_p,
     wg_gait_state_t *__restrict__ states_p, wg_tick_out_t *__restrict__ outs_p, int *__restrict__ diag_p, int advance_calls,
     wg_run_queue *__restrict__ q, int *__restrict__ ring, int *__restrict__ done, unsigned ql_bytes, double *zscratch,
-    unsigned zslot) {
+    unsigned zslot, int elem_cap) {
   extern __shared__ __attribute__((aligned(16))) double wg_lds[];
   const int total = B * n_ticks;
   for (;;) {
@@ -541,7 +579,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NH == -1 ? W
     }
     wg::TickDiag dg = wg::mpc_tick<NH>(model, tb, states + g, outs ? outs + (size_t)t * B + g : nullptr, wg_lds,
                                    reinterpret_cast<char *>(wg_lds) + ql_bytes, nullptr, 0, nullptr,
-                                   zscratch ? zscratch + (size_t)blockIdx.x * zslot : nullptr);
+                                   zscratch ? zscratch + (size_t)blockIdx.x * zslot : nullptr, elem_cap);
     if (diag && lane == 0) {
       int *dq = diag + ((size_t)t * B + g) * 6;
       dq[0] = dg.ifail; dq[1] = dg.n_iter; dq[2] = dg.nact; dq[3] = dg.n; dq[4] = dg.m; dq[5] = dg.ns;
@@ -611,7 +649,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NH == -1 ? W
     int B, int n_ticks, const wg_model_t *__restrict__ model_p, const wg::TickTables *__restrict__ tb_p,
     wg_gait_state_t *__restrict__ states_p, wg_tick_out_t *__restrict__ outs_p, int *__restrict__ diag_p, int advance_calls,
     wg_xrun_ctl *__restrict__ ctl_p, unsigned long long *__restrict__ rings_p, int cap, int *__restrict__ done_p,
-    unsigned ql_bytes, double *zscratch, unsigned zslot, const double *__restrict__ vsched, int vperiod) {
+    unsigned ql_bytes, double *zscratch, unsigned zslot, const double *__restrict__ vsched, int vperiod, int elem_cap) {
   extern __shared__ __attribute__((aligned(16))) double wg_lds[];
   unsigned fresh_gone = 0;                                 // bit y: range y was seen exhausted (the counters only grow)
   for (;;) {
@@ -675,7 +713,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NH == -1 ? W
     }
     wg::TickDiag dg = wg::mpc_tick<NH>(model, tb, states + g, outs ? outs + (size_t)t * B + g : nullptr, wg_lds,
                                    reinterpret_cast<char *>(wg_lds) + ql_bytes, nullptr, 0, nullptr,
-                                   zscratch ? zscratch + (size_t)blockIdx.x * zslot : nullptr);
+                                   zscratch ? zscratch + (size_t)blockIdx.x * zslot : nullptr, elem_cap);
     if (diag && lane == 0) {
       int *dq = diag + ((size_t)t * B + g) * 6;
       dq[0] = dg.ifail; dq[1] = dg.n_iter; dq[2] = dg.nact; dq[3] = dg.n; dq[4] = dg.m; dq[5] = dg.ns;
@@ -792,6 +830,7 @@ int wg_mpc_tick_batch_dev_ctx(wg_ctx_t *ctx, int B, wg_gait_state_t *states, wg_
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   const int grid = B;                             // one gait per block; the dispatcher balances uneven iteration counts
   hipStream_t st = reinterpret_cast<hipStream_t>(hip_stream);
+  const int ecap = tick_elem_cap_arg(ctx->model, view);
   double *zs = nullptr;
   const size_t zslot = tick_z_slot_doubles(ctx->model, view);
   if (tick_z_global(view) || tick16_ext(view)) {
@@ -801,13 +840,13 @@ int wg_mpc_tick_batch_dev_ctx(wg_ctx_t *ctx, int B, wg_gait_state_t *states, wg_
   }
   if (view == 16)
     hipLaunchKernelGGL(wg_mpc_tick_kernel<16>, dim3(grid), dim3(64), lds, st, B, ctx->model, ctx->tables_dev, states, outs, diag,
-                       advance_calls, hist, hist_cap, hist_len, (unsigned)qlb, zs, (unsigned)zslot);
+                       advance_calls, hist, hist_cap, hist_len, (unsigned)qlb, zs, (unsigned)zslot, ecap);
   else if (view == 0)
     hipLaunchKernelGGL(wg_mpc_tick_kernel<0>, dim3(grid), dim3(64), lds, st, B, ctx->model, ctx->tables_dev, states, outs, diag,
-                       advance_calls, hist, hist_cap, hist_len, (unsigned)qlb, zs, (unsigned)zslot);
+                       advance_calls, hist, hist_cap, hist_len, (unsigned)qlb, zs, (unsigned)zslot, ecap);
   else
     hipLaunchKernelGGL(wg_mpc_tick_kernel<-1>, dim3(grid), dim3(64), lds, st, B, ctx->model, ctx->tables_dev, states, outs, diag,
-                       advance_calls, hist, hist_cap, hist_len, (unsigned)qlb, zs, (unsigned)zslot);
+                       advance_calls, hist, hist_cap, hist_len, (unsigned)qlb, zs, (unsigned)zslot, ecap);
   HIP_TRY(hipGetLastError());
   return WG_OK;
 }
@@ -878,6 +917,7 @@ int wg_mpc_run_sched_dev_ctx(wg_ctx_t *ctx, int B, wg_gait_state_t *states, int 
   if (per_cu < 1) per_cu = 1;
   int grid = ctx->num_cu * per_cu;
   if (grid > B) grid = B;
+  const int ecap = tick_elem_cap_arg(ctx->model, view);
   double *zs = nullptr;
   const size_t zslot = tick_z_slot_doubles(ctx->model, view);
   if (tick_z_global(view) || tick16_ext(view)) {
@@ -888,22 +928,22 @@ int wg_mpc_run_sched_dev_ctx(wg_ctx_t *ctx, int B, wg_gait_state_t *states, int 
   if (xcd_mode) {
     if (view == 16)
       hipLaunchKernelGGL(wg_mpc_run_xcd_kernel<16>, dim3(grid), dim3(64), lds, st, B, n_ticks, ctx->model_dev, ctx->tables_dev, states,
-                         outs, diag, advance_calls, xctl, xrings, cap, xdone, (unsigned)qlb, zs, (unsigned)zslot, vref_sched, period);
+                         outs, diag, advance_calls, xctl, xrings, cap, xdone, (unsigned)qlb, zs, (unsigned)zslot, vref_sched, period, ecap);
     else if (view == 0)
       hipLaunchKernelGGL(wg_mpc_run_xcd_kernel<0>, dim3(grid), dim3(64), lds, st, B, n_ticks, ctx->model_dev, ctx->tables_dev, states,
-                         outs, diag, advance_calls, xctl, xrings, cap, xdone, (unsigned)qlb, zs, (unsigned)zslot, vref_sched, period);
+                         outs, diag, advance_calls, xctl, xrings, cap, xdone, (unsigned)qlb, zs, (unsigned)zslot, vref_sched, period, ecap);
     else
       hipLaunchKernelGGL(wg_mpc_run_xcd_kernel<-1>, dim3(grid), dim3(64), lds, st, B, n_ticks, ctx->model_dev, ctx->tables_dev, states,
-                         outs, diag, advance_calls, xctl, xrings, cap, xdone, (unsigned)qlb, zs, (unsigned)zslot, vref_sched, period);
+                         outs, diag, advance_calls, xctl, xrings, cap, xdone, (unsigned)qlb, zs, (unsigned)zslot, vref_sched, period, ecap);
   } else if (view == 16)
     hipLaunchKernelGGL(wg_mpc_run_kernel<16>, dim3(grid), dim3(64), lds, st, B, n_ticks, ctx->model_dev, ctx->tables_dev, states, outs,
-                       diag, advance_calls, q, ring, done, (unsigned)qlb, zs, (unsigned)zslot);
+                       diag, advance_calls, q, ring, done, (unsigned)qlb, zs, (unsigned)zslot, ecap);
   else if (view == 0)
     hipLaunchKernelGGL(wg_mpc_run_kernel<0>, dim3(grid), dim3(64), lds, st, B, n_ticks, ctx->model_dev, ctx->tables_dev, states, outs,
-                       diag, advance_calls, q, ring, done, (unsigned)qlb, zs, (unsigned)zslot);
+                       diag, advance_calls, q, ring, done, (unsigned)qlb, zs, (unsigned)zslot, ecap);
   else
     hipLaunchKernelGGL(wg_mpc_run_kernel<-1>, dim3(grid), dim3(64), lds, st, B, n_ticks, ctx->model_dev, ctx->tables_dev, states, outs,
-                       diag, advance_calls, q, ring, done, (unsigned)qlb, zs, (unsigned)zslot);
+                       diag, advance_calls, q, ring, done, (unsigned)qlb, zs, (unsigned)zslot, ecap);
   HIP_TRY(hipGetLastError());
   return WG_OK;
 }

@@ -94,11 +94,15 @@ struct QlDims {
                 // iteration, early enough for an L2 round trip to hide; freeing them is what lets an eighth gait onto the CU)
   bool cold_lds; // d, wd, wx held in LDS (false: in the global slot too -- the gradient, the saved diagonal and the saved
                  // iterate are read lane-parallel, d once per iteration, the others a few times per solve)
+  int r_cols;    // > 0: the LDS holds only the first r_cols columns of R plus one working column (QlView::nact_cap): a solve
+                 // whose active set would grow past r_cols stops with kQlCapHit and is repeated with R in global memory
   __host__ __device__ QlDims(int n_, int m_, int mmax_, bool dense_ = true, bool a_lds_ = true, int nsc_ = 0,
-                             bool bounds_ = true, bool z_lds_ = true, bool wab_lds_ = true, bool cold_lds_ = true)
+                             bool bounds_ = true, bool z_lds_ = true, bool wab_lds_ = true, bool cold_lds_ = true, int r_cols_ = 0)
       : n(n_), m(m_), mmax(mmax_), ldg(n_ | 1), ldz(n_ | 1), lda(mmax_ | 1), dense(dense_), a_lds(a_lds_),
-        nsc(nsc_ > n_ ? nsc_ : n_), bounds(bounds_), z_lds(z_lds_), wab_lds(wab_lds_), cold_lds(cold_lds_) {}
-  __host__ __device__ int r_len() const { return n * (n + 1) / 2 + n; }
+        nsc(nsc_ > n_ ? nsc_ : n_), bounds(bounds_), z_lds(z_lds_), wab_lds(wab_lds_), cold_lds(cold_lds_),
+        r_cols(r_cols_ > 0 && r_cols_ < n_ ? r_cols_ : 0) {}
+  __host__ __device__ int r_tail() const { return r_cols ? r_cols * (r_cols + 1) / 2 : n * (n + 1) / 2; }
+  __host__ __device__ int r_len() const { return r_tail() + n; }
   __host__ __device__ int n_doubles() const {
     return (dense ? n * ldg + (a_lds ? n * lda : 0) : 0) + (z_lds ? n * ldz : 0) + r_len()   // [G, A,] [Z,] R
            + ((bounds ? 8 : 6) - (cold_lds ? 0 : 3)) * n   // x [d] ww [wd wx] lam [xl xu]
@@ -110,9 +114,14 @@ struct QlDims {
   }
 };
 
+constexpr int kQlCapHit = -7777;                          // QlResult::ifail of a solve stopped by QlView::nact_cap
 struct QlView {
   int n, m, me, mn, ldg, ldz, lda;
+  int r_tail = 0;                                          // offset of the n scratch entries behind R's columns
+  int nact_cap = 0;                                        // > 0: stop (kQlCapHit) when the active set would exceed it
   double *G, *Z, *R, *A;
+  double *Rf;                                              // where the Cholesky factor of G is formed on the way to Z = R^-1 (dead
+                                                           // afterwards): R itself, or a full-size array when R is capped
   double *x, *d, *ww, *wd, *wx, *lam, *xl, *xu, *wa, *b;
   double *sc0, *sc1, *sc2, *sc3, *slot;
   int *iact;
@@ -123,12 +132,13 @@ struct QlView {
   __device__ __forceinline__ void carve(double *base, const QlDims &D, int me_, double *ext_wab = nullptr, int ext_b_off = 0,
                                         double *ext_cold = nullptr, int ext_cold_ld = 0) {
     n = D.n; m = D.m; me = me_; mn = D.m + D.n; ldg = D.ldg; ldz = D.ldz; lda = D.lda;
+    r_tail = D.r_tail(); nact_cap = D.r_cols;
     double *p = base;
     G = nullptr; A = nullptr;
     if (D.dense) { G = p; p += n * ldg; }
     Z = nullptr;
     if (D.z_lds) { Z = p; p += n * ldz; }
-    R = p; p += D.r_len();
+    R = p; p += D.r_len(); Rf = R;
     if (D.dense && D.a_lds) { A = p; p += n * lda; }
     if constexpr (kColdLds) { x = p; p += n;  d = p; p += n;  ww = p; p += n;  wd = p; p += n;  wx = p; p += n; lam = p; p += n; }
     else { x = p; p += n; ww = p; p += n; lam = p; p += n; d = ext_cold; wd = ext_cold + ext_cold_ld; wx = ext_cold + 2 * ext_cold_ld; }
@@ -144,10 +154,11 @@ struct QlView {
   template <int NMAX, int MMAX, int NSC, bool kExt = false>   // kExt: wa / b live in ext_wab (global memory), known at compile time
   __device__ void carve_fixed(double *base, int n_, int m_, int me_, double *ext_wab = nullptr) {
     n = n_; m = m_; me = me_; mn = m_ + n_; ldg = NMAX | 1; ldz = NMAX | 1; lda = MMAX | 1;
+    r_tail = n_ * (n_ + 1) / 2; nact_cap = 0;
     double *p = base;
     G = nullptr; A = nullptr;
     Z = p; p += NMAX * (NMAX | 1);
-    R = p; p += NMAX * (NMAX + 1) / 2 + NMAX;
+    R = p; p += NMAX * (NMAX + 1) / 2 + NMAX; Rf = R;
     x = p; p += NMAX;  d = p; p += NMAX;  ww = p; p += NMAX;  wd = p; p += NMAX;
     wx = p; p += NMAX; lam = p; p += NMAX; xl = nullptr; xu = nullptr;     // bounds come from the problem view
     if constexpr (kExt) { wa = ext_wab; b = ext_wab + (MMAX + NMAX); }
@@ -177,6 +188,7 @@ struct DenseProb {
   __device__ __forceinline__ double xu(const QlView &q, int i) const;
 };
 #define Rp(i, j) q.R[(j) * ((j) + 1) / 2 + (i)]
+#define Rf(i, j) q.Rf[(j) * ((j) + 1) / 2 + (i)]        // the same packing, in the factorisation's array
 
 // ---- optional in-kernel phase timers (diagnostic build only: -DWG_PROFILE) ----
 #ifdef WG_PROFILE
@@ -1025,7 +1037,7 @@ __device__ __forceinline__ QlResult ql_solve(const QlView &q, P &prob, double vs
   int jfinc = -kfinc;
   double xmag = 0.0, vfact = 1.0, res = 0.0, ratio = 0.0, diag = 0.0;
   int knext = 0;
-  const int s_tail = n * (n + 1) / 2;
+  const int s_tail = q.r_tail;                              // n (n + 1) / 2, or the working column of the last allowed nact
   double *s = q.R + s_tail;
   bool early_exit = false;
   PT_DECL
@@ -1104,16 +1116,16 @@ __device__ __forceinline__ QlResult ql_solve(const QlView &q, P &prob, double vs
         for (int j = i + lane; j < n; j += 64) {
           double temp = Gm(i, j);
           WG_UNROLL
-          for (int k = 0; k < i; ++k) temp -= Rp(k, j) * Rp(k, i);
+          for (int k = 0; k < i; ++k) temp -= Rf(k, j) * Rf(k, i);
           if (j == i) {
             if (temp < vsmall) { q.slot[0] = 1.0; q.slot[1] = temp; }
-            else { q.slot[0] = 0.0; Rp(i, i) = sqrt(temp); }
+            else { q.slot[0] = 0.0; Rf(i, i) = sqrt(temp); }
           } else q.sc0[j] = temp;
         }
         WG_WSYNC();
         if (WG_UBOOL(q.slot[0] != 0.0)) { jfail = i; tfail = q.slot[1]; break; }
-        double rii = Rp(i, i);
-        for (int j = i + 1 + lane; j < n; j += 64) Rp(i, j) = q.sc0[j] / rii;
+        double rii = Rf(i, i);
+        for (int j = i + 1 + lane; j < n; j += 64) Rf(i, j) = q.sc0[j] / rii;
         WG_WSYNC();
       }
       jfail = uni(jfail);
@@ -1129,8 +1141,8 @@ __device__ __forceinline__ QlResult ql_solve(const QlView &q, P &prob, double vs
           for (int k = jfail; k >= 1; --k) {
             double sum = 0.0;
             WG_UNROLL
-            for (int i = k; i <= jfail; ++i) sum -= Rp(k - 1, i) * v[i];
-            v[k - 1] = sum / Rp(k - 1, k - 1);
+            for (int i = k; i <= jfail; ++i) sum -= Rf(k - 1, i) * v[i];
+            v[k - 1] = sum / Rf(k - 1, k - 1);
             sumx += v[k - 1] * v[k - 1];
           }
           dnew = diag + vsmall - tfail / sumx;
@@ -1147,7 +1159,7 @@ __device__ __forceinline__ QlResult ql_solve(const QlView &q, P &prob, double vs
     for (int i = lane; i < n; i += 64) {
       WG_UNROLL
       for (int j = 0; j < i; ++j) Zm(i, j) = 0.0;
-      Zm(i, i) = 1.0 / Rp(i, i);
+      Zm(i, i) = 1.0 / Rf(i, i);
     }
     {
       // aligned form: all lanes walk (c, k) together so R(k,c) is a broadcast
@@ -1157,11 +1169,11 @@ __device__ __forceinline__ QlResult ql_solve(const QlView &q, P &prob, double vs
         sum0 = 0.0; sum1 = 0.0;
         WG_UNROLL
         for (int k = 0; k < c; ++k) {
-          double rkc = Rp(k, c);
+          double rkc = Rf(k, c);
           if (i0 <= k) sum0 += Zm(i0, k) * rkc;
           if (i1 <= k) sum1 += Zm(i1, k) * rkc;
         }
-        double rcc = Rp(c, c);
+        double rcc = Rf(c, c);
         if (i0 < c) Zm(i0, c) = -sum0 / rcc;
         if (i1 < c) Zm(i1, c) = -sum1 / rcc;
       }
@@ -1698,6 +1710,7 @@ __device__ __forceinline__ QlResult ql_solve(const QlView &q, P &prob, double vs
       nact++;
       LOG_EVENT(knext);
       WG_WSYNC();
+      if (q.nact_cap > 0 && nact > q.nact_cap) { info = kQlCapHit; st = ST_FINISH; continue; }   // R's LDS part is full
       PT(18);
       double sm = uni(xmag_sum(q, prob, vfact, lane));            // :1776-1786
       xmag = maxd(xmag, sm);
@@ -1724,6 +1737,7 @@ __device__ __forceinline__ QlResult ql_solve(const QlView &q, P &prob, double vs
   if (info == 1) out.ifail = 1;
   else if (info == 2) out.ifail = 2;
   else if (info < 0) out.ifail = -info + 10;
+  if (info == kQlCapHit) out.ifail = kQlCapHit;
   out.n_iter = iterc;
   out.nact = nact;
   return out;

@@ -49,16 +49,16 @@ __device__ __forceinline__ bool herdt_border_rows(const QlView &q, const double 
 #pragma unroll
   for (int f = 0; f < NS; ++f)
     acc[f] = (jerk || (foot && f >= fi)) ? ((foot && f == fi) ? gd[gi] : Gv[gi * kGvLd + f]) : 0.0;
-  const double dreg = jerk ? Rp(i, i) : 1.0;
-  const int colbase = jerk ? i * (i + 1) / 2 : 0;         // R(k, i) = q.R[colbase + k], k <= i (first diagonal block)
+  const double dreg = jerk ? Rf(i, i) : 1.0;
+  const int colbase = jerk ? i * (i + 1) / 2 : 0;         // R(k, i) = q.Rf[colbase + k], k <= i (first diagonal block)
   const int khi = jerk ? i : 0;
   // ---- steps k < N: the divisor is the constant diagonal ----
-  double rnext = (0 < khi) ? q.R[colbase] : 0.0;
+  double rnext = (0 < khi) ? q.Rf[colbase] : 0.0;
   for (int k = 0; k < NH; ++k) {
     const double rki_lds = rnext;                         // R(k, i), fetched one step ahead (clamped address, selected value)
     {
       const int kn = k + 1;
-      const double v = q.R[colbase + (kn < khi ? kn : 0)];
+      const double v = q.Rf[colbase + (kn < khi ? kn : 0)];
       rnext = (kn < khi) ? v : 0.0;
     }
     double bk[NS];
@@ -70,8 +70,8 @@ __device__ __forceinline__ bool herdt_border_rows(const QlView &q, const double 
     if (lane == k) {
 #pragma unroll
       for (int f = 0; f < NS; ++f) {
-        Rp(k, M2 + f) = bk[f]; Rp(NH + k, M2 + NS + f) = bk[f];     // x entry and its y twin
-        Rp(k, M2 + NS + f) = 0.0; Rp(NH + k, M2 + f) = 0.0;         // the two cross entries
+        Rf(k, M2 + f) = bk[f]; Rf(NH + k, M2 + NS + f) = bk[f];     // x entry and its y twin
+        Rf(k, M2 + NS + f) = 0.0; Rf(NH + k, M2 + f) = 0.0;         // the two cross entries
       }
     }
     double rki = rki_lds;
@@ -99,11 +99,11 @@ __device__ __forceinline__ bool herdt_border_rows(const QlView &q, const double 
       if (f > kb) bk[f] = rl(acc[f] / rt, k);
     }
     if (lane == k) {
-      Rp(M2 + kb, M2 + kb) = rt; Rp(M2 + NS + kb, M2 + NS + kb) = rt;
+      Rf(M2 + kb, M2 + kb) = rt; Rf(M2 + NS + kb, M2 + NS + kb) = rt;
 #pragma unroll
       for (int f = 0; f < NS; ++f) {
-        if (f > kb) { Rp(M2 + kb, M2 + f) = bk[f]; Rp(M2 + NS + kb, M2 + NS + f) = bk[f]; }
-        Rp(M2 + kb, M2 + NS + f) = 0.0;                   // x-foot row, y-foot column: cross (its mirror lies below the diagonal)
+        if (f > kb) { Rf(M2 + kb, M2 + f) = bk[f]; Rf(M2 + NS + kb, M2 + NS + f) = bk[f]; }
+        Rf(M2 + kb, M2 + NS + f) = 0.0;                   // x-foot row, y-foot column: cross (its mirror lies below the diagonal)
       }
     }
     double rki = 0.0;
@@ -142,18 +142,18 @@ __device__ __forceinline__ void herdt_border_z(const QlView &q, int lane) {
   for (int k = 0; k < NH; ++k) {                          // k < i: Z(i,k) = +0.0, the products are exact zeros
     const double zk = Zm(zi, k);
 #pragma unroll
-    for (int f = 0; f < NS; ++f) sum[f] += zk * Rp(k, M2 + f);
+    for (int f = 0; f < NS; ++f) sum[f] += zk * Rf(k, M2 + f);
   }
   double zl[NS];
 #pragma unroll
   for (int f = 0; f < NS; ++f) {
     const int c = M2 + f;
-    const double rcc = Rp(c, c);
+    const double rcc = Rf(c, c);
     double sj = sum[f], sf = 0.0;
 #pragma unroll
     for (int g = 0; g < NS; ++g) {
       if (g < f) {
-        const double t = zl[g] * Rp(M2 + g, c);
+        const double t = zl[g] * Rf(M2 + g, c);
         sj += t;                                          // jerk rows: every earlier foot row takes part
         sf = (g >= fi) ? sf + t : sf;                     // foot row fi: rows fi .. f-1
       }
@@ -188,10 +188,10 @@ __device__ __forceinline__ void herdt_constant_blocks(const QlView &q, const dou
       while ((j + 1) * (j + 2) / 2 <= e) ++j;
       const int i = e - j * (j + 1) / 2;
       const double v = R2[e];
-      q.R[e] = v;
-      Rp(NH + i, NH + j) = v;
+      q.Rf[e] = v;
+      Rf(NH + i, NH + j) = v;
     }
-    for (int e = lane; e < NH * NH; e += 64) { const int i = e % NH, j = NH + e / NH; Rp(i, j) = 0.0; }   // cross block of R
+    for (int e = lane; e < NH * NH; e += 64) { const int i = e % NH, j = NH + e / NH; Rf(i, j) = 0.0; }   // cross block of R
     for (int e = lane; e < NH * NH; e += 64) {
       const int i = e % NH, j = e / NH;
       const double v = Z2[i + j * M2];
@@ -215,11 +215,11 @@ __device__ __forceinline__ void herdt_constant_blocks(const QlView &q, const dou
       int j = 0;
       while ((j + 1) * (j + 2) / 2 <= e) ++j;
       const int i = e - j * (j + 1) / 2;
-      q.R[e] = rv[t];
-      Rp(NH + i, NH + j) = rv[t];
+      q.Rf[e] = rv[t];
+      Rf(NH + i, NH + j) = rv[t];
     }
   }
-  for (int e = lane; e < NH * NH; e += 64) { const int i = e % NH, j = NH + e / NH; Rp(i, j) = 0.0; }   // cross block of R
+  for (int e = lane; e < NH * NH; e += 64) { const int i = e % NH, j = NH + e / NH; Rf(i, j) = 0.0; }   // cross block of R
 #pragma unroll
   for (int t = 0; t < TZ; ++t) {
     const int e = lane + 64 * t;

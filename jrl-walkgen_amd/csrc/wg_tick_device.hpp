@@ -499,7 +499,7 @@ struct TickDiag { int ifail, n_iter, nact, n, m, ns; };
 template <int NH>
 __device__ __forceinline__ TickDiag mpc_tick(const wg_model_t &m, const TickTables *__restrict__ tb, wg_gait_state_t *gstate,
                                     wg_tick_out_t *out, double *lds_ql, char *lds_tick, int *hist, int hist_cap,
-                                    int *hist_len, double *zglobal = nullptr) {
+                                    int *hist_len, double *zglobal = nullptr, int elem_nact_cap = 0) {
   const int lane = wg_lane();
   const int N = (NH == 16) ? 16 : m.N;            // compact view: the horizon is a compile-time constant (checked by the host)
   const double T = m.T;
@@ -521,6 +521,7 @@ __device__ __forceinline__ TickDiag mpc_tick(const wg_model_t &m, const TickTabl
   const int eWab = (eMmax + eNmax) + eMmax;
   const int eRows = eWab + eNmax * kGvStride;               // offset of the row tables, then of gd | d | wd | wx
   const int eCold = eRows + 2 * eMmax + (eMmax + 1) / 2 + 2;
+  const int eRfull = eCold + 4 * eNmax;                    // a full-size R (element view with a column cap on its LDS part)
   if constexpr (NH == -1)
     L.template carve<true, true, true>(lds_tick, N, kSMax, kGvStride, reinterpret_cast<char *>(lds_ql), false, extE + eWab,
                                        extE + eRows, extE + eCold);
@@ -672,7 +673,8 @@ __device__ __forceinline__ TickDiag mpc_tick(const wg_model_t &m, const TickTabl
   // element view with a Z slot in global memory: Z leaves the LDS (it is the operand that caps the residency at N = 32)
   constexpr bool z_in_lds = (NH != -1);
   constexpr bool kElemView = (NH == -1);
-  QlDims D(n, mq, mq, !kTableView, true, kCompactView ? 2 * NH + 4 : 0, !kTableView, z_in_lds, !kElemView, !kElemView);   // ordered sums run the static length
+  QlDims D(n, mq, mq, !kTableView, true, kCompactView ? 2 * NH + 4 : 0, !kTableView, z_in_lds, !kElemView, !kElemView,
+           kElemView ? (elem_nact_cap & 0xffff) : 0);       // ordered sums run the static length
   QlView q;
   if constexpr (kCompactView) {
     constexpr int kNmax = 2 * NH + 4, kMmax = 1 + 4 * NH + 10;     // two previewed steps at most (wg_mpc_configure)
@@ -682,6 +684,8 @@ __device__ __forceinline__ TickDiag mpc_tick(const wg_model_t &m, const TickTabl
     if constexpr (kElemView) {
       q.template carve<false, false, false>(lds_ql, D, 0, extE, eMmax + eNmax, extE + eCold + eNmax, eNmax);
       q.Z = zglobal;
+      q.Rf = extE + eRfull;                                 // the LDS may hold only r_cols columns of R: the Cholesky factor needs all n
+      if (q.nact_cap > 0 && (elem_nact_cap >> 16) > 0 && (elem_nact_cap >> 16) < q.nact_cap) q.nact_cap = elem_nact_cap >> 16;   // tests
     }
     else q.carve(lds_ql, D, 0);
   }
@@ -878,6 +882,20 @@ __device__ __forceinline__ TickDiag mpc_tick(const wg_model_t &m, const TickTabl
     prob.rowA = L.rowA; prob.rowB = L.rowB; prob.rowK = L.rowK; prob.stepidx = L.stepidx; prob.V_f = L.V_f;
     prob.R2 = tb->R2; prob.Z2 = tb->Z2; prob.z2sign = tb->z2_cross_sign; prob.blocks_ok = tb->blocks_ok;
     qr = ql_solve(q, prob, 1e-8, hist, hist_cap);
+    if (WG_UBOOL(qr.ifail == kQlCapHit)) {
+      // the active set outgrew the columns of R the LDS holds (rare): the same QP again, from the start, with R in the
+      // per-block slot of global memory -- slow, and the same bytes as an uncapped solve.  What the first attempt changed
+      // of its inputs is put back: the Hessian diagonal from its saved copy (a shift, if any, is re-derived); wa, x, the
+      // multipliers and the active set are (re)initialised by the solver itself.
+      WG_WSYNC();
+      for (int i = lane; i < n; i += 64) prob.setGd(q, i, q.wd[i]);
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      WG_WSYNC();
+      q.R = extE + eRfull; q.Rf = q.R;
+      q.r_tail = n * (n + 1) / 2;
+      q.nact_cap = 0;
+      qr = ql_solve(q, prob, 1e-8, hist, hist_cap);
+    }
     {
       WG_WSYNC();
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");

@@ -178,6 +178,18 @@ def test_config5_horizon_32_runs_through_the_element_view_bit_exact():
     assert max(sizes) == 72 and min(sizes) >= 64                   # all four previewed steps appeared
 
 
+@pytest.mark.parametrize("abort_at", ["6", "31", "47"])
+def test_config5_solves_that_outgrow_the_lds_part_of_R_are_repeated_in_global_memory(abort_at, monkeypatch):
+    """At N = 32 the LDS holds the first 60 columns of R (eight gaits per CU); a solve whose active set would grow past them
+    stops and is repeated from the start with R in the per-block slot of global memory -- the same bytes as an uncapped solve.
+    The benchmark workload never gets there (its active sets stay below 60), so WG_ELEM_ABORT_AT makes the first attempt give
+    up at a smaller active set: at 6 nearly every solve takes the second route, at 31 about half of them, at 47 a few."""
+    monkeypatch.setenv("WG_ELEM_ABORT_AT", abort_at)
+    wg.init(0)
+    sizes = _horizon_vs_oracle(32, 0.1, 0.8, B=5, ticks=36, redraw=12)
+    assert max(sizes) == 72 and min(sizes) >= 64
+
+
 @pytest.mark.parametrize("N", [8, 20])
 def test_element_view_equals_dense_view_on_small_horizons(N, monkeypatch):
     wg.init(0)

@@ -100,7 +100,7 @@ def test_run_batch_dense_view_and_arguments():
 
 
 @pytest.mark.parametrize("N,B,T,period,queue", [(16, 700, 37, 10, "xcd"), (16, 2500, 23, 23, "xcd"), (16, 64, 9, 4, "global"),
-                                              (32, 96, 11, 5, "xcd")])
+                                              (32, 96, 11, 5, "xcd"), (32, 200, 9, 4, "xcd-abort")])
 def test_staged_references_equal_a_loop_of_set_velref_and_run(N, B, T, period, queue, monkeypatch):
     """wg_mpc_run_sched_dev: the velocity references of every stretch staged on the device, ONE launch for all the ticks --
     the same bytes (states, diagnostics, outputs) as wg_mpc_set_velref_dev + wg_mpc_run_batch_dev per stretch.  Also through
@@ -108,6 +108,8 @@ def test_staged_references_equal_a_loop_of_set_velref_and_run(N, B, T, period, q
     wg.init(0)
     if queue == "global":
         monkeypatch.setenv("WG_RUN_QUEUE", "global")
+    if queue == "xcd-abort":                                   # N = 32: most solves repeated with R in global memory
+        monkeypatch.setenv("WG_ELEM_ABORT_AT", "20")
     model = wg.model_defaults(); model.N = N
     wg.mpc_configure(model)
     try:
