@@ -178,6 +178,20 @@ def test_config5_horizon_32_runs_through_the_element_view_bit_exact():
     assert max(sizes) == 72 and min(sizes) >= 64                   # all four previewed steps appeared
 
 
+@pytest.mark.parametrize("N,abort_at", [(28, None), (30, "9"), (31, None)])
+def test_horizons_next_to_32_take_the_element_view_with_their_own_column_cap(N, abort_at, monkeypatch):
+    """N = 28 .. 31 do not fit the dense view either: element view, generic factorisation (the constant factor blocks are
+    instantiated for N = 32 only), n <= 64 at N <= 30 (one row per lane), the host picks the column cap of R per model."""
+    if abort_at:
+        monkeypatch.setenv("WG_ELEM_ABORT_AT", abort_at)
+    wg.init(0)
+    model = wg.model_defaults(); model.N = N
+    lds = wg.lib().wg_mpc_tick_lds_bytes_for(C.byref(model))
+    assert lds <= 20480                                            # eight gaits per CU
+    sizes = _horizon_vs_oracle(N, 0.1, 0.8, B=4, ticks=28, redraw=9)
+    assert max(sizes) > 2 * N
+
+
 @pytest.mark.parametrize("abort_at", ["6", "31", "47"])
 def test_config5_solves_that_outgrow_the_lds_part_of_R_are_repeated_in_global_memory(abort_at, monkeypatch):
     """At N = 32 the LDS holds the first 60 columns of R (eight gaits per CU); a solve whose active set would grow past them
