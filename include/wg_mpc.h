@@ -32,6 +32,7 @@ extern "C" {
 #define WG_ERR_BAD_ARG (-2)
 #define WG_ERR_HIP (-3)
 #define WG_ERR_TOO_LARGE (-4)
+#define WG_ERR_BUSY (-5)      /* a launch of the same context is still in flight on another stream */
 
 /* Library / device management ------------------------------------------- */
 
@@ -264,8 +265,10 @@ int wg_mpc_configure(const wg_model_t *model);
  *   diag    B x 6 ints {ifail, n_iter, nact, n, m, nb_prw_steps} or NULL
  *   hist    B x hist_cap active-set add(+)/drop(-) log or NULL, hist_len B or NULL
  * The kernels keep a few solver arrays per block in a buffer of the context (what does not fit the CU's LDS at the
- * residency they run at): launches of the tick entry points ON ONE CONTEXT must not overlap -- one stream, or events between
- * streams; overlapping streams take one context each (wg_ctx_create). */
+ * residency they run at): launches of the tick / run entry points ON ONE CONTEXT must not overlap -- one stream, or events
+ * between streams; overlapping streams take one context each (wg_ctx_create).  The library checks this: a launch that arrives
+ * on a different stream while the context's previous tick / run launch has not completed returns WG_ERR_BUSY and launches
+ * nothing. */
 int wg_mpc_tick_batch(int B, wg_gait_state_t *states, wg_tick_out_t *outs, int *diag, int advance_calls,
                       int *hist, int hist_cap, int *hist_len);
 int wg_mpc_tick_batch_dev(int B, wg_gait_state_t *states, wg_tick_out_t *outs, int *diag, int advance_calls,
@@ -291,6 +294,25 @@ int wg_mpc_run_sched_dev(int B, wg_gait_state_t *states, int n_ticks, int advanc
 /* NewVelRef_ <- (vx, vy, vyaw) for every gait (":setVelReference", ZMPVelocityReferencedQP.hh:103-114);
  * vref = B x 3 doubles, DEVICE pointers. */
 int wg_mpc_set_velref_dev(int B, wg_gait_state_t *states, const double *vref, void *hip_stream);
+/* One robot (BASELINE configs[1]: batch = 1 -- what a drop-in caller of ZMPVelocityReferencedQP::OnLine has, one tick per
+ * 0.1 s of walking): the same tick with the caller's state, outputs and diagnostics in HOST-MAPPED memory from
+ * wg_host_alloc.  No staging copies and no device synchronisation: the kernel reads the state over the bus, works on a device
+ * copy, writes state / out / diag back and releases a completion counter the call spins on.  Same bytes as
+ * wg_mpc_tick_batch(1, ...); out and diag may be NULL.  Runs on a stream of the context; it must not overlap other tick / run
+ * launches of the same context (WG_ERR_BUSY). */
+int wg_host_alloc(void **out, size_t bytes);
+void wg_host_free(void *p);
+int wg_mpc_tick_pinned(wg_gait_state_t *state, wg_tick_out_t *out, int *diag, int advance_calls);
+/* The QP of every gait's NEXT tick exactly as QPProblem::solve would hand it to ql0001_ (qp-problem.cpp:245-279), without
+ * advancing anything: Q (C), D (d), DU (A, row 0 the dummy row, mmax >= m + 1 rows), DS (b), XL, XU -- the arrays
+ * QPProblem::dump_problem prints (qp-problem.cpp:639-653), which the reference writes to /tmp/Problem_<time>.dat when a solve
+ * fails (ZMPVelocityReferencedQP.cpp:399-402).  Column-major with the caller's leading dimensions (nmax, mmax), zero-padded;
+ * n[g], m[g] receive the sizes (m counts the dummy row, as m_ does).  `advance_calls` as in wg_mpc_tick_batch.  The states are
+ * not modified.  Feeding the result to wg_qp_solve_batch gives the x the fused tick computes, bit for bit. */
+int wg_mpc_assemble_batch(int B, const wg_gait_state_t *states, int advance_calls, int nmax, int mmax, double *C, double *d,
+                          double *A, double *b, double *xl, double *xu, int *n, int *m);
+int wg_mpc_assemble_batch_dev(int B, const wg_gait_state_t *states, int advance_calls, int nmax, int mmax, double *C, double *d,
+                              double *A, double *b, double *xl, double *xu, int *n, int *m, void *hip_stream);
 /* LDS bytes one gait occupies in the tick kernel for the configured model. */
 size_t wg_mpc_tick_lds_bytes(void);
 /* the same figure for any model, without configuring it (host arithmetic: lets callers and tests reason about
@@ -578,6 +600,12 @@ int wg_mpc_run_sched_dev_ctx(wg_ctx_t *ctx, int B, wg_gait_state_t *states, int 
 int wg_mpc_tick_batch_ctx(wg_ctx_t *ctx, int B, wg_gait_state_t *states, wg_tick_out_t *outs, int *diag,
                           int advance_calls, int *hist, int hist_cap, int *hist_len);
 int wg_mpc_set_velref_dev_ctx(wg_ctx_t *ctx, int B, wg_gait_state_t *states, const double *vref, void *hip_stream);
+int wg_mpc_tick_pinned_ctx(wg_ctx_t *ctx, wg_gait_state_t *state, wg_tick_out_t *out, int *diag, int advance_calls);
+int wg_mpc_assemble_batch_ctx(wg_ctx_t *ctx, int B, const wg_gait_state_t *states, int advance_calls, int nmax, int mmax,
+                              double *C, double *d, double *A, double *b, double *xl, double *xu, int *n, int *m);
+int wg_mpc_assemble_batch_dev_ctx(wg_ctx_t *ctx, int B, const wg_gait_state_t *states, int advance_calls, int nmax, int mmax,
+                                  double *C, double *d, double *A, double *b, double *xl, double *xu, int *n, int *m,
+                                  void *hip_stream);
 int wg_pldp_configure_ctx(wg_ctx_t *ctx, int N, const double *iPu, const double *Px, const double *Pu);
 int wg_pldp_solve_batch_dev_ctx(wg_ctx_t *ctx, int B, int mcap, const int *m, const double *D, const double *A,
                                 const double *b, const double *zmpref, const double *xkyk, const int *similar,

@@ -39,20 +39,27 @@ int fail(int code, const char *fmt, ...) {
     if (e_ != hipSuccess) return fail(WG_ERR_HIP, "%s: %s", #expr, hipGetErrorString(e_)); \
   } while (0)
 
-// grow-only device buffer
+// grow-only device buffer.  Growing never frees: a launch enqueued earlier may still be using the old allocation (and
+// hipFree would make the host wait for the whole device), so the old one is retired and freed with the context.
 struct DevBuf {
   void *p = nullptr;
   size_t cap = 0;
+  std::vector<void *> retired;
   int reserve(size_t bytes) {
     if (bytes <= cap) return WG_OK;
-    if (p) (void)hipFree(p);
-    p = nullptr; cap = 0;
-    hipError_t e = hipMalloc(&p, bytes);
+    void *fresh = nullptr;
+    hipError_t e = hipMalloc(&fresh, bytes);
     if (e != hipSuccess) return fail(WG_ERR_HIP, "hipMalloc(%zu): %s", bytes, hipGetErrorString(e));
-    cap = bytes;
+    if (p) retired.push_back(p);
+    p = fresh; cap = bytes;
     return WG_OK;
   }
-  void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+  void release() {
+    if (p) (void)hipFree(p);
+    for (void *r : retired) (void)hipFree(r);
+    retired.clear();
+    p = nullptr; cap = 0;
+  }
 };
 
 }  // namespace
@@ -69,7 +76,17 @@ struct wg_ctx {
   bool model_set = false;
   wg::TickTables *tables_dev = nullptr;
   wg_model_t *model_dev = nullptr;     // the model in device memory (the multi-tick kernels read it through a pointer)
-  DevBuf tick_state, tick_out, tick_aux, run_buf, tick_z;
+  DevBuf tick_state, tick_out, tick_aux, run_buf, tick_z, asm_state;
+  // The tick / run kernels keep their queue and per-block solver slots in run_buf / tick_z: launches of one context must
+  // not overlap.  Every such launch leaves an event behind; a launch that arrives on ANOTHER stream while that event is
+  // still pending is refused (WG_ERR_BUSY) instead of corrupting the slots silently.
+  hipEvent_t guard_ev = nullptr;
+  hipStream_t guard_stream = nullptr;
+  bool guard_armed = false;
+  // one-robot path (wg_mpc_tick_pinned): its own stream, a completion counter in host-mapped memory
+  hipStream_t pin_stream = nullptr;
+  int *pin_flag = nullptr;               // host-mapped; the kernel adds 1 per gait when its outputs are visible
+  int pin_seq = 0;
   // PLDP / Dimitrov
   wg::PldpModel *pldp_dev = nullptr;
   int pldp_N = 0;
@@ -93,8 +110,13 @@ struct wg_ctx {
     if (prev_F) (void)hipFree(prev_F);
     tables_dev = nullptr; model_dev = nullptr; pldp_dev = nullptr; dim_dev = nullptr; prev_F = nullptr;
     model_set = false; pldp_N = 0; dim_set = false; prev_set = false;
-    for (DevBuf *b : {&tick_state, &tick_out, &tick_aux, &run_buf, &tick_z, &pldp_buf, &dim_buf, &prev_buf, &in, &out, &gram_buf, &zd_buf})
+    for (DevBuf *b : {&tick_state, &tick_out, &tick_aux, &run_buf, &tick_z, &asm_state, &pldp_buf, &dim_buf, &prev_buf, &in, &out, &gram_buf, &zd_buf})
       b->release();
+    if (guard_ev) (void)hipEventDestroy(guard_ev);
+    guard_ev = nullptr; guard_armed = false;
+    if (pin_stream) (void)hipStreamDestroy(pin_stream);
+    if (pin_flag) (void)hipHostFree(pin_flag);
+    pin_stream = nullptr; pin_flag = nullptr; pin_seq = 0;
   }
 };
 
@@ -134,6 +156,23 @@ int use_ctx(wg_ctx *ctx) {
   if (!ctx) return fail(WG_ERR_BAD_ARG, "null context");
   int cur = -1;
   if (hipGetDevice(&cur) != hipSuccess || cur != ctx->device) HIP_TRY(hipSetDevice(ctx->device));
+  return WG_OK;
+}
+
+// before a launch that uses the context's queue / solver slots: refuse it while a launch of another stream is pending
+int guard_claim(wg_ctx *ctx, hipStream_t st) {
+  std::lock_guard<std::mutex> lk(ctx->z_mu);
+  if (ctx->guard_armed && ctx->guard_stream != st && hipEventQuery(ctx->guard_ev) == hipErrorNotReady)
+    return fail(WG_ERR_BUSY, "a tick / run launch of this context is still in flight on another stream: launches of one "
+                             "context must not overlap (order them with an event, or give each stream its own wg_ctx)");
+  return WG_OK;
+}
+// after it: the event later launches are checked against
+int guard_mark(wg_ctx *ctx, hipStream_t st) {
+  std::lock_guard<std::mutex> lk(ctx->z_mu);
+  if (!ctx->guard_ev) HIP_TRY(hipEventCreateWithFlags(&ctx->guard_ev, hipEventDisableTiming));
+  HIP_TRY(hipEventRecord(ctx->guard_ev, st));
+  ctx->guard_stream = st; ctx->guard_armed = true;
   return WG_OK;
 }
 
@@ -214,7 +253,7 @@ __global__ __launch_bounds__(64) void wg_ql_dense_kernel(   // never flat_ (thos
 
 extern "C" {
 
-int wg_abi_version(void) { return 2; }
+int wg_abi_version(void) { return 3; }
 
 const char *wg_last_error(void) { return g_err.c_str(); }
 
@@ -491,13 +530,23 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NH == -1 ? W
                                                          wg_tick_out_t *__restrict__ outs, int *__restrict__ diag,
                                                          int advance_calls, int *__restrict__ hist, int hist_cap,
                                                          int *__restrict__ hist_len, unsigned ql_bytes, double *zscratch,
-                                                         unsigned zslot, int elem_cap) {
+                                                         unsigned zslot, int elem_cap,
+                                                         wg_gait_state_t *__restrict__ host_states, int *host_done) {
   extern __shared__ __attribute__((aligned(16))) double wg_lds[];
   const int lane = threadIdx.x & 63;
   // one block = one gait (grid == B): no grid-stride loop, so nothing lane-dependent is hoisted out of it and kept
   // alive (in registers) across the whole tick
   const int g = blockIdx.x;
   if (g < B) {
+    if (host_states) {
+      // one-robot path (wg_mpc_tick_pinned): the caller's state lives in host-mapped memory; the tick works on a device copy
+      const double *src = reinterpret_cast<const double *>(host_states + g);
+      double *dst = reinterpret_cast<double *>(states + g);
+      for (int i = lane; i < (int)(sizeof(wg_gait_state_t) / 8); i += 64)
+        dst[i] = __hip_atomic_load(src + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      WG_WSYNC();
+    }
     if (advance_calls > 0) {
       if (lane == 0) {
         double c = states[g].clock;
@@ -516,6 +565,54 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NH == -1 ? W
       dq[0] = dg.ifail; dq[1] = dg.n_iter; dq[2] = dg.nact; dq[3] = dg.n; dq[4] = dg.m; dq[5] = dg.ns;
     }
     WG_WSYNC();
+    if (host_states) {
+      // state back to the caller's memory; outs / diag were written there directly.  Every store of this wave is performed
+      // (system-scope release) before the completion counter moves: the host spins on it instead of synchronising.
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+      const double *src = reinterpret_cast<const double *>(states + g);
+      double *dst = reinterpret_cast<double *>(host_states + g);
+      for (int i = lane; i < (int)(sizeof(wg_gait_state_t) / 8); i += 64) dst[i] = src[i];
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+      WG_WSYNC();
+      if (lane == 0) __hip_atomic_fetch_add(host_done, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+  }
+}
+
+// The assembled QP of every gait's NEXT tick, without advancing anything: the dense view of the tick run on a scratch copy
+// of the state up to the point where QPProblem::solve would call ql0001_ (qp-problem.cpp:245-279), the arrays written in
+// ql0001_'s layout instead (QPProblem::dump_problem, qp-problem.cpp:639-653: what the reference writes to
+// /tmp/Problem_<time>.dat when a solve fails, ZMPVelocityReferencedQP.cpp:399-402).
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WG_TICK_WPE_MIN, WG_TICK_WPE_MAX))) void wg_mpc_assemble_kernel(
+    int B, wg_model_t model, const wg::TickTables *__restrict__ tb, const wg_gait_state_t *__restrict__ states,
+    wg_gait_state_t *__restrict__ scratch, int advance_calls, unsigned ql_bytes, int nmax, int mmax, double *__restrict__ C,
+    double *__restrict__ d, double *__restrict__ A, double *__restrict__ b, double *__restrict__ xl, double *__restrict__ xu,
+    int *__restrict__ n_out, int *__restrict__ m_out) {
+  extern __shared__ __attribute__((aligned(16))) double wg_lds[];
+  const int lane = threadIdx.x & 63;
+  const int g = blockIdx.x;
+  if (g < B) {
+    {
+      const double *src = reinterpret_cast<const double *>(states + g);
+      double *dst = reinterpret_cast<double *>(scratch + g);
+      for (int i = lane; i < (int)(sizeof(wg_gait_state_t) / 8); i += 64) dst[i] = src[i];
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      WG_WSYNC();
+    }
+    if (advance_calls > 0) {
+      if (lane == 0) {
+        double c = scratch[g].clock;
+        for (int k = 0; k < advance_calls; ++k) c += model.Tctrl;   // PatternGeneratorInterfacePrivate.cpp:1256
+        scratch[g].clock = c;
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      WG_WSYNC();
+    }
+    wg::QpDumpOut o;
+    o.C = C + (size_t)g * nmax * nmax; o.d = d + (size_t)g * nmax; o.A = A + (size_t)g * mmax * nmax; o.b = b + (size_t)g * mmax;
+    o.xl = xl + (size_t)g * nmax; o.xu = xu + (size_t)g * nmax; o.n = n_out + g; o.m = m_out + g; o.nmax = nmax; o.mmax = mmax;
+    (void)wg::mpc_tick<0>(model, tb, scratch + g, nullptr, wg_lds, reinterpret_cast<char *>(wg_lds) + ql_bytes, nullptr, 0, nullptr,
+                          nullptr, 0, &o);
   }
 }
 
@@ -800,6 +897,16 @@ int wg_mpc_configure_ctx(wg_ctx_t *ctx, const wg_model_t *model) {
   HIP_TRY(hipMemcpy(ctx->model_dev, model, sizeof(wg_model_t), hipMemcpyHostToDevice));
   ctx->model = *model;
   ctx->model_set = true;
+  // queue and per-block solver slots of the multi-tick kernels, sized now for every resident block and for fleets of up to
+  // 32 768 gaits: later launches find them in place (a larger job grows them once, without freeing anything in flight)
+  {
+    const int view = tick_view(*model);
+    if (tick_z_global(view) || tick16_ext(view)) {
+      std::lock_guard<std::mutex> zk(ctx->z_mu);
+      if (int rc = ctx->tick_z.reserve((size_t)ctx->num_cu * 8 * tick_z_slot_doubles(*model, view) * 8)) return rc;
+    }
+    if (int rc = ctx->run_buf.reserve(sizeof(wg_xrun_ctl) + (size_t)kXcds * 65536 * 8 + (size_t)32768 * 4)) return rc;
+  }
   return WG_OK;
 }
 
@@ -813,7 +920,9 @@ size_t wg_mpc_tick_lds_bytes_ctx(wg_ctx_t *ctx) {
   return tick_lds_for(ctx->model, tick_view(ctx->model));
 }
 
-int wg_mpc_tick_batch_dev_ctx(wg_ctx_t *ctx, int B, wg_gait_state_t *states, wg_tick_out_t *outs, int *diag, int advance_calls, int *hist, int hist_cap, int *hist_len, void *hip_stream) {
+}  // extern "C"
+namespace {
+int tick_launch(wg_ctx_t *ctx, int B, wg_gait_state_t *states, wg_tick_out_t *outs, int *diag, int advance_calls, int *hist, int hist_cap, int *hist_len, void *hip_stream, wg_gait_state_t *host_states, int *host_done) {
   if (int rc = use_ctx(ctx)) return rc;
   if (!ctx->model_set) return fail(WG_ERR_BAD_ARG, "wg_mpc_configure() has not been called on this context");
   if (B < 0 || !states) return fail(WG_ERR_BAD_ARG, "bad arguments");
@@ -830,6 +939,7 @@ int wg_mpc_tick_batch_dev_ctx(wg_ctx_t *ctx, int B, wg_gait_state_t *states, wg_
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   const int grid = B;                             // one gait per block; the dispatcher balances uneven iteration counts
   hipStream_t st = reinterpret_cast<hipStream_t>(hip_stream);
+  if (int rc = guard_claim(ctx, st)) return rc;
   const int ecap = tick_elem_cap_arg(ctx->model, view);
   double *zs = nullptr;
   const size_t zslot = tick_z_slot_doubles(ctx->model, view);
@@ -840,14 +950,128 @@ int wg_mpc_tick_batch_dev_ctx(wg_ctx_t *ctx, int B, wg_gait_state_t *states, wg_
   }
   if (view == 16)
     hipLaunchKernelGGL(wg_mpc_tick_kernel<16>, dim3(grid), dim3(64), lds, st, B, ctx->model, ctx->tables_dev, states, outs, diag,
-                       advance_calls, hist, hist_cap, hist_len, (unsigned)qlb, zs, (unsigned)zslot, ecap);
+                       advance_calls, hist, hist_cap, hist_len, (unsigned)qlb, zs, (unsigned)zslot, ecap, host_states, host_done);
   else if (view == 0)
     hipLaunchKernelGGL(wg_mpc_tick_kernel<0>, dim3(grid), dim3(64), lds, st, B, ctx->model, ctx->tables_dev, states, outs, diag,
-                       advance_calls, hist, hist_cap, hist_len, (unsigned)qlb, zs, (unsigned)zslot, ecap);
+                       advance_calls, hist, hist_cap, hist_len, (unsigned)qlb, zs, (unsigned)zslot, ecap, host_states, host_done);
   else
     hipLaunchKernelGGL(wg_mpc_tick_kernel<-1>, dim3(grid), dim3(64), lds, st, B, ctx->model, ctx->tables_dev, states, outs, diag,
-                       advance_calls, hist, hist_cap, hist_len, (unsigned)qlb, zs, (unsigned)zslot, ecap);
+                       advance_calls, hist, hist_cap, hist_len, (unsigned)qlb, zs, (unsigned)zslot, ecap, host_states, host_done);
   HIP_TRY(hipGetLastError());
+  return guard_mark(ctx, st);
+}
+}  // namespace
+extern "C" {
+
+int wg_mpc_tick_batch_dev_ctx(wg_ctx_t *ctx, int B, wg_gait_state_t *states, wg_tick_out_t *outs, int *diag, int advance_calls, int *hist, int hist_cap, int *hist_len, void *hip_stream) {
+  return tick_launch(ctx, B, states, outs, diag, advance_calls, hist, hist_cap, hist_len, hip_stream, nullptr, nullptr);
+}
+
+/* ---- one robot (BASELINE configs[1]): state and outputs in host-mapped memory, no copies, no device synchronisation ---- */
+int wg_host_alloc(void **out, size_t bytes) {
+  if (!out || !bytes) return fail(WG_ERR_BAD_ARG, "wg_host_alloc: null pointer or zero size");
+  wg_ctx *c = nullptr;
+  if (int rc = default_ctx(&c)) return rc;               // the allocation needs a device to be mapped to
+  if (int rc = use_ctx(c)) return rc;
+  HIP_TRY(hipHostMalloc(out, bytes, hipHostMallocMapped));
+  memset(*out, 0, bytes);
+  return WG_OK;
+}
+
+void wg_host_free(void *p) { if (p) (void)hipHostFree(p); }
+
+int wg_mpc_tick_pinned_ctx(wg_ctx_t *ctx, wg_gait_state_t *state, wg_tick_out_t *out, int *diag, int advance_calls) {
+  if (int rc = use_ctx(ctx)) return rc;
+  if (!ctx->model_set) return fail(WG_ERR_BAD_ARG, "wg_mpc_configure() has not been called on this context");
+  if (!state) return fail(WG_ERR_BAD_ARG, "null state");
+  void *d_state = nullptr, *d_out = nullptr, *d_diag = nullptr;
+  if (hipHostGetDevicePointer(&d_state, state, 0) != hipSuccess || (out && hipHostGetDevicePointer(&d_out, out, 0) != hipSuccess) ||
+      (diag && hipHostGetDevicePointer(&d_diag, diag, 0) != hipSuccess)) {
+    (void)hipGetLastError();
+    return fail(WG_ERR_BAD_ARG, "wg_mpc_tick_pinned: state / out / diag must come from wg_host_alloc (host-mapped memory)");
+  }
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  if (!ctx->pin_stream) HIP_TRY(hipStreamCreateWithFlags(&ctx->pin_stream, hipStreamNonBlocking));
+  if (!ctx->pin_flag) {
+    HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&ctx->pin_flag), 64, hipHostMallocMapped));
+    *ctx->pin_flag = 0; ctx->pin_seq = 0;
+  }
+  if (int rc = ctx->tick_state.reserve(sizeof(wg_gait_state_t))) return rc;
+  void *d_flag = nullptr;
+  HIP_TRY(hipHostGetDevicePointer(&d_flag, ctx->pin_flag, 0));
+  const int want = ++ctx->pin_seq;
+  int rc = tick_launch(ctx, 1, static_cast<wg_gait_state_t *>(ctx->tick_state.p), static_cast<wg_tick_out_t *>(d_out),
+                       static_cast<int *>(d_diag), advance_calls, nullptr, 0, nullptr, ctx->pin_stream,
+                       static_cast<wg_gait_state_t *>(d_state), static_cast<int *>(d_flag));
+  if (rc) { --ctx->pin_seq; return rc; }
+  // the kernel's last act is a system-scope release on the counter: spin on it (a stream synchronise costs more than the
+  // copies this path avoids); fall back to the runtime if it does not move for a long time (a fault, a hung device)
+  volatile int *flag = ctx->pin_flag;
+  for (long spins = 0; __atomic_load_n(flag, __ATOMIC_ACQUIRE) != want; ++spins) {
+    if (spins > 200000000L) { HIP_TRY(hipStreamSynchronize(ctx->pin_stream)); break; }
+#if defined(__x86_64__)
+    __builtin_ia32_pause();
+#endif
+  }
+  if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) != want) return fail(WG_ERR_HIP, "wg_mpc_tick_pinned: the kernel ended without signalling");
+  return WG_OK;
+}
+
+/* ---- the QP of every gait's next tick at the ql0001_ boundary (QPProblem::dump_problem) -------------------------------- */
+int wg_mpc_assemble_batch_dev_ctx(wg_ctx_t *ctx, int B, const wg_gait_state_t *states, int advance_calls, int nmax, int mmax, double *C, double *d, double *A, double *b, double *xl, double *xu, int *n, int *m, void *hip_stream) {
+  if (int rc = use_ctx(ctx)) return rc;
+  if (!ctx->model_set) return fail(WG_ERR_BAD_ARG, "wg_mpc_configure() has not been called on this context");
+  if (B < 0 || !states || !C || !d || !A || !b || !xl || !xu || !n || !m) return fail(WG_ERR_BAD_ARG, "bad arguments");
+  const wg_model_t &M = ctx->model;
+  const int need_n = 2 * M.N + 2 * wg::kSMax, need_m = 1 + 4 * M.N + 5 * wg::kSMax;
+  const int need_n2 = tick_compact(M) ? 2 * M.N + 4 : need_n, need_m2 = tick_compact(M) ? 1 + 4 * M.N + 10 : need_m;
+  if (nmax < need_n2 || mmax < need_m2 + 1)
+    return fail(WG_ERR_BAD_ARG, "nmax >= %d and mmax >= %d needed for this model (mmax = m + 1, qp-problem.cpp:250)", need_n2, need_m2 + 1);
+  if (B == 0) return WG_OK;
+  // the dense view, laid out for the largest problem any model of this horizon can pose
+  const size_t qlb = (wg::QlDims(need_n, need_m, need_m).bytes() + 15) & ~(size_t)15;
+  const size_t lds = qlb + wg::TickLds::bytes(M.N, wg::kSMax, 0, false, true, true, false);
+  if (lds > 160 * 1024) return fail(WG_ERR_TOO_LARGE, "the dense view of this model needs %zu B of LDS > 160 KiB", lds);
+  if (lds > 64 * 1024)
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(wg_mpc_assemble_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  {
+    std::lock_guard<std::mutex> lk(ctx->z_mu);
+    if (int rc = ctx->asm_state.reserve((size_t)B * sizeof(wg_gait_state_t))) return rc;
+  }
+  hipLaunchKernelGGL(wg_mpc_assemble_kernel, dim3(B), dim3(64), lds, reinterpret_cast<hipStream_t>(hip_stream), B, ctx->model,
+                     ctx->tables_dev, states, static_cast<wg_gait_state_t *>(ctx->asm_state.p), advance_calls, (unsigned)qlb, nmax, mmax,
+                     C, d, A, b, xl, xu, n, m);
+  HIP_TRY(hipGetLastError());
+  return WG_OK;
+}
+
+int wg_mpc_assemble_batch_ctx(wg_ctx_t *ctx, int B, const wg_gait_state_t *states, int advance_calls, int nmax, int mmax, double *C, double *d, double *A, double *b, double *xl, double *xu, int *n, int *m) {
+  if (int rc = use_ctx(ctx)) return rc;
+  if (B < 0 || !states || !C || !d || !A || !b || !xl || !xu || !n || !m || nmax <= 0 || mmax <= 0) return fail(WG_ERR_BAD_ARG, "bad arguments");
+  if (B == 0) return WG_OK;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  const size_t sB = (size_t)B, sn = (size_t)nmax, sm = (size_t)mmax;
+  const size_t off_C = (sB * sizeof(wg_gait_state_t) + 255) & ~(size_t)255, off_d = off_C + sB * sn * sn * 8, off_A = off_d + sB * sn * 8,
+               off_b = off_A + sB * sm * sn * 8, off_xl = off_b + sB * sm * 8, off_xu = off_xl + sB * sn * 8, off_n = off_xu + sB * sn * 8,
+               off_m = off_n + sB * 4, tot = off_m + sB * 4;
+  if (int rc = ctx->in.reserve(tot)) return rc;
+  char *base = static_cast<char *>(ctx->in.p);
+  HIP_TRY(hipMemcpy(base, states, sB * sizeof(wg_gait_state_t), hipMemcpyHostToDevice));
+  int rc = wg_mpc_assemble_batch_dev_ctx(ctx, B, reinterpret_cast<const wg_gait_state_t *>(base), advance_calls, nmax, mmax,
+                                         reinterpret_cast<double *>(base + off_C), reinterpret_cast<double *>(base + off_d),
+                                         reinterpret_cast<double *>(base + off_A), reinterpret_cast<double *>(base + off_b),
+                                         reinterpret_cast<double *>(base + off_xl), reinterpret_cast<double *>(base + off_xu),
+                                         reinterpret_cast<int *>(base + off_n), reinterpret_cast<int *>(base + off_m), nullptr);
+  if (rc) return rc;
+  HIP_TRY(hipDeviceSynchronize());
+  HIP_TRY(hipMemcpy(C, base + off_C, sB * sn * sn * 8, hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(d, base + off_d, sB * sn * 8, hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(A, base + off_A, sB * sm * sn * 8, hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(b, base + off_b, sB * sm * 8, hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(xl, base + off_xl, sB * sn * 8, hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(xu, base + off_xu, sB * sn * 8, hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(n, base + off_n, sB * 4, hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(m, base + off_m, sB * 4, hipMemcpyDeviceToHost));
   return WG_OK;
 }
 
@@ -877,6 +1101,7 @@ int wg_mpc_run_sched_dev_ctx(wg_ctx_t *ctx, int B, wg_gait_state_t *states, int 
   if ((long long)B * n_ticks > 0x3fffffffLL) return fail(WG_ERR_TOO_LARGE, "B * n_ticks = %lld work items", (long long)B * n_ticks);
   const int total = B * n_ticks;
   hipStream_t st = reinterpret_cast<hipStream_t>(hip_stream);
+  if (int rc = guard_claim(ctx, st)) return rc;
   // hand-over inside one XCD (default) or through one device-wide queue (WG_RUN_QUEUE=global: A/B tests)
   bool xcd_mode = true;
   if (const char *e = getenv("WG_RUN_QUEUE")) xcd_mode = e[0] != 'g';
@@ -900,7 +1125,8 @@ int wg_mpc_run_sched_dev_ctx(wg_ctx_t *ctx, int B, wg_gait_state_t *states, int 
     hipLaunchKernelGGL(wg_run_queue_init_kernel, dim3((total + 255) / 256), dim3(256), 0, st, B, total, q, ring, done);
   const size_t qlb = tick_ql_bytes(ctx->model);
   const int view = tick_view(ctx->model);
-  const size_t lds = tick_lds_for(ctx->model, view);
+  size_t lds = tick_lds_for(ctx->model, view);
+  if (const char *pad = getenv("WG_TICK_LDS_PAD")) lds += (size_t)atoi(pad);   // experiments: lower the residency
   if (lds > 64 * 1024) {
     HIP_TRY(hipFuncSetAttribute(view == 16  ? reinterpret_cast<const void *>(wg_mpc_run_kernel<16>)
                                 : view == 0 ? reinterpret_cast<const void *>(wg_mpc_run_kernel<0>)
@@ -945,7 +1171,7 @@ int wg_mpc_run_sched_dev_ctx(wg_ctx_t *ctx, int B, wg_gait_state_t *states, int 
     hipLaunchKernelGGL(wg_mpc_run_kernel<-1>, dim3(grid), dim3(64), lds, st, B, n_ticks, ctx->model_dev, ctx->tables_dev, states, outs,
                        diag, advance_calls, q, ring, done, (unsigned)qlb, zs, (unsigned)zslot, ecap);
   HIP_TRY(hipGetLastError());
-  return WG_OK;
+  return guard_mark(ctx, st);
 }
 
 int wg_mpc_tick_batch_ctx(wg_ctx_t *ctx, int B, wg_gait_state_t *states, wg_tick_out_t *outs, int *diag, int advance_calls, int *hist, int hist_cap, int *hist_len) {
@@ -1637,6 +1863,24 @@ int wg_dimitrov_tick_batch(int B, const wg_zmp_polytope_t *polys, wg_dimitrov_st
   wg_ctx *c = nullptr;
   if (int rc = default_ctx(&c)) return rc;
   return wg_dimitrov_tick_batch_ctx(c, B, polys, states, outs, max_iter);
+}
+
+int wg_mpc_tick_pinned(wg_gait_state_t *state, wg_tick_out_t *out, int *diag, int advance_calls) {
+  wg_ctx *c = nullptr;
+  if (int rc = default_ctx(&c)) return rc;
+  return wg_mpc_tick_pinned_ctx(c, state, out, diag, advance_calls);
+}
+
+int wg_mpc_assemble_batch_dev(int B, const wg_gait_state_t *states, int advance_calls, int nmax, int mmax, double *C, double *d, double *A, double *b, double *xl, double *xu, int *n, int *m, void *hip_stream) {
+  wg_ctx *c = nullptr;
+  if (int rc = default_ctx(&c)) return rc;
+  return wg_mpc_assemble_batch_dev_ctx(c, B, states, advance_calls, nmax, mmax, C, d, A, b, xl, xu, n, m, hip_stream);
+}
+
+int wg_mpc_assemble_batch(int B, const wg_gait_state_t *states, int advance_calls, int nmax, int mmax, double *C, double *d, double *A, double *b, double *xl, double *xu, int *n, int *m) {
+  wg_ctx *c = nullptr;
+  if (int rc = default_ctx(&c)) return rc;
+  return wg_mpc_assemble_batch_ctx(c, B, states, advance_calls, nmax, mmax, C, d, A, b, xl, xu, n, m);
 }
 
 int wg_preview_configure(const wg_preview_gains_t *gains, const double *F) {

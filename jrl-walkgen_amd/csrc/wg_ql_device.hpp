@@ -43,6 +43,16 @@ namespace wg {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");  \
   } while (0)
 
+// Z of the wide views (n > 64) may live in global memory and is streamed: -DWG_Z_NT=1 marks those accesses non-temporal (an
+// experiment knob, tools/probe_elem.py; the default build uses plain accesses)
+#if defined(WG_Z_NT) && WG_Z_NT
+#define WG_ZLD(p) __builtin_nontemporal_load(p)
+#define WG_ZST(p, v) __builtin_nontemporal_store((v), (p))
+#else
+#define WG_ZLD(p) (*(p))
+#define WG_ZST(p, v) (*(p) = (v))
+#endif
+
 // lane index, opaque to the optimiser: inside a persistent loop (wg_mpc_run_kernel) nothing derived from it can be hoisted
 // out of the loop and kept alive across a whole tick (that hoisting costs ~180 spilled registers)
 __device__ __forceinline__ int wg_lane() { int l = threadIdx.x & 63; asm volatile("" : "+v"(l)); return l; }
@@ -360,11 +370,11 @@ __device__ __forceinline__ void zt_times_ww(const QlView &q, double *s, int lane
     for (; j + 8 <= n; j += 8) {
       double u0[8], u1[8], w[8];
 #pragma unroll
-      for (int e = 0; e < 8; ++e) { u0[e] = z0[j + e]; u1[e] = z1[j + e]; w[e] = q.ww[j + e]; }
+      for (int e = 0; e < 8; ++e) { u0[e] = WG_ZLD(z0 + j + e); u1[e] = WG_ZLD(z1 + j + e); w[e] = q.ww[j + e]; }
 #pragma unroll
       for (int e = 0; e < 8; ++e) { a0 += u0[e] * w[e]; a1 += u1[e] * w[e]; }
     }
-    for (; j < n; ++j) { const double w = q.ww[j]; a0 += z0[j] * w; a1 += z1[j] * w; }
+    for (; j < n; ++j) { const double w = q.ww[j]; a0 += WG_ZLD(z0 + j) * w; a1 += WG_ZLD(z1 + j) * w; }
     s[i0] = a0;
     if (lane + 64 < n) s[i1] = a1;
     WG_WSYNC();
@@ -393,14 +403,14 @@ __device__ __forceinline__ void z_rows_times(const QlView &q, const double *s, i
   for (; j + kG <= j1; j += kG) {
     double u0[kG], u1[kG], w[kG];
 #pragma unroll
-    for (int e = 0; e < kG; ++e) { u0[e] = z0[(j + e) * ldz]; u1[e] = z1[(j + e) * ldz]; w[e] = s[j + e]; }
+    for (int e = 0; e < kG; ++e) { u0[e] = WG_ZLD(z0 + (j + e) * ldz); u1[e] = WG_ZLD(z1 + (j + e) * ldz); w[e] = s[j + e]; }
 #pragma unroll
     for (int e = 0; e < kG; ++e) { a0 += u0[e] * w[e]; a1 += u1[e] * w[e]; }
   }
   if (j < j1) {                                             // the odd columns: requested together (clamped), added in order
     double u0[kG - 1], u1[kG - 1];
 #pragma unroll
-    for (int e = 0; e < kG - 1; ++e) { const int jj = j + e < j1 ? j + e : j1 - 1; u0[e] = z0[jj * ldz]; u1[e] = z1[jj * ldz]; }
+    for (int e = 0; e < kG - 1; ++e) { const int jj = j + e < j1 ? j + e : j1 - 1; u0[e] = WG_ZLD(z0 + jj * ldz); u1[e] = WG_ZLD(z1 + jj * ldz); }
 #pragma unroll
     for (int e = 0; e < kG - 1; ++e)
       if (j + e < j1) { const double w = s[j + e]; a0 += u0[e] * w; a1 += u1[e] * w; }
@@ -847,7 +857,7 @@ __device__ __forceinline__ void sweep(const QlView &q, double *s, int nu, int na
     const int i1 = lane + 64 < n ? lane + 64 : lane;
     const int ldz = q.ldz;
     double *z0 = q.Z + i0, *z1 = q.Z + i1;
-    double carry0 = z0[(nu - 1) * ldz], carry1 = z1[(nu - 1) * ldz];
+    double carry0 = WG_ZLD(z0 + (nu - 1) * ldz), carry1 = WG_ZLD(z1 + (nu - 1) * ldz);
     struct Co { double ga[kSwC], gb[kSwC], nr[kSwC]; };
     auto coef = [&](Co &o, int c) {                          // coefficients of rotations c, c-1, .. (clamped: unused past the end)
 #pragma unroll
@@ -860,7 +870,7 @@ __device__ __forceinline__ void sweep(const QlView &q, double *s, int nu, int na
 #pragma unroll
       for (int k = 0; k < kSwC; ++k) {
         const int cc = (c - 1 - k) > nact ? (c - 1 - k) : nact;
-        p0[k] = z0[cc * ldz]; p1[k] = z1[cc * ldz];
+        p0[k] = WG_ZLD(z0 + cc * ldz); p1[k] = WG_ZLD(z1 + cc * ldz);
       }
     };
     auto step = [&](auto may_skip, int c, double zl0, double zl1, double ga, double gb, double nrm) {
@@ -868,12 +878,12 @@ __device__ __forceinline__ void sweep(const QlView &q, double *s, int nu, int na
       const double t1 = ga * zl1 + gb * carry1, w1 = ga * carry1 - gb * zl1;
       if constexpr (decltype(may_skip)::value) {
         const bool skip = (nrm == 0.0);
-        z0[c * ldz] = skip ? carry0 : w0;
-        z1[c * ldz] = skip ? carry1 : w1;
+        WG_ZST(z0 + c * ldz, skip ? carry0 : w0);
+        WG_ZST(z1 + c * ldz, skip ? carry1 : w1);
         carry0 = skip ? zl0 : t0;
         carry1 = skip ? zl1 : t1;
       } else {
-        z0[c * ldz] = w0; z1[c * ldz] = w1;
+        WG_ZST(z0 + c * ldz, w0); WG_ZST(z1 + c * ldz, w1);
         carry0 = t0; carry1 = t1;
       }
     };
@@ -910,8 +920,8 @@ __device__ __forceinline__ void sweep(const QlView &q, double *s, int nu, int na
       }
     };
     if (any_skip) run(std::true_type{}); else run(std::false_type{});
-    z0[nact * ldz] = carry0;
-    z1[nact * ldz] = carry1;
+    WG_ZST(z0 + nact * ldz, carry0);
+    WG_ZST(z1 + nact * ldz, carry1);
     WG_WSYNC();
     return;
   }

@@ -496,10 +496,19 @@ struct TickDiag { int ifail, n_iter, nact, n, m, ns; };
 
 // NH == 16: compact problem view (rows in registers, no G / A anywhere); NH == 0: generic dense view (G, A in LDS);
 // NH == -1: element view (any N <= 32: G / A regenerated per element from the compact tables, wg_ql_herdt.hpp)
+// Where the dense view writes the assembled QP instead of solving it (wg_mpc_assemble_batch): one gait's slice of the
+// arrays QPProblem::solve hands to ql0001_ (qp-problem.cpp:245-279) -- what QPProblem::dump_problem prints (:639-653).
+struct QpDumpOut {
+  double *C, *d, *A, *b, *xl, *xu;     // nmax x nmax | nmax | mmax x nmax (column-major) | mmax | nmax | nmax
+  int *n, *m;
+  int nmax, mmax;
+};
+
 template <int NH>
 __device__ __forceinline__ TickDiag mpc_tick(const wg_model_t &m, const TickTables *__restrict__ tb, wg_gait_state_t *gstate,
                                     wg_tick_out_t *out, double *lds_ql, char *lds_tick, int *hist, int hist_cap,
-                                    int *hist_len, double *zglobal = nullptr, int elem_nact_cap = 0) {
+                                    int *hist_len, double *zglobal = nullptr, int elem_nact_cap = 0,
+                                    const QpDumpOut *dump = nullptr) {
   const int lane = wg_lane();
   const int N = (NH == 16) ? 16 : m.N;            // compact view: the horizon is a compile-time constant (checked by the host)
   const double T = m.T;
@@ -906,6 +915,19 @@ __device__ __forceinline__ TickDiag mpc_tick(const wg_model_t &m, const TickTabl
       WG_WSYNC();
     }
   } else {
+    if (dump) {
+      // assemble only: the problem exactly as the tick would hand it to the solver (b in the caller's sign, row 0 the dummy
+      // row of qp-problem.cpp:248), zero-padded to the caller's leading dimensions; the gait's state is left alone
+      const QpDumpOut &o = *dump;
+      for (int e = lane; e < o.nmax * o.nmax; e += 64) { const int i = e % o.nmax, j = e / o.nmax; o.C[e] = (i < n && j < n) ? GmL(i, j) : 0.0; }
+      for (int e = lane; e < o.mmax * o.nmax; e += 64) { const int k = e % o.mmax, i = e / o.mmax; o.A[e] = (k < mq && i < n) ? AmL(k, i) : 0.0; }
+      for (int i = lane; i < o.nmax; i += 64) { o.d[i] = i < n ? q.d[i] : 0.0; o.xl[i] = i < n ? q.xl[i] : 0.0; o.xu[i] = i < n ? q.xu[i] : 0.0; }
+      for (int k = lane; k < o.mmax; k += 64) o.b[k] = k < mq ? -q.b[k] : 0.0;
+      if (lane == 0) { *o.n = n; *o.m = mq; }
+      TickDiag dg0;
+      dg0.ifail = 0; dg0.n_iter = 0; dg0.nact = 0; dg0.n = n; dg0.m = mq; dg0.ns = ns;
+      return dg0;
+    }
     if (lane == 0 && fabs(GmL(n - 1, n - 1)) == 0.0) GmL(n - 1, n - 1) = 1e-8;   // qld.cpp:442-444 (nmax == n)
     WG_WSYNC();
     DenseProb prob;

@@ -91,6 +91,12 @@ def lib():
         _lib.wg_mpc_run_batch_dev.argtypes = [C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
         _lib.wg_mpc_run_sched_dev.argtypes = [C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
                                               C.c_void_p]
+        _lib.wg_host_alloc.argtypes = [C.c_void_p, C.c_size_t]
+        _lib.wg_host_free.argtypes = [C.c_void_p]
+        _lib.wg_host_free.restype = None
+        _lib.wg_mpc_tick_pinned.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+        _lib.wg_mpc_assemble_batch.argtypes = [C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 8
+        _lib.wg_mpc_assemble_batch_dev.argtypes = _lib.wg_mpc_assemble_batch.argtypes + [C.c_void_p]
         _lib.wg_pldp_lds_bytes.restype = C.c_size_t
         _lib.wg_pldp_configure.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
         _lib.wg_pldp_solve_batch.argtypes = [C.c_int, C.c_int] + [C.c_void_p] * 9 + [C.c_int] + [C.c_void_p] * 6
@@ -129,7 +135,8 @@ def lib():
 
 
 CTX_ENTRY_POINTS = ("wg_qp_solve_batch", "wg_qp_solve_batch_dev", "wg_mpc_configure", "wg_mpc_tick_lds_bytes", "wg_mpc_tick_batch",
-                    "wg_mpc_tick_batch_dev", "wg_mpc_run_batch_dev", "wg_mpc_run_sched_dev", "wg_mpc_set_velref_dev", "wg_pldp_configure",
+                    "wg_mpc_tick_batch_dev", "wg_mpc_run_batch_dev", "wg_mpc_run_sched_dev", "wg_mpc_set_velref_dev", "wg_mpc_tick_pinned",
+                    "wg_mpc_assemble_batch", "wg_mpc_assemble_batch_dev", "wg_pldp_configure",
                     "wg_pldp_solve_batch", "wg_pldp_solve_batch_dev", "wg_dimitrov_configure", "wg_dimitrov_get_constants",
                     "wg_dimitrov_tick_batch", "wg_dimitrov_tick_batch_dev", "wg_preview_configure", "wg_preview_window",
                     "wg_preview_run_batch", "wg_preview_run_batch_dev", "wg_gramian_batch", "wg_gramian_batch_dev",
@@ -310,6 +317,44 @@ def mpc_tick_batch(states, want_out=True, advance_calls=0, hist_cap=0):
                                  advance_calls, _hp(hist), hist_cap, _hp(hlen))
     _check(rc)
     return outs, diag, hist, hlen
+
+
+def mpc_assemble_batch(states, advance_calls=0, nmax=None, mmax=None, model=None):
+    """The QP of every gait's next tick as QPProblem::solve hands it to ql0001_ (wg_mpc_assemble_batch): a pack_qps-style
+    dict (C, d, A, b, xl, xu column-major with strides nmax / mmax, n, m, me) ready for qp_solve_batch.  `states` is a ctypes
+    array (GaitState * B), not modified."""
+    B = len(states)
+    N = model.N if model is not None else 16
+    nmax = nmax or 2 * N + 8
+    mmax = mmax or 1 + 4 * N + 20 + 1
+    Cb = np.zeros((B, nmax * nmax)); Ab = np.zeros((B, mmax * nmax)); d = np.zeros((B, nmax)); b = np.zeros((B, mmax))
+    xl = np.zeros((B, nmax)); xu = np.zeros((B, nmax)); n = np.zeros(B, dtype=np.int32); m = np.zeros(B, dtype=np.int32)
+    _check(lib().wg_mpc_assemble_batch(B, C.addressof(states), int(advance_calls), nmax, mmax, _hp(Cb), _hp(d), _hp(Ab), _hp(b),
+                                       _hp(xl), _hp(xu), _hp(n), _hp(m)))
+    return dict(B=B, nmax=nmax, mmax=mmax, n=n, m=m, me=np.zeros(B, dtype=np.int32), C=Cb, d=d, A=Ab, b=b, xl=xl, xu=xu)
+
+
+class HostMapped:
+    """A block of host-mapped memory from wg_host_alloc holding one GaitState, one TickOut and the 6 diagnostic ints: what
+    wg_mpc_tick_pinned works on (the one-robot path: no staging copies, no device synchronisation)."""
+
+    def __init__(self):
+        p = C.c_void_p()
+        size = C.sizeof(GaitState) + C.sizeof(TickOut) + 64
+        _check(lib().wg_host_alloc(C.byref(p), size))
+        self.ptr = p
+        self.state = GaitState.from_address(p.value)
+        self.out = TickOut.from_address(p.value + C.sizeof(GaitState))
+        self.diag = (C.c_int * 6).from_address(p.value + C.sizeof(GaitState) + C.sizeof(TickOut))
+
+    def tick(self, advance_calls=0, ctx=None):
+        args = (C.addressof(self.state), C.addressof(self.out), C.addressof(self.diag), int(advance_calls))
+        _check(ctx.call("wg_mpc_tick_pinned", *args) if ctx is not None else lib().wg_mpc_tick_pinned(*args))
+
+    def close(self):
+        if self.ptr:
+            lib().wg_host_free(self.ptr)
+            self.ptr = None
 
 
 def mpc_tick_batch_dev(B, states_ptr, outs_ptr=None, diag_ptr=None, advance_calls=0, hist_ptr=None, hist_cap=0,
