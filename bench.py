@@ -31,9 +31,11 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 wg = importlib.import_module("jrl-walkgen_amd")
 shard = importlib.import_module("jrl-walkgen_amd.shard")
+import bench_kernels  # noqa: E402
 
 BATCH_PER_GPU = 4096
 REDRAW_TICKS = 50            # 5 s of walking
+PREROLL_TICKS = 100          # untimed ticks before the warm-up: every timed window, however short, sees the de-synchronised batch
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 FP64_VECTOR_PEAK_TFLOPS = 78.6   # MI355X FP64 vector peak (spec): 256 CUs x 4 SIMDs x 16 lanes x 2 flop x 2.4 GHz
 CONFIG5_BATCH = 8192         # BASELINE configs[4]: N = 32 with foot-placement variables, batch = 8192
@@ -229,14 +231,29 @@ def config5_leg(dev, flags, ticks=40, warm=10):
         d = diag[warm:].cpu().numpy().reshape(-1, 6)
     kern_s = sum(a.elapsed_time(b) for a, b, _ in evs) * 1e-3
     alg = float(algorithmic_bytes(d[:, 3].astype(np.float64), d[:, 4].astype(np.float64)).sum())
+    # HBM-side traffic of this kernel from the rocprofv3 --pmc passes filed in profiles/ (per gait-tick there, per step here)
+    traffic = {"traffic": None}
+    try:
+        e = json.load(open(PMC_SUMMARY))["elem_run_kernel"]
+        traffic = {"traffic": e["hbm_bytes_per_gait_tick"] * B, "traffic_read": e["hbm_read_bytes_per_gait_tick"] * B,
+                   "traffic_read_uncorrected": e["hbm_read_bytes_per_gait_tick_uncorrected"] * B,
+                   "traffic_write": e["hbm_write_bytes_per_gait_tick"] * B,
+                   "traffic_per_gait_tick": e["hbm_bytes_per_gait_tick"],
+                   "traffic_source": "%s: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of `%s` (B = %d, launches of %s ticks), per "
+                                     "gait-tick x this batch; FETCH_SIZE x 2 as calibrated on 8-byte lanes in this kernel's access "
+                                     "shapes (%s)" % (os.path.relpath(PMC_SUMMARY, ROOT), e["command"], e["batch"], e["ticks_per_launch"],
+                                                      e["calibration"])}
+    except Exception:                                                      # noqa: BLE001 -- a missing profile is not fatal
+        pass
     return {"value": B * ticks / wall, "unit": "ticks/s", "batch": B, "horizon_N": 32, "steps": ticks, "warmup": warm,
             "ms_per_step": 1e3 * wall / ticks, "kernel_ms_per_step": 1e3 * kern_s / ticks,
             "hessian_source": "fp32 matrix-core Gramian (WG_FLAG_GRAMIAN_MFMA_F32)" if flags & 4 else "reference-order host loop (bit-exact)",
             "solve_dtype": "f64", "failed_qps": int((d[:, 0] != 0).sum()),
             "mean_iterations": float(d[:, 1].mean()), "max_iterations": int(d[:, 1].max()),
             "n_hist": {str(int(k)): int(v) for k, v in zip(*np.unique(d[:, 3], return_counts=True))},
-            "roofline": {"bound": "hbm", "achieved": alg / kern_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": alg / kern_s / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes_per_step": alg / ticks}}
+            "roofline": dict({"bound": "hbm", "achieved": alg / kern_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                              "frac": alg / kern_s / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes_per_step": alg / ticks,
+                              "kernel": "wg_mpc_run_xcd_kernel<-1>"}, **traffic)}
 
 
 def main():
@@ -251,6 +268,10 @@ def main():
     ap.add_argument("--no-parity", action="store_true", help="skip the golden-file replay (CoM RMSE) after the timed run")
     ap.add_argument("--no-per-tick-leg", action="store_true", help="skip the secondary one-launch-per-tick measurement")
     ap.add_argument("--no-config5", action="store_true", help="skip the N = 32, batch = 8192 leg (BASELINE configs[4])")
+    ap.add_argument("--no-kernels", action="store_true", help="skip the `kernels` legs (PLDP, Dimitrov tick, dense ql0001_ boundary, "
+                    "preview, zmpdisc, Gramian)")
+    ap.add_argument("--preroll", type=int, default=PREROLL_TICKS, help="untimed ticks run before the warm-up steps (redraws every "
+                    "50 as everywhere): a short timed window then sees gaits in every support phase, QPs of n = 32, 34 and 36")
     ap.add_argument("--no-staged-refs", action="store_true", help="one launch per stretch of constant velocity references "
                     "(wg_mpc_set_velref_dev + wg_mpc_run_batch_dev, round 1's plan) instead of one launch with the references "
                     "of every stretch staged on the device (wg_mpc_run_sched_dev)")
@@ -293,7 +314,8 @@ def main():
 
     B = args.batch
     lo, hi = rank * B, (rank + 1) * B                         # weak scaling: B gaits per GPU
-    K, W = args.steps, args.warmup
+    K, W0 = args.steps, args.warmup
+    W = W0 + max(0, args.preroll)                             # pre-roll + warm-up: all untimed, same launch plan
     n_seg = (K + W + min(K, 100) + REDRAW_TICKS - 1) // REDRAW_TICKS
     vtab = torch.from_numpy(velocity_table(lo, hi, n_seg)).to(dev)
     states = start_states(model, B).to(dev)
@@ -313,14 +335,21 @@ def main():
         if t % REDRAW_TICKS == 0 and not is_staged(t, n):
             wg.mpc_set_velref_dev(B, sp, vtab[t // REDRAW_TICKS].data_ptr(), sh)
 
-    def fire(t, n):
+    entry_points = {}                                         # entry point -> launches in the timed region
+
+    def fire(t, n, timed=False):
         adv = 1 if t == 0 else (19 if t == 1 else 20)
         if n == 1 and (t < 2 or args.per_tick_launch):
+            name = "wg_mpc_tick_batch_dev"
             wg.mpc_tick_batch_dev(B, sp, None, dp + t * dstride, adv, stream=sh)
         elif is_staged(t, n):                                 # the references of every stretch of the launch wait on the device
+            name = "wg_mpc_run_sched_dev"
             wg.mpc_run_sched_dev(B, sp, n, vtab[t // REDRAW_TICKS].data_ptr(), REDRAW_TICKS, adv, None, dp + t * dstride, stream=sh)
         else:
+            name = "wg_mpc_run_batch_dev"
             wg.mpc_run_batch_dev(B, sp, n, adv, None, dp + t * dstride, stream=sh)
+        if timed:
+            entry_points[name] = entry_points.get(name, 0) + 1
 
     with torch.cuda.stream(stream):
         for t, n in launches(0, W):
@@ -337,7 +366,7 @@ def main():
         for k, (t, n) in enumerate(timed):
             redraw(t, n)
             ev[k][0].record(stream)
-            fire(t, n)
+            fire(t, n, timed=True)
             ev[k][1].record(stream)
     torch.cuda.synchronize(dev)
     shard.barrier()
@@ -393,7 +422,7 @@ def main():
         useful_tflops = flops_total / (kern_ms_total * 1e-3) / 1e12
         line = {
             "metric": "QP-MPC ticks/sec (batch=4096, N=16)",
-            "value": value, "unit": "ticks/s", "n_gpus": world, "steps": K, "warmup": W,
+            "value": value, "unit": "ticks/s", "n_gpus": world, "steps": K, "warmup": W0,
             "ms_per_step": 1e3 * elapsed / K, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "Herdt2010 N=16 fp64, batch=4096 independent gaits per GPU "
@@ -402,11 +431,12 @@ def main():
                        "velocity_refs": "U[-0.1,0.3] x U[-0.1,0.1] x U[-0.2,0.2], redrawn every 50 ticks, "
                                         "MT19937-64 seed 20100+gait",
                        "sharding": "gaits by contiguous index range, one RCCL broadcast of the model block",
-                       "launch": ("one launch per tick (wg_mpc_tick_batch_dev)" if args.per_tick_launch else
-                                  ("one launch per stretch of constant references (wg_mpc_run_batch_dev, device-side work "
-                                   "queue): %d launches, up to %d ticks each" if args.no_staged_refs else
-                                   "velocity references of every stretch staged on the device (wg_mpc_run_sched_dev, device-side "
-                                   "work queue): %d launch(es), up to %d ticks each") % (len(timed), ticks_per_launch))},
+                       "preroll_ticks": W - W0,
+                       "launch": "%s; %d launch(es) in the timed region, up to %d ticks each (multi-tick launches run the device-side "
+                                 "work queue; wg_mpc_run_sched_dev is the same kernel with the velocity references of later "
+                                 "stretches staged on the device)"
+                                 % (", ".join("%s x %d" % kv for kv in sorted(entry_points.items())), len(timed), ticks_per_launch),
+                       "timed_ticks": [W, W + K]},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": "wg_mpc_tick_kernel" if args.per_tick_launch else "wg_mpc_run_xcd_kernel",
@@ -435,6 +465,9 @@ def main():
         }
         if alt is not None:
             line["per_tick_launch"] = alt
+        if world == 1 and not args.no_kernels:
+            line["kernels"] = bench_kernels.run_all(wg, dev, stream, B, sp, model, algorithmic_bytes)
+            wg.mpc_configure(model)
         if world == 1 and not args.no_config5:
             try:
                 line["config5"] = {"default": config5_leg(dev, 0), "gramian_mfma_f32": config5_leg(dev, 4),

@@ -217,8 +217,15 @@ class ZMPVelocityReferencedQP : public ZMPRefTrajectoryGeneration {
   // ":setfeetconstraint XY mx my" (RelativeFeetInequalities::CallMethod, relative-feet-inequalities.cpp:322-342): security
   // margins of the ZMP polygon; the device model follows
   void SetFeetConstraint(double SecurityMarginX, double SecurityMarginY);
+  // QPProblem::dump(const char *) / dump(double Time) (qp-problem.cpp:656-675): the problem of the NEXT tick -- Q, D, DU, DS, XL,
+  // XU and the solver parameters in the reference's text format -- assembled on the device from the current state
+  // (wg_mpc_assemble_batch).  OnLine writes "<dir>/Problem_<time>.dat" for a tick whose solve failed (Solution().Fail > 0,
+  // ZMPVelocityReferencedQP.cpp:399-402) when the environment has WG_DUMP_FAILED_QP (= a directory, or 1 for /tmp).
+  void dumpProblem(const char *FileName);
+  void dumpProblem(double Time);
 
  private:
+  void dumpState(const wg_gait_state_t &state, const char *FileName);
   ZMPVelocityReferencedQP(const ZMPVelocityReferencedQP &);              // owns a device context: not copyable
   ZMPVelocityReferencedQP &operator=(const ZMPVelocityReferencedQP &);
   wg_ctx_t *Ctx_;    // this object's device-side model tables and workspaces (the reference keeps them per object too)
@@ -354,6 +361,9 @@ class StepStackHandler {
   // ":supportfoot", ":arc", ":lastsupport" (StepStackHandler.cpp:754-764, 299-457, 872-882; CallMethod :929-1040)
   void PrepareForSupportFoot(int SupportFoot);
   void CreateArcInStepStack(double x, double y, double R, double arc_deg, int SupportFoot);
+  // ":arccentered R arc_deg support_foot" (StepStackHandler.cpp:459-752, CallMethod :1011-1037)
+  void CreateArcCenteredInStepStack(double R, double arc_deg, int SupportFoot);
+  void PushFrontAStepInTheStack(RelativeFootPosition &aRFP);                                   // :865-868
   void FinishOnTheLastCorrectSupportFoot();
   void CallMethod(std::string &Method, std::istringstream &strm);
 

@@ -303,10 +303,18 @@ void ZMPVelocityReferencedQP::OnLine(double time, deque<ZMPPosition> &FinalZMPTr
   if (time + 0.00001 > State_.upper_time_limit) {
     State_.clock = time;
     wg_tick_out_t out;
+    const char *dump_dir = getenv("WG_DUMP_FAILED_QP");
+    wg_gait_state_t before;
+    if (dump_dir) before = State_;
     if (wg_mpc_tick_batch_ctx(Ctx_, 1, &State_, &out, 0, 0, 0, 0, 0) != WG_OK) wg_throw("wg_mpc_tick_batch");
     Solution_.NbVariables = out.n; Solution_.NbConstraints = out.m; Solution_.Fail = out.ifail;
     Solution_.NbIterations = out.n_iter; Solution_.NbActiveConstraints = out.nact;
     Solution_.JerkX = out.jerk_x; Solution_.JerkY = out.jerk_y;
+    if (Solution_.Fail > 0 && dump_dir) {                 // Problem_.dump( time ), ZMPVelocityReferencedQP.cpp:399-402
+      char Buffer[1024];
+      snprintf(Buffer, sizeof Buffer, "%s/Problem_%f.dat", (dump_dir[0] == '/' || dump_dir[0] == '.') ? dump_dir : "/tmp", time);
+      dumpState(before, Buffer);
+    }
     if (!FinalLeftFootTraj_deq.empty()) {       // the DS branch rewrites the newest queued sample, OFTG.cpp:333-336
       FinalLeftFootTraj_deq.back() = toFAP(out.lf_back, FinalLeftFootTraj_deq.back().time, FinalLeftFootTraj_deq.back().stepType);
       FinalRightFootTraj_deq.back() = toFAP(out.rf_back, FinalRightFootTraj_deq.back().time, FinalRightFootTraj_deq.back().stepType);
@@ -326,6 +334,48 @@ void ZMPVelocityReferencedQP::OnLine(double time, deque<ZMPPosition> &FinalZMPTr
     }
     Running_ = State_.running != 0;
   }
+}
+
+// QPProblem::dump_problem / dump(Type, aos) / dump_solver_parameters, qp-problem.cpp:548-675: names, shapes and layout as there
+void ZMPVelocityReferencedQP::dumpState(const wg_gait_state_t &state, const char *FileName) {
+  const int nmax = 2 * Model_.N + 2 * 4, mmax = 1 + 4 * Model_.N + 5 * 4 + 1;        // the largest problem a model of this horizon poses
+  vector<double> Q((size_t)nmax * nmax), D(nmax), DU((size_t)mmax * nmax), DS(mmax), XL(nmax), XU(nmax);
+  int n = 0, m = 0;
+  if (wg_mpc_assemble_batch_ctx(Ctx_, 1, &state, 0, nmax, mmax, Q.data(), D.data(), DU.data(), DS.data(), XL.data(), XU.data(), &n, &m) != WG_OK)
+    wg_throw("wg_mpc_assemble_batch");
+  ofstream aof;
+  aof.open(FileName, ofstream::out);
+  if (!aof.is_open()) return;                              // the reference does not check either
+  const int mmax_ = m + 1;                                 // QPProblem::solve: m_ = NbConstraints + 1, mmax_ = m_ + 1 (:249-251)
+  auto mat = [&](const char *Name, const vector<double> &a, int ld, int NbRows, int NbCols) {
+    aof << Name << "[" << NbRows << "," << NbCols << "]" << endl;
+    for (int i = 0; i < NbRows; i++) {
+      for (int j = 0; j < NbCols; j++) aof << a[(size_t)i + (size_t)j * ld] << " ";
+      aof << endl;
+    }
+    aof << endl;
+  };
+  mat("Q", Q, nmax, n, n);
+  mat("D", D, nmax, n, 1);
+  mat("DU", DU, mmax, mmax_, n);
+  mat("DS", DS, mmax, mmax_, 1);
+  mat("XL", XL, nmax, n, 1);
+  mat("XU", XU, nmax, n, 1);
+  aof << "m: " << m << endl << "me: " << 0 << endl << "mmax: " << mmax_ << endl << "n: " << n << endl << "nmax: " << n << endl
+      << "mnn: " << m + 2 * n << endl << "iout: " << 0 << endl << "iprint: " << 1 << endl
+      << "lwar: " << 2 * (3 * n * n / 2 + 10 * n + 2 * m + 20000) << endl << "liwar: " << 2 * n + 1000 << endl << "Eps: " << 1e-8 << endl;
+  aof.close();
+}
+void ZMPVelocityReferencedQP::dumpProblem(const char *FileName) {
+  // the state's clock is the control-loop time of its last tick: the next tick fires one QP period later
+  wg_gait_state_t next = State_;
+  next.clock = State_.upper_time_limit;
+  dumpState(next, FileName);
+}
+void ZMPVelocityReferencedQP::dumpProblem(double Time) {
+  char Buffer[1024];
+  snprintf(Buffer, sizeof Buffer, "/tmp/Problem_%f.dat", Time);
+  dumpProblem(Buffer);
 }
 
 // ---- PatternGeneratorInterfacePrivate (Herdt branch) ------------------------------------------------------------------------
@@ -694,6 +744,71 @@ void StepStackHandler::CreateArcInStepStack(double x, double y, double R, double
   }
   m_KeepLastCorrectSupportFoot = SupportFoot;
 }
+// :459-752: steps of 0.10 m of arc around a centre at distance R to the side, each pair (arc step, closing step) built from
+// homogeneous 2-D transforms: where the non-support foot must land on the rotated radius, expressed in the frame of the current
+// support footprint.  The reference inverts its 3 x 3 matrices numerically (MAL_INVERSE); they are rigid transforms, inverted
+// here in closed form ([R' | -R't]) -- no golden file of the reference reaches this generator (parity unpinned).
+namespace {
+struct M3 {
+  double a[3][3];
+  static M3 rigid(double angle, double tx, double ty) {
+    M3 m;
+    const double c = wg_cos(angle), s = wg_sin(angle);
+    m.a[0][0] = c; m.a[0][1] = -s; m.a[0][2] = tx;
+    m.a[1][0] = s; m.a[1][1] = c;  m.a[1][2] = ty;
+    m.a[2][0] = 0; m.a[2][1] = 0;  m.a[2][2] = 1;
+    return m;
+  }
+  M3 operator*(const M3 &o) const {
+    M3 r;
+    for (int i = 0; i < 3; i++)
+      for (int j = 0; j < 3; j++) {
+        double t = 0.0;
+        for (int k = 0; k < 3; k++) t += a[i][k] * o.a[k][j];
+        r.a[i][j] = t;
+      }
+    return r;
+  }
+  M3 rigid_inverse() const {
+    M3 r;
+    r.a[0][0] = a[0][0]; r.a[0][1] = a[1][0]; r.a[1][0] = a[0][1]; r.a[1][1] = a[1][1];
+    r.a[0][2] = -(a[0][0] * a[0][2] + a[1][0] * a[1][2]);
+    r.a[1][2] = -(a[0][1] * a[0][2] + a[1][1] * a[1][2]);
+    r.a[2][0] = 0; r.a[2][1] = 0; r.a[2][2] = 1;
+    return r;
+  }
+};
+}  // namespace
+void StepStackHandler::CreateArcCenteredInStepStack(double R, double arc_deg, int SupportFoot) {
+  const double kPi = 3.14159265358979323846;
+  const double StepMax = 0.10;
+  const double OmegaTotal = arc_deg * kPi / 180.0;
+  const int NumberOfStep = (int)floor(OmegaTotal * R / StepMax);
+  const double LastStep = OmegaTotal * R - NumberOfStep * StepMax;
+  const double OmegaStep = StepMax / R;
+  const double LastOmegaStep = OmegaTotal - OmegaStep * NumberOfStep;
+  if (SupportFoot * OmegaStep < 0.0) {             // the support foot must be the one that does not lead the motion
+    push_rel(m_RelativeFootPositions, 0, -SupportFoot * 0.095, 0, m_SingleSupportTime, m_DoubleSupportTime);
+    SupportFoot = -SupportFoot;
+  }
+  const double S = -SupportFoot * 0.095;
+  const M3 Romegastep = M3::rigid(OmegaStep, 0, 0);
+  const M3 MFNSF = M3::rigid(0, -R, S), MFSF = M3::rigid(0, -R, -S), Mtmp = M3::rigid(0, 0, 0.19);
+  M3 MSupportFoot = MFSF;
+  auto pair_of_steps = [&](const M3 &Romega, const M3 &turn, double dOmega) {
+    const M3 RiR = (MSupportFoot * turn).rigid_inverse();
+    const M3 FPos = RiR * (Romega * MFNSF);
+    push_rel(m_RelativeFootPositions, FPos.a[0][2], FPos.a[1][2], dOmega * 180.0 / kPi, m_SingleSupportTime, m_DoubleSupportTime);
+    MSupportFoot = Romega * MFNSF;
+    push_rel(m_RelativeFootPositions, 0, SupportFoot * 0.19, 0, m_SingleSupportTime, m_DoubleSupportTime);
+    MSupportFoot = MSupportFoot * Mtmp;
+  };
+  for (int i = 0; i < NumberOfStep; i++) pair_of_steps(M3::rigid((i + 1) * OmegaStep, 0, 0), Romegastep, OmegaStep);
+  if (LastStep != 0.0)
+    pair_of_steps(M3::rigid(LastOmegaStep + NumberOfStep * OmegaStep, 0, 0), M3::rigid(LastOmegaStep, 0, 0), LastOmegaStep);
+  m_KeepLastCorrectSupportFoot = -SupportFoot;
+}
+void StepStackHandler::PushFrontAStepInTheStack(RelativeFootPosition &aRFP) { m_RelativeFootPositions.push_front(aRFP); }   // :865-868
 void StepStackHandler::CallMethod(string &Method, istringstream &strm) {   // :929-1040, the commands restated here
   if (Method == ":singlesupporttime") strm >> m_SingleSupportTime;
   else if (Method == ":doublesupporttime") strm >> m_DoubleSupportTime;
@@ -705,6 +820,12 @@ void StepStackHandler::CallMethod(string &Method, istringstream &strm) {   // :9
     int f = -1;
     strm >> x >> y >> arc_deg >> f;
     CreateArcInStepStack(x, y, 0.0, arc_deg, f);
+  } else if (Method == ":arccentered") {
+    double R = 0, arc_deg = 0;
+    int f = -1;
+    strm >> R >> arc_deg >> f;
+    if (!(R != 0.0)) throw runtime_error(":arccentered needs a non-zero radius");
+    CreateArcCenteredInStepStack(R, arc_deg, f);
   }
 }
 void StepStackHandler::CopyRelativeFootPosition(deque<RelativeFootPosition> &lRelativeFootPositions, bool PerformClean) {
@@ -775,11 +896,24 @@ class PatternGeneratorInterfacePrivate : public virtual PatternGeneratorInterfac
       : PatternGeneratorInterface(aHDR), SimplePlugin(this), m_Model(HumanoidModelFromRobot(aHDR)), m_Robot(aHDR) { Construct(); }
   void Construct() {
     // PatternGeneratorInterfacePrivate.cpp:181-215: the commands this object handles itself
-    string aMethodName[13] = {":samplingperiod", ":setVelReference", ":HerdtOnline", ":setCoMPerturbationForce",
-                              ":SetAlgoForZmpTrajectory", ":wg_legacy_golden", ":stepseq", ":finish", ":supportfoot", ":arc",
-                              ":lastsupport", ":singlesupporttime", ":doublesupporttime"};
-    for (int i = 0; i < 13; i++)
+    // the reference's fifteen (PatternGeneratorInterfacePrivate.cpp:186-201, in its order) ...
+    string aMethodName[15] = {":LimitsFeasibility", ":ZMPShiftParameters", ":TimeDistributionParameters", ":stepseq", ":finish",
+                              ":StartOnLineStepSequencing", ":StopOnLineStepSequencing", ":readfilefromkw", ":SetAlgoForZmpTrajectory",
+                              ":SetAutoFirstStep", ":ChangeNextStep", ":samplingperiod", ":HerdtOnline", ":setVelReference",
+                              ":setCoMPerturbationForce"};
+    for (int i = 0; i < 15; i++)
       if (!SimplePlugin::RegisterMethod(aMethodName[i])) cerr << "Unable to register " << aMethodName[i] << endl;
+    // ... the step-stack commands (StepStackHandler is a plugin of this manager in the reference, StepStackHandler.cpp:61-77) and
+    // this build's switch for the golden file's legacy semantics
+    string aStackMethod[8] = {":supportfoot", ":arc", ":arccentered", ":lastsupport", ":singlesupporttime", ":doublesupporttime",
+                              ":walkmode", ":wg_legacy_golden"};
+    for (int i = 0; i < 8; i++)
+      if (!SimplePlugin::RegisterMethod(aStackMethod[i])) cerr << "Unable to register " << aStackMethod[i] << endl;
+    // :62-79, :115-119
+    m_AutoFirstStep = false;
+    m_TimeDistrFactor.assign({2.0, 3.7, 1.0, 3.0});
+    m_DeltaFeasibilityLimit = 0.0;
+    m_ZMPShift.assign({0.02, 0.07, 0.02, 0.02});
     m_ZMPVRQP = new ZMPVelocityReferencedQP(this, "", &m_Model);
     m_ZMPD = new ZMPDiscretization(this, "", &m_Model);                                    // :223-226
     m_PC = new PreviewControl(this, OptimalControllerSolver::MODE_WITHOUT_INITIALPOS, true);   // :254
@@ -831,8 +965,30 @@ class PatternGeneratorInterfacePrivate : public virtual PatternGeneratorInterfac
       FinishAndRealizeStepSequence();
     } else if (aCmd == ":finish") {                                  // m_FinishAndRealizeStepSequence
       FinishAndRealizeStepSequence();
-    } else if (aCmd == ":supportfoot" || aCmd == ":arc" || aCmd == ":lastsupport" || aCmd == ":singlesupporttime" ||
-               aCmd == ":doublesupporttime") {
+    } else if (aCmd == ":ZMPShiftParameters") {                      // m_SetZMPShiftParameters, :415-446: reaches ZMPDiscretization
+      ReadUpToFour(strm, m_ZMPShift);                                //   through SetZMPShift at the next :stepseq / :finish (:895)
+    } else if (aCmd == ":TimeDistributionParameters") {              // m_SetTimeDistrParameters, :1518-1548: kept; its consumer is
+      ReadUpToFour(strm, m_TimeDistrFactor);                         //   the stepping-over planner (:981), which is not on this path
+    } else if (aCmd == ":LimitsFeasibility") {                       // m_SetLimitsFeasibility, :448-460: kept; consumer as above (:483)
+      while (!strm.eof()) { if (!strm.eof()) strm >> m_DeltaFeasibilityLimit; else break; }
+    } else if (aCmd == ":SetAutoFirstStep") {                        // :1122-1131
+      string lAutoFirstStep;
+      strm >> lAutoFirstStep;
+      if (lAutoFirstStep == "true") m_AutoFirstStep = true;
+      else if (lAutoFirstStep == "false") m_AutoFirstStep = false;
+    } else if (aCmd == ":StartOnLineStepSequencing") {               // :1088-1093; the method throws NotOnThisPath
+      m_InternalClock = 0.0;
+      ReadSequenceOfSteps(strm);
+      StartOnLineStepSequencing();
+    } else if (aCmd == ":StopOnLineStepSequencing") {                // :1094-1095
+      StopOnLineStepSequencing();
+    } else if (aCmd == ":ChangeNextStep") {                          // :1060-1064: parsed, then refused like every generator but
+      double nt;                                                     //   Morisawa's refuses it (ChangeOnLineStep returns -1)
+      ChangeOnLineStep(strm, nt);
+    } else if (aCmd == ":readfilefromkw") {                          // m_ReadFileFromKineoWorks, :1581-1623: KineoWorks paths feed the
+      cerr << "wg: :readfilefromkw ignored (GenerateMotionFromKineoWorks is not on the path of this build)" << endl;   // upper-body planner
+    } else if (aCmd == ":supportfoot" || aCmd == ":arc" || aCmd == ":arccentered" || aCmd == ":lastsupport" ||
+               aCmd == ":singlesupporttime" || aCmd == ":doublesupporttime" || aCmd == ":walkmode") {
       if (aCmd == ":singlesupporttime" || aCmd == ":doublesupporttime") {   // :1085-1094: kept for AddStepInStack too
         istringstream peek(strm.str());
         string skip;
@@ -967,7 +1123,35 @@ class PatternGeneratorInterfacePrivate : public virtual PatternGeneratorInterfac
     vectorN lStartingWaistPose;
     StrategyEvaluateStartingState(lStartingCOMState, lStartingZMPPosition, lStartingWaistPose, InitLeftFootAbsPos,
                                   InitRightFootAbsPos);
+    if (m_AutoFirstStep && !lRelativeFootPositions.empty()) {        // :734-749
+      AutomaticallyAddFirstStep(lRelativeFootPositions, InitLeftFootAbsPos, InitRightFootAbsPos, lStartingCOMState);
+      if (!ClearStepStackHandler) m_SSH.PushFrontAStepInTheStack(lRelativeFootPositions[0]);
+    }
     if (m_Robot) { string aProperty("ResetIteration"), aValue("any"); m_Robot->setProperty(aProperty, aValue); }
+  }
+
+  // :619-686: the step from the CoM's frame to the foot the first given step leaves on the ground, pushed in front of the
+  // sequence (3 x 3 homogeneous transforms: inverse(CoM pose) * pose of that foot).  Angles as the reference takes them
+  // there: radians, straight from the start state.
+  void AutomaticallyAddFirstStep(deque<RelativeFootPosition> &lRelativeFootPositions, FootAbsolutePosition &InitLeftFootAbsPos,
+                                 FootAbsolutePosition &InitRightFootAbsPos, COMState &lStartingCOMState) {
+    const double cc = cos(lStartingCOMState.yaw[0]), sc = sin(lStartingCOMState.yaw[0]);
+    const FootAbsolutePosition &F = lRelativeFootPositions[0].sy > 0 ? InitRightFootAbsPos : InitLeftFootAbsPos;
+    const double cf = cos(F.theta), sf = sin(F.theta);
+    // inverse of [cc -sc x; sc cc y; 0 0 1] times [cf -sf fx; sf cf fy; 0 0 1]
+    const double dx = F.x - lStartingCOMState.x[0], dy = F.y - lStartingCOMState.y[0];
+    const double m00 = cc * cf + sc * sf, m10 = -sc * cf + cc * sf;
+    RelativeFootPosition aRFP;
+    memset(&aRFP, 0, sizeof aRFP);
+    aRFP.sx = cc * dx + sc * dy;
+    aRFP.sy = -sc * dx + cc * dy;
+    aRFP.theta = atan2(m10, m00);
+    lRelativeFootPositions.push_front(aRFP);
+  }
+  static void ReadUpToFour(istringstream &strm, vector<double> &v) {   // the parsing loop of :415-446 / :1518-1548
+    while (!strm.eof()) {
+      for (int i = 0; i < 4; i++) { if (!strm.eof()) strm >> v[i]; else return; }
+    }
   }
 
   // :881-1005 in Kajita mode, stage 1 only: the step stack -> ZMPDiscretization (CreateZMPReferences :1870-1882) -> the
@@ -981,8 +1165,9 @@ class PatternGeneratorInterfacePrivate : public virtual PatternGeneratorInterfac
     FootAbsolutePosition InitLeftFootAbsPos, InitRightFootAbsPos;
     deque<RelativeFootPosition> lRelativeFootPositions;
     vector<double> lCurrentJointValues;
+    m_ZMPD->SetZMPShift(m_ZMPShift);                                                                 // :895
     CommonInitializationOfWalking(lStartingCOMState, lStartingZMPPositionV, BodyAnglesIni, InitLeftFootAbsPos, InitRightFootAbsPos,
-                                  lRelativeFootPositions, lCurrentJointValues, true);                  // :895-904
+                                  lRelativeFootPositions, lCurrentJointValues, true);                  // :897-904
     if (m_ZMPInitialPointSet) lStartingZMPPositionV = m_ZMPInitialPoint;
     double *lStartingZMPPosition = lStartingZMPPositionV.v;
     m_COMBuffer.clear();
@@ -1095,7 +1280,12 @@ class PatternGeneratorInterfacePrivate : public virtual PatternGeneratorInterfac
   void StopOnLineStepSequencing() {}                                                       // :876-879: a flag of the step stack
   void AddOnLineStep(double X, double Y, double Theta) { m_NewStep = true; m_NewStepX = X; m_NewStepY = Y; m_NewTheta = Theta; }   // :1625-1631
   int ChangeOnLineStep(double, FootAbsolutePosition &, double &) { return -1; }            // :1795-1816: Morisawa only
-  void ChangeOnLineStep(istringstream &, double &) {}                                      // m_ChangeNextStep -> the above
+  void ChangeOnLineStep(istringstream &strm, double &newtime) {                            // :1041-1053
+    FootAbsolutePosition aFAP;
+    double ltime;
+    strm >> ltime; strm >> aFAP.x; strm >> aFAP.y; strm >> aFAP.theta;
+    ChangeOnLineStep(ltime, aFAP, newtime);
+  }
   void setZMPInitialPoint(vector3d &lZMPInitialPoint) { m_ZMPInitialPoint = lZMPInitialPoint; m_ZMPInitialPointSet = true; }   // :1914-1918
   void getZMPInitialPoint(vector3d &lZMPInitialPoint) const { lZMPInitialPoint = m_ZMPInitialPoint; }
 
@@ -1171,6 +1361,10 @@ class PatternGeneratorInterfacePrivate : public virtual PatternGeneratorInterfac
   vector3d m_ZMPInitialPoint;
   bool m_ZMPInitialPointSet, m_NewStep;
   double m_NewStepX, m_NewStepY, m_NewTheta, m_TSsupport, m_TDsupport;
+  // :62-79, :115-119: what ":SetAutoFirstStep", ":TimeDistributionParameters", ":LimitsFeasibility", ":ZMPShiftParameters" set
+  bool m_AutoFirstStep;
+  vector<double> m_TimeDistrFactor, m_ZMPShift;
+  double m_DeltaFeasibilityLimit;
   ZMPVelocityReferencedQP *m_ZMPVRQP;
   ZMPDiscretization *m_ZMPD;
   PreviewControl *m_PC;

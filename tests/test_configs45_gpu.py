@@ -1,10 +1,11 @@
 """BASELINE configs 4 and 5 at their stated sizes, on one GPU, through the C ABI's device entry points (the path bench.py
 times): wg_mpc_set_velref_dev + wg_mpc_tick_batch_dev / wg_mpc_run_batch_dev on resident states.
 
-  config 4  "Herdt2010 N=16 fp64, batch=32768 sharded across 8 GPUs": the LAST shard (rank 7 of 8: global gaits
-            28 672 .. 32 767, seeds 20100 + global index) run exactly as bench.py's rank 7 would -- 200 ticks, references
-            redrawn every 50 -- with a seeded sample followed bit for bit by the CPU oracle, and the shard boundaries
-            checked against bench.py's own table generator.  (The 8-GPU launch itself needs the 8-GPU node.)
+  config 4  "Herdt2010 N=16 fp64, batch=32768 sharded across 8 GPUs": ALL EIGHT shards, one after the other on this GPU, each
+            run exactly as bench.py's rank r would run it (global gaits 4096 r .. 4096 r + 4095, seeds 20100 + global index,
+            200 ticks, references redrawn every 50), a seeded sample of every shard followed bit for bit by the CPU oracle; the
+            same job split four ways gives the same bytes; the shard boundaries and references are bench.py's own.  (RCCL with
+            >= 2 ranks is unmeasured on hardware here: the 8-GPU launch itself needs the 8-GPU node.)
   config 5  "Herdt2010 N=32 with foot-placement decision vars, batch=8192": the full batch through the element view, 50
             ticks, as properties -- every QP solves, determinism (two runs, same bytes), batch-composition invariance
             (a permuted sub-batch reproduces its gaits' bytes), multi-tick launch == one launch per tick -- plus a seeded
@@ -88,31 +89,77 @@ def _oracle_follow(pt, model, g, n_ticks):
 
 
 # ---------------------------------------------------------------------------------------------------------- config 4
-def test_config4_last_shard_of_eight_full_size():
-    """rank 7 of world 8, 4096 gaits per GPU: global gaits [28672, 32768)"""
-    import bench
-    shard = importlib.import_module("jrl-walkgen_amd.shard")
+# "Herdt2010 N=16 fp64, batch=32768 sharded across 8 GPUs": ALL eight shards, one after the other on this one GPU, each run
+# exactly as bench.py's rank r would run it (global gaits [4096 r, 4096 (r + 1)), seeds 20100 + global index, 200 ticks,
+# references redrawn every 50).  What one GPU cannot show is the RCCL launch itself: RCCL with >= 2 ranks is UNMEASURED ON
+# HARDWARE in this repository (tests/test_shard_gloo.py covers the rank bookkeeping on gloo; the driver's SCALE run is the
+# only place the 8-GPU job can happen).
+C4_B, C4_T, C4_WORLD = 4096, 200, 8
+
+
+@pytest.fixture(scope="module")
+def config4_shards():
     wg.init(0)
     model = wg.model_defaults()
     wg.mpc_configure(model)
-    B, T, world, rank = 4096, 200, 8, 7
-    lo, hi = rank * B, (rank + 1) * B
+    shard = importlib.import_module("jrl-walkgen_amd.shard")
+    runs = []
+    for rank in range(C4_WORLD):
+        lo, hi = shard.shard_range(C4_WORLD * C4_B, rank, C4_WORLD)
+        assert (lo, hi) == (rank * C4_B, (rank + 1) * C4_B)
+        fin, diag = _run_dev(model, list(range(lo, hi)), C4_T)
+        runs.append((lo, hi, fin, diag))
+    return model, runs
+
+
+def test_config4_all_eight_shards_full_size(config4_shards):
+    """every one of the 32 768 gaits x 200 ticks = 6 553 600 QPs solves; each shard holds different problems; a seeded sample
+    of EVERY shard is followed tick by tick by the CPU oracle to the same bytes"""
+    model, runs = config4_shards
+    pt = _ptrig()
+    seen = set()
+    for rank, (lo, hi, fin, diag) in enumerate(runs):
+        assert int((diag[:, :, 0] != 0).sum()) == 0, rank
+        assert set(np.unique(diag[:, :, 3]).tolist()) <= {32, 34, 36} and diag[:, :, 1].max() < 200
+        st = (wg.GaitState * C4_B).from_buffer_copy(fin.tobytes())
+        assert all(s.tick_count == C4_T and s.running == 1 for s in st)
+        com = np.array([[s.com_x[0], s.com_y[0]] for s in st]); feet = np.array([[s.lf[2].x, s.lf[2].y, s.rf[2].x, s.rf[2].y] for s in st])
+        assert np.isfinite(com).all() and np.abs(com - 0.5 * (feet[:, :2] + feet[:, 2:])).max() < 0.35
+        rows = {r.tobytes() for r in fin}
+        assert len(rows) > 4000 and not (rows & seen), rank        # different problems, and different from every other shard's
+        seen |= rows
+        rng = np.random.default_rng(32768 + rank)
+        for k in sorted(set(rng.choice(C4_B, 6, replace=False).tolist()) | {0, C4_B - 1}):
+            assert _oracle_follow(pt, model, lo + k, C4_T) == fin[k].tobytes(), lo + k
+
+
+def test_config4_results_do_not_depend_on_the_split(config4_shards):
+    """the same 32 768 gaits split over FOUR ranks (8192 per GPU: other batch sizes, other wave placement, other queue
+    traffic): rank q's bytes are shards 2q and 2q + 1 of the eight-way job, byte for byte"""
+    model, runs = config4_shards
+    shard = importlib.import_module("jrl-walkgen_amd.shard")
+    for q in range(4):
+        lo, hi = shard.shard_range(C4_WORLD * C4_B, q, 4)
+        assert (lo, hi) == (2 * q * C4_B, (2 * q + 2) * C4_B)
+        fin, diag = _run_dev(model, list(range(lo, hi)), C4_T, want_diag=(q == 0))
+        assert np.array_equal(fin[:C4_B], runs[2 * q][2]) and np.array_equal(fin[C4_B:], runs[2 * q + 1][2]), q
+        if q == 0:
+            assert np.array_equal(diag[:, :C4_B], runs[0][3]) and np.array_equal(diag[:, C4_B:], runs[1][3])
+
+
+def test_config4_last_shard_of_eight_full_size(config4_shards):
+    """rank 7 of world 8, 4096 gaits per GPU: global gaits [28672, 32768)"""
+    import bench
+    model, runs = config4_shards
+    B, T, rank = C4_B, C4_T, 7
+    lo, hi, fin, diag = runs[rank]
     assert (lo, hi) == (28672, 32768)
-    assert shard.shard_range(world * B, rank, world) == (lo, hi)
     # the references this shard gets are bench.py's table for those global indices (not a re-seeded local table)
     tab = bench.velocity_table(lo, lo + 3, 4)
     for k in range(3):
         assert np.array_equal(tab[:, k, :], _vel(lo + k, 4))
     assert not np.array_equal(_vel(lo, 4), _vel(0, 4))
-    fin, diag = _run_dev(model, list(range(lo, hi)), T)
-    assert int((diag[:, :, 0] != 0).sum()) == 0                    # all 819 200 QPs of the shard solved
-    assert set(np.unique(diag[:, :, 3]).tolist()) <= {32, 34, 36} and diag[:, :, 1].max() < 200
-    st = (wg.GaitState * B).from_buffer_copy(fin.tobytes())
-    assert all(s.tick_count == T and s.running == 1 for s in st)
-    com = np.array([[s.com_x[0], s.com_y[0]] for s in st]); feet = np.array([[s.lf[2].x, s.lf[2].y, s.rf[2].x, s.rf[2].y] for s in st])
-    assert np.isfinite(com).all() and np.abs(com - 0.5 * (feet[:, :2] + feet[:, 2:])).max() < 0.35
-    assert len({r.tobytes() for r in fin}) > 4000                   # gaits really are different problems
-    # a seeded sample of the shard, every tick on the CPU oracle: same bytes
+    # a larger seeded sample of this shard on the CPU oracle: same bytes
     pt = _ptrig()
     rng = np.random.default_rng(32768)
     sample = sorted(set(rng.choice(B, 38, replace=False).tolist()) | {0, B - 1})

@@ -212,3 +212,16 @@ def test_cpp_kajita_fleet_runs_through_the_c_abi():
     assert r.returncode == 0, r.stdout + r.stderr
     assert "device chain == host entry points" in r.stdout and "4002 samples" in r.stdout, r.stdout
     assert "gait 0 ends at x = 2.8" in r.stdout, r.stdout           # fourteen 0.2 m steps
+
+
+def test_every_reference_command_string_through_parsecmd(tmp_path):
+    """host/test_commands.cpp: the fifteen commands PatternGeneratorInterfacePrivate registers (PatternGeneratorInterfacePrivate.cpp:
+    186-201) and the step-stack generators, each sent through ParseCmd and checked for its effect (":ZMPShiftParameters" reaching
+    ZMPDiscretization::SetZMPShift, ":SetAutoFirstStep" = AutomaticallyAddFirstStep, ":arccentered" geometry, the failed-QP dump of
+    ZMPVelocityReferencedQP.cpp:399-402) or for the documented refusal (on-line step sequencing: NotOnThisPath)."""
+    exe = os.path.join(ROOT, "jrl-walkgen_amd", "bin", "test_commands")
+    assert os.path.exists(exe), "build first: python -c 'import __graft_entry__ as g; g.build()'"
+    r = subprocess.run([exe, str(tmp_path)], capture_output=True, text=True, timeout=600)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith(("ok  ", "FAIL"))]
+    assert r.returncode == 0 and len(lines) >= 10 and all(ln.startswith("ok  ") for ln in lines), r.stdout + r.stderr
+    assert "all checks passed" in r.stdout
