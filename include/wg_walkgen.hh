@@ -220,7 +220,8 @@ class ZMPVelocityReferencedQP : public ZMPRefTrajectoryGeneration {
   // QPProblem::dump(const char *) / dump(double Time) (qp-problem.cpp:656-675): the problem of the NEXT tick -- Q, D, DU, DS, XL,
   // XU and the solver parameters in the reference's text format -- assembled on the device from the current state
   // (wg_mpc_assemble_batch).  OnLine writes "<dir>/Problem_<time>.dat" for a tick whose solve failed (Solution().Fail > 0,
-  // ZMPVelocityReferencedQP.cpp:399-402) when the environment has WG_DUMP_FAILED_QP (= a directory, or 1 for /tmp).
+  // ZMPVelocityReferencedQP.cpp:399-402) when the environment has WG_DUMP_FAILED_QP (= a directory, or 1 for /tmp), for every
+  // tick with WG_DUMP_EVERY_QP (the Herdt QP keeps jerk and foot placement free, so a failing one is hard to come by).
   void dumpProblem(const char *FileName);
   void dumpProblem(double Time);
 

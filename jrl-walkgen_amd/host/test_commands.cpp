@@ -158,7 +158,7 @@ int main(int argc, char **argv) {
     // ---- :arccentered: every arc step turns by the same angle and lands on its circle around the centre ----
     {
       PatternGeneratorInterface *pgi = fresh(robot);
-      cmd(*pgi, ":supportfoot 1");
+      cmd(*pgi, ":supportfoot -1");
       cmd(*pgi, ":arccentered 0.75 30.0 -1");
       cmd(*pgi, ":lastsupport");
       cmd(*pgi, ":finish");
@@ -166,25 +166,35 @@ int main(int argc, char **argv) {
       const double th_end = 0.5 * (t.lth.back() + t.rth.back());
       check(t.zx.size() > 1000 && std::fabs(th_end - 30.0) < 1e-6, ":arccentered 0.75 30 -1: " + std::to_string(t.zx.size()) +
                                                                        " control steps, final feet heading " + std::to_string(th_end) + " deg");
-      // footprints (where a foot rests: consecutive equal samples) keep their distance to the centre of rotation
-      double cx = 0, cy = 0, worst = 0.0;
-      bool have_centre = false;
-      int prints = 0;
+      // Where a foot rests (consecutive equal samples) is a footprint.  Each arc step turns both feet by the same angle about the
+      // same centre, so the rigid motion from one footprint of a foot to its next one, seen from the first, is the same every
+      // time (all but the last, shorter step): 0.10 m of arc at radius 0.75 m = 7.639 degrees.
+      double worst = 0.0, dth_seen = 0.0;
+      int pairs = 0;
       for (int foot = 0; foot < 2; foot++) {
         const std::vector<double> &X = foot ? t.rx : t.lx, &Y = foot ? t.ry : t.ly, &TH = foot ? t.rth : t.lth;
-        for (size_t i = 200; i + 1 < X.size(); i += 40) {
-          if (X[i] != X[i + 1] || Y[i] != Y[i + 1]) continue;           // in flight
-          // the foot's lateral axis points at the centre: centre = foot + d * (-sin th, cos th); |d| = R -+ 0.095
-          const double th = TH[i] * 3.14159265358979323846 / 180.0;
-          const double d = foot ? 0.75 + 0.095 : 0.75 - 0.095;
-          const double px = X[i] - d * std::sin(th), py = Y[i] + d * std::cos(th);
-          if (!have_centre) { cx = px; cy = py; have_centre = true; }
-          worst = std::fmax(worst, std::hypot(px - cx, py - cy));
-          prints++;
+        std::vector<std::vector<double> > prints;
+        for (size_t i = 0; i + 1 < X.size(); i++) {
+          if (X[i] != X[i + 1] || Y[i] != Y[i + 1] || TH[i] != TH[i + 1]) continue;         // in flight
+          if (prints.empty() || prints.back()[0] != X[i] || prints.back()[1] != Y[i] || prints.back()[2] != TH[i])
+            prints.push_back({X[i], Y[i], TH[i]});
+        }
+        std::vector<std::vector<double> > rel;
+        for (size_t k = 0; k + 1 < prints.size(); k++) {
+          const double th = prints[k][2] * 3.14159265358979323846 / 180.0, c = std::cos(th), s = std::sin(th);
+          const double dx = prints[k + 1][0] - prints[k][0], dy = prints[k + 1][1] - prints[k][1];
+          rel.push_back({c * dx + s * dy, -s * dx + c * dy, prints[k + 1][2] - prints[k][2]});
+        }
+        // whole arc steps: those that turn by the full step angle
+        for (size_t k = 1; k + 1 < rel.size(); k++) {               // rel[0] starts from the rest posture, not from a footprint of the arc
+          if (std::fabs(rel[k][2] - 7.6394372684109761) > 1e-6 || std::fabs(rel[k + 1][2] - 7.6394372684109761) > 1e-6) continue;
+          for (int e = 0; e < 3; e++) worst = std::fmax(worst, std::fabs(rel[k][e] - rel[k + 1][e]));
+          dth_seen = rel[k][2];
+          pairs++;
         }
       }
-      check(have_centre && prints > 20 && worst < 1e-9, ":arccentered footprints share one centre of rotation (spread " + std::to_string(worst) + " m over " +
-                                                            std::to_string(prints) + " samples)");
+      check(pairs >= 2 && worst < 1e-9, ":arccentered: successive footprints of a foot differ by one and the same rigid motion (" +
+                                            std::to_string(pairs) + " pairs, spread " + std::to_string(worst) + ", turn " + std::to_string(dth_seen) + " deg)");
       delete pgi;
     }
     // ---- Herdt mode: the failed-QP dump (ZMPVelocityReferencedQP.cpp:399-402) and the dump on request ----
@@ -226,19 +236,24 @@ int main(int argc, char **argv) {
       check(nq >= 32 && sym && cols_du == nq && rows_du >= 66 && have_params,
             "dumpProblem writes QPProblem::dump_problem's layout: Q[" + std::to_string(nq) + "," + std::to_string(nq) + "] symmetric, DU[" +
                 std::to_string(rows_du) + "," + std::to_string(cols_du) + "], DS, XL, XU, solver parameters");
-      // a push the ZMP polygon cannot absorb: the QP of the next tick is inconsistent, the reference dumps it
-      setenv("WG_DUMP_FAILED_QP", scratch.c_str(), 1);
-      qp.setCoMPerturbationForce(1.0e5, 0.0);
-      int fail = 0;
-      double t_fail = 0.0;
-      for (int k = 0; k < 40 && !fail; k++) { time += 0.005; qp.OnLine(time, zp, cs, l, r); if (qp.Solution().Fail > 0) { fail = qp.Solution().Fail; t_fail = time; } }
-      unsetenv("WG_DUMP_FAILED_QP");
+      // The dump OnLine writes for a tick (WG_DUMP_EVERY_QP; WG_DUMP_FAILED_QP writes it only when Solution().Fail > 0, as the
+      // reference does) is the problem of THAT tick: the same bytes as a dump taken on request just before the tick fired.
+      const std::string before_file = scratch + "/wg_problem_before_tick.dat";
+      double t_tick = 0.0;
+      setenv("WG_DUMP_EVERY_QP", scratch.c_str(), 1);
+      for (int k = 0; k < 40 && t_tick == 0.0; k++) {
+        const int ticks_before = qp.State().tick_count;
+        qp.dumpProblem(before_file.c_str());
+        time += 0.005;
+        qp.OnLine(time, zp, cs, l, r);
+        if (qp.State().tick_count != ticks_before) t_tick = time;
+      }
+      unsetenv("WG_DUMP_EVERY_QP");
       char name[1024];
-      snprintf(name, sizeof name, "%s/Problem_%f.dat", scratch.c_str(), t_fail);
-      std::ifstream dumped(name);
-      std::string head;
-      dumped >> head;
-      check(fail > 0 && head.compare(0, 2, "Q[") == 0, std::string("a failed solve (ifail ") + std::to_string(fail) + ") leaves " + name);
+      snprintf(name, sizeof name, "%s/Problem_%f.dat", scratch.c_str(), t_tick);
+      auto slurp = [](const std::string &f) { std::ifstream i(f.c_str()); return std::string((std::istreambuf_iterator<char>(i)), std::istreambuf_iterator<char>()); };
+      const std::string a = slurp(name), b = slurp(before_file);
+      check(t_tick > 0.0 && a.size() > 10000 && a == b, std::string("the tick's own problem is what OnLine dumps: ") + name + " (" + std::to_string(a.size()) + " bytes)");
     }
   } catch (std::exception &e) {
     std::cerr << "FAILED: " << e.what() << std::endl;

@@ -303,16 +303,17 @@ void ZMPVelocityReferencedQP::OnLine(double time, deque<ZMPPosition> &FinalZMPTr
   if (time + 0.00001 > State_.upper_time_limit) {
     State_.clock = time;
     wg_tick_out_t out;
-    const char *dump_dir = getenv("WG_DUMP_FAILED_QP");
+    const char *dump_failed = getenv("WG_DUMP_FAILED_QP"), *dump_every = getenv("WG_DUMP_EVERY_QP");
     wg_gait_state_t before;
-    if (dump_dir) before = State_;
+    if (dump_failed || dump_every) before = State_;
     if (wg_mpc_tick_batch_ctx(Ctx_, 1, &State_, &out, 0, 0, 0, 0, 0) != WG_OK) wg_throw("wg_mpc_tick_batch");
     Solution_.NbVariables = out.n; Solution_.NbConstraints = out.m; Solution_.Fail = out.ifail;
     Solution_.NbIterations = out.n_iter; Solution_.NbActiveConstraints = out.nact;
     Solution_.JerkX = out.jerk_x; Solution_.JerkY = out.jerk_y;
-    if (Solution_.Fail > 0 && dump_dir) {                 // Problem_.dump( time ), ZMPVelocityReferencedQP.cpp:399-402
-      char Buffer[1024];
-      snprintf(Buffer, sizeof Buffer, "%s/Problem_%f.dat", (dump_dir[0] == '/' || dump_dir[0] == '.') ? dump_dir : "/tmp", time);
+    if ((Solution_.Fail > 0 && dump_failed) || dump_every) {   // Problem_.dump( time ), ZMPVelocityReferencedQP.cpp:399-402
+      const char *dir = dump_every ? dump_every : dump_failed;   // (the Herdt QP keeps jerk and foot placement free: it practically
+      char Buffer[1024];                                         //  never fails -- WG_DUMP_EVERY_QP writes every tick's problem)
+      snprintf(Buffer, sizeof Buffer, "%s/Problem_%f.dat", strcmp(dir, "1") == 0 ? "/tmp" : dir, time);
       dumpState(before, Buffer);
     }
     if (!FinalLeftFootTraj_deq.empty()) {       // the DS branch rewrites the newest queued sample, OFTG.cpp:333-336
