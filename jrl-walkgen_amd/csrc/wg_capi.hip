@@ -183,7 +183,16 @@ int guard_mark(wg_ctx *ctx, hipStream_t st) {
 // Replaces ql0001_ (qld.hh:27-31) for B problems at once.
 // ---------------------------------------------------------------------------
 template <bool kALds>                                      // where A lives is known at compile time: ds_ or global_ accesses,
-__global__ __launch_bounds__(64) void wg_ql_dense_kernel(   // never flat_ (those also count on lgkmcnt and stall the LDS waits)
+// Left to itself the compiler takes 256 VGPRs plus 3 AGPRs -- 259 registers, one wave per SIMD, four QPs per CU where the LDS
+// would admit five at n = 36, m = 75.  Forced to two waves per SIMD (-DWG_QLD_WPE=2: 256 registers, 2-3 spilled, 12-16 B of
+// scratch) it measured 5 % SLOWER on the Herdt workload's real QPs (1.73 against 1.82 M QPs/s, B = 4096): the fifth QP per CU
+// does not pay for the tighter allocation.  The default stays.
+#ifdef WG_QLD_WPE
+#define WG_QLD_ATTR __attribute__((amdgpu_waves_per_eu(WG_QLD_WPE, WG_QLD_WPE)))
+#else
+#define WG_QLD_ATTR
+#endif
+__global__ __launch_bounds__(64) WG_QLD_ATTR void wg_ql_dense_kernel(   // never flat_ (those also count on lgkmcnt and stall the LDS waits)
     int B, int nmax, int mmax, const int *__restrict__ n_arr, const int *__restrict__ m_arr,
     const int *__restrict__ me_arr, const double *__restrict__ C, const double *__restrict__ dvec,
     const double *__restrict__ A, const double *__restrict__ bvec, const double *__restrict__ xl,
@@ -808,6 +817,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NH == -1 ? W
       xrun_stores_done();                                  // mpc_tick reads the state back from L2
       WG_WSYNC();
     }
+    // (the tick body as a real function call instead of inlined code -- no hoisting across ticks, 50 spilled SGPRs in the loop
+    // instead of 276 -- measured: N = 16 unchanged (-0.7 %), N = 32 a third slower; the inlined body stays)
     wg::TickDiag dg = wg::mpc_tick<NH>(model, tb, states + g, outs ? outs + (size_t)t * B + g : nullptr, wg_lds,
                                    reinterpret_cast<char *>(wg_lds) + ql_bytes, nullptr, 0, nullptr,
                                    zscratch ? zscratch + (size_t)blockIdx.x * zslot : nullptr, elem_cap);

@@ -33,7 +33,43 @@ def _state_tuple(s):
     return (s.n_prev, list(s.prev_active[:s.n_prev]), list(s.prev_zmp), s.internal_time)
 
 
-def _run_lockstep(B, n_ticks, seed0, max_iter=0, mcap=wg.PLDP_MMAX):
+def _ql_gate(dm, p, X, active, gate):
+    """One solved problem against the reference-pinned QL oracle (oracle/ql_oracle.c == the reference's compiled qld.cpp):
+    min 1/2 |v|^2 + D'v  s.t.  A v + b >= 0  has ONE optimum v*.  PLDP is a primal active-set method that never drops a
+    constraint inside a solve (PLDPSolver.cpp:654-1007), so it ends either AT v* (projected gradient gone, multipliers of the
+    right sign) or on a vertex it activated on the way and could not leave -- feasible, objective above the optimum.  Checked on
+    EVERY solve: feasibility, f(X) >= f(v*) (up to what PLDP's own 1e-8 slack outside a face can buy, ComputeAlpha :613-621);
+    where the KKT signs hold: X == v* to 2e-5 (1e-8 of slack over constraint rows of norm ~1e-3 -- 1e-9 on x is below what
+    the method's own tolerance allows) and the objectives to 1e-9 relative."""
+    m, n = p["m"], 2 * dm.N
+    A = p["A"].reshape((n, m + 1)).T[:m]
+    q = dict(n=n, m=m, me=0, mmax=m + 1, nmax=n, C=np.asfortranarray(np.eye(n)), d=p["D"].copy(),
+             A=np.asfortranarray(np.vstack([A, np.zeros((1, n))])), b=np.concatenate([p["b"], [0.0]]),
+             xl=np.full(n, -1e8), xu=np.full(n, 1e8))
+    o = ol.oracle_ql(q)
+    assert o["ifail"] == 0
+    f = lambda z: 0.5 * z @ z + p["D"] @ z  # noqa: E731
+    lam_sum = float(np.abs(o["u"][:m]).sum())
+    assert (A @ X + p["b"]).min() > -5e-8
+    gap = f(X) - f(o["x"])
+    assert gap >= -5e-8 * lam_sum - 1e-9 * max(1.0, abs(f(X))), gap
+    act = np.asarray(active, dtype=int)                        # PLDP's own active set, in activation order
+    if len(act):
+        lam, *_ = np.linalg.lstsq(A[act].T, X + p["D"], rcond=None)
+        kkt = np.abs(A[act].T @ lam - (X + p["D"])).max() < 1e-9 and (lam > -1e-12).all()
+    else:
+        kkt = np.abs(X + p["D"]).max() < 1e-9
+    gate["solves"] += 1
+    if kkt:
+        assert np.abs(X - o["x"]).max() < 2e-5 and abs(gap) <= 5e-8 * lam_sum + 1e-9 * max(1.0, abs(f(X)))
+        gate["optimal"] += 1
+    else:
+        gate["stuck"] += 1
+        gate["worst_gap"] = max(gate["worst_gap"], gap / max(1e-12, abs(f(o["x"]))))
+        gate["worst_dx"] = max(gate["worst_dx"], float(np.abs(X - o["x"]).max()))
+
+
+def _run_lockstep(B, n_ticks, seed0, max_iter=0, mcap=wg.PLDP_MMAX, gate=None):
     dm = dv.Dimitrov()
     M = ol.pldp_setup(dm.N, dm.iPu, dm.Px, dm.Pu)
     wg.init(0)
@@ -66,6 +102,8 @@ def _run_lockstep(B, n_ticks, seed0, max_iter=0, mcap=wg.PLDP_MMAX):
                 stats["neg_alpha"] += (o["ret"] == -2)
                 alive[g] = False                            # the reference process would have exited here
                 continue
+            if gate is not None:
+                _ql_gate(dm, p, out["X"][g], out["active"][g], gate)
             xk[g] = dm.step(xk[g], out["X"][g])
         n_removed = np.array([p["first_rows"] for p in probs], dtype=np.int32)
         starting[:] = 0
@@ -78,6 +116,17 @@ def test_pldp_gaits_bit_exact(a_in_lds, monkeypatch):
     monkeypatch.setenv("WG_PLDP_A_IN_LDS", a_in_lds)
     st = _run_lockstep(B=24, n_ticks=45, seed0=100)
     assert st["solves"] > 600 and max(st["nact"]) >= 10 and max(st["iters"]) >= 6
+
+
+def test_pldp_solutions_against_the_pinned_ql_oracle_on_every_solve():
+    """the property gate of _ql_gate on every successful solve of 24 de-synchronised gaits x 45 ticks (GPU solutions)"""
+    gate = dict(solves=0, optimal=0, stuck=0, worst_gap=0.0, worst_dx=0.0)
+    _run_lockstep(B=24, n_ticks=45, seed0=100, gate=gate)
+    print("PLDP vs QL:", gate)
+    # measured (same numbers on the CPU restatement, whose bits the GPU reproduces): ~7 % of the solves end at the optimum,
+    # the others on a vertex PLDP could not leave (objective up to 2 x the optimum's) -- the method trades optimality for
+    # speed by design (Dimitrov 2008); what holds on every solve is feasibility and f(X) >= f(v*)
+    assert gate["solves"] > 600 and gate["optimal"] >= 30 and gate["optimal"] + gate["stuck"] == gate["solves"], gate
 
 
 def test_pldp_iteration_cap_bit_exact():

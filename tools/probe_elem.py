@@ -28,6 +28,8 @@ for r in range(REPS):
     e0.record(); wg.mpc_run_batch_dev(B, st.data_ptr(), T, 20, None, diag[r * T].data_ptr()); e1.record()
     torch.cuda.synchronize(); ms.append(e0.elapsed_time(e1))
 d = diag.cpu().numpy().reshape(-1, 6)
+na = d[:, 2]
+print("final active-set sizes: mean %.1f, p50 %d, p90 %d, p99 %d, max %d" % (na.mean(), np.percentile(na, 50), np.percentile(na, 90), np.percentile(na, 99), na.max()), flush=True)
 print("N=%d B=%d T=%d lds/gait %d B -> %d gaits per CU: launches %s ms -> %.0f ticks/s (best %.0f); mean QL iterations %.1f, failed %d, state checksum %016x"
       % (model.N, B, T, lds, per_cu, ["%.1f" % m for m in ms], B * T * REPS / sum(ms) * 1e3, B * T / min(ms) * 1e3, d[:, 1].mean(),
          int((d[:, 0] != 0).sum()), int(st.cpu().numpy().view(np.uint64).sum(dtype=np.uint64))), flush=True)

@@ -11,7 +11,7 @@
 set -u
 export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-BENCH="bench.py --steps 200 --warmup 50 --no-cpu-baseline --no-parity --no-per-tick-leg --no-config5"
+BENCH="bench.py --steps 200 --warmup 50 --no-cpu-baseline --no-parity --no-per-tick-leg --no-config5 --no-kernels"
 bash $R/tools/prof.sh tick $BENCH > $R/gpurun_out/prof_tick.log 2>&1
 echo "tick done"
 export WG_RUN_QUEUE=global
@@ -24,6 +24,18 @@ export PN=32 PB=8192 PT=50
 bash $R/tools/prof.sh config5 tools/probe_run.py > $R/gpurun_out/prof_config5.log 2>&1
 unset PN PB PT
 echo "config5 done"
+# the element-view run kernel alone (N = 32, B = 8192, launches of 50 ticks): the traffic bench.py's config5 leg reports
+export PN=32 PB=8192 PT=50 PR=3
+bash $R/tools/prof.sh elem tools/probe_elem.py > $R/gpurun_out/prof_elem.log 2>&1
+unset PN PB PT PR
+echo "elem done"
+# FETCH_SIZE / WRITE_SIZE on known byte counts in the access shapes of that kernel
+$R/tools/micro/fetchcal > $R/gpurun_out/fetchcal.txt 2>&1
+bash $R/tools/pmc_traffic.sh fetchcal $R/tools/micro/fetchcal > $R/gpurun_out/fetchcal_pmc.txt 2>&1
+echo "calibration done"
+# one robot: the tick's latency split
+$R/jrl-walkgen_amd/bin/latency_b1 > $R/gpurun_out/latency_b1.json 2> $R/gpurun_out/latency_b1.err
+echo "latency done"
 # the Gramian kernel with the matrix-core counters (its own passes)
 OUT=$R/gpurun_out/prof_gramian; rm -rf $OUT; mkdir -p $OUT; cd /tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $R/tools/probe_gramian.py > $OUT/trace.log 2>&1

@@ -11,7 +11,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag = sys.argv[1] if len(sys.argv) > 1 else "round2"
 
-B, W, K, REDRAW = 4096, 50, 200, 50
+B, W, K, REDRAW = 4096, 150, 200, 50          # W = bench.py's pre-roll (100) + warm-up (50): all untimed
 
 
 def launch_plan(t0, t1, per_tick=False, redraw=REDRAW):            # bench.launch_plan (staged references), kept in step by hand
@@ -22,7 +22,7 @@ def launch_plan(t0, t1, per_tick=False, redraw=REDRAW):            # bench.launc
     return out
 
 
-names = ["tick", "tickg", "pertick", "config5", "gramian", "dimitrov", "pldp", "preview", "zmpdisc"]
+names = ["tick", "tickg", "pertick", "config5", "elem", "gramian", "dimitrov", "pldp", "preview", "zmpdisc"]
 summ = {}
 for k in names:
     d = os.path.join(ROOT, "gpurun_out", "prof_" + k)
@@ -37,7 +37,7 @@ for k in names:
         shutil.copy(stats[-1], os.path.join(ROOT, "profiles", f"{tag}_{k}_kernel_stats.csv"))
     summ[k] = json.load(open(os.path.join(d, "summary.json")))
     log = os.path.join(d, "trace.log")
-    if k in ("gramian", "config5") and os.path.exists(log):
+    if k in ("gramian", "config5", "elem") and os.path.exists(log):
         keep = [ln for ln in open(log) if ("TFLOP" in ln or "ticks/s" in ln or "same" in ln or "run" in ln) and "amdgpu.ids" not in ln]
         open(os.path.join(ROOT, "profiles", f"{tag}_{k}_probe_output.txt"), "w").writelines(keep)
 
@@ -62,28 +62,64 @@ def per_gait_tick(s, kernel, gait_ticks):
     return r
 
 
+PLAN = launch_plan(0, W) + launch_plan(W, W + K)              # bench.py: the untimed ticks, then the timed region
+run_ticks = sum(n for _, n in PLAN if n > 1)
+n_run = sum(1 for _, n in PLAN if n > 1)
+plan_txt = ", ".join(str(n) for _, n in PLAN if n > 1)
 out = {"tag": tag,
        "how": "rocprofv3 passes of `python3 bench.py --steps 200 --warmup 50 --no-cpu-baseline --no-parity --no-per-tick-leg "
-              "--no-config5` (tools/prof_round.sh): kernel trace + stats, then the counters in separate --pmc passes (FETCH_SIZE and "
+              "--no-config5 --no-kernels` (tools/prof_round.sh): kernel trace + stats, then the counters in separate --pmc passes (FETCH_SIZE and "
               "WRITE_SIZE each in its own).  Units and gfx950 correction per MI355X_MICROARCH.md (HBM / rocprofv3): KiB x 1024, "
               "FETCH_SIZE doubled.  Totals over ALL launches of the kernel divided by the gait-ticks those launches ran "
-              "(B = 4096; multi-tick: one 48-tick launch and one 200-tick launch with the references staged = 248 ticks; the "
-              "device-wide queue takes one launch per stretch: 48 + 4 x 50; per-tick: 250 launches).  valu_busy = "
+              "(B = 4096; bench.py runs 100 pre-roll + 50 warm-up ticks untimed, then the timed 200; multi-tick launches: " + plan_txt + " ticks, "
+              "the references of later stretches staged on the device; the device-wide queue takes one launch per stretch; per-tick: 350 launches).  valu_busy = "
               "2 waves per SIMD x SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES."}
-run_ticks = sum(n for _, n in launch_plan(0, W + K) if n > 1)
-n_run = sum(1 for _, n in launch_plan(0, W + K) if n > 1)
-plan_txt = ", ".join(str(n) for _, n in launch_plan(0, W + K) if n > 1)
 if "tick" in summ:
     out["run_kernel"] = per_gait_tick(summ["tick"], "wg_mpc_run_xcd_kernel<16>", B * run_ticks)
     out["run_kernel"]["ticks_per_launch"] = plan_txt
     assert out["run_kernel"]["launches"] == n_run, (out["run_kernel"]["launches"], n_run)
 if "tickg" in summ:
     out["run_kernel_device_wide_queue"] = per_gait_tick(summ["tickg"], "wg_mpc_run_kernel<16>", B * run_ticks)
-    out["run_kernel_device_wide_queue"]["ticks_per_launch"] = "48, 50, 50, 50, 50"
+    out["run_kernel_device_wide_queue"]["ticks_per_launch"] = "48, 50 x 6"
 if "pertick" in summ:
     out["per_tick_kernel"] = per_gait_tick(summ["pertick"], "wg_mpc_tick_kernel<16>", B * (W + K))
     out["per_tick_kernel"]["ticks_per_launch"] = "1"
+if "elem" in summ:
+    # the N = 32 element-view run kernel: probe_elem.py runs one 10-tick warm-up launch and PR = 3 launches of PT = 50 ticks
+    EB, ET, ER, EW = 8192, 50, 3, 10
+    kern = "wg_mpc_run_xcd_kernel<-1>"
+    c = summ["elem"]["counters"][kern]
+    gt = EB * (ET * ER + EW)
+    tot = lambda n: c[n]["mean_per_launch"] * c[n]["launches"]       # noqa: E731
+    assert int(c["FETCH_SIZE"]["launches"]) == ER + 1, c["FETCH_SIZE"]["launches"]
+    rd_raw = tot("FETCH_SIZE") * 1024; wr = tot("WRITE_SIZE") * 1024
+    cal = ""
+    calf = os.path.join(ROOT, "gpurun_out", "prof_fetchcal", "summary.json")
+    if os.path.exists(calf):
+        cc = json.load(open(calf))["counters"]
+        f8 = cc["wg_cal_rd<double>"]["FETCH_SIZE"]["mean_per_launch"] * 1024 / float(2 << 30)
+        fc = cc["wg_cal_rd8_cols"]["FETCH_SIZE"]["mean_per_launch"] * 1024 / (51072 * 72 * 72 * 8.0)
+        w8 = cc["wg_cal_wr<double>"]["WRITE_SIZE"]["mean_per_launch"] * 1024 / float(2 << 30)
+        cal = ("tools/micro/fetchcal on this box: FETCH_SIZE reports %.3f of the bytes of an 8-B-per-lane coalesced stream, %.3f of the "
+               "useful bytes of the Z^T a column walk (x 2 = %.2f: the walk over-fetches its 584-B-strided rows), WRITE_SIZE %.3f of "
+               "8-B-per-lane stores" % (f8, fc, 2 * fc, w8))
+        shutil.copy(os.path.join(ROOT, "gpurun_out", "fetchcal.txt"), os.path.join(ROOT, "profiles", f"{tag}_fetchcal_rates.txt"))
+        shutil.copy(os.path.join(ROOT, "gpurun_out", "prof_fetchcal", "summary.txt"), os.path.join(ROOT, "profiles", f"{tag}_fetchcal_counters.txt"))
+    out["elem_run_kernel"] = {
+        "kernel": kern, "command": "PN=32 PB=8192 PT=50 PR=3 python3 tools/probe_elem.py", "batch": EB, "ticks_per_launch": "10, 50, 50, 50",
+        "launches": ER + 1, "gait_ticks": gt,
+        "hbm_read_bytes_per_gait_tick_uncorrected": rd_raw / gt, "hbm_read_bytes_per_gait_tick": 2 * rd_raw / gt,
+        "hbm_write_bytes_per_gait_tick": wr / gt, "hbm_bytes_per_gait_tick": (2 * rd_raw + wr) / gt,
+        "calibration": cal,
+        "valu_insts_per_gait_tick": tot("SQ_INSTS_VALU") / gt, "salu_insts_per_gait_tick": tot("SQ_INSTS_SALU") / gt,
+        "lds_insts_per_gait_tick": tot("SQ_INSTS_LDS") / gt, "vmem_insts_per_gait_tick": tot("SQ_INSTS_VMEM") / gt,
+        "valu_busy": 2 * tot("SQ_ACTIVE_INST_VALU") / tot("SQ_WAVE_CYCLES"),
+        "wait_any_frac_per_wave": tot("SQ_WAIT_ANY") / tot("SQ_WAVE_CYCLES"),
+        "avg_kernel_ns_rocprofv3": summ["elem"]["kernels"][kern]["avg_ns"], "kernel_calls_rocprofv3": summ["elem"]["kernels"][kern]["calls"]}
 json.dump(out, open(os.path.join(ROOT, "profiles", "current_tick_pmc.json"), "w"), indent=1)
+lat = os.path.join(ROOT, "gpurun_out", "latency_b1.json")
+if os.path.exists(lat) and os.path.getsize(lat) > 0:
+    shutil.copy(lat, os.path.join(ROOT, "profiles", f"{tag}_latency_b1.json"))
 for src, dst in (("phases_tick.txt", "tick_phase_timers.txt"), ("phases_tick32.txt", "tick32_phase_timers.txt")):
     ph = os.path.join(ROOT, "gpurun_out", src)
     if os.path.exists(ph):
@@ -93,7 +129,7 @@ if "run_kernel" in out:
     r = out["run_kernel"]
     tot_ms = r["avg_kernel_ns_rocprofv3"] * r["kernel_calls_rocprofv3"] / 1e6
     agree = (f"How the run kernel's table lines up with `bench.py`: rocprofv3 saw {r['kernel_calls_rocprofv3']} launches of "
-             f"`wg_mpc_run_xcd_kernel<16>` ({r['ticks_per_launch']} ticks: the warm-up stretch and the timed launch), {tot_ms:.1f} ms in "
+             f"`wg_mpc_run_xcd_kernel<16>` ({r['ticks_per_launch']} ticks: the untimed launches and the timed one), {tot_ms:.1f} ms in "
              f"all = {tot_ms / run_ticks:.4f} ms per tick of the batch; the table's average ({r['avg_kernel_ns_rocprofv3'] / 1e6:.1f} ms) is "
              f"over launches of different lengths, its MaxNs is the timed launch that `bench.py` brackets with HIP events "
              f"(`roofline.kernel_ms` in `{tag}_bench.json`, / `ticks_per_launch` = ms per tick).")
@@ -104,10 +140,14 @@ Everything named `{tag}_*` was produced by ONE run of `tools/prof_round.sh` on a
 
 | files | command profiled | what to read there |
 |---|---|---|
-| `{tag}_tick_*` | `python3 bench.py --steps 200 --warmup 50 --no-cpu-baseline --no-parity --no-per-tick-leg --no-config5` | the benchmarked kernel `wg_mpc_run_xcd_kernel<16>` alone: B = 4096, one launch of 48 ticks (warm-up) and one of 200 ticks with the velocity references of its four stretches staged on the device (plus the two single-tick launches of the control loop's first ticks under their own kernel name); kernel-trace stats and the PMC passes |
+| `{tag}_tick_*` | `python3 bench.py --steps 200 --warmup 50 --no-cpu-baseline --no-parity --no-per-tick-leg --no-config5 --no-kernels` | the benchmarked kernel `wg_mpc_run_xcd_kernel<16>` alone: B = 4096, the untimed launches (pre-roll + warm-up: 48 and 100 ticks) and the timed one of 200 ticks with the velocity references of its four stretches staged on the device (plus the two single-tick launches of the control loop's first ticks under their own kernel name); kernel-trace stats and the PMC passes |
 | `{tag}_tickg_*` | the same with `WG_RUN_QUEUE=global` | the device-wide queue of round 1 (`wg_mpc_run_kernel<16>`): the L2 write-back traffic the XCD-local hand-over removed |
-| `{tag}_pertick_*` | the same with `--per-tick-launch` | `wg_mpc_tick_kernel<16>`, 250 launches of one tick |
+| `{tag}_pertick_*` | the same with `--per-tick-launch` | `wg_mpc_tick_kernel<16>`, 350 launches of one tick |
 | `{tag}_config5_*` | `PN=32 PB=8192 PT=50 python3 tools/probe_run.py` | BASELINE configs[4]'s size: N = 32, B = 8192 (element view), per-tick and multi-tick launches |
+| `{tag}_elem_*` | `PN=32 PB=8192 PT=50 PR=3 python3 tools/probe_elem.py` | the element-view run kernel `wg_mpc_run_xcd_kernel<-1>` alone (what `bench.py`'s `config5` leg times): kernel trace and all PMC passes; `current_tick_pmc.json` -> `elem_run_kernel` holds its HBM-side traffic per gait-tick (FETCH_SIZE x 2 and uncorrected, WRITE_SIZE) |
+| `{tag}_fetchcal_*` | `tools/micro/fetchcal` (plain, then `tools/pmc_traffic.sh`) | FETCH_SIZE / WRITE_SIZE against known byte counts: 4 / 8 / 16 B per lane coalesced, the Z^T a column walk and the sweep's row walk of a 72 x 73 slot |
+| `{tag}_latency_b1.json` | `jrl-walkgen_amd/bin/latency_b1` | one robot (B = 1): host-pointer call, its split (copy in / launch / kernel / copy out) and the host-mapped call |
+| `{tag}_resource_usage.txt` | `python tools/isa_audit.py` (no GPU) | registers, spills, scratch, occupancy of every kernel; where the spill code sits by loop depth; instruction mix of the inner loops |
 | `{tag}_gramian_*` | `python3 tools/probe_gramian.py` | `wg_gramian_kernel`: SQ_INSTS_VALU_MFMA_MOPS_F64 / _F32, SQ_VALU_MFMA_BUSY_CYCLES, duration against the dense MFMA peak (`*_probe_output.txt`) |
 | `{tag}_dimitrov_*`, `{tag}_pldp_*`, `{tag}_preview_*`, `{tag}_zmpdisc_*` | `tools/probe_<name>.py` | the other kernels of the path |
 | `{tag}_tick_phase_timers.txt`, `{tag}_tick32_phase_timers.txt` | `PB=4096 python3 tools/probe_tick_phases.py`, `PN=32 PB=3072 ...` (diagnostic build `lib/libwg_mpc_prof.so`) | in-kernel phase timers of the tick at N = 16 and N = 32 (shader cycles per gait-tick, one launch per tick) |
