@@ -173,13 +173,31 @@ def golden_parity():
     rows = hr.replay(m, s, hr.emergency_stop_events(), 6000, tick=tick, legacy_running=True)
     if rows.shape != datref.shape:
         return {"error": "replay produced %s rows, the golden file has %s" % (rows.shape, datref.shape)}
+    # the same robot through the one-robot entry point: state and outputs in host-mapped memory (wg_mpc_tick_pinned), no copies
+    lat_hm = []
+    try:
+        hm = wg.HostMapped()
+        s1 = wg.gait_init(m, [datref[0, 1], datref[0, 2], datref[0, 3]], [datref[0, 10], datref[0, 11], 0.0], [datref[0, 22], datref[0, 23], 0.0])
+        s1.nb_steps_left = 2; s1.vref[0] = 0.2
+        C.memmove(C.addressof(hm.state), C.byref(s1), C.sizeof(wg.GaitState))
+        for k in range(120):
+            t0 = time.perf_counter()
+            hm.tick(1 if k == 0 else (19 if k == 1 else 20))
+            lat_hm.append(time.perf_counter() - t0)
+        hm.close()
+    except Exception:                                                      # noqa: BLE001 -- reported as missing
+        lat_hm = []
     d = rows - datref
     return {"com_rmse_m": float(np.sqrt((d[:, 1:3] ** 2).mean())), "max_abs_err": float(np.abs(d).max()),
             "rows": int(datref.shape[0]), "columns": int(datref.shape[1]), "tolerance": 1e-6,
             # what a drop-in user with ONE robot sees per MPC tick (every 0.1 s of walking): wg_mpc_tick_batch(B = 1) with
             # host pointers = copy in, launch, synchronise, copy out
             "b1_tick_latency_us": {"median": float(np.median(lat) * 1e6), "p90": float(np.quantile(lat, 0.9) * 1e6),
-                                   "ticks": len(lat)},
+                                   "ticks": len(lat),
+                                   "host_mapped_median": float(np.median(lat_hm[20:]) * 1e6) if lat_hm else None,
+                                   "host_mapped_note": "wg_mpc_tick_pinned: state / outputs in host-mapped memory, the call spins on "
+                                                       "the kernel's completion counter; what is left is the kernel itself (one wave "
+                                                       "alone on a CU; jrl-walkgen_amd/bin/latency_b1 has the split)"},
             "reference": "TestHerdt2010EmergencyStopTestFGPI.datref (the reference's golden file, printed to 1e-7), "
                          "every MPC tick on the GPU, B = 1"}
 

@@ -200,6 +200,19 @@ struct DenseProb {
 #define Rp(i, j) q.R[(j) * ((j) + 1) / 2 + (i)]
 #define Rf(i, j) q.Rf[(j) * ((j) + 1) / 2 + (i)]        // the same packing, in the factorisation's array
 
+// ---- attribution builds (never shipped): -DWG_REPEAT_PHASE=k executes the idempotent phase k of every active-set iteration
+// TWICE (same results: each of these phases only reads the solver state it does not write); the difference of the hardware
+// counters against the plain build is that phase's share (tools/phase_attribution.sh).  The memory clobber makes the second
+// pass reload its operands instead of being folded into the first.
+#ifdef WG_REPEAT_PHASE
+#define WG_REP(id) for (int wg_rep_ = 0; wg_rep_ < (((WG_REPEAT_PHASE) == (id)) ? 2 : 1); ++wg_rep_, ({ asm volatile("" ::: "memory"); }))
+// a phase whose results live in registers only would lose its first pass to dead-code elimination: the sink "uses" them
+#define WG_SINK(x) asm volatile("" ::"v"(x))
+#else
+#define WG_REP(id)
+#define WG_SINK(x) do {} while (0)
+#endif
+
 // ---- optional in-kernel phase timers (diagnostic build only: -DWG_PROFILE) ----
 #ifdef WG_PROFILE
 __device__ unsigned long long g_prof[32];
@@ -567,6 +580,7 @@ __device__ __forceinline__ void sweep_flat(const QlView &q, double *s, int nu, i
   // (untouched until phase 2), norm = chain[c-1] when q != 0 (then cur = norm), skipped when q == 0 (then cur = p).
   // givens_norm runs unguarded on q == 0: its result (|p|, or NaN for 0/0) is discarded by the select.
   double *chain = q.sc2;                                    // nu <= n entries
+  WG_REP(3)
   if (sweep_range_ok(s, nact, nu, lane)) {
     // the usual case: the shorter norm; unrolled by two so that handing the prefetched operand on is a renaming
     double cur = s[nu - 1];
@@ -1324,7 +1338,7 @@ __device__ __forceinline__ QlResult ql_solve(const QlView &q, P &prob, double vs
         WG_WSYNC();
       }
       PT(7);
-      { double sm = uni(xmag_sum(q, prob, vfact, lane)); xmag = maxd(xmag, sm); }
+      { double sm = 0.0; WG_REP(6) { sm = uni(xmag_sum(q, prob, vfact, lane)); WG_SINK(sm); } xmag = maxd(xmag, sm); }
       PT(8);
       if (iflag == itref) { st = ST_RESID; continue; }      // :1226
       // first inequality with a negative multiplier, :1233-1249
@@ -1345,6 +1359,8 @@ __device__ __forceinline__ QlResult ql_solve(const QlView &q, P &prob, double vs
       // ---- most violated normalised constraint, :1255-1331 ----
       double bestv = 0.0, bestres = 0.0;
       int bidx = -1;
+      WG_REP(1) {
+      bestv = 0.0; bestres = 0.0; bidx = -1;
       if constexpr (P::kCompact) {
         constexpr int NH = sizeof(prob.ax) / sizeof(double);
         double xs[2 * NH];
@@ -1510,6 +1526,8 @@ __device__ __forceinline__ QlResult ql_solve(const QlView &q, P &prob, double vs
           bidx = __builtin_amdgcn_readlane(bidx, src);
         }
       }
+      WG_SINK(bestv); WG_SINK(bestres); WG_SINK(bidx);
+      }   // WG_REP(1)
       double cvmax = bestv;
       if (bidx >= 0) { res = bestres; knext = bidx; }
       PT(9);
@@ -1555,6 +1573,7 @@ __device__ __forceinline__ QlResult ql_solve(const QlView &q, P &prob, double vs
 
       // ---- new normal and its products with the columns of Z, :1422-1470 ----
       s = q.R + nact * (nact + 1) / 2;
+      WG_REP(2)
       if (knext <= m) {
         for (int i = lane; i < n; i += 64) q.ww[i] = Am(knext - 1, i);
         WG_WSYNC();
@@ -1582,6 +1601,7 @@ __device__ __forceinline__ QlResult ql_solve(const QlView &q, P &prob, double vs
         if (nact == 0) route = 0;                           // :1488
         else {                                              // :1491-1532
           double suma = 0.0, sumb = 0.0, sumc = 0.0;
+          WG_REP(5) {
           if constexpr (P::kNM > 0) {
             constexpr int NM = P::kNM;
             if (lane < NM) {
@@ -1626,6 +1646,8 @@ __device__ __forceinline__ QlResult ql_solve(const QlView &q, P &prob, double vs
             suma = rl(acc, 0); sumb = rl(acc, 1); sumc = rl(acc, 2);
             WG_WSYNC();
           }
+          WG_SINK(suma); WG_SINK(sumb); WG_SINK(sumc);
+          }   // WG_REP(5)
 #ifdef WG_DEBUG_ROUTE
           if (lane == 0 && blockIdx.x == 2 && iterc == 3) { for (int i = 0; i < n; i++) printf("GPUW %d %.17g %.17g\n", i, q.ww[i], Zm(i, nact)); }
           if (lane == 0) printf("GPU blk %d it %d knext %d nact %d suma %.17g sumb %.17g sumc %.17g wa %.17g\n", (int)blockIdx.x, iterc, knext, nact, suma, sumb, sumc, knext <= m ? q.wa[knext - 1] : 0.0);
@@ -1666,9 +1688,9 @@ __device__ __forceinline__ QlResult ql_solve(const QlView &q, P &prob, double vs
           kdrop = -1;
           if (nact > 0) {
             PT(14);
-            WG_BACKSUB(q, s, nact, lane);
+            WG_REP(4) WG_BACKSUB(q, s, nact, lane);
             PT(15);
-            kdrop = pick_drop(q, nact, res, ratio, lane);
+            WG_REP(7) { kdrop = pick_drop(q, nact, res, ratio, lane); WG_SINK(kdrop); WG_SINK(ratio); }
             PT(16);
             if (kdrop >= 0) {                               // :1734-1743
               double temp = 1.0 - ratio / parinc;
@@ -1722,7 +1744,8 @@ __device__ __forceinline__ QlResult ql_solve(const QlView &q, P &prob, double vs
       WG_WSYNC();
       if (q.nact_cap > 0 && nact > q.nact_cap) { info = kQlCapHit; st = ST_FINISH; continue; }   // R's LDS part is full
       PT(18);
-      double sm = uni(xmag_sum(q, prob, vfact, lane));            // :1776-1786
+      double sm = 0.0;
+      WG_REP(6) { sm = uni(xmag_sum(q, prob, vfact, lane)); WG_SINK(sm); }   // :1776-1786
       xmag = maxd(xmag, sm);
       PT(19);
       if (WG_UBOOL(sm < xmagr * xmag)) st = ST_RESET;

@@ -1,0 +1,54 @@
+#!/usr/bin/env python3
+"""Per-phase shares of the N = 16 tick kernel, measured: reads gpurun_out/attr/ (tools/phase_attribution.sh) and prints, per
+gait-tick, what executing each idempotent phase of the active-set iteration ONCE MORE adds to the hardware counters -- i.e.
+that phase's own VALU / SALU / LDS instruction counts, its parked cycles (SQ_WAIT_ANY: s_waitcnt) and issue stalls
+(SQ_WAIT_INST_ANY), its wave cycles and its share of the tick time.     python tools/phase_attribution.py [> profiles/...]"""
+import collections, csv, glob, os, re, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+D = os.path.join(ROOT, "gpurun_out", "attr")
+B, TICKS = 4096, 10 + 3 * 100                      # probe_elem.py: one 10-tick warm-up launch + PR = 3 launches of PT = 100 ticks
+NAMES = {0: "(plain: nothing repeated)", 1: "violation scan, qld.cpp:1255-1331", 2: "Z^T a of the new normal, :1421-1470",
+         3: "sweep: chain of rotation norms, :1992-2030 (phase 1)", 4: "back substitution of the step, :1824-1851",
+         5: "linear-dependence sums, :1491-1532", 6: "xmag ordered sums (both sites), :2039-2058", 7: "pick_drop, :1861-1889"}
+CNT = ["SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_INSTS_VMEM", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_VALU"]
+
+
+def load(k):
+    tot = collections.Counter()
+    files = sorted(glob.glob(os.path.join(D, "pmc_%d" % k, "**", "*_counter_collection.csv"), recursive=True), key=os.path.getmtime)
+    for f in files[-1:]:                            # gpurun merges runs: the newest pass only
+        for r in csv.DictReader(open(f)):
+            if "wg_mpc_run_xcd_kernel" in r["Kernel_Name"]:
+                tot[r["Counter_Name"]] += float(r["Counter_Value"])
+    txt = open(os.path.join(D, "time_%d.txt" % k)).read()
+    m = re.search(r"-> (\d+) ticks/s .*state checksum (\w+)", txt)
+    return {c: tot[c] / (B * TICKS) for c in CNT}, float(m.group(1)), m.group(2)
+
+
+base, rate0, sum0 = load(0)
+print("# N = 16 tick, B = 4096, multi-tick launches (wg_mpc_run_xcd_kernel<16>): per gait-tick, measured by rocprofv3 --pmc.")
+print("# Row k = counters of the build that runs phase k twice MINUS the plain build = what one execution of that phase costs per")
+print("# gait-tick (%.1f active-set iterations on average).  Same state checksum in every build (the repeated phases are idempotent)." % 22.5)
+print("# plain build: %.0f ticks/s; VALU %.0f, SALU %.0f, LDS %.0f, VMEM %.0f instructions, %.0f wave cycles per gait-tick of which parked"
+      " (s_waitcnt) %.0f = %.1f %%, issue-stalled %.0f = %.1f %%" % (rate0, base["SQ_INSTS_VALU"], base["SQ_INSTS_SALU"], base["SQ_INSTS_LDS"],
+                                                                   base["SQ_INSTS_VMEM"], base["SQ_WAVE_CYCLES"], base["SQ_WAIT_ANY"],
+                                                                   100 * base["SQ_WAIT_ANY"] / base["SQ_WAVE_CYCLES"], base["SQ_WAIT_INST_ANY"],
+                                                                   100 * base["SQ_WAIT_INST_ANY"] / base["SQ_WAVE_CYCLES"]))
+print("%-58s %8s %8s %7s %10s %9s %9s %8s %7s" % ("phase", "VALU", "SALU", "LDS", "wave cyc", "parked", "stalled", "time %", "SALU/VALU"))
+acc = collections.Counter()
+for k in range(1, 8):
+    c, rate, chk = load(k)
+    assert chk == sum0, (k, chk, sum0)
+    d = {n: c[n] - base[n] for n in CNT}
+    share = 100 * (rate0 / rate - 1.0)
+    for n in CNT:
+        acc[n] += d[n]
+    acc["share"] += share
+    print("%-58s %8.0f %8.0f %7.0f %10.0f %9.0f %9.0f %7.1f%% %7.2f" % (NAMES[k][:58], d["SQ_INSTS_VALU"], d["SQ_INSTS_SALU"], d["SQ_INSTS_LDS"],
+                                                                      d["SQ_WAVE_CYCLES"], d["SQ_WAIT_ANY"], d["SQ_WAIT_INST_ANY"], share,
+                                                                      d["SQ_INSTS_SALU"] / max(1.0, d["SQ_INSTS_VALU"])))
+rest = {n: base[n] - acc[n] for n in CNT}
+print("%-58s %8.0f %8.0f %7.0f %10.0f %9.0f %9.0f %7.1f%% %7.2f" % ("everything else (sweep phases 2-3, drops, x / lambda updates,", rest["SQ_INSTS_VALU"], rest["SQ_INSTS_SALU"],
+                                                                  rest["SQ_INSTS_LDS"], rest["SQ_WAVE_CYCLES"], rest["SQ_WAIT_ANY"], rest["SQ_WAIT_INST_ANY"],
+                                                                  100 - acc["share"], rest["SQ_INSTS_SALU"] / max(1.0, rest["SQ_INSTS_VALU"])))
+print("%-58s" % "   factor(), residual refresh, the tick around the solve)")
