@@ -182,15 +182,17 @@ int guard_mark(wg_ctx *ctx, hipStream_t st) {
 // Dense batched QP kernel: one wavefront (= one workgroup) per QP.
 // Replaces ql0001_ (qld.hh:27-31) for B problems at once.
 // ---------------------------------------------------------------------------
-template <bool kALds>                                      // where A lives is known at compile time: ds_ or global_ accesses,
+template <bool kALds, bool kGLds>                          // where A / G live is known at compile time: ds_ or global_ accesses,
 // Left to itself the compiler takes 256 VGPRs plus 3 AGPRs -- 259 registers, one wave per SIMD, four QPs per CU where the LDS
 // would admit five at n = 36, m = 75.  Forced to two waves per SIMD (-DWG_QLD_WPE=2: 256 registers, 2-3 spilled, 12-16 B of
 // scratch) it measured 5 % SLOWER on the Herdt workload's real QPs (1.73 against 1.82 M QPs/s, B = 4096): the fifth QP per CU
 // does not pay for the tighter allocation.  The default stays.
+// With G read in place as well (21.7 KB of LDS at n = 36, m = 75: seven QPs per CU) the residency is worth the 256-register
+// build: that instantiation is compiled for two waves per SIMD.
 #ifdef WG_QLD_WPE
 #define WG_QLD_ATTR __attribute__((amdgpu_waves_per_eu(WG_QLD_WPE, WG_QLD_WPE)))
 #else
-#define WG_QLD_ATTR
+#define WG_QLD_ATTR __attribute__((amdgpu_waves_per_eu(kGLds ? 1 : 2, kGLds ? 8 : 2)))
 #endif
 __global__ __launch_bounds__(64) WG_QLD_ATTR void wg_ql_dense_kernel(   // never flat_ (those also count on lgkmcnt and stall the LDS waits)
     int B, int nmax, int mmax, const int *__restrict__ n_arr, const int *__restrict__ m_arr,
@@ -206,15 +208,21 @@ __global__ __launch_bounds__(64) WG_QLD_ATTR void wg_ql_dense_kernel(   // never
     const int n = n_arr ? n_arr[qp] : nmax;
     const int m = m_arr ? m_arr[qp] : mmax - 1;
     const int me = me_arr ? me_arr[qp] : 0;
-    wg::QlDims D(n, m, m, true, kALds);
+    wg::QlDims D(n, m, m, true, kALds, 0, true, true, true, true, 0, kGLds);
     wg::QlView q;
     q.carve(wg_lds, D, me);
 
     // ---- stage the problem into LDS (coalesced 8-byte lanes) ----
     const double *Cg = C + (size_t)qp * nmax * nmax;
     const double *Ag = A + (size_t)qp * mmax * nmax;
-    for (int j = 0; j < n; ++j)
-      for (int i = lane; i < n; i += 64) q.G[i + j * q.ldg] = Cg[i + (size_t)j * nmax];
+    if constexpr (kGLds) {
+      for (int j = 0; j < n; ++j)
+        for (int i = lane; i < n; i += 64) q.G[i + j * q.ldg] = Cg[i + (size_t)j * nmax];
+    } else {                                   // G is cold after the factorisation: in place (L2), its diagonal in LDS
+      q.G = const_cast<double *>(Cg);
+      q.ldg = nmax;
+      for (int i = lane; i < n; i += 64) q.Gdiag[i] = Cg[i + (size_t)i * nmax];
+    }
     if constexpr (kALds) {
       for (int i = 0; i < n; ++i)
         for (int k = lane; k < m; k += 64) q.A[k + i * q.lda] = Ag[k + (size_t)i * mmax];
@@ -230,11 +238,11 @@ __global__ __launch_bounds__(64) WG_QLD_ATTR void wg_ql_dense_kernel(   // never
     for (int k = lane; k < m; k += 64) q.b[k] = -bvec[(size_t)qp * mmax + k];   // qld.cpp:469-475
     WG_WSYNC();
     // qld.cpp:442-444: c(nmax,nmax) == 0 -> eps (inside the n x n block only if nmax == n)
-    if (nmax == n && lane == 0 && fabs(q.G[(n - 1) + (n - 1) * q.ldg]) == 0.0) q.G[(n - 1) + (n - 1) * q.ldg] = eps;
+    wg::DenseProbT<kGLds> prob;
+    if (nmax == n && lane == 0 && fabs(prob.Gd(q, n - 1)) == 0.0) prob.setGd(q, n - 1, eps);
     WG_WSYNC();
 
     int *hq = hist ? hist + (size_t)qp * hist_cap : nullptr;
-    wg::DenseProb prob;
     wg::QlResult r = wg::ql_solve(q, prob, eps, hq, hist_cap);
 
     // ---- results ----
@@ -339,24 +347,37 @@ int wg_qp_solve_batch_dev_ctx(wg_ctx_t *ctx, int B, int nmax, int mmax, const in
   // A (m x n, the largest operand) is only ever read: staged in LDS it caps the residency (n = 36, m = 75: 54 KB, three QPs
   // per CU), read in place it comes from L2 and the CU holds five -- measured 274 k vs 223 k QPs/s on the probe's QPs.  It
   // goes to LDS only while that does not cost a resident QP (8 per CU = two waves per SIMD is the useful maximum).
-  int a_in_lds = 1;
-  const size_t lds_noa = wg::QlDims(nmax, m_cap, m_cap, true, false).bytes();
-  auto per_cu = [](size_t l) { const size_t k = (160 * 1024) / (l ? l : 1); return k > 8 ? (size_t)8 : k; };
-  if (per_cu(lds_noa) > per_cu(lds)) a_in_lds = 0;
+  int a_in_lds = 1, g_in_lds = 1;
+  auto lds_for = [&](bool a, bool g) { return wg::QlDims(nmax, m_cap, m_cap, true, a, 0, true, true, true, true, 0, g).bytes(); };
+  const size_t lds_noa = lds_for(false, true), lds_noag = lds_for(false, false);
+  // residency each placement reaches: LDS, and the registers -- the kernels with G in LDS take 259 registers (one wave per
+  // SIMD, four QPs per CU), the one with G in place is compiled for two waves per SIMD
+  auto per_cu = [](size_t l, size_t reg_cap) { const size_t k = (160 * 1024) / (l ? l : 1); return k > reg_cap ? reg_cap : k; };
+  if (per_cu(lds_noa, 4) > per_cu(lds, 4)) a_in_lds = 0;
+  // G follows A out of the LDS when that buys at least two more resident QPs (G is cold after the factorisation; measured on the
+  // Herdt workload's real QPs, n = 36, m = 75: 7 per CU against 4)
+  if (!a_in_lds && per_cu(lds_noag, 8) >= per_cu(lds_noa, 4) + 2) g_in_lds = 0;
   if (const char *e = getenv("WG_QL_A_IN_LDS")) a_in_lds = atoi(e) != 0;   // tests force either path
-  if (lds > 160 * 1024 || !a_in_lds) { a_in_lds = 0; lds = lds_noa; }
+  if (const char *e = getenv("WG_QL_G_IN_LDS")) g_in_lds = atoi(e) != 0;
+  if (lds > 160 * 1024) a_in_lds = 0;
+  if (a_in_lds) g_in_lds = 1;                                              // G leaves only after A
+  if (!a_in_lds && lds_noa > 160 * 1024) g_in_lds = 0;
+  lds = lds_for(a_in_lds, g_in_lds);
   if (lds > 160 * 1024) return fail(WG_ERR_TOO_LARGE, "QP (n=%d, m=%d) needs %zu B of LDS > 160 KiB", nmax, m_cap, lds);
-  if (lds > 64 * 1024)
-    HIP_TRY(hipFuncSetAttribute(a_in_lds ? reinterpret_cast<const void *>(wg_ql_dense_kernel<true>)
-                                         : reinterpret_cast<const void *>(wg_ql_dense_kernel<false>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  const void *kfn = a_in_lds ? reinterpret_cast<const void *>(wg_ql_dense_kernel<true, true>)
+                             : (g_in_lds ? reinterpret_cast<const void *>(wg_ql_dense_kernel<false, true>)
+                                         : reinterpret_cast<const void *>(wg_ql_dense_kernel<false, false>));
+  if (lds > 64 * 1024) HIP_TRY(hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   const int grid = B;
   hipStream_t st = reinterpret_cast<hipStream_t>(hip_stream);
   if (a_in_lds)
-    hipLaunchKernelGGL(wg_ql_dense_kernel<true>, dim3(grid), dim3(64), lds, st, B, nmax, mmax, n, m, me, C, d, A, b,
+    hipLaunchKernelGGL((wg_ql_dense_kernel<true, true>), dim3(grid), dim3(64), lds, st, B, nmax, mmax, n, m, me, C, d, A, b,
+                       xl, xu, eps, x, u, ifail, n_iter, iact, nact, hist, hist_cap, hist_len);
+  else if (g_in_lds)
+    hipLaunchKernelGGL((wg_ql_dense_kernel<false, true>), dim3(grid), dim3(64), lds, st, B, nmax, mmax, n, m, me, C, d, A, b,
                        xl, xu, eps, x, u, ifail, n_iter, iact, nact, hist, hist_cap, hist_len);
   else
-    hipLaunchKernelGGL(wg_ql_dense_kernel<false>, dim3(grid), dim3(64), lds, st, B, nmax, mmax, n, m, me, C, d, A, b,
+    hipLaunchKernelGGL((wg_ql_dense_kernel<false, false>), dim3(grid), dim3(64), lds, st, B, nmax, mmax, n, m, me, C, d, A, b,
                        xl, xu, eps, x, u, ifail, n_iter, iact, nact, hist, hist_cap, hist_len);
   HIP_TRY(hipGetLastError());
   return WG_OK;

@@ -106,15 +106,19 @@ struct QlDims {
                  // iterate are read lane-parallel, d once per iteration, the others a few times per solve)
   int r_cols;    // > 0: the LDS holds only the first r_cols columns of R plus one working column (QlView::nact_cap): a solve
                  // whose active set would grow past r_cols stops with kQlCapHit and is repeated with R in global memory
+  bool g_lds;    // dense only: G staged in LDS (false: read in place from global memory, only its diagonal -- the one part ql0002
+                 // writes, :814-854 -- is kept in LDS.  G is cold once Z = R^-1 exists: the residual refresh and the
+                 // objective-increase test read it a few times per solve)
   __host__ __device__ QlDims(int n_, int m_, int mmax_, bool dense_ = true, bool a_lds_ = true, int nsc_ = 0,
-                             bool bounds_ = true, bool z_lds_ = true, bool wab_lds_ = true, bool cold_lds_ = true, int r_cols_ = 0)
+                             bool bounds_ = true, bool z_lds_ = true, bool wab_lds_ = true, bool cold_lds_ = true, int r_cols_ = 0,
+                             bool g_lds_ = true)
       : n(n_), m(m_), mmax(mmax_), ldg(n_ | 1), ldz(n_ | 1), lda(mmax_ | 1), dense(dense_), a_lds(a_lds_),
         nsc(nsc_ > n_ ? nsc_ : n_), bounds(bounds_), z_lds(z_lds_), wab_lds(wab_lds_), cold_lds(cold_lds_),
-        r_cols(r_cols_ > 0 && r_cols_ < n_ ? r_cols_ : 0) {}
+        r_cols(r_cols_ > 0 && r_cols_ < n_ ? r_cols_ : 0), g_lds(g_lds_) {}
   __host__ __device__ int r_tail() const { return r_cols ? r_cols * (r_cols + 1) / 2 : n * (n + 1) / 2; }
   __host__ __device__ int r_len() const { return r_tail() + n; }
   __host__ __device__ int n_doubles() const {
-    return (dense ? n * ldg + (a_lds ? n * lda : 0) : 0) + (z_lds ? n * ldz : 0) + r_len()   // [G, A,] [Z,] R
+    return (dense ? (g_lds ? n * ldg : n) + (a_lds ? n * lda : 0) : 0) + (z_lds ? n * ldz : 0) + r_len()   // [G | diag(G), A,] [Z,] R
            + ((bounds ? 8 : 6) - (cold_lds ? 0 : 3)) * n   // x [d] ww [wd wx] lam [xl xu]
            + (wab_lds ? (m + n) + m : 0)            // wa, b (inner)
            + 4 * nsc + 8;                           // scratch + scalar slots
@@ -130,6 +134,7 @@ struct QlView {
   int r_tail = 0;                                          // offset of the n scratch entries behind R's columns
   int nact_cap = 0;                                        // > 0: stop (kQlCapHit) when the active set would exceed it
   double *G, *Z, *R, *A;
+  double *Gdiag = nullptr;                                 // dense view with G read in place: the diagonal's LDS copy
   double *Rf;                                              // where the Cholesky factor of G is formed on the way to Z = R^-1 (dead
                                                            // afterwards): R itself, or a full-size array when R is capped
   double *x, *d, *ww, *wd, *wx, *lam, *xl, *xu, *wa, *b;
@@ -145,7 +150,10 @@ struct QlView {
     r_tail = D.r_tail(); nact_cap = D.r_cols;
     double *p = base;
     G = nullptr; A = nullptr;
-    if (D.dense) { G = p; p += n * ldg; }
+    if (D.dense) {
+      if (D.g_lds) { G = p; p += n * ldg; }
+      else { Gdiag = p; p += n; }                          // the caller points G (and ldg) at the problem's own array
+    }
     Z = nullptr;
     if (D.z_lds) { Z = p; p += n * ldz; }
     R = p; p += D.r_len(); Rf = R;
@@ -185,7 +193,8 @@ struct QlView {
 #define Am(k, i) prob.A(q, (k), (i))
 
 struct QlView;
-struct DenseProb {
+template <bool kGLds>                       // where G lives is known at compile time (ds_ or global_ accesses, never flat_)
+struct DenseProbT {
   static constexpr bool kCompact = false;
   static constexpr bool kHasFactor = false;    // no structure to exploit: ql0002's own Cholesky and inverse
   static constexpr bool kRowOps = false;   // no structured row products: rows are read element by element
@@ -197,6 +206,7 @@ struct DenseProb {
   __device__ __forceinline__ double xl(const QlView &q, int i) const;
   __device__ __forceinline__ double xu(const QlView &q, int i) const;
 };
+typedef DenseProbT<true> DenseProb;
 #define Rp(i, j) q.R[(j) * ((j) + 1) / 2 + (i)]
 #define Rf(i, j) q.Rf[(j) * ((j) + 1) / 2 + (i)]        // the same packing, in the factorisation's array
 
@@ -238,12 +248,22 @@ struct QlResult {
   int ifail, n_iter, nact, hist_len;
 };
 
-__device__ __forceinline__ double DenseProb::G(const QlView &q, int i, int j) const { return q.G[i + j * q.ldg]; }
-__device__ __forceinline__ double DenseProb::A(const QlView &q, int k, int i) const { return q.A[k + i * q.lda]; }
-__device__ __forceinline__ double DenseProb::Gd(const QlView &q, int i) const { return q.G[i + i * q.ldg]; }
-__device__ __forceinline__ void DenseProb::setGd(const QlView &q, int i, double v) const { q.G[i + i * q.ldg] = v; }
-__device__ __forceinline__ double DenseProb::xl(const QlView &q, int i) const { return q.xl[i]; }
-__device__ __forceinline__ double DenseProb::xu(const QlView &q, int i) const { return q.xu[i]; }
+template <bool kGLds> __device__ __forceinline__ double DenseProbT<kGLds>::G(const QlView &q, int i, int j) const {
+  if constexpr (kGLds) return q.G[i + j * q.ldg];
+  else {
+    const double g = q.G[i + j * q.ldg], dg = q.Gdiag[i];  // both requested: the select costs no round trip
+    return i == j ? dg : g;
+  }
+}
+template <bool kGLds> __device__ __forceinline__ double DenseProbT<kGLds>::A(const QlView &q, int k, int i) const { return q.A[k + i * q.lda]; }
+template <bool kGLds> __device__ __forceinline__ double DenseProbT<kGLds>::Gd(const QlView &q, int i) const {
+  if constexpr (kGLds) return q.G[i + i * q.ldg]; else return q.Gdiag[i];
+}
+template <bool kGLds> __device__ __forceinline__ void DenseProbT<kGLds>::setGd(const QlView &q, int i, double v) const {
+  if constexpr (kGLds) q.G[i + i * q.ldg] = v; else q.Gdiag[i] = v;
+}
+template <bool kGLds> __device__ __forceinline__ double DenseProbT<kGLds>::xl(const QlView &q, int i) const { return q.xl[i]; }
+template <bool kGLds> __device__ __forceinline__ double DenseProbT<kGLds>::xu(const QlView &q, int i) const { return q.xu[i]; }
 
 // ---- wave reductions on the DPP data path (gfx9 row shifts / row broadcasts: one VALU move per 32-bit half and step, no
 // LDS crossbar, no exec-mask branching).  max / min are idempotent, so lanes without a partner just keep their own value

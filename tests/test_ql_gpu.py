@@ -74,18 +74,28 @@ def test_herdt_shape_uniform_batch():
     assert not bad, bad[:5]
 
 
-@pytest.mark.parametrize("a_in_lds", ["0", "1"])
-def test_constraint_matrix_in_lds_or_read_in_place(a_in_lds, monkeypatch):
-    """A is staged in LDS only while that does not cost a resident QP (Herdt-sized QPs read it in place, from L2); both
-    placements are the same arithmetic and are held to the oracle"""
+@pytest.mark.parametrize("a_in_lds,g_in_lds", [("1", "1"), ("0", "1"), ("0", "0")])
+def test_matrices_in_lds_or_read_in_place(a_in_lds, g_in_lds, monkeypatch):
+    """A is staged in LDS only while that does not cost a resident QP (Herdt-sized QPs read it in place, from L2), and G -- cold
+    once Z = R^-1 exists, its diagonal kept in LDS for ql0002's shift -- follows it out when that buys two more resident QPs;
+    every placement is the same arithmetic and is held to the oracle, on Herdt-shaped QPs and on small dense ones, on QPs whose
+    Hessian needs the diagonal shift (singular) and on the c(nmax, nmax) == 0 patch"""
     monkeypatch.setenv("WG_QL_A_IN_LDS", a_in_lds)
+    monkeypatch.setenv("WG_QL_G_IN_LDS", g_in_lds)
     wg = _wg()
     qps = [qpgen.herdt_like(np.random.default_rng(4100 + s), 16, 2) for s in range(64)] + \
           [qpgen.random_pd(np.random.default_rng(4200 + s), 12, 9) for s in range(32)]
     pk = wg.pack_qps(qps)
     res = wg.qp_solve_batch(pk, hist_cap=512)
-    bad = _compare(qps, res, "a_in_lds=" + a_in_lds, pk)
+    bad = _compare(qps, res, "a_in_lds=%s g_in_lds=%s" % (a_in_lds, g_in_lds), pk)
     assert not bad, bad[:5]
+    for family in sorted(qpgen.FAMILIES):
+        gen = qpgen.FAMILIES[family]
+        qps = [gen(np.random.default_rng(9000 + 17 * s)) for s in range(24)]
+        pk = wg.pack_qps(qps)
+        res = wg.qp_solve_batch(pk, hist_cap=512)
+        bad = _compare(qps, res, family, pk)
+        assert not bad, (family, bad[:5])
 
 
 @pytest.mark.parametrize("log2_scale", [0, 380, 450, -380, -450])

@@ -71,7 +71,7 @@ def audit_kernel(lines):
     i = 0
     while i < len(lines):
         s = lines[i].strip()
-        m = re.match(r"^(\.LBB\d+_\d+):(.*)$", s)
+        m = re.match(r"^(\.LBB\d+_\d+|; %bb\.\d+):(.*)$", s)          # a labelled block, or a fall-through block (comment only)
         if m:
             cmt = m.group(2)
             j = i + 1
