@@ -231,7 +231,11 @@ class ZMPVelocityReferencedQP : public ZMPRefTrajectoryGeneration {
   ZMPVelocityReferencedQP &operator=(const ZMPVelocityReferencedQP &);
   wg_ctx_t *Ctx_;    // this object's device-side model tables and workspaces (the reference keeps them per object too)
   wg_model_t Model_;
-  wg_gait_state_t State_;
+  // the gait's flat state and the tick's outputs live in host-mapped memory (wg_host_alloc): OnLine ticks through
+  // wg_mpc_tick_pinned -- no staging copies, no device synchronisation ("one robot")
+  void *Pinned_;
+  wg_gait_state_t &State_;
+  wg_tick_out_t *Out_;
   solution_t Solution_;
   bool Running_, Legacy_;
   int NbStepsSSDS_;

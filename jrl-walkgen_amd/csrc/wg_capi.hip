@@ -1002,10 +1002,11 @@ int wg_mpc_tick_batch_dev_ctx(wg_ctx_t *ctx, int B, wg_gait_state_t *states, wg_
 /* ---- one robot (BASELINE configs[1]): state and outputs in host-mapped memory, no copies, no device synchronisation ---- */
 int wg_host_alloc(void **out, size_t bytes) {
   if (!out || !bytes) return fail(WG_ERR_BAD_ARG, "wg_host_alloc: null pointer or zero size");
-  wg_ctx *c = nullptr;
-  if (int rc = default_ctx(&c)) return rc;               // the allocation needs a device to be mapped to
-  if (int rc = use_ctx(c)) return rc;
-  HIP_TRY(hipHostMalloc(out, bytes, hipHostMallocMapped));
+  int count = 0;
+  hipError_t e = hipGetDeviceCount(&count);
+  if (e != hipSuccess || count <= 0)
+    return fail(WG_ERR_NO_DEVICE, "no HIP device available (%s); this library has no CPU path", e == hipSuccess ? "count = 0" : hipGetErrorString(e));
+  HIP_TRY(hipHostMalloc(out, bytes, hipHostMallocMapped | hipHostMallocPortable));   // visible to every device's contexts
   memset(*out, 0, bytes);
   return WG_OK;
 }

@@ -156,9 +156,15 @@ static wg_ctx_t *NewContext() {
 }
 
 // ZMPVelocityReferencedQP.cpp:56-135
+static void *NewPinnedBlock() {
+  void *p = 0;
+  if (wg_host_alloc(&p, sizeof(wg_gait_state_t) + sizeof(wg_tick_out_t) + 64) != WG_OK) wg_throw("wg_host_alloc");
+  return p;
+}
 ZMPVelocityReferencedQP::ZMPVelocityReferencedQP(SimplePluginManager *SPM, string, const HumanoidModel *aHS)
-    : ZMPRefTrajectoryGeneration(SPM) {
-  if (aHS == 0) throw runtime_error("ZMPVelocityReferencedQP: a HumanoidModel is required");
+    : ZMPRefTrajectoryGeneration(SPM), Pinned_(NewPinnedBlock()), State_(*static_cast<wg_gait_state_t *>(Pinned_)),
+      Out_(reinterpret_cast<wg_tick_out_t *>(static_cast<wg_gait_state_t *>(Pinned_) + 1)) {
+  if (aHS == 0) { wg_host_free(Pinned_); throw runtime_error("ZMPVelocityReferencedQP: a HumanoidModel is required"); }
   Running_ = false;
   Legacy_ = false;
   NbStepsSSDS_ = 2;                           // :79
@@ -177,7 +183,7 @@ ZMPVelocityReferencedQP::ZMPVelocityReferencedQP(SimplePluginManager *SPM, strin
   }
   memset(&State_, 0, sizeof State_);
   Ctx_ = NewContext();
-  if (wg_mpc_configure_ctx(Ctx_, &Model_) != WG_OK) { wg_ctx_destroy(Ctx_); Ctx_ = 0; wg_throw("wg_mpc_configure"); }
+  if (wg_mpc_configure_ctx(Ctx_, &Model_) != WG_OK) { wg_ctx_destroy(Ctx_); Ctx_ = 0; wg_host_free(Pinned_); wg_throw("wg_mpc_configure"); }
   // ":setfeetconstraint" is RelativeFeetInequalities' command in the reference (relative-feet-inequalities.cpp:68-79: of its
   // three names only this one is registered); that object's state is part of the device model here
   const unsigned int NbMethods = 4;
@@ -185,7 +191,7 @@ ZMPVelocityReferencedQP::ZMPVelocityReferencedQP(SimplePluginManager *SPM, strin
   for (unsigned int i = 0; i < NbMethods; i++)
     if (!RegisterMethod(aMethodName[i])) cerr << "Unable to register " << aMethodName[i] << endl;
 }
-ZMPVelocityReferencedQP::~ZMPVelocityReferencedQP() { wg_ctx_destroy(Ctx_); }
+ZMPVelocityReferencedQP::~ZMPVelocityReferencedQP() { wg_ctx_destroy(Ctx_); wg_host_free(Pinned_); }
 
 void ZMPVelocityReferencedQP::setCoMPerturbationForce(istringstream &strm) {   // :162-173 (stored; no reader on the path)
   strm >> PerturbationAcceleration_[2];
@@ -302,11 +308,11 @@ void ZMPVelocityReferencedQP::OnLine(double time, deque<ZMPPosition> &FinalZMPTr
   if (State_.ending_phase && time >= State_.time_to_stop) { m_OnLineMode = false; State_.online = 0; }
   if (time + 0.00001 > State_.upper_time_limit) {
     State_.clock = time;
-    wg_tick_out_t out;
+    const wg_tick_out_t &out = *Out_;
     const char *dump_failed = getenv("WG_DUMP_FAILED_QP"), *dump_every = getenv("WG_DUMP_EVERY_QP");
     wg_gait_state_t before;
     if (dump_failed || dump_every) before = State_;
-    if (wg_mpc_tick_batch_ctx(Ctx_, 1, &State_, &out, 0, 0, 0, 0, 0) != WG_OK) wg_throw("wg_mpc_tick_batch");
+    if (wg_mpc_tick_pinned_ctx(Ctx_, &State_, Out_, 0, 0) != WG_OK) wg_throw("wg_mpc_tick_pinned");
     Solution_.NbVariables = out.n; Solution_.NbConstraints = out.m; Solution_.Fail = out.ifail;
     Solution_.NbIterations = out.n_iter; Solution_.NbActiveConstraints = out.nact;
     Solution_.JerkX = out.jerk_x; Solution_.JerkY = out.jerk_y;
