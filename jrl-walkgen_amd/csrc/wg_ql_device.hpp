@@ -32,6 +32,14 @@ namespace wg {
 #ifndef WG_UNROLL_N
 #define WG_UNROLL_N 4
 #endif
+// prefetch group sizes of the wide (64 < n <= 128) forms: entries requested together ahead of the add chains / rotations.
+// Eight is what 256 registers carry; experiment builds at tighter register budgets lower them (-DWG_ZG=4 -DWG_SWC=4).
+#ifndef WG_ZG
+#define WG_ZG 8
+#endif
+#ifndef WG_SWC
+#define WG_SWC 8
+#endif
 #define WG_PRAGMA(x) _Pragma(#x)
 #define WG_UNROLL_(n) WG_PRAGMA(unroll n)
 #define WG_UNROLL WG_UNROLL_(WG_UNROLL_N)
@@ -400,12 +408,12 @@ __device__ __forceinline__ void zt_times_ww(const QlView &q, double *s, int lane
     const double *z0 = q.Z + (size_t)i0 * q.ldz, *z1 = q.Z + (size_t)i1 * q.ldz;
     double a0 = 0.0, a1 = 0.0;
     int j = 0;
-    for (; j + 8 <= n; j += 8) {
-      double u0[8], u1[8], w[8];
+    for (; j + WG_ZG <= n; j += WG_ZG) {
+      double u0[WG_ZG], u1[WG_ZG], w[WG_ZG];
 #pragma unroll
-      for (int e = 0; e < 8; ++e) { u0[e] = WG_ZLD(z0 + j + e); u1[e] = WG_ZLD(z1 + j + e); w[e] = q.ww[j + e]; }
+      for (int e = 0; e < WG_ZG; ++e) { u0[e] = WG_ZLD(z0 + j + e); u1[e] = WG_ZLD(z1 + j + e); w[e] = q.ww[j + e]; }
 #pragma unroll
-      for (int e = 0; e < 8; ++e) { a0 += u0[e] * w[e]; a1 += u1[e] * w[e]; }
+      for (int e = 0; e < WG_ZG; ++e) { a0 += u0[e] * w[e]; a1 += u1[e] * w[e]; }
     }
     for (; j < n; ++j) { const double w = q.ww[j]; a0 += WG_ZLD(z0 + j) * w; a1 += WG_ZLD(z1 + j) * w; }
     s[i0] = a0;
@@ -430,7 +438,7 @@ __device__ __forceinline__ void z_rows_times(const QlView &q, const double *s, i
   const int n = q.n, ldz = q.ldz;
   const int i0 = lane < n ? lane : n - 1, i1 = lane + 64 < n ? lane + 64 : i0;
   const double *z0 = q.Z + i0, *z1 = q.Z + i1;
-  constexpr int kG = 8;
+  constexpr int kG = WG_ZG;
   double a0 = 0.0, a1 = 0.0;
   int j = j0;
   for (; j + kG <= j1; j += kG) {
@@ -886,7 +894,7 @@ __device__ __forceinline__ void sweep(const QlView &q, double *s, int nu, int na
     // The rotation coefficients of a chunk (LDS, broadcast reads) are fetched at the head of the chunk as well, so that no
     // step waits for an LDS round trip; when no rotation of the sweep is skipped (one ballot in phase 2) the steps run
     // without the selects.
-    constexpr int kSwC = 8;
+    constexpr int kSwC = WG_SWC;
     const int i0 = lane;
     const int i1 = lane + 64 < n ? lane + 64 : lane;
     const int ldz = q.ldz;
