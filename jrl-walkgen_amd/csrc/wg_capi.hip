@@ -436,6 +436,15 @@ int wg_qp_solve_batch_ctx(wg_ctx_t *ctx, int B, int nmax, int mmax, const int *n
 // Herdt-2010 MPC tick, batched (include/wg_mpc.h, second half)
 // ===========================================================================
 
+#ifndef WG_TICK32_WPE
+#define WG_TICK32_WPE 2                                    // element view (N = 32): 256 registers (two gaits on a SIMD)
+#endif
+#ifndef WG_TICK_WPE_MIN
+#define WG_TICK_WPE_MIN 2
+#endif
+#ifndef WG_TICK_WPE_MAX
+#define WG_TICK_WPE_MAX 2
+#endif
 namespace {
 inline bool tick_compact(const wg_model_t &m);
 // at most two step changes fit in the preview window when N*T <= 2*step_period (each change is one step period
@@ -482,7 +491,8 @@ inline int tick_elem_cap(const wg_model_t &m, int view) {
     while (c < n - 1 && !fits(c)) ++c;
     return (c < n && fits(c)) ? c : 0;
   }
-  auto per_cu = [&](int c) { const size_t g = (tick_lds_with_cap(m, view, c) + 1279) / 1280; size_t k = 128 / g; return k > 8 ? (size_t)8 : k; };
+  // waves a CU holds by the registers the element view's kernels are compiled for (WG_TICK32_WPE per SIMD, four SIMDs)
+  auto per_cu = [&](int c) { const size_t g = (tick_lds_with_cap(m, view, c) + 1279) / 1280; size_t k = 128 / g; return k > (size_t)(4 * WG_TICK32_WPE) ? (size_t)(4 * WG_TICK32_WPE) : k; };
   const size_t full = per_cu(0);
   for (int c = n - 1; c >= (3 * n) / 4; --c)
     if (fits(c) && per_cu(c) > full) {
@@ -545,15 +555,6 @@ inline size_t tick_ql_bytes(const wg_model_t &m) {
     (p) = (decltype(p))gp_;                                                                       \
   } while (0)
 
-#ifndef WG_TICK32_WPE
-#define WG_TICK32_WPE 2                                    // element view (N = 32): 256 registers (two gaits on a SIMD)
-#endif
-#ifndef WG_TICK_WPE_MIN
-#define WG_TICK_WPE_MIN 2
-#endif
-#ifndef WG_TICK_WPE_MAX
-#define WG_TICK_WPE_MAX 2
-#endif
 template <int NH>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NH == -1 ? WG_TICK32_WPE : WG_TICK_WPE_MIN, NH == -1 ? WG_TICK32_WPE : WG_TICK_WPE_MAX))) void wg_mpc_tick_kernel(int B, wg_model_t model, const wg::TickTables *__restrict__ tb,
                                                          wg_gait_state_t *__restrict__ states,
@@ -1172,7 +1173,8 @@ int wg_mpc_run_sched_dev_ctx(wg_ctx_t *ctx, int B, wg_gait_state_t *states, int 
   }
   // as many blocks as the device keeps resident: LDS granules (1280 B, 128 per CU), at most 8 waves of 256 registers per CU
   int per_cu = 128 / (int)((lds + 1279) / 1280);
-  if (per_cu > 8) per_cu = 8;
+  const int max_waves = 4 * (view == -1 ? WG_TICK32_WPE : WG_TICK_WPE_MAX);   // what the kernel's register budget admits per CU
+  if (per_cu > max_waves) per_cu = max_waves;
   if (per_cu < 1) per_cu = 1;
   int grid = ctx->num_cu * per_cu;
   if (grid > B) grid = B;

@@ -10,7 +10,7 @@ B = int(os.environ.get("PB", "8192")); T = int(os.environ.get("PT", "50")); REPS
 model = wg.model_defaults(); model.N = int(os.environ.get("PN", "32"))
 wg.mpc_configure(model)
 lds = wg.lib().wg_mpc_tick_lds_bytes() + int(os.environ.get("WG_TICK_LDS_PAD", "0"))
-per_cu = min(8, 128 // ((lds + 1279) // 1280))
+per_cu = min(int(os.environ.get("PMAXW", "8")), 128 // ((lds + 1279) // 1280))
 rng = np.random.default_rng(20100)
 s0 = wg.gait_init(model, [0.0316055, 0.0, 0.7116911], [0.0, 0.09, 0.0], [0.0, -0.09, 0.0]); s0.nb_steps_left = 2
 st = torch.frombuffer(bytearray(bytes(memoryview(s0).cast("B")) * B), dtype=torch.uint8).cuda()
