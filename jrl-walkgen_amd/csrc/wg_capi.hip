@@ -437,7 +437,7 @@ int wg_qp_solve_batch_ctx(wg_ctx_t *ctx, int B, int nmax, int mmax, const int *n
 // ===========================================================================
 
 #ifndef WG_TICK32_WPE
-#define WG_TICK32_WPE 2                                    // element view (N = 32): 256 registers (two gaits on a SIMD)
+#define WG_TICK32_WPE 3                                    // element view (N = 32): 168 registers, three gaits on a SIMD
 #endif
 #ifndef WG_TICK_WPE_MIN
 #define WG_TICK_WPE_MIN 2
@@ -474,10 +474,11 @@ inline size_t tick_lds_with_cap(const wg_model_t &m, int view, int r_cols) {
   return ql + wg::TickLds::bytes(m.N, tick_smax(m), gvld, view == 16, !ext, view != -1, view == -1);
 }
 // Element view: how many columns of R the LDS holds (0: all of them).  R is the operand that decides the residency at N = 32
-// (21.6 KB of the 26.8); with its first 60 columns and one working column the gait takes 20 384 B -- eight gaits per CU, two on
-// every SIMD -- and a solve whose active set outgrows them is repeated with R in global memory (mpc_tick<-1>).  The cap is
-// the largest one that reaches the next residency step and leaves the usual active sets alone (>= 3/4 of n); WG_ELEM_NACT_CAP
-// forces a value (tests run with tiny caps so that every solve takes the second route).
+// (21.6 KB of the 26.8): the LDS keeps the first c columns and one working column, and a solve whose active set outgrows them
+// moves its R to the per-block global slot and GOES ON there (mpc_tick<-1>, QlResume: no repeat; measured: even a cap most solves
+// outgrow costs a few per cent).  So the cap is simply the largest one that reaches the best residency the kernel's register
+// budget admits: 41 columns at N = 32 = 12 640 B of LDS = twelve gaits per CU, three on every SIMD.  WG_ELEM_NACT_CAP forces a
+// value (tests run with tiny caps so that every solve takes the second route).
 inline int tick_elem_cap(const wg_model_t &m, int view) {
   if (view != -1) return 0;
   const int n = tick_max_n(m);
@@ -494,13 +495,11 @@ inline int tick_elem_cap(const wg_model_t &m, int view) {
   // waves a CU holds by the registers the element view's kernels are compiled for (WG_TICK32_WPE per SIMD, four SIMDs)
   auto per_cu = [&](int c) { const size_t g = (tick_lds_with_cap(m, view, c) + 1279) / 1280; size_t k = 128 / g; return k > (size_t)(4 * WG_TICK32_WPE) ? (size_t)(4 * WG_TICK32_WPE) : k; };
   const size_t full = per_cu(0);
-  for (int c = n - 1; c >= (3 * n) / 4; --c)
-    if (fits(c) && per_cu(c) > full) {
-      int best = c;                                      // keep lowering only while the residency keeps growing
-      for (int d = c - 1; d >= (3 * n) / 4; --d) if (fits(d) && per_cu(d) > per_cu(best)) best = d;
-      return best;
-    }
-  return 0;
+  int best = 0;
+  size_t best_k = full;
+  for (int c = n - 1; c >= n / 4; --c)                   // descending: the first cap that reaches a residency is the largest
+    if (fits(c) && per_cu(c) > best_k) { best = c; best_k = per_cu(c); }
+  return best;
 }
 // what the kernels receive: the column cap in the low 16 bits; tests may ask the solver to give up EARLIER than the layout
 // requires (WG_ELEM_ABORT_AT: active-set size at which the first attempt stops), so that the second route is taken often
@@ -936,7 +935,8 @@ int wg_mpc_configure_ctx(wg_ctx_t *ctx, const wg_model_t *model) {
     const int view = tick_view(*model);
     if (tick_z_global(view) || tick16_ext(view)) {
       std::lock_guard<std::mutex> zk(ctx->z_mu);
-      if (int rc = ctx->tick_z.reserve((size_t)ctx->num_cu * 8 * tick_z_slot_doubles(*model, view) * 8)) return rc;
+      const size_t waves = 4 * (size_t)(view == -1 ? WG_TICK32_WPE : WG_TICK_WPE_MAX);
+      if (int rc = ctx->tick_z.reserve((size_t)ctx->num_cu * waves * tick_z_slot_doubles(*model, view) * 8)) return rc;
     }
     if (int rc = ctx->run_buf.reserve(sizeof(wg_xrun_ctl) + (size_t)kXcds * 65536 * 8 + (size_t)32768 * 4)) return rc;
   }

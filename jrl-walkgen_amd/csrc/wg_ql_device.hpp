@@ -32,13 +32,12 @@ namespace wg {
 #ifndef WG_UNROLL_N
 #define WG_UNROLL_N 4
 #endif
-// prefetch group sizes of the wide (64 < n <= 128) forms: entries requested together ahead of the add chains / rotations.
-// Eight is what 256 registers carry; experiment builds at tighter register budgets lower them (-DWG_ZG=4 -DWG_SWC=4).
-#ifndef WG_ZG
-#define WG_ZG 8
-#endif
-#ifndef WG_SWC
-#define WG_SWC 8
+// Prefetch group size of the wide (64 < n <= 128) forms: entries of Z requested together ahead of the add chains / rotations.
+// Eight is what a 256-register kernel carries (the dense boundary kernel); the element view is compiled for 168 registers --
+// three waves per SIMD -- and takes groups of four: measured 7 % slower per wave and, with twelve gaits on a CU instead of eight,
+// 7 % faster overall.
+#ifndef WG_ELEM_GRP
+#define WG_ELEM_GRP 4
 #endif
 #define WG_PRAGMA(x) _Pragma(#x)
 #define WG_UNROLL_(n) WG_PRAGMA(unroll n)
@@ -255,6 +254,14 @@ template <class P> struct ActiveParamsOf<P, typename std::enable_if<P::kCompact>
 struct QlResult {
   int ifail, n_iter, nact, hist_len;
 };
+// The scalar state of ql0002's main loop between two iterations: what a solve stopped by QlView::nact_cap (kQlCapHit) hands to
+// its continuation.  The arrays (x, multipliers, active set, Z, R, wa) stay where they are; the caller moves R to its larger
+// home, clears the cap and calls ql_solve again with `valid` set: the solve goes on where it stopped, same arithmetic.
+struct QlResume {
+  int valid = 0;
+  int nact, info, iterc, itref, iflag, jfinc, knext, st, hist_len;
+  double xmag, vfact, res, ratio, diag;
+};
 
 template <bool kGLds> __device__ __forceinline__ double DenseProbT<kGLds>::G(const QlView &q, int i, int j) const {
   if constexpr (kGLds) return q.G[i + j * q.ldg];
@@ -397,7 +404,7 @@ __device__ __forceinline__ bool significant(double base, double delta_abs) {
 }
 
 // s[i] = sum_j Z(j,i) * ww[j]   (qld.cpp:2071-2085); lane i owns s[i]
-template <int NM = 0>                                     // NM > 0: n <= NM known at compile time (the wide form is left out)
+template <int NM = 0, int GRP = 8>                        // NM > 0: n <= NM known at compile time (the wide form is left out)
 __device__ __forceinline__ void zt_times_ww(const QlView &q, double *s, int lane) {
   const int n = q.n;
   if ((NM == 0 || NM > 64) && n > 64 && n <= 128) {
@@ -408,12 +415,12 @@ __device__ __forceinline__ void zt_times_ww(const QlView &q, double *s, int lane
     const double *z0 = q.Z + (size_t)i0 * q.ldz, *z1 = q.Z + (size_t)i1 * q.ldz;
     double a0 = 0.0, a1 = 0.0;
     int j = 0;
-    for (; j + WG_ZG <= n; j += WG_ZG) {
-      double u0[WG_ZG], u1[WG_ZG], w[WG_ZG];
+    for (; j + GRP <= n; j += GRP) {
+      double u0[GRP], u1[GRP], w[GRP];
 #pragma unroll
-      for (int e = 0; e < WG_ZG; ++e) { u0[e] = WG_ZLD(z0 + j + e); u1[e] = WG_ZLD(z1 + j + e); w[e] = q.ww[j + e]; }
+      for (int e = 0; e < GRP; ++e) { u0[e] = WG_ZLD(z0 + j + e); u1[e] = WG_ZLD(z1 + j + e); w[e] = q.ww[j + e]; }
 #pragma unroll
-      for (int e = 0; e < WG_ZG; ++e) { a0 += u0[e] * w[e]; a1 += u1[e] * w[e]; }
+      for (int e = 0; e < GRP; ++e) { a0 += u0[e] * w[e]; a1 += u1[e] * w[e]; }
     }
     for (; j < n; ++j) { const double w = q.ww[j]; a0 += WG_ZLD(z0 + j) * w; a1 += WG_ZLD(z1 + j) * w; }
     s[i0] = a0;
@@ -434,11 +441,12 @@ __device__ __forceinline__ void zt_times_ww(const QlView &q, double *s, int lane
 // of a matrix of 64 < n <= 128 rows in ONE pass, the entries of eight columns requested together ahead of the two add chains
 // (with Z in global memory an exposed entry is an L2 round trip; one register set only: this sits where many values are live).
 // Surplus lanes shadow a real row.
+template <int GRP = 8>
 __device__ __forceinline__ void z_rows_times(const QlView &q, const double *s, int j0, int j1, int lane, double &r0, double &r1) {
   const int n = q.n, ldz = q.ldz;
   const int i0 = lane < n ? lane : n - 1, i1 = lane + 64 < n ? lane + 64 : i0;
   const double *z0 = q.Z + i0, *z1 = q.Z + i1;
-  constexpr int kG = WG_ZG;
+  constexpr int kG = GRP;
   double a0 = 0.0, a1 = 0.0;
   int j = j0;
   for (; j + kG <= j1; j += kG) {
@@ -779,6 +787,7 @@ __device__ __forceinline__ double xmag_sum(const QlView &q, const P &prob, doubl
 // each; (3) every lane carries its own row of Z through the whole rotation sequence.
 // n <= 64: s[] and the rotation coefficients live in registers (lane c <-> column c) and are handed
 // around with v_readlane, so the dependent chain of phase 1 contains no LDS access at all.
+template <int GRP = 8>
 __device__ __forceinline__ void sweep(const QlView &q, double *s, int nu, int nact, int lane) {
   const int n = q.n;
   if (nu - 1 <= nact) return;
@@ -894,7 +903,7 @@ __device__ __forceinline__ void sweep(const QlView &q, double *s, int nu, int na
     // The rotation coefficients of a chunk (LDS, broadcast reads) are fetched at the head of the chunk as well, so that no
     // step waits for an LDS round trip; when no rotation of the sweep is skipped (one ballot in phase 2) the steps run
     // without the selects.
-    constexpr int kSwC = WG_SWC;
+    constexpr int kSwC = GRP;
     const int i0 = lane;
     const int i1 = lane + 64 < n ? lane + 64 : lane;
     const int ldz = q.ldz;
@@ -1074,14 +1083,15 @@ __device__ __forceinline__ bool independent_coordinate(const QlView &q, const P 
 // one row of Z per lane (n <= 64): the branch-free, prefetching form -- the compact view always, the dense view by size (the
 // element view is built for n > 64: it keeps the one form it needs, its kernel is large enough as it is)
 #define WG_SWEEP(q, s, nu, nact, lane) \
-  do { if (P::kNM > 0 || (!P::kRowOps && q.n <= 64)) sweep_flat(q, s, nu, nact, lane); else sweep(q, s, nu, nact, lane); } while (0)
+  do { if (P::kNM > 0 || (!P::kRowOps && q.n <= 64)) sweep_flat(q, s, nu, nact, lane); else sweep<(P::kRowOps ? WG_ELEM_GRP : 8)>(q, s, nu, nact, lane); } while (0)
 
 template <class P>
-__device__ __forceinline__ QlResult ql_solve(const QlView &q, P &prob, double vsmall, int *hist, int hist_cap) {
+__device__ __forceinline__ QlResult ql_solve(const QlView &q, P &prob, double vsmall, int *hist, int hist_cap, QlResume *rs = nullptr) {
   const int lane = wg_lane();
   const int n = q.n, m = q.m, me = q.me, mn = q.mn;
   QlResult out;
   out.hist_len = 0;
+  const bool resuming = rs != nullptr && rs->valid != 0;     // wave-uniform; a compile-time constant where rs is
   int nact = 0, info = 0, iterc = 1, itref = 0, iflag = 0;
   const int maxit = (m + n) * 40;                       // :459
   const double onha = 1.5, xmagr = .01, diagr = 2.0;
@@ -1092,7 +1102,13 @@ __device__ __forceinline__ QlResult ql_solve(const QlView &q, P &prob, double vs
   const int s_tail = q.r_tail;                              // n (n + 1) / 2, or the working column of the last allowed nact
   double *s = q.R + s_tail;
   bool early_exit = false;
+  bool cap_hit = false;
   PT_DECL
+  if (resuming) {
+    nact = rs->nact; info = rs->info; iterc = rs->iterc; itref = rs->itref; iflag = rs->iflag; jfinc = rs->jfinc; knext = rs->knext;
+    out.hist_len = rs->hist_len;
+    xmag = rs->xmag; vfact = rs->vfact; res = rs->res; ratio = rs->ratio; diag = rs->diag;
+  }
 
 #define LOG_EVENT(code)                                                   \
   do {                                                                    \
@@ -1101,7 +1117,7 @@ __device__ __forceinline__ QlResult ql_solve(const QlView &q, P &prob, double vs
   } while (0)
 
   // ---- reciprocal lengths of the constraint normals, :769-807 ----
-  {
+  if (!resuming) {
     int fatal = 0x7fffffff;
     if constexpr (P::kCompact) {
       fatal = prob.norms(q, lane);
@@ -1125,7 +1141,7 @@ __device__ __forceinline__ QlResult ql_solve(const QlView &q, P &prob, double vs
   }
   PT(0);
 
-  if (!early_exit) {
+  if (!early_exit && !resuming) {
     // ---- make the Hessian numerically positive definite, :814-854 ----
     for (int i = lane; i < n; i += 64) q.wd[i] = prob.Gd(q, i);
     WG_WSYNC();
@@ -1237,6 +1253,7 @@ __device__ __forceinline__ QlResult ql_solve(const QlView &q, P &prob, double vs
   PT(3);
   enum { ST_RESET, ST_RESID, ST_SCAN, ST_CONVERGED, ST_FINISH };
   int st = early_exit ? ST_FINISH : ST_RESET;
+  if (resuming) st = rs->st;
   while (st != ST_FINISH) {
     if (st == ST_RESET || st == ST_RESID) {
       s = q.R + s_tail;
@@ -1317,7 +1334,7 @@ __device__ __forceinline__ QlResult ql_solve(const QlView &q, P &prob, double vs
         PT(26);
         if (P::kNM == 0 && n > 64 && n <= 128) {
           double r0, r1;
-          z_rows_times(q, s, 0, nact, lane, r0, r1);
+          z_rows_times<(P::kRowOps ? WG_ELEM_GRP : 8)>(q, s, 0, nact, lane, r0, r1);
           q.x[lane] += r0; q.sc0[lane] = r0;
           if (lane + 64 < n) { q.x[lane + 64] += r1; q.sc0[lane + 64] = r1; }
         } else
@@ -1341,12 +1358,12 @@ __device__ __forceinline__ QlResult ql_solve(const QlView &q, P &prob, double vs
         WG_WSYNC();
       }
       PT(4);
-      zt_times_ww<P::kNM>(q, s, lane);                      // :1175-1177
+      zt_times_ww<P::kNM, (P::kRowOps ? WG_ELEM_GRP : 8)>(q, s, lane);                      // :1175-1177
       PT(5);
       if (nact != n) {                                      // :1186-1201
         if (P::kNM == 0 && n > 64 && n <= 128) {
           double r0, r1;
-          z_rows_times(q, s, nact, n, lane, r0, r1);
+          z_rows_times<(P::kRowOps ? WG_ELEM_GRP : 8)>(q, s, nact, n, lane, r0, r1);
           q.x[lane] -= r0;
           if (lane + 64 < n) q.x[lane + 64] -= r1;
         } else
@@ -1606,7 +1623,7 @@ __device__ __forceinline__ QlResult ql_solve(const QlView &q, P &prob, double vs
         for (int i = lane; i < n; i += 64) q.ww[i] = Am(knext - 1, i);
         WG_WSYNC();
         if constexpr (P::kCompact) prob.zt_row(q, s, knext - 1, lane);
-        else zt_times_ww<P::kNM>(q, s, lane);
+        else zt_times_ww<P::kNM, (P::kRowOps ? WG_ELEM_GRP : 8)>(q, s, lane);
       } else {
         int k1 = knext - m;
         double sg = 1.0;
@@ -1770,7 +1787,6 @@ __device__ __forceinline__ QlResult ql_solve(const QlView &q, P &prob, double vs
       nact++;
       LOG_EVENT(knext);
       WG_WSYNC();
-      if (q.nact_cap > 0 && nact > q.nact_cap) { info = kQlCapHit; st = ST_FINISH; continue; }   // R's LDS part is full
       PT(18);
       double sm = 0.0;
       WG_REP(6) { sm = uni(xmag_sum(q, prob, vfact, lane)); WG_SINK(sm); }   // :1776-1786
@@ -1779,6 +1795,9 @@ __device__ __forceinline__ QlResult ql_solve(const QlView &q, P &prob, double vs
       if (WG_UBOOL(sm < xmagr * xmag)) st = ST_RESET;
       else if (itref <= 0) st = ST_SCAN;
       else st = ST_RESID;
+      // R's LDS part is full (its columns and the working column hold nact finished columns): stop BETWEEN two iterations,
+      // the loop's state goes to the caller, who moves R and resumes (or, without rs, repeats the solve from the start)
+      if (q.nact_cap > 0 && nact > q.nact_cap) { cap_hit = true; break; }
       continue;
     }
 
@@ -1793,12 +1812,20 @@ __device__ __forceinline__ QlResult ql_solve(const QlView &q, P &prob, double vs
 
   PT(20);
   PT_FLUSH;
+  if (cap_hit) {
+    if (rs) {
+      rs->nact = nact; rs->info = info; rs->iterc = iterc; rs->itref = itref; rs->iflag = iflag; rs->jfinc = jfinc; rs->knext = knext;
+      rs->st = st; rs->hist_len = out.hist_len;
+      rs->xmag = xmag; rs->vfact = vfact; rs->res = res; rs->ratio = ratio; rs->diag = diag;
+    }
+    out.ifail = kQlCapHit; out.n_iter = iterc; out.nact = nact;
+    return out;
+  }
   // ---- ql0001 epilogue, :497-608 ----
   out.ifail = 0;
   if (info == 1) out.ifail = 1;
   else if (info == 2) out.ifail = 2;
   else if (info < 0) out.ifail = -info + 10;
-  if (info == kQlCapHit) out.ifail = kQlCapHit;
   out.n_iter = iterc;
   out.nact = nact;
   return out;

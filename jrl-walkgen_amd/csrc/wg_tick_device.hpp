@@ -890,20 +890,23 @@ __device__ __forceinline__ TickDiag mpc_tick(const wg_model_t &m, const TickTabl
     prob.N = N; prob.ns = ns; prob.Qb = &tb->Qb[0][0]; prob.u = L.uvec; prob.Gv = L.Gv; prob.gd = L.gd;
     prob.rowA = L.rowA; prob.rowB = L.rowB; prob.rowK = L.rowK; prob.stepidx = L.stepidx; prob.V_f = L.V_f;
     prob.R2 = tb->R2; prob.Z2 = tb->Z2; prob.z2sign = tb->z2_cross_sign; prob.blocks_ok = tb->blocks_ok;
-    qr = ql_solve(q, prob, 1e-8, hist, hist_cap);
+    QlResume rs;
+    qr = ql_solve(q, prob, 1e-8, hist, hist_cap, &rs);
     if (WG_UBOOL(qr.ifail == kQlCapHit)) {
-      // the active set outgrew the columns of R the LDS holds (rare): the same QP again, from the start, with R in the
-      // per-block slot of global memory -- slow, and the same bytes as an uncapped solve.  What the first attempt changed
-      // of its inputs is put back: the Hessian diagonal from its saved copy (a shift, if any, is re-derived); wa, x, the
-      // multipliers and the active set are (re)initialised by the solver itself.
+      // the active set outgrew the columns of R the LDS holds: the finished columns (packed, qr.nact of them: the capped part
+      // and the working column behind it are one contiguous triangle) move to the full-size R of the per-block global slot
+      // -- dead since Z = R^-1 was formed -- and the SAME solve goes on there: same arithmetic, slower reads from here on.
       WG_WSYNC();
-      for (int i = lane; i < n; i += 64) prob.setGd(q, i, q.wd[i]);
+      double *Rg = extE + eRfull;
+      const int cnt = qr.nact * (qr.nact + 1) / 2;
+      for (int i = lane; i < cnt; i += 64) Rg[i] = q.R[i];
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
       WG_WSYNC();
-      q.R = extE + eRfull; q.Rf = q.R;
+      q.R = Rg; q.Rf = q.R;
       q.r_tail = n * (n + 1) / 2;
       q.nact_cap = 0;
-      qr = ql_solve(q, prob, 1e-8, hist, hist_cap);
+      rs.valid = 1;
+      qr = ql_solve(q, prob, 1e-8, hist, hist_cap, &rs);
     }
     {
       WG_WSYNC();
