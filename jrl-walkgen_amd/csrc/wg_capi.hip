@@ -484,8 +484,9 @@ inline int tick_elem_cap(const wg_model_t &m, int view) {
   const int n = tick_max_n(m);
   const size_t overlay = wg::TickLds::pre_bytes(m.N, tick_smax(m)) + sizeof(wg_gait_state_t) + 32;
   // the pre-solve overlay -- the parked state copy at its end is fetched back right after the solve, while x still holds the
-  // solution -- must lie within R alone; sized for the smallest problem of the model (no previewed step: n = 2N)
-  auto fits = [&](int c) { return (size_t)8 * ((size_t)c * (c + 1) / 2 + (size_t)(2 * m.N)) >= overlay; };
+  // solution -- must lie within R and the four scratch vectors behind it (QlView::carve, lean layout); sized for the smallest
+  // problem of the model (no previewed step: n = 2N: working column and scratch vectors of 2N entries each)
+  auto fits = [&](int c) { return (size_t)8 * ((size_t)c * (c + 1) / 2 + (size_t)(2 * m.N) + (size_t)(4 * 2 * m.N)) >= overlay; };
   if (const char *e = getenv("WG_ELEM_NACT_CAP")) {
     int c = atoi(e);
     if (c <= 0 || c >= n) return 0;

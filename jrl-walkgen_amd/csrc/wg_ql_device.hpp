@@ -166,10 +166,16 @@ struct QlView {
     R = p; p += D.r_len(); Rf = R;
     if (D.dense && D.a_lds) { A = p; p += n * lda; }
     if constexpr (kColdLds) { x = p; p += n;  d = p; p += n;  ww = p; p += n;  wd = p; p += n;  wx = p; p += n; lam = p; p += n; }
-    else { x = p; p += n; ww = p; p += n; lam = p; p += n; d = ext_cold; wd = ext_cold + ext_cold_ld; wx = ext_cold + 2 * ext_cold_ld; }
+    else {
+      // lean layout (element view): the four scratch vectors come right behind R -- like R they are dead outside the solve, so the
+      // tick's pre-solve overlay may run over both (the smaller R's LDS part, the more gaits fit a CU) -- and x, which must
+      // survive the solve, after them
+      sc0 = p; p += D.nsc; sc1 = p; p += D.nsc; sc2 = p; p += D.nsc; sc3 = p; p += D.nsc;
+      x = p; p += n; ww = p; p += n; lam = p; p += n; d = ext_cold; wd = ext_cold + ext_cold_ld; wx = ext_cold + 2 * ext_cold_ld;
+    }
     if constexpr (kBounds) { xl = p; p += n; xu = p; p += n; } else { xl = nullptr; xu = nullptr; }
     if constexpr (kWabLds) { wa = p; p += m + n; b = p; p += m; } else { wa = ext_wab; b = ext_wab + ext_b_off; }
-    sc0 = p; p += D.nsc; sc1 = p; p += D.nsc; sc2 = p; p += D.nsc; sc3 = p; p += D.nsc;
+    if constexpr (kColdLds) { sc0 = p; p += D.nsc; sc1 = p; p += D.nsc; sc2 = p; p += D.nsc; sc3 = p; p += D.nsc; }
     slot = p; p += 8;
     iact = reinterpret_cast<int *>(p);
   }
