@@ -1,5 +1,6 @@
 #!/bin/bash
-# N = 32 at more than eight gaits per CU: a 168-register build (lib/libwg_mpc_x3.so = -DWG_TICK32_WPE=3 -DWG_ZG=4 -DWG_SWC=4)
+# N = 32 at more than eight gaits per CU: a 168-register build (the default since round 3; lib/libwg_mpc_x3.so:
+#   make -C jrl-walkgen_amd lib/libwg_mpc_x3.so EXTRA=-DWG_TICK32_WPE=3)
 # with the LDS part of R capped at fewer columns (WG_ELEM_NACT_CAP); a solve that outgrows them moves R to the global slot and
 # goes on where it stopped (no repeat).  Same state checksum = same bits.
 set -u

@@ -2,7 +2,9 @@
 # Round-3 experiments on the N = 32 element-view kernel (run on the GPU box via gpurun):
 #   1. FETCH_SIZE / WRITE_SIZE calibrated on known byte counts in this kernel's access shapes (tools/micro/fetchcal)
 #   2. residency sweep 8 / 6 / 5 / 4 / 3 gaits per CU (WG_TICK_LDS_PAD): ticks/s, and the traffic per gait-tick at 8, 4, 3
-#   3. the Z stream marked non-temporal (lib/libwg_mpc_x1.so = -DWG_Z_NT=1)
+#   3. the Z stream marked non-temporal (lib/libwg_mpc_x1.so = -DWG_Z_NT=1; build it first:
+#      make -C jrl-walkgen_amd lib/libwg_mpc_x1.so EXTRA=-DWG_Z_NT=1).  These rows were measured with round 2's 256-register
+#      build of the element view (make ... EXTRA="-DWG_TICK32_WPE=2 -DWG_ELEM_GRP=8" reproduces it).
 set -u
 R=$GRAFT_REPO_ROOT
 mkdir -p $R/gpurun_out

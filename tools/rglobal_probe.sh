@@ -1,5 +1,6 @@
 #!/bin/bash
-# What would R outside the LDS cost / buy at N = 32?  (A) default build, every solve repeated with R in the global slot after one
+# What would R outside the LDS cost / buy at N = 32?  (build first: make -C jrl-walkgen_amd lib/libwg_mpc_x3.so EXTRA=-DWG_TICK32_WPE=3;
+# measured in round 3 BEFORE the hand-over became a continuation: WG_ELEM_ABORT_AT then meant "repeat from scratch")  (A) default build, every solve repeated with R in the global slot after one
 # iteration (WG_ELEM_ABORT_AT=1): the price of R (and the working column) in global memory at unchanged residency;
 # (B) 168-register build with a small LDS part of R (WG_ELEM_NACT_CAP): twelve gaits per CU, most solves aborted and repeated.
 set -u

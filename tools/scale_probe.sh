@@ -1,6 +1,7 @@
 #!/bin/bash
 # Does the element view keep scaling past eight gaits per CU?  N = 20 forced onto the element view (n <= 48: 13 KB of LDS per gait)
-# with the 168-register build (lib/libwg_mpc_x3.so = -DWG_TICK32_WPE=3 -DWG_ZG=4 -DWG_SWC=4), residency lowered by LDS padding.
+# with the 168-register build (since round 3 the default: WG_TICK32_WPE=3, WG_ELEM_GRP=4; lib/libwg_mpc_x3.so may be any build of it:
+#   make -C jrl-walkgen_amd lib/libwg_mpc_x3.so EXTRA=-DWG_TICK32_WPE=3), residency lowered by LDS padding.
 set -u
 cd $GRAFT_REPO_ROOT
 export WG_LIB_PATH=$GRAFT_REPO_ROOT/jrl-walkgen_amd/lib/libwg_mpc_x3.so WG_TICK_VIEW=e PN=20 PB=8192 PT=50 PR=2 PMAXW=12
