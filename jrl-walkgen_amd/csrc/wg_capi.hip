@@ -47,6 +47,7 @@ struct DevBuf {
   std::vector<void *> retired;
   int reserve(size_t bytes) {
     if (bytes <= cap) return WG_OK;
+    if (p && bytes < cap + cap / 2) bytes = cap + cap / 2;   // grow geometrically: what is retired stays below twice what is live
     void *fresh = nullptr;
     hipError_t e = hipMalloc(&fresh, bytes);
     if (e != hipSuccess) return fail(WG_ERR_HIP, "hipMalloc(%zu): %s", bytes, hipGetErrorString(e));
