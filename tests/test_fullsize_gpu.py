@@ -160,13 +160,28 @@ def _horizon_vs_oracle(N, T, step, B, ticks, redraw):
         wg.mpc_configure(wg.model_defaults())
 
 
-@pytest.mark.parametrize("N,T,step", [(8, 0.1, 0.8), (12, 0.1, 0.8), (16, 0.05, 0.8), (20, 0.1, 0.8)])
-def test_other_horizons_run_through_the_dense_policy_bit_exact(N, T, step):
-    """The register-resident problem view is instantiated for N = 16 with <= 2 previewed steps; every other model goes
-    through the generic (dense, LDS) policy of the same solver and must agree with the oracle just the same."""
+@pytest.mark.parametrize("N,T,step", [(8, 0.1, 0.8), (12, 0.1, 0.8), (16, 0.05, 0.8), (20, 0.1, 0.8), (24, 0.1, 0.8)])
+def test_other_horizons_run_through_the_dense_policy_bit_exact(N, T, step, monkeypatch):
+    """The register-resident problem view is instantiated for N = 16 with <= 2 previewed steps; the generic (dense, LDS) policy
+    of the same solver takes any other model whose matrices fit a CU and must agree with the oracle just the same.  (Since round
+    3 the element view is preferred wherever it applies -- WG_TICK_DENSE=1 keeps the dense policy under test.)"""
+    monkeypatch.setenv("WG_TICK_DENSE", "1")
     wg.init(0)
     sizes = _horizon_vs_oracle(N, T, step, B=6, ticks=40, redraw=15)
     assert max(sizes) > 2 * N                                      # foot-placement variables did appear
+
+
+@pytest.mark.parametrize("N,T,step", [(12, 0.1, 0.8), (16, 0.05, 0.8), (20, 0.1, 0.8), (24, 0.1, 0.8)])
+def test_other_horizons_by_default_bit_exact(N, T, step):
+    """the same models through whatever view wg_mpc_configure picks: the element view from N = 17 on (12.5 KB of LDS per gait,
+    twelve per CU, where the dense view's G and A take 100 KB at N = 20 -- one gait per CU, a quarter of the rate)"""
+    wg.init(0)
+    model = wg.model_defaults(); model.N = N; model.T = T; model.t_double = T; model.step_period = step; model.Tctrl = T / 20.0
+    lds = wg.lib().wg_mpc_tick_lds_bytes_for(C.byref(model))
+    if N >= 20:
+        assert lds <= 12800, lds                                   # the element view: twelve gaits per CU
+    sizes = _horizon_vs_oracle(N, T, step, B=6, ticks=40, redraw=15)
+    assert max(sizes) > 2 * N
 
 
 def test_config5_horizon_32_runs_through_the_element_view_bit_exact():
@@ -187,17 +202,18 @@ def test_horizons_next_to_32_take_the_element_view_with_their_own_column_cap(N, 
     wg.init(0)
     model = wg.model_defaults(); model.N = N
     lds = wg.lib().wg_mpc_tick_lds_bytes_for(C.byref(model))
-    assert lds <= 20480                                            # eight gaits per CU
+    assert lds <= 12800                                            # twelve gaits per CU
     sizes = _horizon_vs_oracle(N, 0.1, 0.8, B=4, ticks=28, redraw=9)
     assert max(sizes) > 2 * N
 
 
 @pytest.mark.parametrize("abort_at", ["6", "31", "47"])
 def test_config5_solves_that_outgrow_the_lds_part_of_R_are_repeated_in_global_memory(abort_at, monkeypatch):
-    """At N = 32 the LDS holds the first 60 columns of R (eight gaits per CU); a solve whose active set would grow past them
-    stops and is repeated from the start with R in the per-block slot of global memory -- the same bytes as an uncapped solve.
-    The benchmark workload never gets there (its active sets stay below 60), so WG_ELEM_ABORT_AT makes the first attempt give
-    up at a smaller active set: at 6 nearly every solve takes the second route, at 31 about half of them, at 47 a few."""
+    """At N = 32 the LDS holds the first 41 columns of R (twelve gaits per CU); a solve whose active set grows past them hands
+    its loop state out (QlResume), R's finished columns move to the per-block slot of global memory and the same solve goes on
+    there -- the same bytes as an uncapped solve.  WG_ELEM_ABORT_AT makes the hand-over happen at a smaller active set: at 6
+    nearly every solve continues in global memory almost from the start, at 31 most of them, at 47 (beyond the layout's own
+    41) the layout's cap decides."""
     monkeypatch.setenv("WG_ELEM_ABORT_AT", abort_at)
     wg.init(0)
     sizes = _horizon_vs_oracle(32, 0.1, 0.8, B=5, ticks=36, redraw=12)
