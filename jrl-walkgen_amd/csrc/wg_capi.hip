@@ -455,9 +455,10 @@ inline int tick_max_n(const wg_model_t &m) { return 2 * m.N + 2 * tick_smax(m); 
 inline int tick_max_m(const wg_model_t &m) { return 1 + 4 * m.N + 5 * tick_smax(m); }
 // Problem views of the tick kernel (template argument of wg_mpc_tick_kernel):
 //   16  compact  rows in registers, no G / A anywhere: N == 16 with at most two previewed steps (the benchmark model)
-//    0  dense    G and A as LDS matrices: any other model whose matrices fit the CU's 160 KiB
-//   -1  element  G / A regenerated per element from the compact tables: what does not fit (N = 32: n <= 72, m <= 149)
-// WG_TICK_DENSE=1 forces the dense view, WG_TICK_VIEW=element the element view (tests).
+//   -1  element  G / A regenerated per element from the compact tables, Z in a global slot: every other model
+//    0  dense    G and A as LDS matrices: on request (WG_TICK_DENSE=1, while they fit the CU's 160 KiB) and for
+//                wg_mpc_assemble_batch, which writes the QP out
+// WG_TICK_VIEW=element sends N == 16 through the element view as well (tests).
 inline bool tick_compact(const wg_model_t &m) {
   const char *e = getenv("WG_TICK_DENSE");
   const char *v = getenv("WG_TICK_VIEW");
@@ -467,10 +468,16 @@ inline bool tick_compact(const wg_model_t &m) {
 inline bool tick_z_global(int view) { return view == -1; }
 // compact view (N = 16): wa, b and the border block Gv in a per-block slot of global memory (decided at compile time: mpc_tick<16>)
 inline bool tick16_ext(int view) { return view == 16; }
+// the solver area of a wave's LDS (the tick's own arrays follow it); element view: behind the pad short horizons need
+inline size_t tick_ql_bytes_for(const wg_model_t &m, int view, int r_cols) {
+  const bool ext = tick16_ext(view) || tick_z_global(view);
+  const size_t pad = view == -1 ? (size_t)8 * wg::TickLds::elem_pad_doubles(m.N, sizeof(wg_gait_state_t)) : 0;
+  return (pad + wg::QlDims(tick_max_n(m), tick_max_m(m), tick_max_m(m), view == 0, true, 0, view == 0, !tick_z_global(view),
+                           !ext, view != -1, r_cols).bytes() + 15) & ~(size_t)15;
+}
 inline size_t tick_lds_with_cap(const wg_model_t &m, int view, int r_cols) {
   const bool ext = tick16_ext(view) || tick_z_global(view);        // wa, b, Gv (element view: the rows too) in the global slot
-  const size_t ql = (wg::QlDims(tick_max_n(m), tick_max_m(m), tick_max_m(m), view == 0, true, 0, view == 0, !tick_z_global(view),
-                                !ext, view != -1, r_cols).bytes() + 15) & ~(size_t)15;
+  const size_t ql = tick_ql_bytes_for(m, view, r_cols);
   const int gvld = view == 16 ? wg::kGvLd : (view == -1 ? wg::kGvLdElem : 0);
   return ql + wg::TickLds::bytes(m.N, tick_smax(m), gvld, view == 16, !ext, view != -1, view == -1);
 }
@@ -488,6 +495,7 @@ inline int tick_elem_cap(const wg_model_t &m, int view) {
   // solution -- must lie within R and the four scratch vectors behind it (QlView::carve, lean layout); sized for the smallest
   // problem of the model (no previewed step: n = 2N: working column and scratch vectors of 2N entries each)
   auto fits = [&](int c) { return (size_t)8 * ((size_t)c * (c + 1) / 2 + (size_t)(2 * m.N) + (size_t)(4 * 2 * m.N)) >= overlay; };
+  if (wg::TickLds::elem_pad_doubles(m.N, sizeof(wg_gait_state_t)) > 0) return 0;   // short horizons: R whole, behind its pad
   if (const char *e = getenv("WG_ELEM_NACT_CAP")) {
     int c = atoi(e);
     if (c <= 0 || c >= n) return 0;
@@ -521,25 +529,15 @@ inline size_t tick_z_slot_doubles(const wg_model_t &m, int view) {
 inline size_t tick_lds_for(const wg_model_t &m, int view) { return tick_lds_with_cap(m, view, tick_elem_cap(m, view)); }
 inline int tick_view(const wg_model_t &m) {
   if (tick_compact(m)) return 16;
-  // the element view parks the pre-solve scratch on Z (n >= 2N): tiny horizons whose Z is smaller than that stay dense
-  // (with Z in global memory the first array of the solver area is R: (2N)(2N+1)/2 + 2N doubles at the least)
-  // (the element view also parks its copy of the state there)
-  const bool overlay_fits = wg::TickLds::pre_bytes(m.N, tick_smax(m)) + sizeof(wg_gait_state_t) + 32 <=
-                            (size_t)8 * ((size_t)(2 * m.N) * (2 * m.N + 1) / 2 + 2 * m.N);
   const bool dense_fits = tick_lds_for(m, 0) <= 160 * 1024;
   const char *d = getenv("WG_TICK_DENSE");
   if (d && atoi(d) != 0 && dense_fits) return 0;          // tests: the dense view where the element view would be taken
-  // Wherever it applies the element view wins: 12.5 KB of LDS per gait (twelve per CU) against the dense view's G and A
-  // (N = 20: 100 KB, ONE per CU -- measured 1.65 M against 0.39 M ticks/s; N = 24: 1.15 M against 0.27 M; same bits)
-  if (overlay_fits) return -1;
-  return dense_fits ? 0 : -1;
+  // Everywhere else the element view: 5 - 12.6 KB of LDS per gait (twelve per CU, three on every SIMD) against the dense view's
+  // G and A as LDS matrices (N = 20: 100 KB, ONE gait per CU -- measured 1.65 M against 0.39 M ticks/s; N = 24: 1.15 M against
+  // 0.27 M; same bits).  Its pre-solve group lies over R (short horizons: over a pad in front of it, TickLds::elem_pad_doubles)
+  return -1;
 }
-inline size_t tick_ql_bytes(const wg_model_t &m) {
-  size_t b = wg::QlDims(tick_max_n(m), tick_max_m(m), tick_max_m(m), tick_view(m) == 0, true, 0, tick_view(m) == 0,
-                        !tick_z_global(tick_view(m)), !(tick16_ext(tick_view(m)) || tick_z_global(tick_view(m))),
-                        tick_view(m) != -1, tick_elem_cap(m, tick_view(m))).bytes();
-  return (b + 15) & ~(size_t)15;
-}
+inline size_t tick_ql_bytes(const wg_model_t &m) { return tick_ql_bytes_for(m, tick_view(m), tick_elem_cap(m, tick_view(m))); }
 }  // namespace
 
 // Waves per SIMD the tick kernel is compiled for: 2 => at most 256 registers per lane.  With 26.2 KB of LDS per gait six

@@ -239,6 +239,15 @@ struct TickLds {
       st = reinterpret_cast<wg_gait_state_t *>(q);
     }
   }
+  // Element view: its pre-solve group and the parked state copy lie over R and the four scratch vectors of the solver area
+  // (dead outside the solve).  Short horizons have a smaller R than that (N <= 13): the solver area then starts this many
+  // doubles into the wave's LDS, so that x -- the first array that must survive -- begins behind the overlay for the smallest
+  // problem of the model (n = 2N; a larger n only moves x further back)
+  __host__ __device__ static int elem_pad_doubles(int N, size_t state_bytes) {
+    const long need = (long)((pre_bytes(N, kSMax) + state_bytes + 32 + 7) / 8);
+    const long have = (long)(2 * N) * (2 * N + 1) / 2 + 2 * N + 4 * 2 * N;
+    return need > have ? (int)((need - have + 1) & ~1L) : 0;
+  }
   __host__ __device__ static size_t overlay_bytes(int N, int smax) {   // what the compact view parks on Z before the solve
     const int m = 1 + 4 * N + 5 * smax;
     return pre_bytes(N, smax) + 16 * (size_t)m + 4 * (size_t)((m + 1) & ~1) + 16 + ((sizeof(wg_gait_state_t) + 15) & ~(size_t)15);
@@ -691,7 +700,8 @@ __device__ __forceinline__ TickDiag mpc_tick(const wg_model_t &m, const TickTabl
     q.template carve_fixed<kNmax, kMmax, kNmax, true>(lds_ql, n, mq, 0, ext16);
   } else {
     if constexpr (kElemView) {
-      q.template carve<false, false, false>(lds_ql, D, 0, extE, eMmax + eNmax, extE + eCold + eNmax, eNmax);
+      q.template carve<false, false, false>(lds_ql + TickLds::elem_pad_doubles(N, sizeof(wg_gait_state_t)), D, 0, extE, eMmax + eNmax,
+                                            extE + eCold + eNmax, eNmax);
       q.Z = zglobal;
       q.Rf = extE + eRfull;                                 // the LDS may hold only r_cols columns of R: the Cholesky factor needs all n
       if (q.nact_cap > 0 && (elem_nact_cap >> 16) > 0 && (elem_nact_cap >> 16) < q.nact_cap) q.nact_cap = elem_nact_cap >> 16;   // tests

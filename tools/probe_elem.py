@@ -1,6 +1,6 @@
 """Element-view (N = 32, BASELINE configs[4]) throughput probe: B gaits, multi-tick launches of wg_mpc_run_batch_dev only, timed
 with events on the launch stream.  Knobs: PB (8192), PT ticks per launch (50), PR launches (3), WG_TICK_LDS_PAD (bytes of LDS
-added per gait: lowers the residency), WG_LIB_PATH (an experiment build of the library).  Run under rocprofv3 --pmc FETCH_SIZE /
+added per gait: lowers the residency), WG_LIB_PATH (an experiment build of the library), PQT (QP sampling period).  Run under rocprofv3 --pmc FETCH_SIZE /
 WRITE_SIZE passes for the traffic per gait-tick (tools/elem_sweep.sh)."""
 import importlib, os, sys, numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -8,6 +8,8 @@ sys.path.insert(0, ROOT)
 wg = importlib.import_module("jrl-walkgen_amd"); wg.init(0)
 B = int(os.environ.get("PB", "8192")); T = int(os.environ.get("PT", "50")); REPS = int(os.environ.get("PR", "3"))
 model = wg.model_defaults(); model.N = int(os.environ.get("PN", "32"))
+if "PQT" in os.environ:                                   # QP sampling period (short horizons need a longer one to preview a step)
+    model.T = float(os.environ["PQT"]); model.t_double = model.T; model.Tctrl = model.T / 20.0
 wg.mpc_configure(model)
 lds = wg.lib().wg_mpc_tick_lds_bytes() + int(os.environ.get("WG_TICK_LDS_PAD", "0"))
 per_cu = min(int(os.environ.get("PMAXW", "8")), 128 // ((lds + 1279) // 1280))
