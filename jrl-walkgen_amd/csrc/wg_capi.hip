@@ -739,12 +739,19 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NH == -1 ? W
 //     so visible everywhere: an XCD that received no wave leaves no gait behind);
 //   * a wave that finds nothing to do exits: a gait in flight is always held by a live wave, which offers it to its own
 //     ring and takes it back if nobody else does -- every gait reaches n_ticks whatever the placement of the waves;
-//   * ring entries carry their position as a tag, so slots are reused without being cleared.
+//   * ring entries carry their position as a tag, so slots are reused without being cleared;
+//   * a wave KEEPS its gait for the next tick when the gait is behind its XCD's mean progress (prog counts the XCD's finished
+//     ticks; behind: (t + 1 + keep_k) * gaits of the XCD <= prog).  A ring alone serves first-in first-out, so a gait's period
+//     is the ring's revolution PLUS its own solve: gaits with long solves fall behind (ticks per gait after a 200-tick launch
+//     spread by tens), the ring drains with them still far from done, and the waves leave early -- 4.3 - 4.9 % of the wave-time
+//     of a B = 4096 launch was that tail (tools/xrun_stats.py on an experiment build; tools/xrun_sim.py replays the policies on
+//     the measured solve times: FIFO +4.2 % over the work bound, keep +0.2 %).  Keeping also saves the laggards' hand-overs.
+//     WG_RUN_KEEP=k sets keep_k (default 0), WG_RUN_KEEP=off restores the plain ring.
 // Counters and ring entries are only touched by read-modify-write atomics (one coherence point whatever the hardware does
 // with them); the XCD a wave runs on is read from the hardware register, not inferred from blockIdx.
 constexpr int kXcds = 8;
 struct wg_xrun_ctl {
-  struct alignas(64) { int fresh, fresh_end, head, tail; } x[kXcds];
+  struct alignas(64) { int fresh, fresh_end, head, tail, prog, count; } x[kXcds];
 };
 
 __global__ void wg_xrun_init_kernel(int B, wg_xrun_ctl *ctl, unsigned long long *rings, int cap, int *done) {
@@ -753,6 +760,7 @@ __global__ void wg_xrun_init_kernel(int B, wg_xrun_ctl *ctl, unsigned long long 
     ctl->x[i].fresh = (int)((long long)B * i / kXcds);
     ctl->x[i].fresh_end = (int)((long long)B * (i + 1) / kXcds);
     ctl->x[i].head = 0; ctl->x[i].tail = 0;
+    ctl->x[i].prog = 0; ctl->x[i].count = ctl->x[i].fresh_end - ctl->x[i].fresh;
   }
   if (i < kXcds * cap) rings[i] = 0ull;
   if (i < B) done[i] = 0;
@@ -780,9 +788,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NH == -1 ? W
     int B, int n_ticks, const wg_model_t *__restrict__ model_p, const wg::TickTables *__restrict__ tb_p,
     wg_gait_state_t *__restrict__ states_p, wg_tick_out_t *__restrict__ outs_p, int *__restrict__ diag_p, int advance_calls,
     wg_xrun_ctl *__restrict__ ctl_p, unsigned long long *__restrict__ rings_p, int cap, int *__restrict__ done_p,
-    unsigned ql_bytes, double *zscratch, unsigned zslot, const double *__restrict__ vsched, int vperiod, int elem_cap) {
+    unsigned ql_bytes, double *zscratch, unsigned zslot, const double *__restrict__ vsched, int vperiod, int elem_cap, int keep_k) {
   extern __shared__ __attribute__((aligned(16))) double wg_lds[];
   unsigned fresh_gone = 0;                                 // bit y: range y was seen exhausted (the counters only grow)
+  int kept_g = -1, kept_t = 0;                             // the gait this wave goes on with (it was behind its XCD's mean progress)
   for (;;) {
     int lane = threadIdx.x & 63;
     asm volatile("" : "+v"(lane));
@@ -795,8 +804,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NH == -1 ? W
     int xcc;
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID, 0, 4)" : "=s"(xcc));
     xcc &= kXcds - 1;
-    int g = -1, t = 0;
-    if (lane == 0) {
+    int g = kept_g, t = kept_t;
+    kept_g = -1;
+    if (g < 0 && lane == 0) {
       if (!((fresh_gone >> xcc) & 1u)) {
         g = xrun_take_fresh(ctl, xcc);
         if (g < 0) fresh_gone |= 1u << xcc;
@@ -850,9 +860,25 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NH == -1 ? W
     if (diag && lane == 0) {
       int *dq = diag + ((size_t)t * B + g) * 6;
       dq[0] = dg.ifail; dq[1] = dg.n_iter; dq[2] = dg.nact; dq[3] = dg.n; dq[4] = dg.m; dq[5] = dg.ns;
+#ifdef WG_XRUN_STATS
+      // experiment build (tools/xrun_stats.py): when this tick ended (100 MHz counter), where it ran (block, XCD)
+      dq[3] = (int)(unsigned)wall_clock64(); dq[4] = (int)blockIdx.x; dq[5] = xcc;
+#endif
     }
     WG_WSYNC();
     if (t + 1 < n_ticks) {
+      if (keep_k >= 0) {
+        int keep = 0;
+        if (lane == 0) {
+          const int p = __hip_atomic_fetch_add(&ctl->x[xcc].prog, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          keep = (long long)(t + 1 + keep_k) * ctl->x[xcc].count <= (long long)p;
+        }
+        if (wg::uni(keep)) {
+          xrun_stores_done();                              // the state is read back from L2 by the next tick
+          kept_g = g; kept_t = t + 1;
+          continue;
+        }
+      }
       if (lane == 0) done[g] = t + 1;
       xrun_stores_done();                                  // state and tick count are in this XCD's L2 before the gait is offered
       if (lane == 0) {
@@ -1190,16 +1216,19 @@ int wg_mpc_run_sched_dev_ctx(wg_ctx_t *ctx, int B, wg_gait_state_t *states, int 
     if (int rc = ctx->tick_z.reserve((size_t)grid * zslot * 8)) return rc;
     zs = static_cast<double *>(ctx->tick_z.p);
   }
+  int keep_k = 0;                                    // a wave keeps a gait that is behind its XCD's mean progress (see the kernel)
+  if (const char *e = getenv("WG_RUN_KEEP")) keep_k = (e[0] == 'o' || e[0] == '-') ? -1 : atoi(e);
+  else if (B <= grid) keep_k = -1;                   // a wave per gait: nothing waits, the launch takes what its slowest gait takes
   if (xcd_mode) {
     if (view == 16)
       hipLaunchKernelGGL(wg_mpc_run_xcd_kernel<16>, dim3(grid), dim3(64), lds, st, B, n_ticks, ctx->model_dev, ctx->tables_dev, states,
-                         outs, diag, advance_calls, xctl, xrings, cap, xdone, (unsigned)qlb, zs, (unsigned)zslot, vref_sched, period, ecap);
+                         outs, diag, advance_calls, xctl, xrings, cap, xdone, (unsigned)qlb, zs, (unsigned)zslot, vref_sched, period, ecap, keep_k);
     else if (view == 0)
       hipLaunchKernelGGL(wg_mpc_run_xcd_kernel<0>, dim3(grid), dim3(64), lds, st, B, n_ticks, ctx->model_dev, ctx->tables_dev, states,
-                         outs, diag, advance_calls, xctl, xrings, cap, xdone, (unsigned)qlb, zs, (unsigned)zslot, vref_sched, period, ecap);
+                         outs, diag, advance_calls, xctl, xrings, cap, xdone, (unsigned)qlb, zs, (unsigned)zslot, vref_sched, period, ecap, keep_k);
     else
       hipLaunchKernelGGL(wg_mpc_run_xcd_kernel<-1>, dim3(grid), dim3(64), lds, st, B, n_ticks, ctx->model_dev, ctx->tables_dev, states,
-                         outs, diag, advance_calls, xctl, xrings, cap, xdone, (unsigned)qlb, zs, (unsigned)zslot, vref_sched, period, ecap);
+                         outs, diag, advance_calls, xctl, xrings, cap, xdone, (unsigned)qlb, zs, (unsigned)zslot, vref_sched, period, ecap, keep_k);
   } else if (view == 16)
     hipLaunchKernelGGL(wg_mpc_run_kernel<16>, dim3(grid), dim3(64), lds, st, B, n_ticks, ctx->model_dev, ctx->tables_dev, states, outs,
                        diag, advance_calls, q, ring, done, (unsigned)qlb, zs, (unsigned)zslot, ecap);
