@@ -468,18 +468,21 @@ inline bool tick_compact(const wg_model_t &m) {
 inline bool tick_z_global(int view) { return view == -1; }
 // compact view (N = 16): wa, b and the border block Gv in a per-block slot of global memory (decided at compile time: mpc_tick<16>)
 inline bool tick16_ext(int view) { return view == 16; }
-// the solver area of a wave's LDS (the tick's own arrays follow it); element view: behind the pad short horizons need
+// the solver area of a wave's LDS (the tick's own arrays follow it)
 inline size_t tick_ql_bytes_for(const wg_model_t &m, int view, int r_cols) {
   const bool ext = tick16_ext(view) || tick_z_global(view);
-  const size_t pad = view == -1 ? (size_t)8 * wg::TickLds::elem_pad_doubles(m.N, sizeof(wg_gait_state_t)) : 0;
-  return (pad + wg::QlDims(tick_max_n(m), tick_max_m(m), tick_max_m(m), view == 0, true, 0, view == 0, !tick_z_global(view),
+  return (wg::QlDims(tick_max_n(m), tick_max_m(m), tick_max_m(m), view == 0, true, 0, view == 0, !tick_z_global(view),
                            !ext, view != -1, r_cols).bytes() + 15) & ~(size_t)15;
 }
 inline size_t tick_lds_with_cap(const wg_model_t &m, int view, int r_cols) {
   const bool ext = tick16_ext(view) || tick_z_global(view);        // wa, b, Gv (element view: the rows too) in the global slot
   const size_t ql = tick_ql_bytes_for(m, view, r_cols);
   const int gvld = view == 16 ? wg::kGvLd : (view == -1 ? wg::kGvLdElem : 0);
-  return ql + wg::TickLds::bytes(m.N, tick_smax(m), gvld, view == 16, !ext, view != -1, view == -1);
+  size_t tick = wg::TickLds::bytes(m.N, tick_smax(m), gvld, view == 16, !ext, view != -1, view == -1);
+  // element view, short horizons: the pre-solve overlay does not fit over R; it gets its own bytes behind the tick's arrays
+  if (view == -1 && wg::TickLds::elem_overlay_apart(m.N, sizeof(wg_gait_state_t)))
+    tick = ((tick + 15) & ~(size_t)15) + wg::TickLds::elem_overlay_need(m.N, sizeof(wg_gait_state_t));
+  return ql + tick;
 }
 // Element view: how many columns of R the LDS holds (0: all of them).  R is the operand that decides the residency at N = 32
 // (21.6 KB of the 26.8): the LDS keeps the first c columns and one working column, and a solve whose active set outgrows them
@@ -495,7 +498,7 @@ inline int tick_elem_cap(const wg_model_t &m, int view) {
   // solution -- must lie within R and the four scratch vectors behind it (QlView::carve, lean layout); sized for the smallest
   // problem of the model (no previewed step: n = 2N: working column and scratch vectors of 2N entries each)
   auto fits = [&](int c) { return (size_t)8 * ((size_t)c * (c + 1) / 2 + (size_t)(2 * m.N) + (size_t)(4 * 2 * m.N)) >= overlay; };
-  if (wg::TickLds::elem_pad_doubles(m.N, sizeof(wg_gait_state_t)) > 0) return 0;   // short horizons: R whole, behind its pad
+  if (wg::TickLds::elem_overlay_apart(m.N, sizeof(wg_gait_state_t))) return 0;     // short horizons: R whole, the overlay apart
   if (const char *e = getenv("WG_ELEM_NACT_CAP")) {
     int c = atoi(e);
     if (c <= 0 || c >= n) return 0;
@@ -534,7 +537,7 @@ inline int tick_view(const wg_model_t &m) {
   if (d && atoi(d) != 0 && dense_fits) return 0;          // tests: the dense view where the element view would be taken
   // Everywhere else the element view: 5 - 12.6 KB of LDS per gait (twelve per CU, three on every SIMD) against the dense view's
   // G and A as LDS matrices (N = 20: 100 KB, ONE gait per CU -- measured 1.65 M against 0.39 M ticks/s; N = 24: 1.15 M against
-  // 0.27 M; same bits).  Its pre-solve group lies over R (short horizons: over a pad in front of it, TickLds::elem_pad_doubles)
+  // 0.27 M; same bits).  Its pre-solve group lies over R (short horizons: in bytes of its own, TickLds::elem_overlay_apart)
   return -1;
 }
 inline size_t tick_ql_bytes(const wg_model_t &m) { return tick_ql_bytes_for(m, tick_view(m), tick_elem_cap(m, tick_view(m))); }

@@ -239,14 +239,14 @@ struct TickLds {
       st = reinterpret_cast<wg_gait_state_t *>(q);
     }
   }
-  // Element view: its pre-solve group and the parked state copy lie over R and the four scratch vectors of the solver area
-  // (dead outside the solve).  Short horizons have a smaller R than that (N <= 13): the solver area then starts this many
-  // doubles into the wave's LDS, so that x -- the first array that must survive -- begins behind the overlay for the smallest
-  // problem of the model (n = 2N; a larger n only moves x further back)
-  __host__ __device__ static int elem_pad_doubles(int N, size_t state_bytes) {
-    const long need = (long)((pre_bytes(N, kSMax) + state_bytes + 32 + 7) / 8);
-    const long have = (long)(2 * N) * (2 * N + 1) / 2 + 2 * N + 4 * 2 * N;
-    return need > have ? (int)((need - have + 1) & ~1L) : 0;
+  // Element view: its pre-solve group and the state copy lie over R and the four scratch vectors of the solver area (dead outside
+  // the solve; the state copy is fetched back from its HBM slot right after the solve, while x still holds the solution).  Short
+  // horizons (N <= 13) have a smaller R than that: their overlay gets its own bytes behind the tick's arrays instead -- the
+  // solver area itself stays at the start of the wave's LDS for every model (a run-time offset there turns every address of R,
+  // x, ... from an immediate into a register: measured at N = 32, 70 more spilled registers and -4.7 %)
+  __host__ __device__ static size_t elem_overlay_need(int N, size_t state_bytes) { return (pre_bytes(N, kSMax) + state_bytes + 32 + 15) & ~(size_t)15; }
+  __host__ __device__ static bool elem_overlay_apart(int N, size_t state_bytes) {
+    return elem_overlay_need(N, state_bytes) > (size_t)8 * ((size_t)(2 * N) * (2 * N + 1) / 2 + 2 * N + 4 * 2 * N);
   }
   __host__ __device__ static size_t overlay_bytes(int N, int smax) {   // what the compact view parks on Z before the solve
     const int m = 1 + 4 * N + 5 * smax;
@@ -540,9 +540,12 @@ __device__ __forceinline__ TickDiag mpc_tick(const wg_model_t &m, const TickTabl
   const int eRows = eWab + eNmax * kGvStride;               // offset of the row tables, then of gd | d | wd | wx
   const int eCold = eRows + 2 * eMmax + (eMmax + 1) / 2 + 2;
   const int eRfull = eCold + 4 * eNmax;                    // a full-size R (element view with a column cap on its LDS part)
-  if constexpr (NH == -1)
-    L.template carve<true, true, true>(lds_tick, N, kSMax, kGvStride, reinterpret_cast<char *>(lds_ql), false, extE + eWab,
-                                       extE + eRows, extE + eCold);
+  if constexpr (NH == -1) {
+    char *ovl = reinterpret_cast<char *>(lds_ql);
+    if (TickLds::elem_overlay_apart(N, sizeof(wg_gait_state_t)))           // short horizons: behind the tick's own arrays
+      ovl = lds_tick + ((TickLds::bytes(N, kSMax, kGvStride, false, false, false, true) + 15) & ~(size_t)15);
+    L.template carve<true, true, true>(lds_tick, N, kSMax, kGvStride, ovl, false, extE + eWab, extE + eRows, extE + eCold);
+  }
   else
     L.template carve<NH == 16>(lds_tick, N, (NH == 16) ? 2 : kSMax, kGvStride, reinterpret_cast<char *>(lds_ql), NH == 16,
                                (NH == 16) ? ext16 + kExtWab : nullptr);
@@ -700,8 +703,7 @@ __device__ __forceinline__ TickDiag mpc_tick(const wg_model_t &m, const TickTabl
     q.template carve_fixed<kNmax, kMmax, kNmax, true>(lds_ql, n, mq, 0, ext16);
   } else {
     if constexpr (kElemView) {
-      q.template carve<false, false, false>(lds_ql + TickLds::elem_pad_doubles(N, sizeof(wg_gait_state_t)), D, 0, extE, eMmax + eNmax,
-                                            extE + eCold + eNmax, eNmax);
+      q.template carve<false, false, false>(lds_ql, D, 0, extE, eMmax + eNmax, extE + eCold + eNmax, eNmax);
       q.Z = zglobal;
       q.Rf = extE + eRfull;                                 // the LDS may hold only r_cols columns of R: the Cholesky factor needs all n
       if (q.nact_cap > 0 && (elem_nact_cap >> 16) > 0 && (elem_nact_cap >> 16) < q.nact_cap) q.nact_cap = elem_nact_cap >> 16;   // tests

@@ -176,8 +176,8 @@ def test_other_horizons_run_through_the_dense_policy_bit_exact(N, T, step, monke
 def test_other_horizons_by_default_bit_exact(N, T, step):
     """the same models through the view wg_mpc_configure picks: the element view for every model but the benchmark's (at most
     12.6 KB of LDS per gait, twelve per CU, where the dense view's G and A take 100 KB at N = 20 -- one gait per CU, a quarter
-    of the rate).  Horizons up to 13 have a smaller R than the pre-solve group that lies over it: their solver area starts
-    behind a pad (TickLds::elem_pad_doubles)."""
+    of the rate).  Horizons up to 13 have a smaller R than the pre-solve group that lies over it: theirs gets bytes of its own
+    behind the tick's arrays (TickLds::elem_overlay_apart)."""
     wg.init(0)
     model = wg.model_defaults(); model.N = N; model.T = T; model.t_double = T; model.step_period = step; model.Tctrl = T / 20.0
     lds = wg.lib().wg_mpc_tick_lds_bytes_for(C.byref(model))

@@ -12,7 +12,7 @@ if "PQT" in os.environ:                                   # QP sampling period (
     model.T = float(os.environ["PQT"]); model.t_double = model.T; model.Tctrl = model.T / 20.0
 wg.mpc_configure(model)
 lds = wg.lib().wg_mpc_tick_lds_bytes() + int(os.environ.get("WG_TICK_LDS_PAD", "0"))
-per_cu = min(int(os.environ.get("PMAXW", "8")), 128 // ((lds + 1279) // 1280))
+per_cu = min(int(os.environ.get("PMAXW", "8" if model.N == 16 and "WG_TICK_VIEW" not in os.environ else "12")), 128 // ((lds + 1279) // 1280))
 rng = np.random.default_rng(20100)
 s0 = wg.gait_init(model, [0.0316055, 0.0, 0.7116911], [0.0, 0.09, 0.0], [0.0, -0.09, 0.0]); s0.nb_steps_left = 2
 st = torch.frombuffer(bytearray(bytes(memoryview(s0).cast("B")) * B), dtype=torch.uint8).cuda()
