@@ -99,6 +99,35 @@ def test_run_batch_dense_view_and_arguments():
         wg.mpc_configure(wg.model_defaults())
 
 
+@pytest.mark.parametrize("N,B,T,keep", [(16, 5000, 15, "off"), (16, 5000, 15, "0"), (16, 5000, 15, "3"), (16, 300, 9, "0"),
+                                        (32, 3500, 6, "0"), (32, 3500, 6, "off"), (20, 700, 8, "1")])
+def test_hand_over_policy_does_not_change_a_byte(N, B, T, keep, monkeypatch):
+    """The multi-tick kernel lets a wave keep a gait that is behind its XCD's mean progress (WG_RUN_KEEP = margin in ticks; "off":
+    the plain ring; by default 0, and off when every gait has a wave of its own).  Which wave runs which tick of which gait in
+    which order is scheduling only: states and per-tick diagnostics are the bytes of one launch per tick."""
+    wg.init(0)
+    monkeypatch.setenv("WG_RUN_KEEP", keep)
+    model = wg.model_defaults(); model.N = N
+    wg.mpc_configure(model)
+    try:
+        rng = np.random.default_rng(N + B + T)
+        host = _start(model, B, rng)
+        adv = int(round(model.T / model.Tctrl))
+        a = _dev(host); b = _dev(host)
+        for st in (a, b):
+            wg.mpc_tick_batch_dev(B, st.data_ptr(), None, None, 1)
+            wg.mpc_tick_batch_dev(B, st.data_ptr(), None, None, adv - 1)
+        da = torch.zeros(T, B, 6, dtype=torch.int32, device="cuda"); db = torch.zeros_like(da)
+        for t in range(T):
+            wg.mpc_tick_batch_dev(B, a.data_ptr(), None, da[t].data_ptr(), adv)
+        wg.mpc_run_batch_dev(B, b.data_ptr(), T, adv, None, db.data_ptr())
+        torch.cuda.synchronize()
+        assert torch.equal(a, b) and torch.equal(da, db)
+        assert int(da[:, :, 0].abs().sum()) == 0
+    finally:
+        wg.mpc_configure(wg.model_defaults())
+
+
 @pytest.mark.parametrize("N,B,T,period,queue", [(16, 700, 37, 10, "xcd"), (16, 2500, 23, 23, "xcd"), (16, 64, 9, 4, "global"),
                                               (32, 96, 11, 5, "xcd"), (32, 200, 9, 4, "xcd-abort")])
 def test_staged_references_equal_a_loop_of_set_velref_and_run(N, B, T, period, queue, monkeypatch):
