@@ -268,7 +268,9 @@ int wg_mpc_configure(const wg_model_t *model);
  * residency they run at): launches of the tick / run entry points ON ONE CONTEXT must not overlap -- one stream, or events
  * between streams; overlapping streams take one context each (wg_ctx_create).  The library checks this: a launch that arrives
  * on a different stream while the context's previous tick / run launch has not completed returns WG_ERR_BUSY and launches
- * nothing. */
+ * nothing.
+ * With more gaits than the device keeps resident, a call that follows another one on the same `states` array starts the gaits
+ * in the order of decreasing QL iteration count of that previous tick (scheduling only: no result depends on it). */
 int wg_mpc_tick_batch(int B, wg_gait_state_t *states, wg_tick_out_t *outs, int *diag, int advance_calls,
                       int *hist, int hist_cap, int *hist_len);
 int wg_mpc_tick_batch_dev(int B, wg_gait_state_t *states, wg_tick_out_t *outs, int *diag, int advance_calls,

@@ -128,6 +128,37 @@ def test_hand_over_policy_does_not_change_a_byte(N, B, T, keep, monkeypatch):
         wg.mpc_configure(wg.model_defaults())
 
 
+@pytest.mark.parametrize("N,B", [(16, 2600), (32, 3300)])
+def test_start_order_of_a_one_launch_tick_does_not_change_a_byte(N, B, monkeypatch):
+    """With more gaits than resident waves wg_mpc_tick_batch_dev starts the gaits longest-solve-first, by the iteration counts of
+    the previous call on the same state array (WG_TICK_LPT=0: index order).  States, diagnostics and outputs are the same bytes."""
+    wg.init(0)
+    model = wg.model_defaults(); model.N = N
+    wg.mpc_configure(model)
+    try:
+        rng = np.random.default_rng(N + B)
+        host = _start(model, B, rng)
+        adv = int(round(model.T / model.Tctrl))
+        osz = C.sizeof(wg.TickOut)
+        res = []
+        for lpt in ("0", "1"):
+            monkeypatch.setenv("WG_TICK_LPT", lpt)
+            st = _dev(host)
+            T = 5
+            dg = torch.zeros(T + 2, B, 6, dtype=torch.int32, device="cuda")
+            out = torch.zeros(T + 2, B, osz, dtype=torch.uint8, device="cuda")
+            for t, a in enumerate([1, adv - 1] + [adv] * T):
+                wg.mpc_tick_batch_dev(B, st.data_ptr(), out[t].data_ptr(), dg[t].data_ptr(), a)
+            torch.cuda.synchronize()
+            res.append((st, dg, out))
+        assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1]) and torch.equal(res[0][2], res[1][2])
+        assert int(res[0][1][:, :, 0].abs().sum()) == 0
+        its = res[1][1][2:, :, 1].cpu().numpy()
+        assert its.max() > its.min() + 5                               # there was something to order
+    finally:
+        wg.mpc_configure(wg.model_defaults())
+
+
 @pytest.mark.parametrize("N,B,T,period,queue", [(16, 700, 37, 10, "xcd"), (16, 2500, 23, 23, "xcd"), (16, 64, 9, 4, "global"),
                                               (32, 96, 11, 5, "xcd"), (32, 200, 9, 4, "xcd-abort")])
 def test_staged_references_equal_a_loop_of_set_velref_and_run(N, B, T, period, queue, monkeypatch):
