@@ -79,6 +79,12 @@ struct wg_ctx {
   wg_model_t *model_dev = nullptr;     // the model in device memory (the multi-tick kernels read it through a pointer)
   DevBuf tick_state, tick_out, tick_aux, run_buf, tick_z, asm_state;
   // one launch per tick: the gaits are started longest-solve-first, by the iteration counts of their previous tick
+  // dense ql0001_ boundary: wa | b of every QP in a slot of global memory when that buys the eighth QP per CU; one launch at a
+  // time uses the slots (a launch that arrives on another stream while one is pending keeps wa | b in LDS instead)
+  DevBuf qp_slot;
+  hipEvent_t qp_ev = nullptr;
+  hipStream_t qp_stream = nullptr;
+  bool qp_armed = false;
   DevBuf lpt_buf;                        // [iterations of the last tick (B) | start order (B)]
   const wg_gait_state_t *lpt_states = nullptr;
   int lpt_B = 0;
@@ -115,10 +121,12 @@ struct wg_ctx {
     if (prev_F) (void)hipFree(prev_F);
     tables_dev = nullptr; model_dev = nullptr; pldp_dev = nullptr; dim_dev = nullptr; prev_F = nullptr;
     model_set = false; pldp_N = 0; dim_set = false; prev_set = false;
-    for (DevBuf *b : {&tick_state, &tick_out, &tick_aux, &run_buf, &tick_z, &asm_state, &lpt_buf, &pldp_buf, &dim_buf, &prev_buf, &in, &out, &gram_buf, &zd_buf})
+    for (DevBuf *b : {&tick_state, &tick_out, &tick_aux, &run_buf, &tick_z, &asm_state, &lpt_buf, &qp_slot, &pldp_buf, &dim_buf, &prev_buf, &in, &out, &gram_buf, &zd_buf})
       b->release();
     if (guard_ev) (void)hipEventDestroy(guard_ev);
     guard_ev = nullptr; guard_armed = false;
+    if (qp_ev) (void)hipEventDestroy(qp_ev);
+    qp_ev = nullptr; qp_armed = false;
     lpt_states = nullptr; lpt_B = 0;
     if (pin_stream) (void)hipStreamDestroy(pin_stream);
     if (pin_flag) (void)hipHostFree(pin_flag);
@@ -188,7 +196,7 @@ int guard_mark(wg_ctx *ctx, hipStream_t st) {
 // Dense batched QP kernel: one wavefront (= one workgroup) per QP.
 // Replaces ql0001_ (qld.hh:27-31) for B problems at once.
 // ---------------------------------------------------------------------------
-template <bool kALds, bool kGLds>                          // where A / G live is known at compile time: ds_ or global_ accesses,
+template <bool kALds, bool kGLds, bool kWLds = true>       // where A / G / wa | b live is known at compile time: ds_ or global_ accesses,
 // Left to itself the compiler takes 256 VGPRs plus 3 AGPRs -- 259 registers, one wave per SIMD, four QPs per CU where the LDS
 // would admit five at n = 36, m = 75.  Forced to two waves per SIMD (-DWG_QLD_WPE=2: 256 registers, 2-3 spilled, 12-16 B of
 // scratch) it measured 5 % SLOWER on the Herdt workload's real QPs (1.73 against 1.82 M QPs/s, B = 4096): the fifth QP per CU
@@ -206,7 +214,7 @@ __global__ __launch_bounds__(64) WG_QLD_ATTR void wg_ql_dense_kernel(   // never
     const double *__restrict__ A, const double *__restrict__ bvec, const double *__restrict__ xl,
     const double *__restrict__ xu, double eps, double *__restrict__ x, double *__restrict__ u,
     int *__restrict__ ifail, int *__restrict__ n_iter, int *__restrict__ iact, int *__restrict__ nact,
-    int *__restrict__ hist, int hist_cap, int *__restrict__ hist_len) {
+    int *__restrict__ hist, int hist_cap, int *__restrict__ hist_len, double *__restrict__ wab_slots) {
   extern __shared__ __attribute__((aligned(16))) double wg_lds[];
   const int lane = threadIdx.x & 63;
   const int qp = blockIdx.x;                     // one QP per block (grid == B): nothing lane-dependent lives across QPs
@@ -214,9 +222,12 @@ __global__ __launch_bounds__(64) WG_QLD_ATTR void wg_ql_dense_kernel(   // never
     const int n = n_arr ? n_arr[qp] : nmax;
     const int m = m_arr ? m_arr[qp] : mmax - 1;
     const int me = me_arr ? me_arr[qp] : 0;
-    wg::QlDims D(n, m, m, true, kALds, 0, true, true, true, true, 0, kGLds);
+    wg::QlDims D(n, m, m, true, kALds, 0, true, true, kWLds, true, 0, kGLds);
     wg::QlView q;
-    q.carve(wg_lds, D, me);
+    // kWLds = false: the constraint weights wa (m + n) and b (m) -- read lane-parallel once per iteration -- live in this
+    // block's slot of global memory [wa (mmax + nmax) | b (mmax)]: 1.5 KB less LDS, the eighth QP on the CU at n = 36, m = 75
+    if constexpr (kWLds) q.carve(wg_lds, D, me);
+    else q.template carve<true, false, true>(wg_lds, D, me, wab_slots + (size_t)qp * (2 * (size_t)mmax + nmax), mmax + nmax);
 
     // ---- stage the problem into LDS (coalesced 8-byte lanes) ----
     const double *Cg = C + (size_t)qp * nmax * nmax;
@@ -370,21 +381,48 @@ int wg_qp_solve_batch_dev_ctx(wg_ctx_t *ctx, int B, int nmax, int mmax, const in
   if (!a_in_lds && lds_noa > 160 * 1024) g_in_lds = 0;
   lds = lds_for(a_in_lds, g_in_lds);
   if (lds > 160 * 1024) return fail(WG_ERR_TOO_LARGE, "QP (n=%d, m=%d) needs %zu B of LDS > 160 KiB", nmax, m_cap, lds);
+  hipStream_t st = reinterpret_cast<hipStream_t>(hip_stream);
+  // wa | b follow A and G out of the LDS when that buys one more resident QP (n = 36, m = 75: 21.7 -> 20.2 KB, the eighth QP
+  // of the CU -- a batch of 4096 is then exactly two rounds of the 2048 resident waves).  WG_QL_W_IN_LDS=0/1 forces either.
+  double *wab = nullptr;
+  if (!a_in_lds && !g_in_lds) {
+    const size_t lds_now = wg::QlDims(nmax, m_cap, m_cap, true, false, 0, true, true, false, true, 0, false).bytes();
+    auto gran_per_cu = [](size_t l) { const size_t k = 128 / ((l + 1279) / 1280); return k > 8 ? (size_t)8 : k; };
+    bool w_out = gran_per_cu(lds_now) > gran_per_cu(lds);
+    if (const char *e = getenv("WG_QL_W_IN_LDS")) w_out = atoi(e) == 0;
+    if (w_out) {
+      std::lock_guard<std::mutex> lk(ctx->z_mu);
+      const bool busy = ctx->qp_armed && ctx->qp_stream != st && hipEventQuery(ctx->qp_ev) == hipErrorNotReady;
+      if (!busy) {
+        if (int rc = ctx->qp_slot.reserve((size_t)B * (2 * (size_t)mmax + nmax) * 8)) return rc;
+        wab = static_cast<double *>(ctx->qp_slot.p);
+        lds = lds_now;
+      }
+    }
+  }
   const void *kfn = a_in_lds ? reinterpret_cast<const void *>(wg_ql_dense_kernel<true, true>)
                              : (g_in_lds ? reinterpret_cast<const void *>(wg_ql_dense_kernel<false, true>)
-                                         : reinterpret_cast<const void *>(wg_ql_dense_kernel<false, false>));
+                                         : (wab ? reinterpret_cast<const void *>(wg_ql_dense_kernel<false, false, false>)
+                                                : reinterpret_cast<const void *>(wg_ql_dense_kernel<false, false>)));
   if (lds > 64 * 1024) HIP_TRY(hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   const int grid = B;
-  hipStream_t st = reinterpret_cast<hipStream_t>(hip_stream);
   if (a_in_lds)
     hipLaunchKernelGGL((wg_ql_dense_kernel<true, true>), dim3(grid), dim3(64), lds, st, B, nmax, mmax, n, m, me, C, d, A, b,
-                       xl, xu, eps, x, u, ifail, n_iter, iact, nact, hist, hist_cap, hist_len);
+                       xl, xu, eps, x, u, ifail, n_iter, iact, nact, hist, hist_cap, hist_len, wab);
   else if (g_in_lds)
     hipLaunchKernelGGL((wg_ql_dense_kernel<false, true>), dim3(grid), dim3(64), lds, st, B, nmax, mmax, n, m, me, C, d, A, b,
-                       xl, xu, eps, x, u, ifail, n_iter, iact, nact, hist, hist_cap, hist_len);
-  else
+                       xl, xu, eps, x, u, ifail, n_iter, iact, nact, hist, hist_cap, hist_len, wab);
+  else if (!wab)
     hipLaunchKernelGGL((wg_ql_dense_kernel<false, false>), dim3(grid), dim3(64), lds, st, B, nmax, mmax, n, m, me, C, d, A, b,
-                       xl, xu, eps, x, u, ifail, n_iter, iact, nact, hist, hist_cap, hist_len);
+                       xl, xu, eps, x, u, ifail, n_iter, iact, nact, hist, hist_cap, hist_len, wab);
+  else {
+    hipLaunchKernelGGL((wg_ql_dense_kernel<false, false, false>), dim3(grid), dim3(64), lds, st, B, nmax, mmax, n, m, me, C, d, A, b,
+                       xl, xu, eps, x, u, ifail, n_iter, iact, nact, hist, hist_cap, hist_len, wab);
+    std::lock_guard<std::mutex> lk(ctx->z_mu);
+    if (!ctx->qp_ev) HIP_TRY(hipEventCreateWithFlags(&ctx->qp_ev, hipEventDisableTiming));
+    HIP_TRY(hipEventRecord(ctx->qp_ev, st));
+    ctx->qp_stream = st; ctx->qp_armed = true;
+  }
   HIP_TRY(hipGetLastError());
   return WG_OK;
 }

@@ -74,20 +74,22 @@ def test_herdt_shape_uniform_batch():
     assert not bad, bad[:5]
 
 
-@pytest.mark.parametrize("a_in_lds,g_in_lds", [("1", "1"), ("0", "1"), ("0", "0")])
-def test_matrices_in_lds_or_read_in_place(a_in_lds, g_in_lds, monkeypatch):
+@pytest.mark.parametrize("a_in_lds,g_in_lds,w_in_lds", [("1", "1", "1"), ("0", "1", "1"), ("0", "0", "1"), ("0", "0", "0")])
+def test_matrices_in_lds_or_read_in_place(a_in_lds, g_in_lds, w_in_lds, monkeypatch):
     """A is staged in LDS only while that does not cost a resident QP (Herdt-sized QPs read it in place, from L2), and G -- cold
-    once Z = R^-1 exists, its diagonal kept in LDS for ql0002's shift -- follows it out when that buys two more resident QPs;
+    once Z = R^-1 exists, its diagonal kept in LDS for ql0002's shift -- follows it out when that buys two more resident QPs,
+    the constraint weights wa | b (a slot of global memory per QP) when that buys the eighth;
     every placement is the same arithmetic and is held to the oracle, on Herdt-shaped QPs and on small dense ones, on QPs whose
     Hessian needs the diagonal shift (singular) and on the c(nmax, nmax) == 0 patch"""
     monkeypatch.setenv("WG_QL_A_IN_LDS", a_in_lds)
     monkeypatch.setenv("WG_QL_G_IN_LDS", g_in_lds)
+    monkeypatch.setenv("WG_QL_W_IN_LDS", w_in_lds)
     wg = _wg()
     qps = [qpgen.herdt_like(np.random.default_rng(4100 + s), 16, 2) for s in range(64)] + \
           [qpgen.random_pd(np.random.default_rng(4200 + s), 12, 9) for s in range(32)]
     pk = wg.pack_qps(qps)
     res = wg.qp_solve_batch(pk, hist_cap=512)
-    bad = _compare(qps, res, "a_in_lds=%s g_in_lds=%s" % (a_in_lds, g_in_lds), pk)
+    bad = _compare(qps, res, "a_in_lds=%s g_in_lds=%s w_in_lds=%s" % (a_in_lds, g_in_lds, w_in_lds), pk)
     assert not bad, bad[:5]
     for family in sorted(qpgen.FAMILIES):
         gen = qpgen.FAMILIES[family]
