@@ -173,7 +173,7 @@ __device__ void dimitrov_tick(const DimitrovConst &K, unsigned char *lds, const 
       W.b[idx] = (xk[0] * px[0] + xk[1] * px[1] + xk[2] * px[2]) * a0 + (xk[3] * px[0] + xk[4] * px[1] + xk[5] * px[2]) * a1 +
                  polys[i].B[j];
       const int sim = polys[i].similar[j];
-      W.similar[idx] = sim;
+      W.similar[idx] = (short)sim;
       W.state[idx] = 0;
       if (sim > 0 || idx + sim < 0) bad = true;
       W.c0[idx] = a0; W.c1[idx] = a1; W.slot[idx] = i;          // DPu(idx, k) = a0 Pu[k][i], DPu(idx, k+N) = a1 Pu[k][i]

@@ -38,7 +38,11 @@ struct PldpModel {               // device-resident constants (wg_pldp_configure
 struct PldpLds {
   double *A, *L, *b, *c, *d, *Vk, *v2, *tmp1;
   double *c0, *c1, *PuL;         // structured view: A(row, k) = c0[row] * Pu[k][slot[row]], A(row, k+N) = c1[row] * Pu[k][slot[row]]
-  int *similar, *act, *state;    // state[row]: 1 active, 0 not
+  // per-row marks in their narrowest types (similar: offset to an earlier row, -mcap < s <= 0; state: 1 active, 0 not, 2 pending):
+  // with ints the dense view took 10.9 KB at mcap = 128 -- nine LDS granules, 14 problems per CU; 10 240 B are eight, 16 per CU
+  short *similar;
+  int *act;
+  signed char *state;
   int *slot;
   int lda, cap, N;
   __host__ __device__ static int lda_for(int mcap) { return (mcap + 1) | 1; }
@@ -48,8 +52,8 @@ struct PldpLds {
     const size_t n = 2 * WG_PLDP_N;
     size_t dbl = (structured ? (size_t)2 * mcap + WG_PLDP_N * WG_PLDP_N : (a_lds ? (size_t)lda_for(mcap) * n : 0)) +
                  (size_t)cap * (cap + 1) / 2 + mcap /*b*/ + 3 * n /*c d Vk*/ + cap /*v2*/ + mcap /*tmp1*/;
-    size_t ints = (size_t)mcap /*similar*/ + cap /*act*/ + mcap /*state*/ + (structured ? mcap : 0) /*slot*/;
-    return dbl * 8 + ((ints * 4 + 7) & ~size_t(7));
+    size_t marks = (size_t)4 * cap /*act*/ + (structured ? (size_t)4 * mcap : 0) /*slot*/ + (size_t)2 * mcap /*similar*/ + mcap /*state*/;
+    return dbl * 8 + ((marks + 7) & ~size_t(7));
   }
   __device__ void carve(unsigned char *base, int mcap, int cap_ = WG_PLDP_ACTIVE_CAP, bool structured = false, int N_ = WG_PLDP_N,
                         bool a_lds = true) {
@@ -67,10 +71,10 @@ struct PldpLds {
     v2 = p; p += cap;
     tmp1 = p; p += mcap;
     int *q = reinterpret_cast<int *>(p);
-    similar = q; q += mcap;
     act = q; q += cap;
-    state = q; q += mcap;
-    if (structured) slot = q;
+    if (structured) { slot = q; q += mcap; }
+    similar = reinterpret_cast<short *>(q);
+    state = reinterpret_cast<signed char *>(similar + mcap);
   }
   // element (row, col) of the constraint matrix; ST selects the structured view at compile time.  The structured
   // product c * Pu is the very multiplication BuildConstraintMatrices performs (:893-905), so the value is identical.
@@ -316,7 +320,7 @@ __device__ __forceinline__ void pldp_problem(const PldpModel &M, unsigned char *
   bool bad = false;
   for (int li = lane; li < m; li += 64) {
     const int sim = similar[li];
-    W.similar[li] = sim;
+    W.similar[li] = (short)sim;
     W.state[li] = 0;
     W.b[li] = bvec[li];
     if (sim > 0 || li + sim < 0) bad = true;
