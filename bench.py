@@ -261,6 +261,9 @@ def config5_leg(dev, flags, ticks=40, warm=10):
                                      "gait-tick x this batch; FETCH_SIZE x 2 as calibrated on 8-byte lanes in this kernel's access "
                                      "shapes (%s)" % (os.path.relpath(PMC_SUMMARY, ROOT), e["command"], e["batch"], e["ticks_per_launch"],
                                                       e["calibration"])}
+        # the rate at which this kernel moves those bytes: what actually bounds it
+        traffic["traffic_gbs"] = traffic["traffic"] * ticks / kern_s / 1e9
+        traffic["traffic_frac_of_peak"] = traffic["traffic_gbs"] / HBM_PEAK_GBS
     except Exception:                                                      # noqa: BLE001 -- a missing profile is not fatal
         pass
     return {"value": B * ticks / wall, "unit": "ticks/s", "batch": B, "horizon_N": 32, "steps": ticks, "warmup": warm,
