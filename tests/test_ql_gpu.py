@@ -100,6 +100,33 @@ def test_matrices_in_lds_or_read_in_place(a_in_lds, g_in_lds, w_in_lds, monkeypa
         assert not bad, (family, bad[:5])
 
 
+def test_two_streams_share_one_context(monkeypatch):
+    """Herdt-sized QPs keep wa | b in a slot of global memory per QP (a buffer of the context): a launch that arrives on another
+    stream while the slots are in use takes the placement with wa | b in LDS instead -- both batches solve to the oracle's
+    bytes (here: the same problems on two streams at once give the same answers as one after the other)."""
+    import torch
+    wg = _wg()
+    qps = [qpgen.herdt_like(np.random.default_rng(31000 + s), 16, 2) for s in range(3000)]
+    pk = wg.pack_qps(qps)
+    ref = wg.qp_solve_batch(pk, hist_cap=64)
+    B, nmax, mmax = pk["B"], pk["nmax"], pk["mmax"]
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    dev_in = {k: t(pk[k]) for k in ("n", "m", "me", "C", "d", "A", "b", "xl", "xu")}
+    outs = []
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    torch.cuda.synchronize()
+    for st in streams:
+        x = torch.zeros(B, nmax, dtype=torch.float64, device="cuda"); u = torch.zeros(B, mmax + 2 * nmax, dtype=torch.float64, device="cuda")
+        ifail = torch.full((B,), -99, dtype=torch.int32, device="cuda"); nit = torch.zeros(B, dtype=torch.int32, device="cuda")
+        wg.qp_solve_batch_dev(B, nmax, mmax, dev_in["n"], dev_in["m"], dev_in["me"], dev_in["C"], dev_in["d"], dev_in["A"], dev_in["b"],
+                              dev_in["xl"], dev_in["xu"], 1e-8, x, u, ifail, nit, stream=st.cuda_stream)
+        outs.append((x, u, ifail, nit))
+    torch.cuda.synchronize()
+    for x, u, ifail, nit in outs:
+        assert np.array_equal(x.cpu().numpy(), ref["x"]) and np.array_equal(u.cpu().numpy(), ref["u"])
+        assert np.array_equal(ifail.cpu().numpy(), ref["ifail"]) and np.array_equal(nit.cpu().numpy(), ref["n_iter"])
+
+
 @pytest.mark.parametrize("log2_scale", [0, 380, 450, -380, -450])
 def test_sweep_norm_range_guard(log2_scale):
     """The sweep's norm chain takes a shorter instruction sequence when every operand is zero or within [2^-400, 2^400]
