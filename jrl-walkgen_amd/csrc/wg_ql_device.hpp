@@ -386,7 +386,14 @@ __device__ __forceinline__ double givens_norm_fast(double p, double qq) {
 }
 // every entry of s[lo, hi) is zero or has its magnitude in [2^-400, 2^400] (then every norm of a sweep over them, being at
 // least its larger operand and at most sqrt(n) times the largest entry, is zero or in [2^-400, 2^404]); wave-uniform
+template <bool kOnePass = false>                          // kOnePass: hi - lo <= 64 (the caller's n <= 64)
 __device__ __forceinline__ bool sweep_range_ok(const double *s, int lo, int hi, int lane) {
+  if constexpr (kOnePass) {                                 // one entry per lane: no lane-dependent loop, no exec-mask juggling
+    const int j = lo + lane;
+    const bool in = j < hi;
+    const double v = fabs(s[in ? j : lo]);
+    return __ballot(in && !(v == 0.0 || (v >= 0x1p-400 && v <= 0x1p400))) == 0ull;
+  }
   bool bad = false;
   for (int j = lo + lane; j < hi; j += 64) {
     const double v = fabs(s[j]);
@@ -529,7 +536,10 @@ __device__ __forceinline__ void bs_row(const QlView &q, double *buf, int j, BsSt
   // was fetched one row ahead, and a wave's LDS operations execute in order (the barrier only pins the compiler)
   {
     const double val = (lane >= j + 1 && S.mine) ? S.rr * S.w : 0.0;
-    if (lane < kBsLen) bn[lane] = val;
+    // no exec-mask juggling on the chain's path: lanes past the buffer hold +0.0 (they are beyond nact) and write it to the
+    // last slot, which is +0.0 anyway (kBsLen >= nact + 12)
+    if constexpr (kBsLen <= 64) bn[lane < kBsLen ? lane : kBsLen - 1] = val;
+    else bn[lane] = val;
     S.rr = Rp(jnn, S.col);
   }
   __builtin_amdgcn_wave_barrier();
@@ -623,7 +633,7 @@ __device__ __forceinline__ void sweep_flat(const QlView &q, double *s, int nu, i
   // givens_norm runs unguarded on q == 0: its result (|p|, or NaN for 0/0) is discarded by the select.
   double *chain = q.sc2;                                    // nu <= n entries
   WG_REP(3)
-  if (sweep_range_ok(s, nact, nu, lane)) {
+  if (sweep_range_ok<true>(s, nact, nu, lane)) {
     // the usual case: the shorter norm; unrolled by two so that handing the prefetched operand on is a renaming
     double cur = s[nu - 1];
     double pa = s[nu - 2], pb;
@@ -741,9 +751,18 @@ __device__ __forceinline__ void sweep_flat(const QlView &q, double *s, int nu, i
 }
 
 // qld.cpp:1861-1889.  Returns kdrop (0-based) or -1; ratio updated when found.
+template <bool kOnePass = false>                          // kOnePass: nact <= 64 known at compile time (n <= 64)
 __device__ __forceinline__ int pick_drop(const QlView &q, int nact, double res, double &ratio, int lane) {
   double best = 0.0, bestt = 0.0;
   int bidx = -1;
+  if constexpr (kOnePass) {                                 // one multiplier per lane: selects instead of a lane-dependent loop
+    const bool in = lane < nact;
+    const int kc = in ? lane : 0;
+    const double w = q.ww[kc];
+    const bool cand = in && q.iact[kc] > q.me && !(res * w >= 0.0);
+    const double temp = q.lam[kc] / w;
+    best = cand ? -fabs(temp) : 0.0; bestt = cand ? temp : 0.0; bidx = cand ? lane : -1;
+  } else
   for (int k = lane; k < nact; k += 64) {
     if (q.iact[k] <= q.me) continue;
     double w = q.ww[k];
@@ -1548,6 +1567,16 @@ __device__ __forceinline__ QlResult ql_solve(const QlView &q, P &prob, double vs
         bestv = sumx; bestres = sum; bidx = k + 1;
       }
       }
+      if constexpr (P::kNM > 0) {                            // n <= 64: one bound pair per lane, selects instead of continues
+        const bool in = lane < n;
+        const int kc = in ? lane : n - 1;
+        const double w = q.wa[m + kc], xk = q.x[kc];
+        const double s1 = prob.xl(q, kc) - xk;
+        const bool upper = s1 < 0.0;
+        const double sum = upper ? xk - prob.xu(q, kc) : s1;
+        const bool take = in && !(w <= 0.0) && !(s1 == 0.0) && !(sum <= 0.0) && !(bidx >= 0 && sum <= bestv);
+        bestv = take ? sum : bestv; bestres = take ? -sum : bestres; bidx = take ? (upper ? kc + 1 + mn : kc + 1 + m) : bidx;
+      } else
       for (int k = lane; k < n; k += 64) {
         if (q.wa[m + k] <= 0.0) continue;
         bool lower = true;
@@ -1626,7 +1655,8 @@ __device__ __forceinline__ QlResult ql_solve(const QlView &q, P &prob, double vs
       s = q.R + nact * (nact + 1) / 2;
       WG_REP(2)
       if (knext <= m) {
-        for (int i = lane; i < n; i += 64) q.ww[i] = Am(knext - 1, i);
+        if constexpr (P::kCompact) prob.fill_row(q, knext - 1, q.ww, lane);
+        else for (int i = lane; i < n; i += 64) q.ww[i] = Am(knext - 1, i);
         WG_WSYNC();
         if constexpr (P::kCompact) prob.zt_row(q, s, knext - 1, lane);
         else zt_times_ww<P::kNM, (P::kRowOps ? WG_ELEM_GRP : 8)>(q, s, lane);
@@ -1722,7 +1752,7 @@ __device__ __forceinline__ QlResult ql_solve(const QlView &q, P &prob, double vs
       if (route != 0) PT_COUNT(30);
       if (route != 0) {
         if (route == 1) WG_BACKSUB(q, s, nact, lane);
-        kdrop = pick_drop(q, nact, res, ratio, lane);
+        kdrop = pick_drop<(P::kNM > 0)>(q, nact, res, ratio, lane);
         info = -knext;                                      // :1663
         if (kdrop < 0) { st = ST_CONVERGED; continue; }
         parinc = ratio;
@@ -1741,7 +1771,7 @@ __device__ __forceinline__ QlResult ql_solve(const QlView &q, P &prob, double vs
             PT(14);
             WG_REP(4) WG_BACKSUB(q, s, nact, lane);
             PT(15);
-            WG_REP(7) { kdrop = pick_drop(q, nact, res, ratio, lane); WG_SINK(kdrop); WG_SINK(ratio); }
+            WG_REP(7) { kdrop = pick_drop<(P::kNM > 0)>(q, nact, res, ratio, lane); WG_SINK(kdrop); WG_SINK(ratio); }
             PT(16);
             if (kdrop >= 0) {                               // :1734-1743
               double temp = 1.0 - ratio / parinc;

@@ -305,6 +305,41 @@ struct HerdtProb {
     return 0.0 + (0.0 + b * V_f[kk * kSMaxQ + j]) * -1.0;
   }
 
+  // dst[i] = A(k, i) for i < n, lane i its own entry (k wave-uniform): the element access above without a lane-dependent branch
+  // (every lane-dependent `if` in a loop of the solver costs an exec-mask save / branch / restore, ~27 cycles on the spot).  The
+  // same expressions on the same operands, chosen by selects; lanes past n shadow lane n - 1 (same address, same value).
+  __device__ __forceinline__ void fill_row(const QlView &q, int k, double *dst, int lane) const {
+    const int n = q.n;
+    const int i = lane < n ? lane : n - 1;
+    k = uni(k);
+    if (k == 0) { dst[i] = 0.0; return; }
+    const bool cop = k <= 4 * NH;
+    const int src = cop ? k - 1 : k - 1 - 4 * NH;
+    const double a = cop ? rl(ra, src) : rl(ga, src), b = cop ? rl(rb, src) : rl(gb, src);
+    const int kk = cop ? (k - 1) >> 2 : __builtin_amdgcn_readlane(gk, src);
+    const bool jerk = i < 2 * NH, xpart = i < NH;
+    const int jf = jerk ? 0 : i - 2 * NH;                    // foot-variable index 0 .. 2 ns - 1
+    const bool second = jf >= ns;                            // its y half
+    const int jj = second ? jf - ns : jf;
+    double val;
+    if (cop) {
+      const int r = kk;
+      const int c = xpart ? i : (jerk ? i - NH : 0);
+      const bool low = c <= r;
+      const double uu = u[low ? r - c : 0];
+      const double jv = low ? 0.0 + (0.0 + (xpart ? a : b) * uu) * -1.0 : 0.0;
+      const double v = (stepidx[r] == jj + 1) ? 1.0 : 0.0;
+      const double fv = 0.0 + (0.0 + (second ? b : a) * v) * 1.0;
+      val = jerk ? jv : fv;
+    } else {
+      const int kc = kk < 0 ? 0 : kk;
+      const double vf = V_f[kc * kSMaxQ + jj];
+      const double fv = 0.0 + (0.0 + (second ? b : a) * vf) * -1.0;
+      val = (kk < 0 || jerk) ? 0.0 : fv;
+    }
+    dst[i] = val;
+  }
+
   // ------------------------------------------------------------------ per-lane rows into registers
   __device__ __forceinline__ void load_rows(int lane, const double *bvec) {
     bcop = bvec[lane + 1];
