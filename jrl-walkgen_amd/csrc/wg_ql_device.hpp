@@ -572,9 +572,17 @@ template <int kBsLen = 48>                                  // nact <= 64 (one m
 __device__ __forceinline__ void backsub_lds(const QlView &q, const double *s, int nact, int lane, double *buf) {
   BsState S;
   S.mine = lane < nact; S.nact = nact; S.lane = lane;
-  S.sreg = S.mine ? s[lane] : 0.0;
-  S.dreg = S.mine ? Rp(lane, lane) : 1.0;
-  if constexpr (kBsLen <= 64) { if (lane < kBsLen) { buf[lane] = 0.0; buf[kBsLen + lane] = 0.0; } }
+  if constexpr (kBsLen <= 64) {
+    // loads from clamped addresses and selects: a load under a lane-dependent condition is an exec-mask save / restore
+    const int ml = S.mine ? lane : 0;
+    const double sv = s[ml], dv = Rp(ml, ml);
+    S.sreg = S.mine ? sv : 0.0;
+    S.dreg = S.mine ? dv : 1.0;
+  } else {                                                  // the 168-register kernels (N = 32) keep the predicated form: measured
+    S.sreg = S.mine ? s[lane] : 0.0;
+    S.dreg = S.mine ? Rp(lane, lane) : 1.0;
+  }
+  if constexpr (kBsLen <= 64) { const int zl = lane < kBsLen ? lane : kBsLen - 1; buf[zl] = 0.0; buf[kBsLen + zl] = 0.0; }
   else { for (int e = lane; e < kBsLen; e += 64) { buf[e] = 0.0; buf[kBsLen + e] = 0.0; } }
   S.col = S.mine ? lane : 0;
   S.w = 0.0; S.wprev = 0.0;
@@ -583,7 +591,12 @@ __device__ __forceinline__ void backsub_lds(const QlView &q, const double *s, in
   int j = nact - 1;
   for (; j >= 1; j -= 2) { bs_row<kBsLen>(q, buf, j, S, A9, B9); bs_row<kBsLen>(q, buf, j - 1, S, B9, A9); }
   if (j == 0) bs_row<kBsLen>(q, buf, 0, S, A9, B9);
-  if (S.mine) q.ww[lane] = S.w;
+  if constexpr (kBsLen <= 64) {
+    if (nact > 0) {                                         // lanes past nact shadow lane nact - 1: its value to its address
+      const double wl = rl(S.w, nact - 1);
+      q.ww[S.mine ? lane : nact - 1] = S.mine ? S.w : wl;
+    }
+  } else if (S.mine) q.ww[lane] = S.w;
   WG_WSYNC();
 }
 
@@ -601,7 +614,11 @@ __device__ __forceinline__ void backsub_lds(const QlView &q, const double *s, in
 constexpr int kOsChunk = WG_OS_CHUNK;
 template <int NM>
 __device__ __forceinline__ double ordered_sum_lds(double term, double *scratch, int cnt, int lane) {
-  if (lane < NM) scratch[lane] = (lane < cnt) ? term : 0.0;
+  {
+    const double v = (lane < cnt) ? term : 0.0;
+    const double vl = rl(v, NM - 1);                        // lanes past NM shadow lane NM - 1
+    scratch[lane < NM ? lane : NM - 1] = lane < NM ? v : vl;
+  }
   WG_WSYNC();
   // loads in groups of kOsChunk ahead of the add chain: enough to cover the LDS latency, few enough live registers
   double sum = 0.0;
@@ -677,7 +694,8 @@ __device__ __forceinline__ void sweep_flat(const QlView &q, double *s, int nu, i
     const int c = mine ? lane : nu - 1;
     myP = s[c - 1];
     myQ = (c == nu - 1) ? s[nu - 1] : chain[c];
-    myN = (myQ == 0.0) ? 0.0 : chain[c - 1];
+    const double chl = chain[c - 1];
+    myN = (myQ == 0.0) ? 0.0 : chl;
   }
   WG_WSYNC();
   double *gab = q.sc0;                                      // pairs {ga, gb}; sc0 and sc1 are adjacent (2n doubles)
@@ -691,7 +709,8 @@ __device__ __forceinline__ void sweep_flat(const QlView &q, double *s, int nu, i
     // a skipped rotation is rare: when the sweep has none -- one ballot -- phase 3 runs without the selects
     any_skip = __ballot(mine && gb == 0.0) != 0ull;
     const int cl = mine ? lane : nu - 1;                    // lanes without a rotation shadow lane nu-1 ... with ITS values
-    const double ga_w = mine ? ga : rl(ga, nu - 1), gb_w = mine ? gb : rl(gb, nu - 1);
+    const double ga_l = rl(ga, nu - 1), gb_l = rl(gb, nu - 1);
+    const double ga_w = mine ? ga : ga_l, gb_w = mine ? gb : gb_l;
     gab[2 * cl] = ga_w; gab[2 * cl + 1] = gb_w;
     if (rot) s[lane - 1] = myN;
   }
@@ -759,7 +778,8 @@ __device__ __forceinline__ int pick_drop(const QlView &q, int nact, double res, 
     const bool in = lane < nact;
     const int kc = in ? lane : 0;
     const double w = q.ww[kc];
-    const bool cand = in && q.iact[kc] > q.me && !(res * w >= 0.0);
+    const int ia = q.iact[kc];
+    const bool cand = in & (ia > q.me) & !(res * w >= 0.0);
     const double temp = q.lam[kc] / w;
     best = cand ? -fabs(temp) : 0.0; bestt = cand ? temp : 0.0; bidx = cand ? lane : -1;
   } else
@@ -786,8 +806,9 @@ template <class P>
 __device__ __forceinline__ double xmag_sum(const QlView &q, const P &prob, double vfact, int lane) {
   const int n = q.n;
   if constexpr (P::kNM > 0) {
-    double term = 0.0;
-    if (lane < n) { const double xi = q.x[lane]; term = fabs(xi) * vfact * (fabs(q.d[lane]) + fabs(prob.Gd(q, lane) * xi)); }
+    const int il = lane < n ? lane : n - 1;                 // surplus lanes compute lane n - 1's term and drop it
+    const double xi = q.x[il];
+    const double term = fabs(xi) * vfact * (fabs(q.d[il]) + fabs(prob.Gd(q, il) * xi));
     return ordered_sum_lds<P::kNM>(term, q.sc3, n, lane);
   }
   for (int i = lane; i < n; i += 64) {
@@ -1450,24 +1471,26 @@ __device__ __forceinline__ QlResult ql_solve(const QlView &q, P &prob, double vs
             t = q.x[2 * NH + prob.ns + prob.fj] * prob.fb; sum += t; asum += fabs(t);
           }
           const double sumx = -sum * wak;
-          if (wak > 0.0 && !(sumx <= 0.0)) {
+          {                                           // the reference's tests in its order, as one predicate and three selects
             const double tempa = asum + fabs(sum);
             const double temp2 = asum + onha * fabs(sum);
-            if (!(tempa <= asum) && !(temp2 <= tempa)) { bestv = sumx; bestres = sum; bidx = k + 1; }
+            const bool take = (wak > 0.0) & !(sumx <= 0.0) & !(tempa <= asum) & !(temp2 <= tempa);
+            bestv = take ? sumx : bestv; bestres = take ? sum : bestres; bidx = take ? k + 1 : bidx;
           }
         }
-        if (has_foot) {
-          const int k = kf;                           // the lane's foot-placement row
+        {
+          // the lane's foot-placement row; lanes without one walk the all-zero dummy row 0 (weight 0: never a candidate) on
+          // valid columns with zero coefficients
+          const int k = kf;
           const double wak = wakf, bk = bkf;
           double sum = -bk, asum = fabs(bk);
 #pragma unroll
           for (int e = 0; e < 4; ++e) { const double t = q.x[prob.f2c[e]] * prob.f2v[e]; sum += t; asum += fabs(t); }
           const double sumx = -sum * wak;
-          if (wak > 0.0 && !(sumx <= 0.0) && !(bidx >= 0 && sumx <= bestv)) {
-            const double tempa = asum + fabs(sum);
-            const double temp2 = asum + onha * fabs(sum);
-            if (!(tempa <= asum) && !(temp2 <= tempa)) { bestv = sumx; bestres = sum; bidx = k + 1; }
-          }
+          const double tempa = asum + fabs(sum);
+          const double temp2 = asum + onha * fabs(sum);
+          const bool take = has_foot & (wak > 0.0) & !(sumx <= 0.0) & !((bidx >= 0) & (sumx <= bestv)) & !(tempa <= asum) & !(temp2 <= tempa);
+          bestv = take ? sumx : bestv; bestres = take ? sum : bestres; bidx = take ? k + 1 : bidx;
         }
       } else {
       if constexpr (P::kRowOps) {
@@ -1779,12 +1802,24 @@ __device__ __forceinline__ QlResult ql_solve(const QlView &q, P &prob, double vs
               else { step = ratio * sumy; parinc = ratio; res = temp * res; }
             }
           }
-          for (int i = lane; i < n; i += 64) q.x[i] += step * Zm(i, nact);   // :1749-1755
+          if constexpr (P::kNM > 0) {                       // :1749-1755; surplus lanes shadow lane n - 1 (same address, same value)
+            const int il = lane < n ? lane : n - 1;
+            q.x[il] = q.x[il] + step * Zm(il, nact);
+          } else
+          for (int i = lane; i < n; i += 64) q.x[i] += step * Zm(i, nact);
           parnew += parinc;
           WG_WSYNC();
           if (nact < 1) break;
         }
         dual_only = false;
+        if constexpr (P::kNM > 0) {                         // :1677-1687; surplus lanes shadow lane nact - 1
+          if (nact > 0) {
+            const int kl = lane < nact ? lane : nact - 1;
+            const double l0 = q.lam[kl] - parinc * q.ww[kl];
+            const int ia = q.iact[kl];
+            q.lam[kl] = (ia > me) ? maxd(0.0, l0) : l0;
+          }
+        } else
         for (int k = lane; k < nact; k += 64) {             // :1677-1687
           double l = q.lam[k] - parinc * q.ww[k];
           if (q.iact[k] > me) l = maxd(0.0, l);
