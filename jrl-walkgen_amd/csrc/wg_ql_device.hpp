@@ -526,7 +526,10 @@ __device__ __forceinline__ void backsub(const QlView &q, const double *s, int na
 // one row of backsub_lds: P = {terms k = j+2 .. j+9, R(j, j+1)} prefetched by the previous row, Nx receives the same for
 // row j-1.  Two copies of this body with P / Nx swapped make the hand-over a renaming instead of nine register moves.
 struct BsState { double w, wprev, rr, sreg, dreg; int col, nact, lane; bool mine; };
-template <int kBsLen>                                       // length of each of the two product buffers (>= nact + 12)
+// kHead: what is known about the row's length at compile time (the rows go from the bottom up, so the r-th row from the bottom has
+// r terms): -1 nothing (three uniform branches per row), 0 no term, 4 / 8 at most so many (the prefetched head only: entries
+// past the row are +0.0), 9 more than eight (head and tail loop, no test) -- backsub_lds unrolls the first nine rows that way
+template <int kBsLen, int kHead = -1>                       // kBsLen: length of each of the two product buffers (>= nact + 12)
 __device__ __forceinline__ void bs_row(const QlView &q, double *buf, int j, BsState &S, const double (&P)[9], double (&Nx)[9]) {
   const double *bj = buf + (j & 1) * kBsLen;
   double *bn = buf + ((j & 1) ^ 1) * kBsLen;
@@ -548,6 +551,21 @@ __device__ __forceinline__ void bs_row(const QlView &q, double *buf, int j, BsSt
   Nx[8] = Rp(jn, jn + 1);
   const double sj = rl(S.sreg, j), dj = rl(S.dreg, j);
   double sum = 0.0;
+  if constexpr (kHead >= 4) {
+    sum += P[8] * S.wprev;
+    sum += P[0]; sum += P[1]; sum += P[2]; sum += P[3];
+    if constexpr (kHead >= 8) { sum += P[4]; sum += P[5]; sum += P[6]; sum += P[7]; }
+    if constexpr (kHead >= 9) {
+      double a0 = bj[j + 10], a1 = bj[j + 11], a2 = bj[j + 12], a3 = bj[j + 13];
+      for (int k = j + 10; k < nact; k += 4) {
+        const int kn = k + 4 < kBsLen - 4 ? k + 4 : kBsLen - 4;                    // clamped: unused past the end
+        const double b0 = bj[kn], b1 = bj[kn + 1], b2 = bj[kn + 2], b3 = bj[kn + 3];
+        sum += a0; sum += a1; sum += a2; sum += a3;
+        a0 = b0; a1 = b1; a2 = b2; a3 = b3;
+      }
+    }
+  } else if constexpr (kHead == 0) {
+  } else
   if (j + 1 < nact) {
     sum += P[8] * S.wprev;
     sum += P[0]; sum += P[1]; sum += P[2]; sum += P[3];
@@ -589,8 +607,24 @@ __device__ __forceinline__ void backsub_lds(const QlView &q, const double *s, in
   S.rr = Rp(nact >= 2 ? nact - 2 : 0, S.col);               // R(j-1, lane) of the row whose products are formed next
   double A9[9] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0}, B9[9];
   int j = nact - 1;
-  for (; j >= 1; j -= 2) { bs_row<kBsLen>(q, buf, j, S, A9, B9); bs_row<kBsLen>(q, buf, j - 1, S, B9, A9); }
-  if (j == 0) bs_row<kBsLen>(q, buf, 0, S, A9, B9);
+  if constexpr (kBsLen <= 64) {
+    // the first nine rows unrolled with their lengths known (one uniform test per row instead of three), the rest in pairs
+    if (nact > 0) { bs_row<kBsLen, 0>(q, buf, nact - 1, S, A9, B9);
+    if (nact > 1) { bs_row<kBsLen, 4>(q, buf, nact - 2, S, B9, A9);
+    if (nact > 2) { bs_row<kBsLen, 4>(q, buf, nact - 3, S, A9, B9);
+    if (nact > 3) { bs_row<kBsLen, 4>(q, buf, nact - 4, S, B9, A9);
+    if (nact > 4) { bs_row<kBsLen, 4>(q, buf, nact - 5, S, A9, B9);
+    if (nact > 5) { bs_row<kBsLen, 8>(q, buf, nact - 6, S, B9, A9);
+    if (nact > 6) { bs_row<kBsLen, 8>(q, buf, nact - 7, S, A9, B9);
+    if (nact > 7) { bs_row<kBsLen, 8>(q, buf, nact - 8, S, B9, A9);
+    if (nact > 8) { bs_row<kBsLen, 8>(q, buf, nact - 9, S, A9, B9);
+      for (j = nact - 10; j >= 1; j -= 2) { bs_row<kBsLen, 9>(q, buf, j, S, B9, A9); bs_row<kBsLen, 9>(q, buf, j - 1, S, A9, B9); }
+      if (j == 0) bs_row<kBsLen, 9>(q, buf, 0, S, B9, A9);
+    }}}}}}}}}
+  } else {
+    for (; j >= 1; j -= 2) { bs_row<kBsLen>(q, buf, j, S, A9, B9); bs_row<kBsLen>(q, buf, j - 1, S, B9, A9); }
+    if (j == 0) bs_row<kBsLen>(q, buf, 0, S, A9, B9);
+  }
   if constexpr (kBsLen <= 64) {
     if (nact > 0) {                                         // lanes past nact shadow lane nact - 1: its value to its address
       const double wl = rl(S.w, nact - 1);
