@@ -619,9 +619,14 @@ struct HerdtProb {
         // entries of the row beyond its instant are exact zeros: their products leave acc unchanged, so the
         // loops can run the full static length.  Loads are issued in groups of kZtChunk ahead of the add chain (left to
         // itself the register-limited build waits for every pair of loads: 16 LDS round trips instead of 4).
+        // A CoP row of instant r has its entries in columns 0 .. r and NH .. NH + r: a chunk that lies wholly beyond r holds
+        // nothing but exact zeros (their products are +-0, and acc -- started from +0.0 -- is never -0.0: adding them changes
+        // nothing), so it is skipped: one wave-uniform test per chunk, a quarter of the chunks on average
         constexpr int kZtChunk = 8;
+        const int r = (rk - 1) >> 2;
 #pragma unroll
         for (int j0 = 0; j0 < 2 * NH; j0 += kZtChunk) {
+          if ((j0 < NH ? j0 : j0 - NH) > r) continue;
           double zz[kZtChunk], wv[kZtChunk];
 #pragma unroll
           for (int c = 0; c < kZtChunk; ++c) { zz[c] = zc[j0 + c]; wv[c] = q.ww[j0 + c]; }
