@@ -89,7 +89,12 @@ def soak(N, B, n_ticks, workers):
 if __name__ == "__main__":
     wg.init(0)
     workers = min(os.cpu_count() or 8, 64)
-    bad = soak(16, 4096, 250, workers)
+    # SOAK_LONG=1: four times the ticks at N = 16 and other horizons through the element view as well
+    long_run = os.environ.get("SOAK_LONG") == "1"
+    bad = soak(16, 4096, 1000 if long_run else 250, workers)
     bad += soak(32, 8192, 50, workers)
+    if long_run:
+        for N, B, T in ((20, 2048, 100), (24, 2048, 80), (28, 2048, 60)):
+            bad += soak(N, B, T, workers)
     print("soak parity: %s" % ("PASS (bit-identical)" if bad == 0 else "FAIL"))
     sys.exit(1 if bad else 0)
