@@ -152,6 +152,7 @@ Everything named `{tag}_*` was produced by ONE run of `tools/prof_round.sh` on a
 | `{tag}_dimitrov_*`, `{tag}_pldp_*`, `{tag}_preview_*`, `{tag}_zmpdisc_*` | `tools/probe_<name>.py` | the other kernels of the path |
 | `{tag}_tick_phase_timers.txt`, `{tag}_tick32_phase_timers.txt` | `PB=4096 python3 tools/probe_tick_phases.py`, `PN=32 PB=3072 ...` (diagnostic build `lib/libwg_mpc_prof.so`) | in-kernel phase timers of the tick at N = 16 and N = 32 (shader cycles per gait-tick, one launch per tick) |
 | `{tag}_soak_parity.txt` | `python tools/soak_parity.py` | every gait of the benchmark workload (4096 x 250 ticks at N = 16, 8192 x 50 at N = 32) advanced as `bench.py` does it, final states byte for byte against the CPU checker on the host cores |
+| `{tag}_soak_parity_long.txt` | `SOAK_LONG=1 python tools/soak_parity.py` | the same at four times the length (4096 x 1000 ticks at N = 16) and through the element view at N = 20, 24, 28, 32: 5.0 M MPC ticks byte for byte |
 | `current_tick_pmc.json` | derived from `{tag}_tick_*`, `{tag}_tickg_*`, `{tag}_pertick_*` | per gait-tick: HBM bytes read / written (FETCH_SIZE x 2 and WRITE_SIZE, KiB units, separate passes), VALU / SALU / LDS / VMEM instructions, VALU busy; `bench.py` scales `roofline.traffic` and its second axis from this file |
 
 {agree}
