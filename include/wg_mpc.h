@@ -32,7 +32,7 @@ extern "C" {
 #define WG_ERR_BAD_ARG (-2)
 #define WG_ERR_HIP (-3)
 #define WG_ERR_TOO_LARGE (-4)
-#define WG_ERR_BUSY (-5)      /* a launch of the same context is still in flight on another stream */
+#define WG_ERR_BUSY (-5)      /* WG_OVERLAP_STRICT=1 only: a launch of the same context is still in flight on another stream */
 
 /* Library / device management ------------------------------------------- */
 
@@ -255,6 +255,10 @@ void wg_gait_init(const wg_model_t *model, wg_gait_state_t *state,
  * the host in the reference's exact summation order -- so that the per-tick QPs are bit-identical to the
  * reference's -- and uploaded once. */
 int wg_mpc_configure(const wg_model_t *model);
+/* Optional: allocate the tick / run kernels' per-block solver slots and work queue for fleets of up to max_gaits now.  Without
+ * it every launch sizes them for its own grid (a one-robot caller pays for one slot, not for a fleet's; growing never frees
+ * what a launch in flight may be using). */
+int wg_mpc_reserve(int max_gaits);
 
 /* One MPC tick for each of B gaits (replaces B calls of ZMPVelocityReferencedQP::OnLine with
  * time + 1e-5 > UpperTimeLimitToUpdate_, ZMPVelocityReferencedQP.cpp:346-452).
@@ -265,10 +269,13 @@ int wg_mpc_configure(const wg_model_t *model);
  *   diag    B x 6 ints {ifail, n_iter, nact, n, m, nb_prw_steps} or NULL
  *   hist    B x hist_cap active-set add(+)/drop(-) log or NULL, hist_len B or NULL
  * The kernels keep a few solver arrays per block in a buffer of the context (what does not fit the CU's LDS at the
- * residency they run at): launches of the tick / run entry points ON ONE CONTEXT must not overlap -- one stream, or events
- * between streams; overlapping streams take one context each (wg_ctx_create).  The library checks this: a launch that arrives
- * on a different stream while the context's previous tick / run launch has not completed returns WG_ERR_BUSY and launches
- * nothing.
+ * residency they run at), so launches of the tick / run entry points ON ONE CONTEXT do not overlap on the device.  The library
+ * sees to that itself: a launch that arrives on a different stream while the context's previous tick / run launch has not
+ * completed is enqueued BEHIND it (hipStreamWaitEvent on an event the previous launch left) -- a pipeline that orders its
+ * streams with events of its own is accepted as it is, an unordered one is serialised instead of corrupted.  Streams that
+ * are meant to overlap take one context each (wg_ctx_create).  With WG_OVERLAP_STRICT=1 in the environment such a launch is
+ * refused instead (WG_ERR_BUSY, nothing launched): a way to find serialisation that was not intended.  The ordering test, the
+ * launch and the event record are one critical section per context (host threads may share a context).
  * With more gaits than the device keeps resident, a call that follows another one on the same `states` array starts the gaits
  * in the order of decreasing QL iteration count of that previous tick (scheduling only: no result depends on it). */
 int wg_mpc_tick_batch(int B, wg_gait_state_t *states, wg_tick_out_t *outs, int *diag, int advance_calls,
@@ -300,8 +307,8 @@ int wg_mpc_set_velref_dev(int B, wg_gait_state_t *states, const double *vref, vo
  * 0.1 s of walking): the same tick with the caller's state, outputs and diagnostics in HOST-MAPPED memory from
  * wg_host_alloc.  No staging copies and no device synchronisation: the kernel reads the state over the bus, works on a device
  * copy, writes state / out / diag back and releases a completion counter the call spins on.  Same bytes as
- * wg_mpc_tick_batch(1, ...); out and diag may be NULL.  Runs on a stream of the context; it must not overlap other tick / run
- * launches of the same context (WG_ERR_BUSY). */
+ * wg_mpc_tick_batch(1, ...); out and diag may be NULL.  Runs on a stream of the context, ordered behind the context's other
+ * tick / run launches like any launch on another stream (above). */
 int wg_host_alloc(void **out, size_t bytes);
 void wg_host_free(void *p);
 int wg_mpc_tick_pinned(wg_gait_state_t *state, wg_tick_out_t *out, int *diag, int advance_calls);
@@ -597,6 +604,7 @@ int wg_qp_solve_batch_ctx(wg_ctx_t *ctx, int B, int nmax, int mmax, const int *n
                           int *nact, int *hist, int hist_cap, int *hist_len);
 int wg_mpc_configure_ctx(wg_ctx_t *ctx, const wg_model_t *model);
 size_t wg_mpc_tick_lds_bytes_ctx(wg_ctx_t *ctx);
+int wg_mpc_reserve_ctx(wg_ctx_t *ctx, int max_gaits);
 int wg_mpc_tick_batch_dev_ctx(wg_ctx_t *ctx, int B, wg_gait_state_t *states, wg_tick_out_t *outs, int *diag,
                               int advance_calls, int *hist, int hist_cap, int *hist_len, void *hip_stream);
 int wg_mpc_run_batch_dev_ctx(wg_ctx_t *ctx, int B, wg_gait_state_t *states, int n_ticks, int advance_calls,

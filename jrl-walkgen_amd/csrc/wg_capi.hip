@@ -71,7 +71,10 @@ struct DevBuf {
 struct wg_ctx {
   int device = 0;
   int num_cu = 256;
-  std::mutex mu, z_mu;
+  std::mutex mu;
+  // held from the ordering test of a launch that uses per-context device state (queue, solver slots, scratch states) through the
+  // launch itself and the event record behind it: two host threads cannot both pass the test.  Lock order: mu -> launch_mu
+  std::mutex launch_mu;
   // Herdt-2010 tick
   wg_model_t model;
   bool model_set = false;
@@ -82,18 +85,19 @@ struct wg_ctx {
   // dense ql0001_ boundary: wa | b of every QP in a slot of global memory when that buys the eighth QP per CU; one launch at a
   // time uses the slots (a launch that arrives on another stream while one is pending keeps wa | b in LDS instead)
   DevBuf qp_slot;
-  hipEvent_t qp_ev = nullptr;
-  hipStream_t qp_stream = nullptr;
-  bool qp_armed = false;
+  struct SlotOrder { hipEvent_t ev = nullptr; hipStream_t stream = nullptr; bool armed = false; };
+  SlotOrder qp_order;
   DevBuf lpt_buf;                        // [iterations of the last tick (B) | start order (B)]
   const wg_gait_state_t *lpt_states = nullptr;
   int lpt_B = 0;
   // The tick / run kernels keep their queue and per-block solver slots in run_buf / tick_z: launches of one context must
-  // not overlap.  Every such launch leaves an event behind; a launch that arrives on ANOTHER stream while that event is
-  // still pending is refused (WG_ERR_BUSY) instead of corrupting the slots silently.
-  hipEvent_t guard_ev = nullptr;
-  hipStream_t guard_stream = nullptr;
-  bool guard_armed = false;
+  // not overlap ON THE DEVICE.  Every such launch leaves an event behind; a launch that arrives on ANOTHER stream while that
+  // event is still pending is made to wait for it (hipStreamWaitEvent: ordered, not refused -- a double-buffered pipeline that
+  // orders its streams with events of its own is enqueued ahead of time and must be accepted).  WG_OVERLAP_STRICT=1 refuses such a
+  // launch instead (WG_ERR_BUSY, nothing launched): a way to find serialisation one did not intend.
+  SlotOrder guard_order;
+  // wg_mpc_assemble_batch_dev runs the tick on scratch copies of the states kept per context (asm_state): same ordering
+  SlotOrder asm_order;
   // one-robot path (wg_mpc_tick_pinned): its own stream, a completion counter in host-mapped memory
   hipStream_t pin_stream = nullptr;
   int *pin_flag = nullptr;               // host-mapped; the kernel adds 1 per gait when its outputs are visible
@@ -123,10 +127,10 @@ struct wg_ctx {
     model_set = false; pldp_N = 0; dim_set = false; prev_set = false;
     for (DevBuf *b : {&tick_state, &tick_out, &tick_aux, &run_buf, &tick_z, &asm_state, &lpt_buf, &qp_slot, &pldp_buf, &dim_buf, &prev_buf, &in, &out, &gram_buf, &zd_buf})
       b->release();
-    if (guard_ev) (void)hipEventDestroy(guard_ev);
-    guard_ev = nullptr; guard_armed = false;
-    if (qp_ev) (void)hipEventDestroy(qp_ev);
-    qp_ev = nullptr; qp_armed = false;
+    for (SlotOrder *o : {&guard_order, &qp_order, &asm_order}) {
+      if (o->ev) (void)hipEventDestroy(o->ev);
+      o->ev = nullptr; o->armed = false; o->stream = nullptr;
+    }
     lpt_states = nullptr; lpt_B = 0;
     if (pin_stream) (void)hipStreamDestroy(pin_stream);
     if (pin_flag) (void)hipHostFree(pin_flag);
@@ -173,20 +177,25 @@ int use_ctx(wg_ctx *ctx) {
   return WG_OK;
 }
 
-// before a launch that uses the context's queue / solver slots: refuse it while a launch of another stream is pending
-int guard_claim(wg_ctx *ctx, hipStream_t st) {
-  std::lock_guard<std::mutex> lk(ctx->z_mu);
-  if (ctx->guard_armed && ctx->guard_stream != st && hipEventQuery(ctx->guard_ev) == hipErrorNotReady)
-    return fail(WG_ERR_BUSY, "a tick / run launch of this context is still in flight on another stream: launches of one "
-                             "context must not overlap (order them with an event, or give each stream its own wg_ctx)");
+// Both with ctx->launch_mu held, around the launch.
+// before a launch that uses device state of the context (`o`): behind the previous such launch, whatever stream that was on
+inline bool overlap_strict() { const char *e = getenv("WG_OVERLAP_STRICT"); return e && atoi(e) != 0; }
+inline bool slot_pending_elsewhere(const wg_ctx::SlotOrder &o, hipStream_t st) {
+  return o.armed && o.stream != st && hipEventQuery(o.ev) == hipErrorNotReady;
+}
+int slot_claim(wg_ctx::SlotOrder &o, hipStream_t st, const char *what) {
+  if (!slot_pending_elsewhere(o, st)) return WG_OK;
+  if (overlap_strict())
+    return fail(WG_ERR_BUSY, "a %s launch of this context is still in flight on another stream (WG_OVERLAP_STRICT: launches of one "
+                             "context are refused instead of ordered; give each stream its own wg_ctx to overlap them)", what);
+  HIP_TRY(hipStreamWaitEvent(st, o.ev, 0));
   return WG_OK;
 }
-// after it: the event later launches are checked against
-int guard_mark(wg_ctx *ctx, hipStream_t st) {
-  std::lock_guard<std::mutex> lk(ctx->z_mu);
-  if (!ctx->guard_ev) HIP_TRY(hipEventCreateWithFlags(&ctx->guard_ev, hipEventDisableTiming));
-  HIP_TRY(hipEventRecord(ctx->guard_ev, st));
-  ctx->guard_stream = st; ctx->guard_armed = true;
+// after it: the event later launches are ordered behind
+int slot_mark(wg_ctx::SlotOrder &o, hipStream_t st) {
+  if (!o.ev) HIP_TRY(hipEventCreateWithFlags(&o.ev, hipEventDisableTiming));
+  HIP_TRY(hipEventRecord(o.ev, st));
+  o.stream = st; o.armed = true;
   return WG_OK;
 }
 
@@ -384,20 +393,20 @@ int wg_qp_solve_batch_dev_ctx(wg_ctx_t *ctx, int B, int nmax, int mmax, const in
   hipStream_t st = reinterpret_cast<hipStream_t>(hip_stream);
   // wa | b follow A and G out of the LDS when that buys one more resident QP (n = 36, m = 75: 21.7 -> 20.2 KB, the eighth QP
   // of the CU -- a batch of 4096 is then exactly two rounds of the 2048 resident waves).  WG_QL_W_IN_LDS=0/1 forces either.
+  // The slots are used by one launch at a time: the test "are they free", the launch and the event behind it happen under one
+  // lock (two host threads on two streams cannot both find them free); a launch that finds them in use by another stream keeps
+  // wa | b in LDS instead of waiting for them.
+  std::lock_guard<std::mutex> launch_lk(ctx->launch_mu);
   double *wab = nullptr;
   if (!a_in_lds && !g_in_lds) {
     const size_t lds_now = wg::QlDims(nmax, m_cap, m_cap, true, false, 0, true, true, false, true, 0, false).bytes();
     auto gran_per_cu = [](size_t l) { const size_t k = 128 / ((l + 1279) / 1280); return k > 8 ? (size_t)8 : k; };
     bool w_out = gran_per_cu(lds_now) > gran_per_cu(lds);
     if (const char *e = getenv("WG_QL_W_IN_LDS")) w_out = atoi(e) == 0;
-    if (w_out) {
-      std::lock_guard<std::mutex> lk(ctx->z_mu);
-      const bool busy = ctx->qp_armed && ctx->qp_stream != st && hipEventQuery(ctx->qp_ev) == hipErrorNotReady;
-      if (!busy) {
-        if (int rc = ctx->qp_slot.reserve((size_t)B * (2 * (size_t)mmax + nmax) * 8)) return rc;
-        wab = static_cast<double *>(ctx->qp_slot.p);
-        lds = lds_now;
-      }
+    if (w_out && !slot_pending_elsewhere(ctx->qp_order, st)) {
+      if (int rc = ctx->qp_slot.reserve((size_t)B * (2 * (size_t)mmax + nmax) * 8)) return rc;
+      wab = static_cast<double *>(ctx->qp_slot.p);
+      lds = lds_now;
     }
   }
   const void *kfn = a_in_lds ? reinterpret_cast<const void *>(wg_ql_dense_kernel<true, true>)
@@ -418,10 +427,7 @@ int wg_qp_solve_batch_dev_ctx(wg_ctx_t *ctx, int B, int nmax, int mmax, const in
   else {
     hipLaunchKernelGGL((wg_ql_dense_kernel<false, false, false>), dim3(grid), dim3(64), lds, st, B, nmax, mmax, n, m, me, C, d, A, b,
                        xl, xu, eps, x, u, ifail, n_iter, iact, nact, hist, hist_cap, hist_len, wab);
-    std::lock_guard<std::mutex> lk(ctx->z_mu);
-    if (!ctx->qp_ev) HIP_TRY(hipEventCreateWithFlags(&ctx->qp_ev, hipEventDisableTiming));
-    HIP_TRY(hipEventRecord(ctx->qp_ev, st));
-    ctx->qp_stream = st; ctx->qp_armed = true;
+    if (int rc = slot_mark(ctx->qp_order, st)) return rc;
   }
   HIP_TRY(hipGetLastError());
   return WG_OK;
@@ -1027,17 +1033,9 @@ int wg_mpc_configure_ctx(wg_ctx_t *ctx, const wg_model_t *model) {
   HIP_TRY(hipMemcpy(ctx->model_dev, model, sizeof(wg_model_t), hipMemcpyHostToDevice));
   ctx->model = *model;
   ctx->model_set = true;
-  // queue and per-block solver slots of the multi-tick kernels, sized now for every resident block and for fleets of up to
-  // 32 768 gaits: later launches find them in place (a larger job grows them once, without freeing anything in flight)
-  {
-    const int view = tick_view(*model);
-    if (tick_z_global(view) || tick16_ext(view)) {
-      std::lock_guard<std::mutex> zk(ctx->z_mu);
-      const size_t waves = 4 * (size_t)(view == -1 ? WG_TICK32_WPE : WG_TICK_WPE_MAX);
-      if (int rc = ctx->tick_z.reserve((size_t)ctx->num_cu * waves * tick_z_slot_doubles(*model, view) * 8)) return rc;
-    }
-    if (int rc = ctx->run_buf.reserve(sizeof(wg_xrun_ctl) + (size_t)kXcds * 65536 * 8 + (size_t)32768 * 4)) return rc;
-  }
+  // The queue and the per-block solver slots of the tick / run kernels are sized by the launches themselves, for the grid they have
+  // (a one-robot facade object -- B = 1 through wg_mpc_tick_pinned -- pays for ONE slot, 74 KB at N = 32, not for a fleet's
+  // 230 MB); wg_mpc_reserve sizes them ahead of time for a fleet that wants no allocation on its first launch.
   return WG_OK;
 }
 
@@ -1049,6 +1047,21 @@ size_t wg_mpc_tick_lds_bytes_for(const wg_model_t *model) {   // host arithmetic
 size_t wg_mpc_tick_lds_bytes_ctx(wg_ctx_t *ctx) {
   if (!ctx || !ctx->model_set) return 0;
   return tick_lds_for(ctx->model, tick_view(ctx->model));
+}
+
+/* The tick / run kernels' per-block solver slots and queue for fleets of up to max_gaits, allocated now instead of by the first
+ * launch that needs them (the launches size them for their own grid otherwise). */
+int wg_mpc_reserve_ctx(wg_ctx_t *ctx, int max_gaits) {
+  if (int rc = use_ctx(ctx)) return rc;
+  if (!ctx->model_set) return fail(WG_ERR_BAD_ARG, "wg_mpc_configure() has not been called on this context");
+  if (max_gaits < 1) return fail(WG_ERR_BAD_ARG, "max_gaits = %d", max_gaits);
+  const int view = tick_view(ctx->model);
+  std::lock_guard<std::mutex> launch_lk(ctx->launch_mu);
+  if (tick_z_global(view) || tick16_ext(view))
+    if (int rc = ctx->tick_z.reserve((size_t)max_gaits * tick_z_slot_doubles(ctx->model, view) * 8)) return rc;
+  int cap = 1;
+  while (cap < 2 * max_gaits) cap <<= 1;
+  return ctx->run_buf.reserve(sizeof(wg_xrun_ctl) + (size_t)kXcds * cap * 8 + (size_t)max_gaits * 4);
 }
 
 }  // extern "C"
@@ -1070,12 +1083,14 @@ int tick_launch(wg_ctx_t *ctx, int B, wg_gait_state_t *states, wg_tick_out_t *ou
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   const int grid = B;                             // one gait per block; the dispatcher balances uneven iteration counts
   hipStream_t st = reinterpret_cast<hipStream_t>(hip_stream);
-  if (int rc = guard_claim(ctx, st)) return rc;
+  std::lock_guard<std::mutex> launch_lk(ctx->launch_mu);   // ordering test, launch and event record are one critical section
+  if (int rc = slot_claim(ctx->guard_order, st, "tick / run")) return rc;
   const int ecap = tick_elem_cap_arg(ctx->model, view);
   double *zs = nullptr;
   const size_t zslot = tick_z_slot_doubles(ctx->model, view);
   if (tick_z_global(view) || tick16_ext(view)) {
-    std::lock_guard<std::mutex> lk(ctx->z_mu);       // its own lock: the host-pointer entry points hold ctx->mu around this call
+    // sized here, for the grid this launch has (a one-robot facade pays for one slot, a fleet for its resident waves); growing
+    // never frees what a launch in flight may be using (DevBuf); wg_mpc_reserve sizes it ahead of time
     if (int rc = ctx->tick_z.reserve((size_t)grid * zslot * 8)) return rc;
     zs = static_cast<double *>(ctx->tick_z.p);
   }
@@ -1089,7 +1104,6 @@ int tick_launch(wg_ctx_t *ctx, int B, wg_gait_state_t *states, wg_tick_out_t *ou
     bool lpt = B > ctx->num_cu * per_cu && !host_states;
     if (const char *e = getenv("WG_TICK_LPT")) lpt = lpt && atoi(e) != 0;
     if (lpt) {
-      std::lock_guard<std::mutex> lk(ctx->z_mu);
       const bool known = ctx->lpt_states == states && ctx->lpt_B == B && ctx->lpt_buf.p;
       if (int rc = ctx->lpt_buf.reserve((size_t)B * 2 * sizeof(int))) return rc;
       iters_out = static_cast<int *>(ctx->lpt_buf.p);
@@ -1110,7 +1124,7 @@ int tick_launch(wg_ctx_t *ctx, int B, wg_gait_state_t *states, wg_tick_out_t *ou
     hipLaunchKernelGGL(wg_mpc_tick_kernel<-1>, dim3(grid), dim3(64), lds, st, B, ctx->model, ctx->tables_dev, states, outs, diag,
                        advance_calls, hist, hist_cap, hist_len, (unsigned)qlb, zs, (unsigned)zslot, ecap, host_states, host_done, order, iters_out);
   HIP_TRY(hipGetLastError());
-  return guard_mark(ctx, st);
+  return slot_mark(ctx->guard_order, st);
 }
 }  // namespace
 extern "C" {
@@ -1187,15 +1201,16 @@ int wg_mpc_assemble_batch_dev_ctx(wg_ctx_t *ctx, int B, const wg_gait_state_t *s
   if (lds > 160 * 1024) return fail(WG_ERR_TOO_LARGE, "the dense view of this model needs %zu B of LDS > 160 KiB", lds);
   if (lds > 64 * 1024)
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(wg_mpc_assemble_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  {
-    std::lock_guard<std::mutex> lk(ctx->z_mu);
-    if (int rc = ctx->asm_state.reserve((size_t)B * sizeof(wg_gait_state_t))) return rc;
-  }
-  hipLaunchKernelGGL(wg_mpc_assemble_kernel, dim3(B), dim3(64), lds, reinterpret_cast<hipStream_t>(hip_stream), B, ctx->model,
+  // the scratch copies of the states are the context's: assemble launches of one context are ordered like its tick / run launches
+  hipStream_t st = reinterpret_cast<hipStream_t>(hip_stream);
+  std::lock_guard<std::mutex> launch_lk(ctx->launch_mu);
+  if (int rc = slot_claim(ctx->asm_order, st, "assemble")) return rc;
+  if (int rc = ctx->asm_state.reserve((size_t)B * sizeof(wg_gait_state_t))) return rc;
+  hipLaunchKernelGGL(wg_mpc_assemble_kernel, dim3(B), dim3(64), lds, st, B, ctx->model,
                      ctx->tables_dev, states, static_cast<wg_gait_state_t *>(ctx->asm_state.p), advance_calls, (unsigned)qlb, nmax, mmax,
                      C, d, A, b, xl, xu, n, m);
   HIP_TRY(hipGetLastError());
-  return WG_OK;
+  return slot_mark(ctx->asm_order, st);
 }
 
 int wg_mpc_assemble_batch_ctx(wg_ctx_t *ctx, int B, const wg_gait_state_t *states, int advance_calls, int nmax, int mmax, double *C, double *d, double *A, double *b, double *xl, double *xu, int *n, int *m) {
@@ -1216,7 +1231,7 @@ int wg_mpc_assemble_batch_ctx(wg_ctx_t *ctx, int B, const wg_gait_state_t *state
                                          reinterpret_cast<double *>(base + off_xl), reinterpret_cast<double *>(base + off_xu),
                                          reinterpret_cast<int *>(base + off_n), reinterpret_cast<int *>(base + off_m), nullptr);
   if (rc) return rc;
-  HIP_TRY(hipDeviceSynchronize());
+  HIP_TRY(hipStreamSynchronize(nullptr));   // the stream the launch went to, not every stream of the device
   HIP_TRY(hipMemcpy(C, base + off_C, sB * sn * sn * 8, hipMemcpyDeviceToHost));
   HIP_TRY(hipMemcpy(d, base + off_d, sB * sn * 8, hipMemcpyDeviceToHost));
   HIP_TRY(hipMemcpy(A, base + off_A, sB * sm * sn * 8, hipMemcpyDeviceToHost));
@@ -1254,14 +1269,14 @@ int wg_mpc_run_sched_dev_ctx(wg_ctx_t *ctx, int B, wg_gait_state_t *states, int 
   if ((long long)B * n_ticks > 0x3fffffffLL) return fail(WG_ERR_TOO_LARGE, "B * n_ticks = %lld work items", (long long)B * n_ticks);
   const int total = B * n_ticks;
   hipStream_t st = reinterpret_cast<hipStream_t>(hip_stream);
-  if (int rc = guard_claim(ctx, st)) return rc;
+  std::lock_guard<std::mutex> launch_lk(ctx->launch_mu);   // ordering test, launch and event record are one critical section
+  if (int rc = slot_claim(ctx->guard_order, st, "tick / run")) return rc;
   // hand-over inside one XCD (default) or through one device-wide queue (WG_RUN_QUEUE=global: A/B tests)
   bool xcd_mode = true;
   if (const char *e = getenv("WG_RUN_QUEUE")) xcd_mode = e[0] != 'g';
   int cap = 1;
   while (cap < 2 * B) cap <<= 1;                   // ring slots per XCD: a gait is in at most one ring, at most once
   {
-    std::lock_guard<std::mutex> lk(ctx->mu);
     const size_t need = xcd_mode ? sizeof(wg_xrun_ctl) + (size_t)kXcds * cap * 8 + (size_t)B * 4
                                  : sizeof(wg_run_queue) + (size_t)(total + B) * 4;
     if (int rc = ctx->run_buf.reserve(need)) return rc;
@@ -1301,7 +1316,6 @@ int wg_mpc_run_sched_dev_ctx(wg_ctx_t *ctx, int B, wg_gait_state_t *states, int 
   double *zs = nullptr;
   const size_t zslot = tick_z_slot_doubles(ctx->model, view);
   if (tick_z_global(view) || tick16_ext(view)) {
-    std::lock_guard<std::mutex> lk(ctx->z_mu);       // its own lock: the host-pointer entry points hold ctx->mu around this call
     if (int rc = ctx->tick_z.reserve((size_t)grid * zslot * 8)) return rc;
     zs = static_cast<double *>(ctx->tick_z.p);
   }
@@ -1328,7 +1342,7 @@ int wg_mpc_run_sched_dev_ctx(wg_ctx_t *ctx, int B, wg_gait_state_t *states, int 
     hipLaunchKernelGGL(wg_mpc_run_kernel<-1>, dim3(grid), dim3(64), lds, st, B, n_ticks, ctx->model_dev, ctx->tables_dev, states, outs,
                        diag, advance_calls, q, ring, done, (unsigned)qlb, zs, (unsigned)zslot, ecap);
   HIP_TRY(hipGetLastError());
-  return guard_mark(ctx, st);
+  return slot_mark(ctx->guard_order, st);
 }
 
 int wg_mpc_tick_batch_ctx(wg_ctx_t *ctx, int B, wg_gait_state_t *states, wg_tick_out_t *outs, int *diag, int advance_calls, int *hist, int hist_cap, int *hist_len) {
@@ -1943,6 +1957,12 @@ int wg_mpc_configure(const wg_model_t *model) {
   wg_ctx *c = nullptr;
   if (int rc = default_ctx(&c)) return rc;
   return wg_mpc_configure_ctx(c, model);
+}
+
+int wg_mpc_reserve(int max_gaits) {
+  wg_ctx *c = nullptr;
+  if (int rc = default_ctx(&c)) return rc;
+  return wg_mpc_reserve_ctx(c, max_gaits);
 }
 
 size_t wg_mpc_tick_lds_bytes(void) {                 // a query: does not create the default context

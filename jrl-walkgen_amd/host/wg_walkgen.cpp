@@ -685,10 +685,12 @@ void StepStackHandler::ReadStepSequenceAccordingToWalkMode(istringstream &strm) 
   m_RelativeFootPositions.clear();
   RelativeFootPosition aFootPosition;
   memset(&aFootPosition, 0, sizeof aFootPosition);
+  // a token that is not a number sets failbit without ever reaching eof: the extraction's own result ends the loop
+  // (well-formed input takes the same path as the reference's eof tests)
   while (!strm.eof()) {
-    if (!strm.eof()) strm >> aFootPosition.sx; else break;
-    if (!strm.eof()) strm >> aFootPosition.sy; else break;
-    if (!strm.eof()) strm >> aFootPosition.theta; else break;
+    if (strm.eof() || !(strm >> aFootPosition.sx)) break;
+    if (strm.eof() || !(strm >> aFootPosition.sy)) break;
+    if (strm.eof() || !(strm >> aFootPosition.theta)) break;
     aFootPosition.DeviationHipHeight = 0;
     aFootPosition.SStime = m_SingleSupportTime;
     aFootPosition.DStime = m_DoubleSupportTime;
@@ -977,7 +979,7 @@ class PatternGeneratorInterfacePrivate : public virtual PatternGeneratorInterfac
     } else if (aCmd == ":TimeDistributionParameters") {              // m_SetTimeDistrParameters, :1518-1548: kept; its consumer is
       ReadUpToFour(strm, m_TimeDistrFactor);                         //   the stepping-over planner (:981), which is not on this path
     } else if (aCmd == ":LimitsFeasibility") {                       // m_SetLimitsFeasibility, :448-460: kept; consumer as above (:483)
-      while (!strm.eof()) { if (!strm.eof()) strm >> m_DeltaFeasibilityLimit; else break; }
+      while (!strm.eof()) { if (!(strm >> m_DeltaFeasibilityLimit)) break; }   // a non-numeric token ends it (failbit never reaches eof)
     } else if (aCmd == ":SetAutoFirstStep") {                        // :1122-1131
       string lAutoFirstStep;
       strm >> lAutoFirstStep;
@@ -1157,7 +1159,7 @@ class PatternGeneratorInterfacePrivate : public virtual PatternGeneratorInterfac
   }
   static void ReadUpToFour(istringstream &strm, vector<double> &v) {   // the parsing loop of :415-446 / :1518-1548
     while (!strm.eof()) {
-      for (int i = 0; i < 4; i++) { if (!strm.eof()) strm >> v[i]; else return; }
+      for (int i = 0; i < 4; i++) { if (strm.eof() || !(strm >> v[i])) return; }   // also ends on a non-numeric token (failbit)
     }
   }
 

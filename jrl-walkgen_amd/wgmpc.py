@@ -127,6 +127,7 @@ def lib():
         _lib.wg_ctx_destroy.restype = None
         _lib.wg_ctx_device.argtypes = [C.c_void_p]
         _lib.wg_mpc_configure.argtypes = [C.c_void_p]
+        _lib.wg_mpc_reserve.argtypes = [C.c_int]
         for name in CTX_ENTRY_POINTS:
             base, fn = getattr(_lib, name), getattr(_lib, name + "_ctx")
             fn.argtypes = [C.c_void_p] + list(base.argtypes or [])
@@ -134,7 +135,7 @@ def lib():
     return _lib
 
 
-CTX_ENTRY_POINTS = ("wg_qp_solve_batch", "wg_qp_solve_batch_dev", "wg_mpc_configure", "wg_mpc_tick_lds_bytes", "wg_mpc_tick_batch",
+CTX_ENTRY_POINTS = ("wg_qp_solve_batch", "wg_qp_solve_batch_dev", "wg_mpc_configure", "wg_mpc_reserve", "wg_mpc_tick_lds_bytes", "wg_mpc_tick_batch",
                     "wg_mpc_tick_batch_dev", "wg_mpc_run_batch_dev", "wg_mpc_run_sched_dev", "wg_mpc_set_velref_dev", "wg_mpc_tick_pinned",
                     "wg_mpc_assemble_batch", "wg_mpc_assemble_batch_dev", "wg_pldp_configure",
                     "wg_pldp_solve_batch", "wg_pldp_solve_batch_dev", "wg_dimitrov_configure", "wg_dimitrov_get_constants",

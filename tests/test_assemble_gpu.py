@@ -1,5 +1,5 @@
 """wg_mpc_assemble_batch (the QP at the ql0001_ boundary, QPProblem::dump_problem), wg_mpc_tick_pinned (the one-robot path in
-host-mapped memory) and the context's overlap guard -- through the C ABI on the GPU, against the CPU oracle."""
+host-mapped memory) and the ordering of one context's launches -- through the C ABI on the GPU, against the CPU oracle."""
 import ctypes as C
 import importlib
 import os
@@ -120,9 +120,11 @@ def test_one_robot_in_host_mapped_memory_equals_the_host_pointer_call():
     assert rc == -2 and b"wg_host_alloc" in wg.lib().wg_last_error()
 
 
-def test_overlapping_launches_of_one_context_are_refused():
-    """The tick / run kernels keep their queue and solver slots in the context: a launch on a second stream while the first is
-    in flight must come back WG_ERR_BUSY (and launch nothing); after the first has finished, or on a context of its own, it runs."""
+def test_overlapping_launches_of_one_context_are_ordered(monkeypatch):
+    """The tick / run kernels keep their queue and solver slots in the context.  A launch on a second stream while the first is
+    in flight is enqueued BEHIND it (hipStreamWaitEvent on the event the first left) -- an event-ordered double-buffered pipeline
+    is accepted as it is, an unordered one is serialised, nothing is corrupted; another context overlaps freely.  With
+    WG_OVERLAP_STRICT=1 such a launch comes back WG_ERR_BUSY instead and launches nothing."""
     import torch
     wg = _wg()
     model = wg.model_defaults()
@@ -131,25 +133,81 @@ def test_overlapping_launches_of_one_context_are_refused():
     mk = lambda: torch.frombuffer(bytearray(one * B), dtype=torch.uint8).cuda()   # noqa: E731
     with wg.Context(0) as ctx, wg.Context(0) as other:
         ctx.mpc_configure(model); other.mpc_configure(model)
-        a, b, ref = mk(), mk(), mk()
+        a, b, c, ref = mk(), mk(), mk(), mk()
         s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
         torch.cuda.synchronize()
+        # ---- default: ordered.  Two launches of ONE context on two streams, the second while the first is in flight
         ctx.mpc_run_batch_dev(B, a.data_ptr(), 60, 20, None, None, s1.cuda_stream)          # tens of milliseconds
-        rc = ctx.call("wg_mpc_tick_batch_dev", B, C.c_void_p(b.data_ptr()), None, None, 20, None, 0, None, C.c_void_p(s2.cuda_stream))
-        assert rc == -5, rc                                                             # WG_ERR_BUSY
-        assert b"in flight" in wg.lib().wg_last_error()
-        rc = ctx.call("wg_mpc_run_batch_dev", B, C.c_void_p(b.data_ptr()), 2, 20, None, None, C.c_void_p(s2.cuda_stream))
-        assert rc == -5, rc
-        # the same stream queues behind it; another context overlaps freely
-        ctx.mpc_tick_batch_dev(B, a.data_ptr(), None, None, 20, stream=s1.cuda_stream)
-        other.mpc_tick_batch_dev(B, b.data_ptr(), None, None, 20, stream=s2.cuda_stream)
+        ctx.mpc_tick_batch_dev(B, b.data_ptr(), None, None, 20, stream=s2.cuda_stream)      # accepted: runs behind it
+        ctx.mpc_run_batch_dev(B, b.data_ptr(), 1, 20, None, None, s2.cuda_stream)
+        ctx.mpc_tick_batch_dev(B, a.data_ptr(), None, None, 20, stream=s1.cuda_stream)      # back on the first stream
+        other.mpc_run_batch_dev(B, c.data_ptr(), 2, 20, None, None, s2.cuda_stream)         # another context: no ordering needed
         torch.cuda.synchronize()
-        ctx.mpc_tick_batch_dev(B, b.data_ptr(), None, None, 20, stream=s2.cuda_stream)      # first launch done: accepted
-        torch.cuda.synchronize()
-        # nothing was corrupted: a = 61 ticks, b = 2 ticks of the same gait, against a plain sequence on one stream
+        # nothing was corrupted: a = 61 ticks, b = c = 2 ticks of the same gait, against a plain sequence on one stream
         other.mpc_run_batch_dev(B, ref.data_ptr(), 2, 20, None, None, None)
         torch.cuda.synchronize()
-        assert torch.equal(b, ref)
+        assert torch.equal(b, ref) and torch.equal(c, ref)
         other.mpc_run_batch_dev(B, ref.data_ptr(), 59, 20, None, None, None)
         torch.cuda.synchronize()
         assert torch.equal(a, ref)
+        # ---- strict mode: refused
+        monkeypatch.setenv("WG_OVERLAP_STRICT", "1")
+        a2, b2 = mk(), mk()
+        torch.cuda.synchronize()
+        ctx.mpc_run_batch_dev(B, a2.data_ptr(), 60, 20, None, None, s1.cuda_stream)
+        rc = ctx.call("wg_mpc_tick_batch_dev", B, C.c_void_p(b2.data_ptr()), None, None, 20, None, 0, None, C.c_void_p(s2.cuda_stream))
+        assert rc == -5, rc                                                             # WG_ERR_BUSY
+        assert b"in flight" in wg.lib().wg_last_error()
+        rc = ctx.call("wg_mpc_run_batch_dev", B, C.c_void_p(b2.data_ptr()), 2, 20, None, None, C.c_void_p(s2.cuda_stream))
+        assert rc == -5, rc
+        ctx.mpc_tick_batch_dev(B, a2.data_ptr(), None, None, 20, stream=s1.cuda_stream)     # the same stream queues behind it
+        torch.cuda.synchronize()
+        ctx.mpc_tick_batch_dev(B, b2.data_ptr(), None, None, 20, stream=s2.cuda_stream)     # first launch done: accepted
+        torch.cuda.synchronize()
+        assert torch.equal(a2, a)
+        one_tick = mk()
+        other.mpc_tick_batch_dev(B, one_tick.data_ptr(), None, None, 20)
+        torch.cuda.synchronize()
+        assert torch.equal(b2, one_tick)
+
+
+def test_assemble_launches_of_one_context_on_two_streams():
+    """wg_mpc_assemble_batch_dev runs the tick on scratch copies of the states that belong to the context: two assemble launches
+    of one context on two streams are ordered by the library and write the QPs of their own gaits."""
+    import torch
+    wg = _wg()
+    model = wg.model_defaults()
+    wg.mpc_configure(model)
+    B = 1024
+    nmax, mmax = 36, 76
+    ga, gb = _gaits(wg, model, 1, 9), _gaits(wg, model, 1, 10)
+    for g in (ga, gb):
+        wg.mpc_tick_batch(g, advance_calls=1)
+        for _ in range(30):
+            wg.mpc_tick_batch(g, advance_calls=20)
+    ref = {}
+    for key, g in (("a", ga), ("b", gb)):
+        ref[key] = wg.mpc_assemble_batch(g, 20, nmax, mmax)
+    mk = lambda g: torch.frombuffer(bytearray(_bytes(g[0]) * B), dtype=torch.uint8).cuda()   # noqa: E731
+    sa, sb = mk(ga), mk(gb)
+    def bufs():
+        return dict(C=torch.zeros(B, nmax * nmax, dtype=torch.float64, device="cuda"), d=torch.zeros(B, nmax, dtype=torch.float64, device="cuda"),
+                    A=torch.zeros(B, mmax * nmax, dtype=torch.float64, device="cuda"), b=torch.zeros(B, mmax, dtype=torch.float64, device="cuda"),
+                    xl=torch.zeros(B, nmax, dtype=torch.float64, device="cuda"), xu=torch.zeros(B, nmax, dtype=torch.float64, device="cuda"),
+                    n=torch.zeros(B, dtype=torch.int32, device="cuda"), m=torch.zeros(B, dtype=torch.int32, device="cuda"))
+    with wg.Context(0) as ctx:
+        ctx.mpc_configure(model)
+        s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+        oa, ob = bufs(), bufs()
+        torch.cuda.synchronize()
+        for st, states, o in ((s1, sa, oa), (s2, sb, ob), (s1, sa, oa), (s2, sb, ob)):
+            rc = ctx.call("wg_mpc_assemble_batch_dev", B, C.c_void_p(states.data_ptr()), 20, nmax, mmax, *[C.c_void_p(o[k].data_ptr()) for k in ("C", "d", "A", "b", "xl", "xu", "n", "m")],
+                          C.c_void_p(st.cuda_stream))
+            assert rc == 0, wg.lib().wg_last_error()
+        torch.cuda.synchronize()
+        for key, o in (("a", oa), ("b", ob)):
+            r = ref[key]
+            for k in ("C", "d", "A", "b"):
+                got = o[k].cpu().numpy()
+                assert (got == got[0]).all(), (key, k)                       # every copy of the gait gives the same QP
+                assert got[0].tobytes() == np.ascontiguousarray(r[k][0]).tobytes(), (key, k)

@@ -127,6 +127,54 @@ def test_two_streams_share_one_context(monkeypatch):
         assert np.array_equal(ifail.cpu().numpy(), ref["ifail"]) and np.array_equal(nit.cpu().numpy(), ref["n_iter"])
 
 
+def test_two_host_threads_share_one_context():
+    """The test "are the wa | b slots free", the launch and the event behind it are one critical section of the context: two host
+    threads that submit Herdt-sized batches on two streams of ONE context at the same moment, over and over, both get the
+    oracle's bytes (before, both could find the slots free and run on the same slots)."""
+    import threading
+    import torch
+    wg = _wg()
+    qps = [qpgen.herdt_like(np.random.default_rng(32000 + s), 16, 2) for s in range(2048)]
+    pk = wg.pack_qps(qps)
+    ref = wg.qp_solve_batch(pk, hist_cap=64)
+    B, nmax, mmax = pk["B"], pk["nmax"], pk["mmax"]
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()   # noqa: E731
+    dev_in = {k: t(pk[k]) for k in ("n", "m", "me", "C", "d", "A", "b", "xl", "xu")}
+    rounds = 6
+    outs = [[None] * rounds for _ in range(2)]
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    for w in range(2):
+        for r in range(rounds):
+            outs[w][r] = (torch.zeros(B, nmax, dtype=torch.float64, device="cuda"), torch.zeros(B, mmax + 2 * nmax, dtype=torch.float64, device="cuda"),
+                          torch.full((B,), -99, dtype=torch.int32, device="cuda"), torch.zeros(B, dtype=torch.int32, device="cuda"))
+    torch.cuda.synchronize()
+    gate = threading.Barrier(2)
+    errs = []
+
+    def worker(w):
+        try:
+            for r in range(rounds):
+                x, u, ifail, nit = outs[w][r]
+                gate.wait()
+                wg.qp_solve_batch_dev(B, nmax, mmax, dev_in["n"], dev_in["m"], dev_in["me"], dev_in["C"], dev_in["d"], dev_in["A"], dev_in["b"],
+                                      dev_in["xl"], dev_in["xu"], 1e-8, x, u, ifail, nit, stream=streams[w].cuda_stream)
+        except Exception as e:            # noqa: BLE001
+            errs.append(e)
+
+    th = [threading.Thread(target=worker, args=(w,)) for w in range(2)]
+    for t_ in th:
+        t_.start()
+    for t_ in th:
+        t_.join()
+    torch.cuda.synchronize()
+    assert not errs, errs
+    for w in range(2):
+        for r in range(rounds):
+            x, u, ifail, nit = outs[w][r]
+            assert np.array_equal(x.cpu().numpy(), ref["x"]) and np.array_equal(u.cpu().numpy(), ref["u"]), (w, r)
+            assert np.array_equal(ifail.cpu().numpy(), ref["ifail"]) and np.array_equal(nit.cpu().numpy(), ref["n_iter"]), (w, r)
+
+
 @pytest.mark.parametrize("log2_scale", [0, 380, 450, -380, -450])
 def test_sweep_norm_range_guard(log2_scale):
     """The sweep's norm chain takes a shorter instruction sequence when every operand is zero or within [2^-400, 2^400]
