@@ -28,6 +28,7 @@
 #include <vector>
 
 #include "../../include/wg_mpc.h"
+#include "wg_rendezvous.hpp"
 
 #define CHECK_HIP(e) do { hipError_t r_ = (e); if (r_ != hipSuccess) { fprintf(stderr, "FAILED: %s: %s\n", #e, hipGetErrorString(r_)); return 1; } } while (0)
 #define CHECK_WG(e) do { int r_ = (e); if (r_ != WG_OK) { fprintf(stderr, "FAILED: %s: %s\n", #e, wg_last_error()); return 1; } } while (0)
@@ -35,28 +36,14 @@
 
 static int env_int(const char *k, int dflt) { const char *e = getenv(k); return e ? atoi(e) : dflt; }
 
-// rank 0 publishes the RCCL unique id through a file (written under another name, then renamed: readers never see a torn id)
+// rank 0 publishes the RCCL unique id through a file named after the job; the other ranks take it only if it IS this job's
+// (host/wg_rendezvous.hpp: a file older than the job's launcher is a previous job's and is ignored)
 static int exchange_id(const std::string &path, int rank, ncclUniqueId *id) {
   if (rank == 0) {
     CHECK_NCCL(ncclGetUniqueId(id));
-    const std::string tmp = path + ".tmp";
-    FILE *f = fopen(tmp.c_str(), "wb");
-    if (!f || fwrite(id, sizeof *id, 1, f) != 1) { fprintf(stderr, "FAILED: cannot write %s\n", tmp.c_str()); return 1; }
-    fclose(f);
-    if (rename(tmp.c_str(), path.c_str()) != 0) { fprintf(stderr, "FAILED: rename %s\n", path.c_str()); return 1; }
-    return 0;
+    return wg_rdv::publish(path, id, sizeof *id);
   }
-  for (int tries = 0; tries < 6000; ++tries) {          // up to 60 s
-    FILE *f = fopen(path.c_str(), "rb");
-    if (f) {
-      const size_t n = fread(id, sizeof *id, 1, f);
-      fclose(f);
-      if (n == 1) return 0;
-    }
-    std::this_thread::sleep_for(std::chrono::milliseconds(10));
-  }
-  fprintf(stderr, "FAILED: rank %d never saw %s\n", rank, path.c_str());
-  return 1;
+  return wg_rdv::fetch(path, id, sizeof *id, wg_rdv::job_not_before());
 }
 
 int main(int argc, char **argv) {
@@ -125,8 +112,7 @@ int main(int argc, char **argv) {
   ncclComm_t comm = nullptr;
   double *d_red = nullptr;                                      // one double for the barriers / the max over ranks
   if (use_rccl) {
-    std::string idpath = getenv("WG_NCCL_ID_FILE") ? getenv("WG_NCCL_ID_FILE")
-                                                   : "/tmp/wg_fleet_" + std::to_string(env_int("MASTER_PORT", 29511)) + ".id";
+    const std::string idpath = wg_rdv::id_path();            // WG_NCCL_ID_FILE, or named after port, run id and launcher
     ncclUniqueId id;
     if (exchange_id(idpath, rank, &id)) return 1;
     CHECK_NCCL(ncclCommInitRank(&comm, world, id, rank));
@@ -138,6 +124,8 @@ int main(int argc, char **argv) {
     CHECK_HIP(hipStreamSynchronize(st));
     CHECK_HIP(hipMemcpy(&model, d_model, sizeof model, hipMemcpyDeviceToHost));
     (void)hipFree(d_model);
+    // the broadcast needed every rank inside the communicator: all of them have read the id, the file has served
+    if (rank == 0) unlink(idpath.c_str());
   }
   if (model.N <= 0) { fprintf(stderr, "FAILED: rank %d did not receive the model\n", rank); return 1; }
   CHECK_WG(wg_mpc_configure_ctx(ctx, &model));                  // tables rebuilt locally from the 208-byte block
