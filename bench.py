@@ -142,7 +142,27 @@ def cpu_baseline(n_gaits, n_ticks):
     return one, allc
 
 
-def golden_parity():
+def oracle_golden_rows():
+    """cpu_baseline leg (runs before this process touches the GPU): the EmergencyStop scenario through the CPU checker -- libm
+    trigonometry, every QP solved by the reference's compiled ql0001_ when oracle/_ref was built -- as the 38-column rows of
+    tests/TestObject.cpp.  golden_parity() compares the GPU's replay with it: the file is printed to 1e-7, this is not."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import herdt_replay as hr
+    import oraclelib as ol
+    lib = ol.oracle()
+    kind = "port"
+    lib.wgo_set_reference_ql(None)
+    if ol.have_ref():
+        lib.wgo_set_reference_ql(C.cast(getattr(ol.ref(), ol.REF_SYM), C.c_void_p))
+        kind = "reference"
+    datref = np.load(os.path.join(ROOT, "tests", "golden", "herdt_emergency_stop_datref.npz"))["datref"]
+    model, state, events = hr.emergency_stop_setup(datref)
+    rows = hr.replay(model, state, events, 6000, tick=hr.oracle_tick, legacy_running=True)
+    lib.wgo_set_reference_ql(None)
+    return rows, kind
+
+
+def golden_parity(oracle_rows=None):
     """The second half of BASELINE's metric ("CoM RMSE vs ref"): the reference's own golden file
     TestHerdt2010EmergencyStopTestFGPI.datref (config 2: one gait, 22.5 s) replayed with every MPC tick on the GPU through
     the C ABI (tests/herdt_replay.py is the 5 ms control loop around the tick; no oracle call on this path)."""
@@ -188,7 +208,16 @@ def golden_parity():
     except Exception:                                                      # noqa: BLE001 -- reported as missing
         lat_hm = []
     d = rows - datref
-    return {"com_rmse_m": float(np.sqrt((d[:, 1:3] ** 2).mean())), "max_abs_err": float(np.abs(d).max()),
+    vs_oracle = {}
+    if oracle_rows is not None and oracle_rows[0].shape == rows.shape:
+        do = rows - oracle_rows[0]
+        vs_oracle = {"com_max_abs_vs_libm_oracle_m": float(np.abs(do[:, 1:3]).max()),
+                     "com_rmse_vs_libm_oracle_m": float(np.sqrt((do[:, 1:3] ** 2).mean())),
+                     "max_abs_vs_libm_oracle_all_columns": float(np.abs(do).max()),
+                     "libm_oracle": "oracle/herdt_oracle.c with libm trigonometry, QP solve by %s, same scenario on the host "
+                                    "(cpu_baseline leg); BASELINE's bar is CoM <= 1e-9 m" %
+                                    ("the reference's compiled ql0001_ (oracle/_ref)" if oracle_rows[1] == "reference" else "the restated QL")}
+    return {"com_rmse_m": float(np.sqrt((d[:, 1:3] ** 2).mean())), "max_abs_err": float(np.abs(d).max()), **vs_oracle,
             "rows": int(datref.shape[0]), "columns": int(datref.shape[1]), "tolerance": 1e-6,
             # what a drop-in user with ONE robot sees per MPC tick (every 0.1 s of walking): wg_mpc_tick_batch(B = 1) with
             # host pointers = copy in, launch, synchronise, copy out
@@ -293,6 +322,10 @@ def main():
                     "preview, zmpdisc, Gramian)")
     ap.add_argument("--preroll", type=int, default=PREROLL_TICKS, help="untimed ticks run before the warm-up steps (redraws every "
                     "50 as everywhere): a short timed window then sees gaits in every support phase, QPs of n = 32, 34 and 36")
+    ap.add_argument("--outs-on", action="store_true", help="the timed launches store the tick's deliverable (wg_tick_out_t: the 20 CoM / "
+                    "ZMP / feet samples per tick the reference pushes on its deques, ZMPVelocityReferencedQP.cpp:405-442) for every "
+                    "gait-tick -- the primary figure then is the outs-on rate (profiling runs; the default line carries it as `outs_on`)")
+    ap.add_argument("--no-outs-leg", action="store_true", help="skip the secondary outs-on measurement")
     ap.add_argument("--no-staged-refs", action="store_true", help="one launch per stretch of constant velocity references "
                     "(wg_mpc_set_velref_dev + wg_mpc_run_batch_dev, round 1's plan) instead of one launch with the references "
                     "of every stretch staged on the device (wg_mpc_run_sched_dev)")
@@ -300,7 +333,13 @@ def main():
 
     # CPU baseline first: it forks one worker per host core, which must happen before this process touches the GPU
     cpu_line = None
+    oracle_rows = None
     if int(os.environ.get("WORLD_SIZE", "1")) == 1 and not args.no_cpu_baseline:
+        if not args.no_parity:
+            try:
+                oracle_rows = oracle_golden_rows()
+            except Exception:                                             # noqa: BLE001 -- the checker's figure, never fatal
+                oracle_rows = None
         ng, nt = 1024, 200                                   # ~13 s on one core
         one, allc = cpu_baseline(ng, nt)
         solver = ("QP solve by the reference's qld.cpp compiled -O3 -DNDEBUG (oracle/_ref)" if one["kind"] == "reference"
@@ -337,7 +376,7 @@ def main():
     lo, hi = rank * B, (rank + 1) * B                         # weak scaling: B gaits per GPU
     K, W0 = args.steps, args.warmup
     W = W0 + max(0, args.preroll)                             # pre-roll + warm-up: all untimed, same launch plan
-    n_seg = (K + W + min(K, 100) + REDRAW_TICKS - 1) // REDRAW_TICKS
+    n_seg = (K + W + min(K, 100) + K + REDRAW_TICKS - 1) // REDRAW_TICKS
     vtab = torch.from_numpy(velocity_table(lo, hi, n_seg)).to(dev)
     states = start_states(model, B).to(dev)
     diag = torch.zeros(K + W, B, 6, dtype=torch.int32, device=dev)
@@ -357,18 +396,27 @@ def main():
             wg.mpc_set_velref_dev(B, sp, vtab[t // REDRAW_TICKS].data_ptr(), sh)
 
     entry_points = {}                                         # entry point -> launches in the timed region
+    # the tick's deliverable (the 20 samples per tick the reference pushes on its four deques): K x B structs, tick-major, when a
+    # leg asks for it.  Throughput figures without it advance the closed loop only (outs = NULL: SURVEY 8d's metric)
+    out_bytes = C.sizeof(wg.TickOut)
+    outs_buf = None
+    if args.outs_on or not (args.no_outs_leg or args.per_tick_launch):
+        outs_buf = torch.empty(K * B * out_bytes, dtype=torch.uint8, device=dev)
 
-    def fire(t, n, timed=False):
+    def fire(t, n, timed=False, outs_base=None, diag_ptr=True):
+        """outs_base = (first tick of the window that stores outs): tick t's structs go to slot t - outs_base of outs_buf"""
         adv = 1 if t == 0 else (19 if t == 1 else 20)
+        op = None if outs_base is None else outs_buf.data_ptr() + (t - outs_base) * B * out_bytes
+        dq = dp + t * dstride if diag_ptr else None
         if n == 1 and (t < 2 or args.per_tick_launch):
             name = "wg_mpc_tick_batch_dev"
-            wg.mpc_tick_batch_dev(B, sp, None, dp + t * dstride, adv, stream=sh)
+            wg.mpc_tick_batch_dev(B, sp, op, dq, adv, stream=sh)
         elif is_staged(t, n):                                 # the references of every stretch of the launch wait on the device
             name = "wg_mpc_run_sched_dev"
-            wg.mpc_run_sched_dev(B, sp, n, vtab[t // REDRAW_TICKS].data_ptr(), REDRAW_TICKS, adv, None, dp + t * dstride, stream=sh)
+            wg.mpc_run_sched_dev(B, sp, n, vtab[t // REDRAW_TICKS].data_ptr(), REDRAW_TICKS, adv, op, dq, stream=sh)
         else:
             name = "wg_mpc_run_batch_dev"
-            wg.mpc_run_batch_dev(B, sp, n, adv, None, dp + t * dstride, stream=sh)
+            wg.mpc_run_batch_dev(B, sp, n, adv, op, dq, stream=sh)
         if timed:
             entry_points[name] = entry_points.get(name, 0) + 1
 
@@ -387,7 +435,7 @@ def main():
         for k, (t, n) in enumerate(timed):
             redraw(t, n)
             ev[k][0].record(stream)
-            fire(t, n, timed=True)
+            fire(t, n, timed=True, outs_base=W if args.outs_on else None)
             ev[k][1].record(stream)
     torch.cuda.synchronize(dev)
     shard.barrier()
@@ -410,6 +458,26 @@ def main():
             e2 = shard.max_over_ranks(time.perf_counter() - t1, dev)
             alt = {"value": shard.sum_over_ranks(B * K2, dev) / e2, "steps": K2, "ms_per_step": 1e3 * e2 / K2,
                    "note": "same workload continued with one launch per tick (wg_mpc_tick_batch_dev)"}
+
+    # secondary figure: the same launches with the deliverable stored (outs non-NULL), on the following ticks of the same gaits
+    outs_leg = None
+    if outs_buf is not None and not args.outs_on:
+        t_first = W + K + (min(K, 100) if alt is not None else 0)
+        plan = launches(t_first, t_first + K)
+        shard.barrier(); torch.cuda.synchronize(dev)
+        t1 = time.perf_counter()
+        with torch.cuda.stream(stream):
+            for t, n in plan:
+                redraw(t, n)
+                fire(t, n, outs_base=t_first, diag_ptr=False)
+        torch.cuda.synchronize(dev); shard.barrier()
+        e3 = shard.max_over_ranks(time.perf_counter() - t1, dev)
+        outs_leg = {"value": shard.sum_over_ranks(B * K, dev) / e3, "unit": "ticks/s", "steps": K, "ms_per_step": 1e3 * e3 / K,
+                    "launches": len(plan), "out_bytes_per_gait_tick": out_bytes,
+                    "stored_gb": B * K * out_bytes / 1e9, "store_rate_gbs": B * K * out_bytes / e3 / 1e9,
+                    "note": "the same launches on the following %d ticks with outs non-NULL: every gait-tick stores its wg_tick_out_t (20 "
+                            "CoM / ZMP / feet / trunk samples, what ZMPVelocityReferencedQP::OnLine pushes on its deques, "
+                            "ZMPVelocityReferencedQP.cpp:405-442), tick-major, K x B structs" % K}
 
     durs = [a.elapsed_time(b) for a, b in ev]
     kern_ms_total = float(np.sum(durs))
@@ -486,6 +554,17 @@ def main():
         }
         if alt is not None:
             line["per_tick_launch"] = alt
+        if args.outs_on:
+            line["config"]["outs"] = "stored: every gait-tick writes its wg_tick_out_t (%d B)" % out_bytes
+        else:
+            line["config"]["outs"] = "NULL in the timed region (closed loop advanced only, SURVEY 8d); `outs_on` has the rate with them stored"
+        if outs_leg is not None:
+            outs_leg["delta_vs_value"] = outs_leg["value"] / value - 1.0
+            if pmc is not None and "run_kernel_outs" in pmc:
+                outs_leg["hbm_write_bytes_per_gait_tick_measured"] = pmc["run_kernel_outs"].get("hbm_write_bytes_per_gait_tick")
+                outs_leg["hbm_bytes_per_gait_tick_measured"] = pmc["run_kernel_outs"].get("hbm_bytes_per_gait_tick")
+                outs_leg["traffic_source"] = "%s: rocprofv3 --pmc WRITE_SIZE / FETCH_SIZE passes of `bench.py --outs-on`" % os.path.relpath(PMC_SUMMARY, ROOT)
+            line["outs_on"] = outs_leg
         if world == 1 and not args.no_kernels:
             line["kernels"] = bench_kernels.run_all(wg, dev, stream, B, sp, model, algorithmic_bytes)
             wg.mpc_configure(model)
@@ -498,7 +577,7 @@ def main():
                 line["config5"] = {"error": str(e)}
             wg.mpc_configure(model)
         if world == 1 and not args.no_parity:
-            line["parity"] = golden_parity()
+            line["parity"] = golden_parity(oracle_rows)
             if cpu_line is not None and "b1_tick_latency_us" in line["parity"]:
                 line["parity"]["b1_tick_latency_us"]["cpu_reference_us_per_tick_one_core"] = 1e6 / cpu_line["value"]
         if cpu_line is not None:

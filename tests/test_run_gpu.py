@@ -35,7 +35,7 @@ def _dev(arr):
     return torch.frombuffer(bytearray(bytes(memoryview(arr).cast("B"))), dtype=torch.uint8).cuda()
 
 
-@pytest.mark.parametrize("B,T,want_out", [(40, 30, True), (1, 7, False), (3000, 12, False), (64, 1, True)])
+@pytest.mark.parametrize("B,T,want_out", [(40, 30, True), (1, 7, False), (3000, 12, False), (64, 1, True), (2600, 10, True)])
 def test_run_batch_equals_single_tick_launches_and_oracle(B, T, want_out):
     wg.init(0)
     model = wg.model_defaults()

@@ -14,6 +14,9 @@ R=$GRAFT_REPO_ROOT
 BENCH="bench.py --steps 200 --warmup 50 --no-cpu-baseline --no-parity --no-per-tick-leg --no-config5 --no-kernels"
 bash $R/tools/prof.sh tick $BENCH > $R/gpurun_out/prof_tick.log 2>&1
 echo "tick done"
+# the same with the tick's deliverable stored in the timed launch (wg_tick_out_t per gait-tick): the WRITE_SIZE of the outs-on leg
+bash $R/tools/prof.sh ticko $BENCH --outs-on > $R/gpurun_out/prof_ticko.log 2>&1
+echo "ticko done"
 export WG_RUN_QUEUE=global
 bash $R/tools/prof.sh tickg $BENCH > $R/gpurun_out/prof_tickg.log 2>&1
 unset WG_RUN_QUEUE

@@ -22,7 +22,7 @@ def launch_plan(t0, t1, per_tick=False, redraw=REDRAW):            # bench.launc
     return out
 
 
-names = ["tick", "tickg", "pertick", "config5", "elem", "gramian", "dimitrov", "pldp", "preview", "zmpdisc"]
+names = ["tick", "ticko", "tickg", "pertick", "config5", "elem", "gramian", "dimitrov", "pldp", "preview", "zmpdisc"]
 summ = {}
 for k in names:
     d = os.path.join(ROOT, "gpurun_out", "prof_" + k)
@@ -78,6 +78,17 @@ if "tick" in summ:
     out["run_kernel"] = per_gait_tick(summ["tick"], "wg_mpc_run_xcd_kernel<16>", B * run_ticks)
     out["run_kernel"]["ticks_per_launch"] = plan_txt
     assert out["run_kernel"]["launches"] == n_run, (out["run_kernel"]["launches"], n_run)
+if "ticko" in summ:
+    # the same launches with the tick's deliverable stored (bench.py --outs-on): every gait-tick of the TIMED launch writes its
+    # wg_tick_out_t; the untimed launches before it run without (so the per-gait-tick figures below are over the timed launch's
+    # gait-ticks for the stores and over all launches for the rest: the stores are reported separately)
+    o = per_gait_tick(summ["ticko"], "wg_mpc_run_xcd_kernel<16>", B * run_ticks)
+    o["ticks_per_launch"] = plan_txt
+    base = out.get("run_kernel")
+    if base:
+        # extra bytes of the outs-on run, all of them in the timed launch (K ticks)
+        o["extra_write_bytes_per_stored_gait_tick"] = (o["hbm_write_bytes_per_gait_tick"] - base["hbm_write_bytes_per_gait_tick"]) * run_ticks / K
+    out["run_kernel_outs"] = o
 if "tickg" in summ:
     out["run_kernel_device_wide_queue"] = per_gait_tick(summ["tickg"], "wg_mpc_run_kernel<16>", B * run_ticks)
     out["run_kernel_device_wide_queue"]["ticks_per_launch"] = "48, 50 x 6"
