@@ -198,6 +198,31 @@ struct QlView {
     slot = p; p += 8;
     iact = reinterpret_cast<int *>(p);
   }
+  // Element view with the horizon known at compile time (NMAX = 2N + 2 kSMax, MMAX = 1 + 4N + 5 kSMax): the lean partition of
+  // carve<false, false, false> laid out for the model's LARGEST problem whatever n and m the tick has, so that every LDS array
+  // sits at a constant offset from the wave's base (immediates in the ds instructions instead of address registers) and Z's
+  // leading dimension is the constant NMAX | 1:   x | ww | lam | slot | iact | sc0 sc1 sc2 sc3 | R.
+  // R comes last: its length -- r_cols columns and one working column, or all n -- is the one thing the column cap decides.  The
+  // tick's pre-solve overlay lies over sc0 .. R (dead outside the solve).  Z, wa | b and d | wd | wx live in the per-block global
+  // slot (the caller passes them: constants behind one base).  Same bytes as QlDims(NMAX, MMAX, ...).bytes().
+  template <int NMAX, int MMAX>
+  __device__ __forceinline__ void carve_fixed_elem(double *base, int n_, int m_, int me_, int r_cols, double *z_ext, double *wa_ext,
+                                                    double *b_ext, double *d_ext, double *wd_ext, double *wx_ext, double *rf_ext) {
+    n = n_; m = m_; me = me_; mn = m_ + n_; ldg = NMAX | 1; ldz = NMAX | 1; lda = MMAX | 1;
+    const bool capped = r_cols > 0 && r_cols < n_;
+    nact_cap = capped ? r_cols : 0;
+    r_tail = capped ? r_cols * (r_cols + 1) / 2 : n_ * (n_ + 1) / 2;
+    G = nullptr; A = nullptr; xl = nullptr; xu = nullptr;
+    double *p = base;
+    x = p; p += NMAX; ww = p; p += NMAX; lam = p; p += NMAX;
+    slot = p; p += 8;
+    iact = reinterpret_cast<int *>(p); p += ((NMAX + 1) & ~1) / 2;
+    sc0 = p; p += NMAX; sc1 = p; p += NMAX; sc2 = p; p += NMAX; sc3 = p; p += NMAX;
+    R = p;
+    Z = z_ext; wa = wa_ext; b = b_ext; d = d_ext; wd = wd_ext; wx = wx_ext; Rf = rf_ext;
+  }
+  // doubles in front of sc0 in that layout (where the tick's overlay starts)
+  template <int NMAX> static constexpr int fixed_elem_head() { return 3 * NMAX + 8 + ((NMAX + 1) & ~1) / 2; }
 };
 
 #define Zm(i, j) q.Z[(i) + (j) * q.ldz]
@@ -212,6 +237,7 @@ struct DenseProbT {
   static constexpr bool kHasFactor = false;    // no structure to exploit: ql0002's own Cholesky and inverse
   static constexpr bool kRowOps = false;   // no structured row products: rows are read element by element
   static constexpr int kNM = 0;        // no compile-time bound on n
+  static constexpr bool kWideN = false;  // 64 <= n <= 128 is not known at compile time: the wide (two rows / columns per lane) forms by test
   __device__ __forceinline__ double G(const QlView &q, int i, int j) const;
   __device__ __forceinline__ double A(const QlView &q, int k, int i) const;
   __device__ __forceinline__ double Gd(const QlView &q, int i) const;
@@ -417,10 +443,10 @@ __device__ __forceinline__ bool significant(double base, double delta_abs) {
 }
 
 // s[i] = sum_j Z(j,i) * ww[j]   (qld.cpp:2071-2085); lane i owns s[i]
-template <int NM = 0, int GRP = 8>                        // NM > 0: n <= NM known at compile time (the wide form is left out)
-__device__ __forceinline__ void zt_times_ww(const QlView &q, double *s, int lane) {
+template <int NM = 0, int GRP = 8, bool kWide = false>   // NM > 0: n <= NM known at compile time (the wide form is left out)
+__device__ __forceinline__ void zt_times_ww(const QlView &q, double *s, int lane) {   // kWide: 64 <= n <= 128 known at compile time
   const int n = q.n;
-  if ((NM == 0 || NM > 64) && n > 64 && n <= 128) {
+  if (kWide || ((NM == 0 || NM > 64) && n > 64 && n <= 128)) {
     // two columns per lane in ONE pass (the second pass of the strided form has n - 64 useful lanes), loads in groups of
     // eight ahead of the two add chains: at this size Z may live in global memory (L2), where every exposed round trip
     // costs hundreds of cycles
@@ -896,11 +922,11 @@ __device__ __forceinline__ double xmag_sum(const QlView &q, const P &prob, doubl
 // each; (3) every lane carries its own row of Z through the whole rotation sequence.
 // n <= 64: s[] and the rotation coefficients live in registers (lane c <-> column c) and are handed
 // around with v_readlane, so the dependent chain of phase 1 contains no LDS access at all.
-template <int GRP = 8>
+template <int GRP = 8, bool kWide = false>                 // kWide: 64 <= n <= 128 known at compile time (only that form is compiled)
 __device__ __forceinline__ void sweep(const QlView &q, double *s, int nu, int nact, int lane) {
   const int n = q.n;
   if (nu - 1 <= nact) return;
-  if (n <= 64) {
+  if (!kWide && n <= 64) {
     const double sreg = (lane < nu) ? s[lane] : 0.0;
     double myP = 0.0, myQ = 0.0, myN = 0.0;
     {
@@ -1000,7 +1026,7 @@ __device__ __forceinline__ void sweep(const QlView &q, double *s, int nu, int na
     }
   }
   WG_WSYNC();
-  if (n <= 128) {
+  if (kWide || n <= 128) {
     // phase 3 for 64 < n <= 128: two rows per lane in one pass.  Rotation c reads Z(i, c-1) BEFORE any rotation rewrites it,
     // so the row entries are independent of the carry chain: they are fetched a chunk of kSwC columns at a time, the next
     // chunk while the current one is rotated (two register sets, loop unrolled by two so that handing a set on is a renaming).
@@ -1085,6 +1111,7 @@ __device__ __forceinline__ void sweep(const QlView &q, double *s, int nu, int na
     WG_WSYNC();
     return;
   }
+  if constexpr (!kWide)
   for (int i = lane; i < n; i += 64) {
     double carry = Zm(i, nu - 1);
     for (int c = nu - 1; c > nact; --c) {
@@ -1184,7 +1211,7 @@ __device__ __forceinline__ bool independent_coordinate(const QlView &q, const P 
 #define WG_BACKSUB(q, s, nact, lane)                                                                   \
   do {                                                                                                 \
     if constexpr (P::kNM > 0 && P::kNM + 12 <= 48) backsub_lds<48>(q, s, nact, lane, q.sc0);          \
-    else if (P::kNM == 0 && q.n >= 48 && (nact) <= 60) backsub_lds<96>(q, s, nact, lane, q.sc0);     \
+    else if (P::kNM == 0 && (P::kWideN || q.n >= 48) && (nact) <= 60) backsub_lds<96>(q, s, nact, lane, q.sc0);     \
     else if (P::kNM == 0 && !P::kRowOps && q.n >= 24 && (nact) <= 36) backsub_lds<48>(q, s, nact, lane, q.sc0); \
     else backsub(q, s, nact, lane);                                                                    \
   } while (0)
@@ -1192,7 +1219,7 @@ __device__ __forceinline__ bool independent_coordinate(const QlView &q, const P 
 // one row of Z per lane (n <= 64): the branch-free, prefetching form -- the compact view always, the dense view by size (the
 // element view is built for n > 64: it keeps the one form it needs, its kernel is large enough as it is)
 #define WG_SWEEP(q, s, nu, nact, lane) \
-  do { if (P::kNM > 0 || (!P::kRowOps && q.n <= 64)) sweep_flat(q, s, nu, nact, lane); else sweep<(P::kRowOps ? WG_ELEM_GRP : 8)>(q, s, nu, nact, lane); } while (0)
+  do { if (P::kNM > 0 || (!P::kRowOps && q.n <= 64)) sweep_flat(q, s, nu, nact, lane); else sweep<(P::kRowOps ? WG_ELEM_GRP : 8), P::kWideN>(q, s, nu, nact, lane); } while (0)
 
 template <class P>
 __device__ __forceinline__ QlResult ql_solve(const QlView &q, P &prob, double vsmall, int *hist, int hist_cap, QlResume *rs = nullptr) {
@@ -1441,7 +1468,7 @@ __device__ __forceinline__ QlResult ql_solve(const QlView &q, P &prob, double vs
           }
         }
         PT(26);
-        if (P::kNM == 0 && n > 64 && n <= 128) {
+        if (P::kWideN || (P::kNM == 0 && n > 64 && n <= 128)) {
           double r0, r1;
           z_rows_times<(P::kRowOps ? WG_ELEM_GRP : 8)>(q, s, 0, nact, lane, r0, r1);
           q.x[lane] += r0; q.sc0[lane] = r0;
@@ -1467,10 +1494,10 @@ __device__ __forceinline__ QlResult ql_solve(const QlView &q, P &prob, double vs
         WG_WSYNC();
       }
       PT(4);
-      zt_times_ww<P::kNM, (P::kRowOps ? WG_ELEM_GRP : 8)>(q, s, lane);                      // :1175-1177
+      zt_times_ww<P::kNM, (P::kRowOps ? WG_ELEM_GRP : 8), P::kWideN>(q, s, lane);                      // :1175-1177
       PT(5);
       if (nact != n) {                                      // :1186-1201
-        if (P::kNM == 0 && n > 64 && n <= 128) {
+        if (P::kWideN || (P::kNM == 0 && n > 64 && n <= 128)) {
           double r0, r1;
           z_rows_times<(P::kRowOps ? WG_ELEM_GRP : 8)>(q, s, nact, n, lane, r0, r1);
           q.x[lane] -= r0;
@@ -1745,7 +1772,7 @@ __device__ __forceinline__ QlResult ql_solve(const QlView &q, P &prob, double vs
         else for (int i = lane; i < n; i += 64) q.ww[i] = Am(knext - 1, i);
         WG_WSYNC();
         if constexpr (P::kCompact) prob.zt_row(q, s, knext - 1, lane);
-        else zt_times_ww<P::kNM, (P::kRowOps ? WG_ELEM_GRP : 8)>(q, s, lane);
+        else zt_times_ww<P::kNM, (P::kRowOps ? WG_ELEM_GRP : 8), P::kWideN>(q, s, lane);
       } else {
         int k1 = knext - m;
         double sg = 1.0;

@@ -239,6 +239,7 @@ struct HerdtProb {
   static constexpr bool kHasFactor = true;
   static constexpr bool kRowOps = false;       // the compact view has its own register-row paths
   static constexpr int kNM = 2 * NH + 2 * 2;   // n <= 2N + 2*2: at most two previewed steps (checked by wg_mpc_configure)
+  static constexpr bool kWideN = false;
   static_assert(4 * NH == 64, "one CoP row per lane needs 4N == 64");
   // ---- LDS / global tables (wave-uniform pointers) ----
   const double *Qb;       // global (L1/L2-resident constant of the model), NH x kQbLd
@@ -648,12 +649,19 @@ struct HerdtProb {
 // border block: x-group rows (jerk-x rows and x-foot rows) only meet x-foot columns, y-group rows only y-foot columns, so
 // one half-width table suffices: Gv[i][c'] with c' the column index inside the row's own group
 constexpr int kGvLdElem = kSMaxQ;
-struct HerdtElemProb {
+// NHC > 0: the horizon is that compile-time constant (BASELINE config 5: 32) -- N folds into every loop bound and table stride,
+// n = 2N + 2ns >= 64 is known (the solver compiles only its two-rows-per-lane forms: kWideN), the factor() dispatch is static;
+// NHC == -1: any horizon, read from the member.
+template <int NHC>
+struct HerdtElemProbT {
   static constexpr bool kCompact = false;
   static constexpr bool kHasFactor = true;     // constant factor blocks + structured border (N == 32 only, see factor())
   static constexpr bool kRowOps = true;        // row products walk the row's structure instead of calling A() per element
   static constexpr int kNM = 0;
-  int N, ns;
+  static constexpr bool kWideN = NHC >= 32;    // 64 <= n <= 128 for every problem of the model
+  struct NConst { static constexpr int v = NHC; __device__ __forceinline__ NConst &operator=(int) { return *this; } __device__ __forceinline__ operator int() const { return v; } };
+  typename std::conditional<(NHC > 0), NConst, int>::type N;   // assigning to the constant form is a no-op
+  int ns;
   const double *Qb;       // global, N x kQbLd
   const double *u;        // LDS, N
   double *Gv;             // LDS, n x kGvLdElem: G(i, 2N + c) of the row's own column group
@@ -668,7 +676,7 @@ struct HerdtElemProb {
   // (herdt_constant_blocks, herdt_border_rows, herdt_border_z): instantiated for BASELINE config 5's horizon, N = 32, with
   // 1..4 previewed steps; other horizons of this view take the solver's generic factorisation (return false).
   __device__ __forceinline__ bool factor(const QlView &q, double vsmall, int lane) const {
-    if (N != 32 || ns < 1 || ns > 4) return false;
+    if ((int)N != 32 || ns < 1 || ns > 4) return false;
     constexpr int NHc = 32;
     herdt_constant_blocks<NHc>(q, R2, Z2, z2sign, lane);
     WG_WSYNC();
@@ -771,6 +779,7 @@ struct HerdtElemProb {
       const int klast = (k0 + 63 < 4 * N) ? k0 + 63 : 4 * N;
       const int rmax = (klast - 1) >> 2;                    // instant of the pass's last CoP row
       const double ac = cop ? a : 0.0, bc = cop ? b : 0.0;
+#pragma unroll 1
       for (int c0 = 0; c0 <= rmax; c0 += 4) {
         double vv[4], uu[4];
 #pragma unroll
@@ -778,6 +787,7 @@ struct HerdtElemProb {
 #pragma unroll
         for (int e = 0; e < 4; ++e) { const double t = vv[e] * (0.0 - ac * uu[e]); sum += t; asum += fabs(t); }
       }
+#pragma unroll 1
       for (int c0 = 0; c0 <= rmax; c0 += 4) {
         double vv[4], uu[4];
 #pragma unroll
@@ -821,5 +831,6 @@ struct HerdtElemProb {
     return sum;
   }
 };
+typedef HerdtElemProbT<-1> HerdtElemProb;
 
 }  // namespace wg

@@ -505,6 +505,8 @@ struct TickDiag { int ifail, n_iter, nact, n, m, ns; };
 
 // NH == 16: compact problem view (rows in registers, no G / A anywhere); NH == 0: generic dense view (G, A in LDS);
 // NH == -1: element view (any N <= 32: G / A regenerated per element from the compact tables, wg_ql_herdt.hpp)
+// NH == 32: the element view with BASELINE config 5's horizon as a compile-time constant: every offset of the per-block global
+//           slot and of the wave's LDS is a constant behind one base, the solver keeps only its two-rows-per-lane forms
 // Where the dense view writes the assembled QP instead of solving it (wg_mpc_assemble_batch): one gait's slice of the
 // arrays QPProblem::solve hands to ql0001_ (qp-problem.cpp:245-279) -- what QPProblem::dump_problem prints (:639-653).
 struct QpDumpOut {
@@ -519,14 +521,20 @@ __device__ __forceinline__ TickDiag mpc_tick(const wg_model_t &m, const TickTabl
                                     int *hist_len, double *zglobal = nullptr, int elem_nact_cap = 0,
                                     const QpDumpOut *dump = nullptr) {
   const int lane = wg_lane();
-  const int N = (NH == 16) ? 16 : m.N;            // compact view: the horizon is a compile-time constant (checked by the host)
+  constexpr bool kElem = (NH == -1 || NH == 32);  // element view: any horizon (-1), or the horizon as a constant (32)
+  // compact view: the horizon is a compile-time constant everywhere (checked by the host).  Fixed element view: a constant where
+  // it decides ADDRESSES (kNC below: slot and LDS offsets, table strides), but the trip count of the assembly's loops stays a
+  // scalar the compiler cannot see through -- unrolled 32-fold they cost the kernel 856 spilled VGPRs and 1248 B of scratch
+  constexpr int kNC = (NH > 0) ? NH : 0;
+  int N = (NH == 16) ? 16 : m.N;
+  if constexpr (NH == 32) { N = 32; asm volatile("" : "+s"(N)); }
   const double T = m.T;
   const int K = WG_SAMPLES_PER_TICK;
   TickLds L;
   // compact: the pre-solve group is overlaid on Z, the first array of the solver's area (QlView::carve without G)
   static_assert(sizeof(Sup) % 8 == 0, "Sup must keep doubles aligned");
-  constexpr int kGvStride = (NH == 16) ? kGvLd : (NH == -1 ? kGvLdElem : 0);
-  constexpr int kGvOff = (NH == -1) ? 0 : 1;
+  constexpr int kGvStride = (NH == 16) ? kGvLd : (kElem ? kGvLdElem : 0);
+  constexpr int kGvOff = kElem ? 0 : 1;
   // compact view with a global slot: [wa (kMmax + kNmax) | b (kMmax) | Gv (kNmax x kGvLd)] leave the LDS -- 2.6 KB, the
   // difference between seven and eight gaits per CU.  All three are read lane-parallel, early in their phases.
   constexpr int kExtWab = (2 * 16 + 4) + 2 * (1 + 4 * 16 + 10);
@@ -534,13 +542,23 @@ __device__ __forceinline__ TickDiag mpc_tick(const wg_model_t &m, const TickTabl
   // element view: the slot holds [Z (nmax x (nmax|1)) | wa (mmax + nmax) | b (mmax) | Gv (nmax x kGvLdElem) | rowA | rowB | rowK
   // (2 mmax + (mmax + 1) / 2 + 2 doubles) | gd | d | wd | wx (nmax each)] for the largest problem of the model -- with all of
   // them in LDS a CU holds four gaits at N = 32, without them six
-  const int eNmax = 2 * N + 2 * kSMax, eMmax = 1 + 4 * N + 5 * kSMax;
-  double *extE = (NH == -1) ? zglobal + (size_t)eNmax * (eNmax | 1) : nullptr;
+  const int eNmax = 2 * (kNC ? kNC : N) + 2 * kSMax, eMmax = 1 + 4 * (kNC ? kNC : N) + 5 * kSMax;
+  double *extE = kElem ? zglobal + (size_t)eNmax * (eNmax | 1) : nullptr;
   const int eWab = (eMmax + eNmax) + eMmax;
   const int eRows = eWab + eNmax * kGvStride;               // offset of the row tables, then of gd | d | wd | wx
   const int eCold = eRows + 2 * eMmax + (eMmax + 1) / 2 + 2;
   const int eRfull = eCold + 4 * eNmax;                    // a full-size R (element view with a column cap on its LDS part)
-  if constexpr (NH == -1) {
+  if constexpr (NH == 32) {
+    // fixed layout: the tick's own arrays first (their size is a constant of the horizon), the solver area behind them with R
+    // last (QlView::carve_fixed_elem) -- every LDS address of the tick is the wave's base plus a constant; the pre-solve overlay
+    // lies over the solver's scratch vectors and R
+    const size_t tb_bytes = (TickLds::bytes(32, kSMax, kGvStride, false, false, false, true) + 15) & ~(size_t)15;
+    lds_tick = reinterpret_cast<char *>(lds_ql);
+    lds_ql = reinterpret_cast<double *>(lds_tick + tb_bytes);
+    char *ovl = reinterpret_cast<char *>(lds_ql + QlView::fixed_elem_head<2 * 32 + 2 * kSMax>());
+    L.template carve<true, true, true>(lds_tick, kNC, kSMax, kGvStride, ovl, false, extE + eWab, extE + eRows, extE + eCold);
+  }
+  else if constexpr (NH == -1) {
     char *ovl = reinterpret_cast<char *>(lds_ql);
     if (TickLds::elem_overlay_apart(N, sizeof(wg_gait_state_t)))           // short horizons: behind the tick's own arrays
       ovl = lds_tick + ((TickLds::bytes(N, kSMax, kGvStride, false, false, false, true) + 15) & ~(size_t)15);
@@ -690,10 +708,10 @@ __device__ __forceinline__ TickDiag mpc_tick(const wg_model_t &m, const TickTabl
   const int n = 2 * N + 2 * ns;
   const int mq = 1 + 4 * N + 5 * ns;     // rows incl. the dummy row 0 (qp-problem.cpp:248)
   constexpr bool kCompactView = (NH == 16);
-  constexpr bool kTableView = (NH == 16) || (NH == -1);   // Hessian / constraints kept as compact tables
+  constexpr bool kTableView = (NH == 16) || kElem;        // Hessian / constraints kept as compact tables
   // element view with a Z slot in global memory: Z leaves the LDS (it is the operand that caps the residency at N = 32)
-  constexpr bool z_in_lds = (NH != -1);
-  constexpr bool kElemView = (NH == -1);
+  constexpr bool z_in_lds = !kElem;
+  constexpr bool kElemView = kElem;
   QlDims D(n, mq, mq, !kTableView, true, kCompactView ? 2 * NH + 4 : 0, !kTableView, z_in_lds, !kElemView, !kElemView,
            kElemView ? (elem_nact_cap & 0xffff) : 0);       // ordered sums run the static length
   QlView q;
@@ -702,7 +720,13 @@ __device__ __forceinline__ TickDiag mpc_tick(const wg_model_t &m, const TickTabl
     // same footprint as QlDims(kNmax, kMmax, kMmax, dense = false, nsc = kNmax, bounds = false), which sized the LDS on the host
     q.template carve_fixed<kNmax, kMmax, kNmax, true>(lds_ql, n, mq, 0, ext16);
   } else {
-    if constexpr (kElemView) {
+    if constexpr (NH == 32) {
+      q.template carve_fixed_elem<2 * 32 + 2 * kSMax, 1 + 4 * 32 + 5 * kSMax>(lds_ql, n, mq, 0, elem_nact_cap & 0xffff, zglobal, extE, extE + (eMmax + eNmax),
+                                                                              extE + eCold + eNmax, extE + eCold + 2 * eNmax, extE + eCold + 3 * eNmax,
+                                                                              extE + eRfull);
+      if (q.nact_cap > 0 && (elem_nact_cap >> 16) > 0 && (elem_nact_cap >> 16) < q.nact_cap) q.nact_cap = elem_nact_cap >> 16;   // tests
+    }
+    else if constexpr (kElemView) {
       q.template carve<false, false, false>(lds_ql, D, 0, extE, eMmax + eNmax, extE + eCold + eNmax, eNmax);
       q.Z = zglobal;
       q.Rf = extE + eRfull;                                 // the LDS may hold only r_cols columns of R: the Cholesky factor needs all n
@@ -888,7 +912,7 @@ __device__ __forceinline__ TickDiag mpc_tick(const wg_model_t &m, const TickTabl
         dst[i] = __hip_atomic_load(src + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       WG_WSYNC();
     }
-  } else if constexpr (NH == -1) {
+  } else if constexpr (kElem) {
     if (lane == 0 && fabs(L.gd[n - 1]) == 0.0) L.gd[n - 1] = 1e-8;               // qld.cpp:442-444 (nmax == n)
     WG_WSYNC();
     {
@@ -898,7 +922,7 @@ __device__ __forceinline__ TickDiag mpc_tick(const wg_model_t &m, const TickTabl
       for (int i = lane; i < (int)(sizeof(wg_gait_state_t) / 8); i += 64) dst[i] = src[i];
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // gd / d (global slot) written above are read by other lanes below
     }
-    HerdtElemProb prob;
+    HerdtElemProbT<(NH == 32) ? 32 : -1> prob;
     prob.N = N; prob.ns = ns; prob.Qb = &tb->Qb[0][0]; prob.u = L.uvec; prob.Gv = L.Gv; prob.gd = L.gd;
     prob.rowA = L.rowA; prob.rowB = L.rowB; prob.rowK = L.rowK; prob.stepidx = L.stepidx; prob.V_f = L.V_f;
     prob.R2 = tb->R2; prob.Z2 = tb->Z2; prob.z2sign = tb->z2_cross_sign; prob.blocks_ok = tb->blocks_ok;

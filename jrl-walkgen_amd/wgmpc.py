@@ -127,8 +127,11 @@ def lib():
         _lib.wg_ctx_destroy.restype = None
         _lib.wg_ctx_device.argtypes = [C.c_void_p]
         _lib.wg_mpc_configure.argtypes = [C.c_void_p]
-        _lib.wg_mpc_reserve.argtypes = [C.c_int]
+        if hasattr(_lib, "wg_mpc_reserve"):                 # absent from older experiment builds (WG_LIB_PATH, A/B runs)
+            _lib.wg_mpc_reserve.argtypes = [C.c_int]
         for name in CTX_ENTRY_POINTS:
+            if not hasattr(_lib, name):
+                continue
             base, fn = getattr(_lib, name), getattr(_lib, name + "_ctx")
             fn.argtypes = [C.c_void_p] + list(base.argtypes or [])
             fn.restype = base.restype

@@ -186,10 +186,14 @@ def test_other_horizons_by_default_bit_exact(N, T, step):
     assert max(sizes) > 2 * N
 
 
-def test_config5_horizon_32_runs_through_the_element_view_bit_exact():
+@pytest.mark.parametrize("generic", [False, True])
+def test_config5_horizon_32_runs_through_the_element_view_bit_exact(generic, monkeypatch):
     """BASELINE config 5's problem size (N = 32, foot-placement variables kept: n up to 72, m up to 149), in fp64: its
     dense matrices do not fit a CU's LDS, so the tick regenerates G / A per element from the compact tables.  Z (42 KB) sits
-    in a per-block slot of global memory (four gaits per CU instead of two)."""
+    in a per-block slot of global memory.  N = 32 has a kernel instantiated for that horizon (every slot / LDS offset a constant);
+    WG_TICK_ELEM_GENERIC=1 sends it through the any-horizon kernel: both against the oracle."""
+    if generic:
+        monkeypatch.setenv("WG_TICK_ELEM_GENERIC", "1")
     wg.init(0)
     sizes = _horizon_vs_oracle(32, 0.1, 0.8, B=5, ticks=36, redraw=12)
     assert max(sizes) == 72 and min(sizes) >= 64                   # all four previewed steps appeared
@@ -209,13 +213,16 @@ def test_horizons_next_to_32_take_the_element_view_with_their_own_column_cap(N, 
     assert max(sizes) > 2 * N
 
 
-@pytest.mark.parametrize("abort_at", ["6", "31", "47"])
+@pytest.mark.parametrize("abort_at", ["6", "31", "47", "31-generic"])
 def test_config5_solves_that_outgrow_the_lds_part_of_R_are_repeated_in_global_memory(abort_at, monkeypatch):
     """At N = 32 the LDS holds the first 41 columns of R (twelve gaits per CU); a solve whose active set grows past them hands
     its loop state out (QlResume), R's finished columns move to the per-block slot of global memory and the same solve goes on
     there -- the same bytes as an uncapped solve.  WG_ELEM_ABORT_AT makes the hand-over happen at a smaller active set: at 6
     nearly every solve continues in global memory almost from the start, at 31 most of them, at 47 (beyond the layout's own
     41) the layout's cap decides."""
+    if abort_at.endswith("-generic"):
+        monkeypatch.setenv("WG_TICK_ELEM_GENERIC", "1")                # the any-horizon kernel at N = 32
+        abort_at = abort_at.split("-")[0]
     monkeypatch.setenv("WG_ELEM_ABORT_AT", abort_at)
     wg.init(0)
     sizes = _horizon_vs_oracle(32, 0.1, 0.8, B=5, ticks=36, redraw=12)

@@ -114,16 +114,22 @@ def test_two_streams_share_one_context(monkeypatch):
     dev_in = {k: t(pk[k]) for k in ("n", "m", "me", "C", "d", "A", "b", "xl", "xu")}
     outs = []
     streams = [torch.cuda.Stream(), torch.cuda.Stream()]
-    torch.cuda.synchronize()
+    # the outputs exist BEFORE the launches: torch fills them on its default stream, which nothing orders against the two
+    # non-blocking streams -- with the device full of the first launch's blocks a fill enqueued next to the second launch could
+    # land after that launch's first blocks had written their results (seen: a few early QPs of launch 1 read back as zeros)
     for st in streams:
         x = torch.zeros(B, nmax, dtype=torch.float64, device="cuda"); u = torch.zeros(B, mmax + 2 * nmax, dtype=torch.float64, device="cuda")
         ifail = torch.full((B,), -99, dtype=torch.int32, device="cuda"); nit = torch.zeros(B, dtype=torch.int32, device="cuda")
-        wg.qp_solve_batch_dev(B, nmax, mmax, dev_in["n"], dev_in["m"], dev_in["me"], dev_in["C"], dev_in["d"], dev_in["A"], dev_in["b"],
-                              dev_in["xl"], dev_in["xu"], 1e-8, x, u, ifail, nit, stream=st.cuda_stream)
         outs.append((x, u, ifail, nit))
     torch.cuda.synchronize()
-    for x, u, ifail, nit in outs:
-        assert np.array_equal(x.cpu().numpy(), ref["x"]) and np.array_equal(u.cpu().numpy(), ref["u"])
+    for st, (x, u, ifail, nit) in zip(streams, outs):
+        wg.qp_solve_batch_dev(B, nmax, mmax, dev_in["n"], dev_in["m"], dev_in["me"], dev_in["C"], dev_in["d"], dev_in["A"], dev_in["b"],
+                              dev_in["xl"], dev_in["xu"], 1e-8, x, u, ifail, nit, stream=st.cuda_stream)
+    torch.cuda.synchronize()
+    for k, (x, u, ifail, nit) in enumerate(outs):
+        bad = np.nonzero((x.cpu().numpy() != ref["x"]).any(axis=1))[0]
+        assert len(bad) == 0, "launch %d: %d of %d QPs differ, first %s" % (k, len(bad), B, bad[:8])
+        assert np.array_equal(u.cpu().numpy(), ref["u"])
         assert np.array_equal(ifail.cpu().numpy(), ref["ifail"]) and np.array_equal(nit.cpu().numpy(), ref["n_iter"])
 
 

@@ -100,13 +100,15 @@ def test_run_batch_dense_view_and_arguments():
 
 
 @pytest.mark.parametrize("N,B,T,keep", [(16, 5000, 15, "off"), (16, 5000, 15, "0"), (16, 5000, 15, "3"), (16, 300, 9, "0"),
-                                        (32, 3500, 6, "0"), (32, 3500, 6, "off"), (20, 700, 8, "1")])
+                                        (32, 3500, 6, "0"), (32, 3500, 6, "off"), (20, 700, 8, "1"), (-32, 3500, 6, "0")])
 def test_hand_over_policy_does_not_change_a_byte(N, B, T, keep, monkeypatch):
     """The multi-tick kernel lets a wave keep a gait that is behind its XCD's mean progress (WG_RUN_KEEP = margin in ticks; "off":
     the plain ring; by default 0, and off when every gait has a wave of its own).  Which wave runs which tick of which gait in
     which order is scheduling only: states and per-tick diagnostics are the bytes of one launch per tick."""
     wg.init(0)
     monkeypatch.setenv("WG_RUN_KEEP", keep)
+    if N < 0:                                                  # N = 32 through the any-horizon element kernel
+        monkeypatch.setenv("WG_TICK_ELEM_GENERIC", "1"); N = -N
     model = wg.model_defaults(); model.N = N
     wg.mpc_configure(model)
     try:
