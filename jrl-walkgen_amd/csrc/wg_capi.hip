@@ -353,9 +353,9 @@ void wg_shutdown(void) {
 
 #ifdef WG_PROFILE
 // diagnostic build only: read-and-reset the in-kernel phase timers (shader cycles)
-int wg_prof_read(unsigned long long *out32) {
-  if (hipMemcpyFromSymbol(out32, HIP_SYMBOL(wg::g_prof), 32 * sizeof(unsigned long long)) != hipSuccess) return -1;
-  unsigned long long z[32] = {0};
+int wg_prof_read(unsigned long long *out40) {          // 40 counters (wg_ql_device.hpp, g_prof)
+  if (hipMemcpyFromSymbol(out40, HIP_SYMBOL(wg::g_prof), 40 * sizeof(unsigned long long)) != hipSuccess) return -1;
+  unsigned long long z[40] = {0};
   if (hipMemcpyToSymbol(HIP_SYMBOL(wg::g_prof), z, sizeof z) != hipSuccess) return -1;
   return 0;
 }
@@ -571,7 +571,9 @@ inline size_t tick_z_slot_doubles(const wg_model_t &m, int view) {
   const size_t n = (size_t)tick_max_n(m), mm = (size_t)tick_max_m(m);
   if (view == 16) return (n + 2 * mm) + n * wg::kGvLd;       // wa | b | Gv
   // element view: Z | wa | b | Gv | rowA | rowB | rowK | gd | d | wd | wx | R in full (mpc_tick<-1>)
-  return n * (n | 1) + (n + 2 * mm) + n * wg::kGvLdElem + 2 * mm + (mm + 1) / 2 + 2 + 4 * n + (n * (n + 1) / 2 + n);
+  // (the fixed N = 32 view keeps Z with leading dimension n: whole cache lines per column; slots are multiples of 64 bytes)
+  const size_t zd = view == 32 ? n * n : n * (n | 1);
+  return (zd + (n + 2 * mm) + n * wg::kGvLdElem + 2 * mm + (mm + 1) / 2 + 2 + 4 * n + (n * (n + 1) / 2 + n) + 7) & ~(size_t)7;
 }
 inline size_t tick_lds_for(const wg_model_t &m, int view) { return tick_lds_with_cap(m, view, tick_elem_cap(m, view)); }
 inline int tick_view(const wg_model_t &m) {

@@ -201,14 +201,14 @@ struct QlView {
   // Element view with the horizon known at compile time (NMAX = 2N + 2 kSMax, MMAX = 1 + 4N + 5 kSMax): the lean partition of
   // carve<false, false, false> laid out for the model's LARGEST problem whatever n and m the tick has, so that every LDS array
   // sits at a constant offset from the wave's base (immediates in the ds instructions instead of address registers) and Z's
-  // leading dimension is the constant NMAX | 1:   x | ww | lam | slot | iact | sc0 sc1 sc2 sc3 | R.
+  // leading dimension is the constant NMAX:   x | ww | lam | slot | iact | sc0 sc1 sc2 sc3 | R.
   // R comes last: its length -- r_cols columns and one working column, or all n -- is the one thing the column cap decides.  The
   // tick's pre-solve overlay lies over sc0 .. R (dead outside the solve).  Z, wa | b and d | wd | wx live in the per-block global
   // slot (the caller passes them: constants behind one base).  Same bytes as QlDims(NMAX, MMAX, ...).bytes().
   template <int NMAX, int MMAX>
   __device__ __forceinline__ void carve_fixed_elem(double *base, int n_, int m_, int me_, int r_cols, double *z_ext, double *wa_ext,
                                                     double *b_ext, double *d_ext, double *wd_ext, double *wx_ext, double *rf_ext) {
-    n = n_; m = m_; me = me_; mn = m_ + n_; ldg = NMAX | 1; ldz = NMAX | 1; lda = MMAX | 1;
+    n = n_; m = m_; me = me_; mn = m_ + n_; ldg = NMAX | 1; ldz = NMAX; lda = MMAX | 1;   // Z is global here: whole cache lines per column
     const bool capped = r_cols > 0 && r_cols < n_;
     nact_cap = capped ? r_cols : 0;
     r_tail = capped ? r_cols * (r_cols + 1) / 2 : n_ * (n_ + 1) / 2;
@@ -264,15 +264,24 @@ typedef DenseProbT<true> DenseProb;
 
 // ---- optional in-kernel phase timers (diagnostic build only: -DWG_PROFILE) ----
 #ifdef WG_PROFILE
-__device__ unsigned long long g_prof[32];
-#define PT_DECL unsigned long long pt_acc[28] = {0}; unsigned long long pt_cnt[4] = {0}; unsigned long long pt_last = clock64();
+__device__ unsigned long long g_prof[40];               // 32..34: the sweep's three phases (norm chain, coefficients, row rotations)
+#define PT_DECL unsigned long long pt_acc[28] = {0}; unsigned long long pt_cnt[4] = {0}; unsigned long long pt_sw[3] = {0}; unsigned long long pt_last = clock64();
 #define PT(k) do { unsigned long long t_ = clock64(); pt_acc[k] += t_ - pt_last; pt_last = t_; } while (0)
 #define PT_FLUSH do { if ((threadIdx.x & 63) == 0) { for (int k_ = 0; k_ < 28; ++k_) if (k_ < 21 || k_ > 23) atomicAdd(&g_prof[k_], pt_acc[k_]); \
-                                                      for (int k_ = 0; k_ < 4; ++k_) atomicAdd(&g_prof[28 + k_], pt_cnt[k_]); } } while (0)
+                                                      for (int k_ = 0; k_ < 4; ++k_) atomicAdd(&g_prof[28 + k_], pt_cnt[k_]); \
+                                                      for (int k_ = 0; k_ < 3; ++k_) atomicAdd(&g_prof[32 + k_], pt_sw[k_]); } } while (0)
+#define PT_SW_PARAM , unsigned long long *ptsw = nullptr
+#define PT_SW_ARG , pt_sw
+#define PT_SW(k) do { if (ptsw) { unsigned long long t_ = clock64(); ptsw[k] += t_ - ptsw_last; ptsw_last = t_; } } while (0)
+#define PT_SW_BEGIN unsigned long long ptsw_last = clock64();
 // event counters 28..31: kept in registers and flushed once (a global atomic per event would show up in the phase it sits in)
 #define PT_COUNT(k) do { pt_cnt[(k) - 28]++; } while (0)
 #else
 #define PT_COUNT(k) do {} while (0)
+#define PT_SW_PARAM
+#define PT_SW_ARG
+#define PT_SW(k) do {} while (0)
+#define PT_SW_BEGIN
 #define PT_DECL
 #define PT(k) do {} while (0)
 #define PT_FLUSH do {} while (0)
@@ -701,9 +710,10 @@ __device__ __forceinline__ double ordered_sum_lds(double term, double *scratch, 
 //   phase 1  chain of rotation norms (all lanes redundantly; s[c-1] prefetched); lane c records its rotation;
 //   phase 2  lane c turns (p, q, norm) into (ga, gb) and publishes the pair in LDS;
 //   phase 3  lane i carries row i of Z through the rotations.
-__device__ __forceinline__ void sweep_flat(const QlView &q, double *s, int nu, int nact, int lane) {
+__device__ __forceinline__ void sweep_flat(const QlView &q, double *s, int nu, int nact, int lane PT_SW_PARAM) {
   const int n = q.n;
   if (nu - 1 <= nact) return;
+  PT_SW_BEGIN
   // Phase 1 leaves ONE value per rotation behind -- `cur` as it leaves rotation c, in chain[c - 1] -- from which lane c
   // rebuilds its rotation afterwards: q = the value that entered (chain[c], or s[nu-1] for the first one), p = s[c-1]
   // (untouched until phase 2), norm = chain[c-1] when q != 0 (then cur = norm), skipped when q == 0 (then cur = p).
@@ -748,6 +758,7 @@ __device__ __forceinline__ void sweep_flat(const QlView &q, double *s, int nu, i
     }
   }
   WG_WSYNC();
+  PT_SW(0);
   double myP = 0.0, myQ = 0.0, myN = 0.0;
   {
     const bool mine = lane > nact && lane < nu;
@@ -775,6 +786,7 @@ __device__ __forceinline__ void sweep_flat(const QlView &q, double *s, int nu, i
     if (rot) s[lane - 1] = myN;
   }
   WG_WSYNC();
+  PT_SW(1);
   {
     // phase 3: lane i carries row i of Z through the rotations.  Operands of rotation c -- Z(i, c-1) and the pair
     // (ga, gb) -- are fetched three rotations ahead into one of three register sets used in turn (an unroll by three, so
@@ -856,6 +868,7 @@ __device__ __forceinline__ void sweep_flat(const QlView &q, double *s, int nu, i
     zp[0] = carry;                                           // Z(i, nact)
   }
   WG_WSYNC();
+  PT_SW(2);
 }
 
 // qld.cpp:1861-1889.  Returns kdrop (0-based) or -1; ratio updated when found.
@@ -1219,7 +1232,7 @@ __device__ __forceinline__ bool independent_coordinate(const QlView &q, const P 
 // one row of Z per lane (n <= 64): the branch-free, prefetching form -- the compact view always, the dense view by size (the
 // element view is built for n > 64: it keeps the one form it needs, its kernel is large enough as it is)
 #define WG_SWEEP(q, s, nu, nact, lane) \
-  do { if (P::kNM > 0 || (!P::kRowOps && q.n <= 64)) sweep_flat(q, s, nu, nact, lane); else sweep<(P::kRowOps ? WG_ELEM_GRP : 8), P::kWideN>(q, s, nu, nact, lane); } while (0)
+  do { if (P::kNM > 0 || (!P::kRowOps && q.n <= 64)) sweep_flat(q, s, nu, nact, lane PT_SW_ARG); else sweep<(P::kRowOps ? WG_ELEM_GRP : 8), P::kWideN>(q, s, nu, nact, lane); } while (0)
 
 template <class P>
 __device__ __forceinline__ QlResult ql_solve(const QlView &q, P &prob, double vsmall, int *hist, int hist_cap, QlResume *rs = nullptr) {
@@ -1234,6 +1247,7 @@ __device__ __forceinline__ QlResult ql_solve(const QlView &q, P &prob, double vs
   const int ifinc = 3, kfinc = n > 10 ? n : 10;
   int jfinc = -kfinc;
   double xmag = 0.0, vfact = 1.0, res = 0.0, ratio = 0.0, diag = 0.0;
+  double wsel = 1.0;                                        // wa[.] of the constraint knext, as the scan read it (positive)
   int knext = 0;
   const int s_tail = q.r_tail;                              // n (n + 1) / 2, or the working column of the last allowed nact
   double *s = q.R + s_tail;
@@ -1538,10 +1552,13 @@ __device__ __forceinline__ QlResult ql_solve(const QlView &q, P &prob, double vs
 
     if (st == ST_SCAN) {
       // ---- most violated normalised constraint, :1255-1331 ----
-      double bestv = 0.0, bestres = 0.0;
+      // bestw: the weight wa[.] of the lane's candidate as the scan read it.  The winner's is kept (wsel): the linear-dependence
+      // test divides by it and the activation stores its negative -- wa may live in global memory (L2), where reading it again on
+      // the critical path is an exposed round trip per iteration (the same value: nothing writes wa between the scan and the add)
+      double bestv = 0.0, bestres = 0.0, bestw = 0.0;
       int bidx = -1;
       WG_REP(1) {
-      bestv = 0.0; bestres = 0.0; bidx = -1;
+      bestv = 0.0; bestres = 0.0; bestw = 0.0; bidx = -1;
       if constexpr (P::kCompact) {
         constexpr int NH = sizeof(prob.ax) / sizeof(double);
         double xs[2 * NH];
@@ -1565,7 +1582,7 @@ __device__ __forceinline__ QlResult ql_solve(const QlView &q, P &prob, double vs
             const double tempa = asum + fabs(sum);
             const double temp2 = asum + onha * fabs(sum);
             const bool take = (wak > 0.0) & !(sumx <= 0.0) & !(tempa <= asum) & !(temp2 <= tempa);
-            bestv = take ? sumx : bestv; bestres = take ? sum : bestres; bidx = take ? k + 1 : bidx;
+            bestv = take ? sumx : bestv; bestres = take ? sum : bestres; bestw = take ? wak : bestw; bidx = take ? k + 1 : bidx;
           }
         }
         {
@@ -1580,7 +1597,7 @@ __device__ __forceinline__ QlResult ql_solve(const QlView &q, P &prob, double vs
           const double tempa = asum + fabs(sum);
           const double temp2 = asum + onha * fabs(sum);
           const bool take = has_foot & (wak > 0.0) & !(sumx <= 0.0) & !((bidx >= 0) & (sumx <= bestv)) & !(tempa <= asum) & !(temp2 <= tempa);
-          bestv = take ? sumx : bestv; bestres = take ? sum : bestres; bidx = take ? k + 1 : bidx;
+          bestv = take ? sumx : bestv; bestres = take ? sum : bestres; bestw = take ? wak : bestw; bidx = take ? k + 1 : bidx;
         }
       } else {
       if constexpr (P::kRowOps) {
@@ -1617,7 +1634,7 @@ __device__ __forceinline__ QlResult ql_solve(const QlView &q, P &prob, double vs
           if (tempa <= temp) continue;
           temp += onha * fabs(sum);
           if (temp <= tempa) continue;
-          bestv = sumx; bestres = sum; bidx = k + 1;
+          bestv = sumx; bestres = sum; bestw = wak; bidx = k + 1;
         }
       } else
       // dense rows: ONE walk of the row for both sums (sum += x_i a_ki, temp += |x_i a_ki|, i ascending: the same values the
@@ -1677,7 +1694,7 @@ __device__ __forceinline__ QlResult ql_solve(const QlView &q, P &prob, double vs
         if (tempa <= temp) continue;
         temp += onha * fabs(sum);
         if (temp <= tempa) continue;
-        bestv = sumx; bestres = sum; bidx = k + 1;
+        bestv = sumx; bestres = sum; bestw = wak; bidx = k + 1;
       }
       }
       if constexpr (P::kNM > 0) {                            // n <= 64: one bound pair per lane, selects instead of continues
@@ -1688,17 +1705,18 @@ __device__ __forceinline__ QlResult ql_solve(const QlView &q, P &prob, double vs
         const bool upper = s1 < 0.0;
         const double sum = upper ? xk - prob.xu(q, kc) : s1;
         const bool take = in && !(w <= 0.0) && !(s1 == 0.0) && !(sum <= 0.0) && !(bidx >= 0 && sum <= bestv);
-        bestv = take ? sum : bestv; bestres = take ? -sum : bestres; bidx = take ? (upper ? kc + 1 + mn : kc + 1 + m) : bidx;
+        bestv = take ? sum : bestv; bestres = take ? -sum : bestres; bestw = take ? w : bestw; bidx = take ? (upper ? kc + 1 + mn : kc + 1 + m) : bidx;
       } else
       for (int k = lane; k < n; k += 64) {
-        if (q.wa[m + k] <= 0.0) continue;
+        const double w = q.wa[m + k];
+        if (w <= 0.0) continue;
         bool lower = true;
         double sum = prob.xl(q, k) - q.x[k];
         if (sum == 0.0) continue;
         if (sum < 0.0) { sum = q.x[k] - prob.xu(q, k); lower = false; }
         if (sum <= 0.0) continue;               // cvmax starts at 0
         if (bidx >= 0 && sum <= bestv) continue;
-        bestv = sum; bestres = -sum; bidx = lower ? k + 1 + m : k + 1 + mn;
+        bestv = sum; bestres = -sum; bestw = w; bidx = lower ? k + 1 + m : k + 1 + mn;
       }
       {
         // order key: general rows 1..m, then bounds by variable; lower/upper of one
@@ -1716,13 +1734,14 @@ __device__ __forceinline__ QlResult ql_solve(const QlView &q, P &prob, double vs
           src = __ffsll((long long)mask) - 1;
           bestv = rl(bestv, src);
           bestres = rl(bestres, src);
+          bestw = rl(bestw, src);
           bidx = __builtin_amdgcn_readlane(bidx, src);
         }
       }
-      WG_SINK(bestv); WG_SINK(bestres); WG_SINK(bidx);
+      WG_SINK(bestv); WG_SINK(bestres); WG_SINK(bestw); WG_SINK(bidx);
       }   // WG_REP(1)
       double cvmax = bestv;
-      if (bidx >= 0) { res = bestres; knext = bidx; }
+      if (bidx >= 0) { res = bestres; knext = bidx; wsel = bestw; }
       PT(9);
       info = 0;
       if (WG_UBOOL(cvmax <= vsmall)) { st = ST_CONVERGED; continue; }  // :1336
@@ -1849,7 +1868,7 @@ __device__ __forceinline__ QlResult ql_solve(const QlView &q, P &prob, double vs
           if (WG_UBOOL(!significant(sumb, fabs(suma)) || !(sumb > vsmall))) route = 1;
           else {
             sumc = sqrt(sumc);
-            if (knext <= m) sumc /= q.wa[knext - 1];
+            if (knext <= m) sumc /= wsel;                    // wa[knext - 1]: the value the scan read
             if (WG_UBOOL(significant(sumc, fabs(suma)))) route = 0;
             else {                                          // :1538-1540
               PT_COUNT(29);
@@ -1943,7 +1962,7 @@ __device__ __forceinline__ QlResult ql_solve(const QlView &q, P &prob, double vs
         q.iact[nact] = knext;
         int ia = knext - 1;
         if (knext > mn) ia -= n;
-        q.wa[ia] = -q.wa[ia];
+        q.wa[ia] = -wsel;                                   // = -wa[ia]: a store, not a read-modify-write
       }
       nact++;
       LOG_EVENT(knext);

@@ -543,7 +543,10 @@ __device__ __forceinline__ TickDiag mpc_tick(const wg_model_t &m, const TickTabl
   // (2 mmax + (mmax + 1) / 2 + 2 doubles) | gd | d | wd | wx (nmax each)] for the largest problem of the model -- with all of
   // them in LDS a CU holds four gaits at N = 32, without them six
   const int eNmax = 2 * (kNC ? kNC : N) + 2 * kSMax, eMmax = 1 + 4 * (kNC ? kNC : N) + 5 * kSMax;
-  double *extE = kElem ? zglobal + (size_t)eNmax * (eNmax | 1) : nullptr;
+  // fixed element view: Z's leading dimension is eNmax itself -- every column is 9 whole 64-byte lines and every 64-row load of the
+  // sweep 8 whole lines (the slot is 64-byte aligned); the odd leading dimension of the other views (bank-conflict-free in LDS)
+  // makes each column straddle a tenth line: measured 1.29 x the useful bytes in the Z^T a walk (profiles/round3_fetchcal_*)
+  double *extE = kElem ? zglobal + (size_t)eNmax * (NH == 32 ? eNmax : (eNmax | 1)) : nullptr;
   const int eWab = (eMmax + eNmax) + eMmax;
   const int eRows = eWab + eNmax * kGvStride;               // offset of the row tables, then of gd | d | wd | wx
   const int eCold = eRows + 2 * eMmax + (eMmax + 1) / 2 + 2;

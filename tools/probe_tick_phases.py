@@ -14,7 +14,7 @@ s0 = wg.gait_init(model, [0.0316055, 0.0, 0.7116911], [0.0, 0.09, 0.0], [0.0, -0
 for g in range(B): C.memmove(C.byref(states[g]), C.byref(s0), C.sizeof(wg.GaitState))
 dev = torch.frombuffer(bytearray(bytes(memoryview(states).cast("B"))), dtype=torch.uint8).cuda()
 diag = torch.zeros(B, 6, dtype=torch.int32, device="cuda")
-buf = (C.c_ulonglong * 32)()
+buf = (C.c_ulonglong * 40)()
 its = 0
 for tick in range(WARM + MEAS):
     if tick % 50 == 0:
@@ -35,3 +35,6 @@ print(f"gait-ticks={n} mean QL iters={its/n:.1f} cycles/tick={tot/n:.0f}  route 
 print(f"   of 'inverse' (factor): constant blocks into LDS {v[2]/n:.0f} cyc/tick, border rows of R {v[31]/n:.0f} cyc/tick")
 for k, nme in enumerate(names):
     print(f"{k:2d} {nme:22s} {v[k]/n:12.0f} cyc/tick  {100*v[k]/tot:5.1f}%")
+    if k == 12 and v[32:35].sum() > 0:                       # the compact view's sweep by phase (sweep_flat)
+        for j, ph in enumerate(["phase 1: chain of rotation norms", "phase 2: ga / gb of every rotation, one lane each", "phase 3: lane i carries row i of Z through the rotations"]):
+            print(f"      sweep {ph:58s} {v[32+j]/n:10.0f} cyc/tick  {100*v[32+j]/tot:5.1f}%")
