@@ -93,6 +93,15 @@ __device__ __forceinline__ double lane_sum_ordered(double v, int lo, int hi) {
   }
   return sum;
 }
+// A double constant materialised where it is used (two s_mov_b32), opaque to the optimiser: left to itself the compiler hoists
+// 64-bit literals (0.1, 0.2, 1e-8, 0.01, 1.5 ...) out of the persistent loop into VGPR pairs at kernel entry, runs out of
+// registers, SPILLS them and reloads them from scratch memory inside the active-set loop -- seen in the 256-register tick kernel:
+// every scratch_ instruction at loop depth 2 was the reload of such a constant.
+__device__ __forceinline__ double wg_kconst(double c) {
+  int lo = __double2loint(c), hi = __double2hiint(c);
+  asm volatile("" : "+s"(lo), "+s"(hi));
+  return __hiloint2double(hi, lo);
+}
 // f2c.h max/min (qld.cpp:269-270)
 __device__ __forceinline__ double maxd(double a, double b) { return a >= b ? a : b; }
 __device__ __forceinline__ double mind(double a, double b) { return a <= b ? a : b; }
@@ -444,8 +453,8 @@ __device__ __forceinline__ void givens(double p, double qq, double &ga, double &
   nrm = sum;
 }
 __device__ __forceinline__ bool significant(double base, double delta_abs) {
-  double temp = base + delta_abs * .1;
-  double tempa = base + delta_abs * .2;
+  double temp = base + delta_abs * wg_kconst(.1);
+  double tempa = base + delta_abs * wg_kconst(.2);
   if (temp <= base) return false;
   if (tempa <= temp) return false;
   return true;
@@ -1236,7 +1245,7 @@ __device__ __forceinline__ bool independent_coordinate(const QlView &q, const P 
 
 template <class P>
 __device__ __forceinline__ QlResult ql_solve(const QlView &q, P &prob, double vsmall, int *hist, int hist_cap, QlResume *rs = nullptr) {
-  const int lane = wg_lane();
+  int lane = wg_lane();
   const int n = q.n, m = q.m, me = q.me, mn = q.mn;
   QlResult out;
   out.hist_len = 0;
@@ -1405,6 +1414,10 @@ __device__ __forceinline__ QlResult ql_solve(const QlView &q, P &prob, double vs
   int st = early_exit ? ST_FINISH : ST_RESET;
   if (resuming) st = rs->st;
   while (st != ST_FINISH) {
+    // the lane index is made opaque once per iteration: otherwise everything derived from it alone (clamped indices, LDS
+    // addresses of the lane's entries) is computed in front of the loop and kept alive -- in the 256-register kernel: spilled
+    // there and reloaded from scratch memory in every iteration
+    asm volatile("" : "+v"(lane));
     if (st == ST_RESET || st == ST_RESID) {
       s = q.R + s_tail;
       if (st == ST_RESET) {                                 // :989-1027
@@ -1574,8 +1587,8 @@ __device__ __forceinline__ QlResult ql_solve(const QlView &q, P &prob, double vs
           double sum = -bk, asum = fabs(bk);
           prob.cop_row_dot(xs, sum, asum);
           if (prob.fj >= 0) {
-            double t = q.x[2 * NH + prob.fj] * prob.fa; sum += t; asum += fabs(t);
-            t = q.x[2 * NH + prob.ns + prob.fj] * prob.fb; sum += t; asum += fabs(t);
+            double t = q.x[2 * NH + prob.fj] * prob.fa(); sum += t; asum += fabs(t);
+            t = q.x[2 * NH + prob.ns + prob.fj] * prob.fb(); sum += t; asum += fabs(t);
           }
           const double sumx = -sum * wak;
           {                                           // the reference's tests in its order, as one predicate and three selects
@@ -1591,8 +1604,9 @@ __device__ __forceinline__ QlResult ql_solve(const QlView &q, P &prob, double vs
           const int k = kf;
           const double wak = wakf, bk = bkf;
           double sum = -bk, asum = fabs(bk);
+          const auto fr = prob.foot_row();
 #pragma unroll
-          for (int e = 0; e < 4; ++e) { const double t = q.x[prob.f2c[e]] * prob.f2v[e]; sum += t; asum += fabs(t); }
+          for (int e = 0; e < 4; ++e) { const double t = q.x[fr.c[e]] * fr.v[e]; sum += t; asum += fabs(t); }
           const double sumx = -sum * wak;
           const double tempa = asum + fabs(sum);
           const double temp2 = asum + onha * fabs(sum);
@@ -1744,7 +1758,7 @@ __device__ __forceinline__ QlResult ql_solve(const QlView &q, P &prob, double vs
       if (bidx >= 0) { res = bestres; knext = bidx; wsel = bestw; }
       PT(9);
       info = 0;
-      if (WG_UBOOL(cvmax <= vsmall)) { st = ST_CONVERGED; continue; }  // :1336
+      if (WG_UBOOL(cvmax <= wg_kconst(vsmall))) { st = ST_CONVERGED; continue; }  // :1336
 
       // ---- has the objective stopped increasing?  :1343-1408 ----
       ++jfinc;
@@ -1865,7 +1879,7 @@ __device__ __forceinline__ QlResult ql_solve(const QlView &q, P &prob, double vs
           if (lane == 0 && blockIdx.x == 2 && iterc == 3) { for (int i = 0; i < n; i++) printf("GPUW %d %.17g %.17g\n", i, q.ww[i], Zm(i, nact)); }
           if (lane == 0) printf("GPU blk %d it %d knext %d nact %d suma %.17g sumb %.17g sumc %.17g wa %.17g\n", (int)blockIdx.x, iterc, knext, nact, suma, sumb, sumc, knext <= m ? q.wa[knext - 1] : 0.0);
 #endif
-          if (WG_UBOOL(!significant(sumb, fabs(suma)) || !(sumb > vsmall))) route = 1;
+          if (WG_UBOOL(!significant(sumb, fabs(suma)) || !(sumb > wg_kconst(vsmall)))) route = 1;
           else {
             sumc = sqrt(sumc);
             if (knext <= m) sumc /= wsel;                    // wa[knext - 1]: the value the scan read
@@ -1972,7 +1986,7 @@ __device__ __forceinline__ QlResult ql_solve(const QlView &q, P &prob, double vs
       WG_REP(6) { sm = uni(xmag_sum(q, prob, vfact, lane)); WG_SINK(sm); }   // :1776-1786
       xmag = maxd(xmag, sm);
       PT(19);
-      if (WG_UBOOL(sm < xmagr * xmag)) st = ST_RESET;
+      if (WG_UBOOL(sm < wg_kconst(xmagr) * xmag)) st = ST_RESET;
       else if (itref <= 0) st = ST_SCAN;
       else st = ST_RESID;
       // R's LDS part is full (its columns and the working column hold nact finished columns): stop BETWEEN two iterations,

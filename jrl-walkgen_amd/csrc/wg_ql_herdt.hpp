@@ -90,7 +90,7 @@ __device__ __forceinline__ bool herdt_border_rows(const QlView &q, const double 
   for (int kb = 0; kb < NS; ++kb) {
     const int k = NH + kb;                                // lane that holds the row
     const double t = rl(acc[kb], k);                      // the pivot, wave-uniform
-    ok = ok && !(t < vsmall);                             // a failed pivot: the rest is computed and discarded (caller: generic path)
+    ok = ok && !(t < wg_kconst(vsmall));                  // a failed pivot: the rest is computed and discarded (caller: generic path)
     const double rt = sqrt(t);
     double bk[NS];
 #pragma unroll
@@ -163,8 +163,8 @@ __device__ __forceinline__ void herdt_border_z(const QlView &q, int lane) {
     zl[f] = z;
     if (row) {
       Zm(gi, c) = z; Zm(gy, M2 + NS + f) = z;             // the entry and its y twin
-      Zm(gi, M2 + NS + f) = -0.0;                         // x row, y-foot column: cross, above the diagonal
-      Zm(gy, c) = jerk ? -0.0 : 0.0;                      // y row, x-foot column: above (jerk-y rows) / below (y-foot rows) it
+      Zm(gi, M2 + NS + f) = wg_kconst(-0.0);                         // x row, y-foot column: cross, above the diagonal
+      Zm(gy, c) = jerk ? wg_kconst(-0.0) : 0.0;                      // y row, x-foot column: above (jerk-y rows) / below (y-foot rows) it
     }
   }
 }
@@ -197,7 +197,7 @@ __device__ __forceinline__ void herdt_constant_blocks(const QlView &q, const dou
       const double v = Z2[i + j * M2];
       Zm(i, j) = v; Zm(NH + i, NH + j) = v;
       Zm(NH + i, j) = 0.0;
-      Zm(i, NH + j) = ((z2sign[e >> 6] >> (e & 63)) & 1ull) ? -0.0 : 0.0;
+      Zm(i, NH + j) = ((z2sign[e >> 6] >> (e & 63)) & 1ull) ? wg_kconst(-0.0) : 0.0;
     }
     for (int e = lane; e < (n - M2) * M2; e += 64) { const int i = M2 + e % (n - M2), j = e / (n - M2); Zm(i, j) = 0.0; }
     return;
@@ -227,7 +227,7 @@ __device__ __forceinline__ void herdt_constant_blocks(const QlView &q, const dou
       const int i = e % NH, j = e / NH;
       Zm(i, j) = zv[t]; Zm(NH + i, NH + j) = zv[t];
       Zm(NH + i, j) = 0.0;
-      Zm(i, NH + j) = ((z2sign[e >> 6] >> (e & 63)) & 1ull) ? -0.0 : 0.0;
+      Zm(i, NH + j) = ((z2sign[e >> 6] >> (e & 63)) & 1ull) ? wg_kconst(-0.0) : 0.0;
     }
   }
   for (int e = lane; e < (n - M2) * M2; e += 64) { const int i = M2 + e % (n - M2), j = e / (n - M2); Zm(i, j) = 0.0; }
@@ -256,14 +256,34 @@ struct HerdtProb {
   int ns;
   // ---- per-lane registers: the lane's own constraint rows ----
   double ax[NH], ay[NH];  // CoP row (lane+1): x- and y-jerk parts
-  double fa, fb; int fj;  // its two foot-variable entries (columns 2N+fj, 2N+ns+fj), fj < 0: none
-  double f2v[4]; int f2c[4]; int f2n;   // foot-placement row (1+4N+lane), entries in column order
+  int fj;                 // its two foot-variable entries sit in columns 2N+fj, 2N+ns+fj (fj < 0: none); their values fa(), fb()
+  // (the entries of the lane's CoP row toward the foot variables and of its foot-placement row are NOT kept: they are one
+  //  addition away from the edge coefficients ra / rb / ga / gb below -- 17 registers of per-lane state that lived across the whole
+  //  solve and were what the 256-register kernel spilled inside the active-set loop)
   // raw edge coefficients of the lane's two rows (rowA / rowB / rowK live in LDS only until the solver starts: their
   // storage is part of the pre-solve overlay): any row's (a, b, k) is one v_readlane away
   double ra, rb;          // CoP row lane+1
   double bcop;            // b of the CoP row lane+1 (constant during the solve; b itself lives in global memory, and the scan's
                           // first operation on a row is sum = -b: from a register it does not wait for an L2 round trip)
   double ga, gb; int gk;  // foot-placement row 1+4N+lane (gk < 0: unused row)
+  // the assembly's 0.0 + (0.0 + a * 1.0) * 1.0 is a with a zero of either sign made +0.0: a + 0.0, exactly
+  __device__ __forceinline__ double fa() const { return ra + 0.0; }
+  __device__ __forceinline__ double fb() const { return rb + 0.0; }
+  // The lane's foot-placement row (1 + 4N + lane), entries in column order [2N+kk-1] 2N+kk [2N+ns+kk-1] 2N+ns+kk (without a
+  // predecessor step the two "-1" entries are zeros); an unused row is zeros on a valid column.  The assembly's expressions
+  // 0.0 + (0.0 + a * -1.0) * -1.0 and 0.0 + (0.0 + a * 1.0) * -1.0 are a + 0.0 and 0.0 - a for every a (signed zeros included).
+  struct FootRow { double v[4]; int c[4]; };
+  __device__ __forceinline__ FootRow foot_row() const {
+    const bool used = gk >= 0, pred = gk > 0;
+    const int kk = used ? gk : 0;
+    FootRow r;
+    const int c1 = 2 * NH + kk, c3 = 2 * NH + ns + kk;
+    r.c[0] = used ? (pred ? c1 - 1 : c1) : 2 * NH; r.c[1] = used ? c1 : 2 * NH;
+    r.c[2] = used ? (pred ? c3 - 1 : c3) : 2 * NH; r.c[3] = used ? c3 : 2 * NH;
+    r.v[0] = pred ? ga + 0.0 : 0.0; r.v[1] = used ? 0.0 - ga : 0.0;
+    r.v[2] = pred ? gb + 0.0 : 0.0; r.v[3] = used ? 0.0 - gb : 0.0;
+    return r;
+  }
 
   // ------------------------------------------------------------------ element access (rare paths)
   __device__ __forceinline__ double G(const QlView &q, int i, int j) const {
@@ -356,29 +376,12 @@ struct HerdtProb {
         ay[c] = (c <= r) ? 0.0 + (0.0 + b * uu) * -1.0 : 0.0;
       }
       fj = stepidx[r] - 1;
-      fa = 0.0 + (0.0 + a * 1.0) * 1.0;
-      fb = 0.0 + (0.0 + b * 1.0) * 1.0;
       if (fj >= ns) fj = -1;
     }
-    f2n = 0;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) { f2v[e] = 0.0; f2c[e] = 2 * NH; }   // unused entries: value 0 on a valid column
     ga = 0.0; gb = 0.0; gk = -1;
     if (lane < 5 * ns) {
       const int k = 1 + 4 * NH + lane;
-      const int kk = rowK[k];
-      ga = rowA[k]; gb = rowB[k]; gk = kk;
-      if (kk >= 0) {
-        const double a = rowA[k], b = rowB[k];
-        // column order: [2N+kk-1] 2N+kk [2N+ns+kk-1] 2N+ns+kk ; without a predecessor the two "-1" entries are zeros
-        const bool pred = kk > 0;
-        f2c[0] = pred ? 2 * NH + kk - 1 : 2 * NH + kk;  f2v[0] = pred ? 0.0 + (0.0 + a * -1.0) * -1.0 : 0.0;
-        f2c[1] = 2 * NH + kk;                            f2v[1] = 0.0 + (0.0 + a * 1.0) * -1.0;
-        f2c[2] = pred ? 2 * NH + ns + kk - 1 : 2 * NH + ns + kk;  f2v[2] = pred ? 0.0 + (0.0 + b * -1.0) * -1.0 : 0.0;
-        f2c[3] = 2 * NH + ns + kk;                       f2v[3] = 0.0 + (0.0 + b * 1.0) * -1.0;
-        const int e = 4;
-        f2n = e;
-      }
+      ga = rowA[k]; gb = rowB[k]; gk = rowK[k];
     }
   }
 
@@ -391,7 +394,7 @@ struct HerdtProb {
       for (int c = 0; c < NH; ++c) sum += ax[c] * ax[c];
 #pragma unroll
       for (int c = 0; c < NH; ++c) sum += ay[c] * ay[c];
-      if (fj >= 0) { sum += fa * fa; sum += fb * fb; }
+      if (fj >= 0) { sum += fa() * fa(); sum += fb() * fb(); }
       const int k = lane + 1;
       if (sum > 0.0) sum = 1.0 / sqrt(sum);
       else if (q.b[k] == 0.0) {}
@@ -400,8 +403,9 @@ struct HerdtProb {
     }
     if (lane < 5 * ns) {
       double sum = 0.0;
+      const FootRow fr = foot_row();
 #pragma unroll
-      for (int e = 0; e < 4; ++e) sum += f2v[e] * f2v[e];
+      for (int e = 0; e < 4; ++e) sum += fr.v[e] * fr.v[e];
       const int k = 1 + 4 * NH + lane;
       if (sum > 0.0) sum = 1.0 / sqrt(sum);
       else if (q.b[k] == 0.0) {}
@@ -546,14 +550,15 @@ struct HerdtProb {
       for (int c = 0; c < NH; ++c) sk -= xs[c] * ax[c];
 #pragma unroll
       for (int c = 0; c < NH; ++c) sk -= xs[NH + c] * ay[c];
-      if (fj >= 0) { sk -= q.x[2 * NH + fj] * fa; sk -= q.x[2 * NH + ns + fj] * fb; }
+      if (fj >= 0) { sk -= q.x[2 * NH + fj] * fa(); sk -= q.x[2 * NH + ns + fj] * fb(); }
       out[rk] = sk;
     }
     if (lane < 5 * ns) {
       const int rk = 1 + 4 * NH + lane;
       double sk = q.b[rk];
+      const FootRow fr = foot_row();
 #pragma unroll
-      for (int e = 0; e < 4; ++e) sk -= q.x[f2c[e]] * f2v[e];
+      for (int e = 0; e < 4; ++e) sk -= q.x[fr.c[e]] * fr.v[e];
       out[rk] = sk;
     }
     if (lane == 0) out[0] = q.b[0];

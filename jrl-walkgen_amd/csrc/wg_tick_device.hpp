@@ -572,7 +572,7 @@ __device__ __forceinline__ TickDiag mpc_tick(const wg_model_t &m, const TickTabl
                                (NH == 16) ? ext16 + kExtWab : nullptr);
   wg_gait_state_t *s = L.st;
 #ifdef WG_PROFILE
-  unsigned long long tk0 = clock64(), tk1 = 0, tk2 = 0, tk3 = 0;
+  unsigned long long tk0 = clock64(), tk1 = 0, tk2 = 0, tk3 = 0, tka = 0, tkb = 0, tkc = 0, tkd = 0;
 #endif
 
   // ---- state: HBM -> LDS (coalesced 8-byte lanes) ----
@@ -585,6 +585,9 @@ __device__ __forceinline__ TickDiag mpc_tick(const wg_model_t &m, const TickTabl
   }
   WG_WSYNC();
   const double time = s->clock;
+#ifdef WG_PROFILE
+  tka = clock64();
+#endif
 
   // ---- lane 0: support FSM, selection, orientations, polygon edges ----
   if (lane == 0) {
@@ -626,12 +629,18 @@ __device__ __forceinline__ TickDiag mpc_tick(const wg_model_t &m, const TickTabl
     int ns = L.sup[N].step_number;
     constexpr int kSCap = (NH == 16) ? 2 : kSMax;   // compact kernel: N*T <= 2*step_period is checked at configure time
     if (ns > kSCap) ns = kSCap;                     // cannot happen; keeps every index in range
+#ifdef WG_PROFILE
+    tkb = clock64();
+#endif
     op_preview(m, s, time, ref, L.sup, L.sup_angles, L.trunk);
     *L.sup0 = L.sup[0];
     L.misc[0] = (double)ns;
     L.misc[1] = ref[0]; L.misc[2] = ref[1]; L.misc[3] = ref[2];
   }
   WG_WSYNC();
+#ifdef WG_PROFILE
+  tkc = clock64();
+#endif
 
   // ---- lane-parallel part of the bookkeeping: one previewed instant per lane ----
   {
@@ -889,7 +898,7 @@ __device__ __forceinline__ TickDiag mpc_tick(const wg_model_t &m, const TickTabl
 #endif
   QlResult qr;
   if constexpr (kCompactView) {
-    if (lane == 0 && fabs(L.gd[n - 1]) == 0.0) L.gd[n - 1] = 1e-8;               // qld.cpp:442-444 (nmax == n)
+    if (lane == 0 && fabs(L.gd[n - 1]) == 0.0) L.gd[n - 1] = wg_kconst(1e-8);   // qld.cpp:442-444 (nmax == n)
     WG_WSYNC();
     {
       // the state's LDS copy sits on Z: park it in its HBM slot (L2) for the duration of the solve
@@ -1041,6 +1050,9 @@ __device__ __forceinline__ TickDiag mpc_tick(const wg_model_t &m, const TickTabl
   }
   WG_WSYNC();
 
+#ifdef WG_PROFILE
+  tkd = clock64();
+#endif
   // ---- lane 0: trunk and feet (sequential in k) ----
   if (lane == 0) {
     const Sup cs = *L.sup0;
@@ -1193,6 +1205,11 @@ __device__ __forceinline__ TickDiag mpc_tick(const wg_model_t &m, const TickTabl
     atomicAdd(&g_prof[21], tk1 - tk0);                 // state load + lane-0 scalar part
     atomicAdd(&g_prof[22], tk2 - tk1);                 // QP assembly
     atomicAdd(&g_prof[23], clock64() - tk3);           // post-processing + state store
+    atomicAdd(&g_prof[35], tka - tk0);                 // of 21: state HBM -> LDS
+    atomicAdd(&g_prof[36], tkb - tka);                 //        lane 0: support FSM + preview of the support states
+    atomicAdd(&g_prof[37], tkc - tkb);                 //        lane 0: orientation preview
+    atomicAdd(&g_prof[38], tk1 - tkc);                 //        one instant per lane: selection, rotated references, hull edges
+    atomicAdd(&g_prof[39], tkd - tk3);                 // of 23: state fetched back, jerk, CoM samples, LIPM step
   }
 #endif
   TickDiag dg;

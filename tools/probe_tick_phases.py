@@ -35,6 +35,13 @@ print(f"gait-ticks={n} mean QL iters={its/n:.1f} cycles/tick={tot/n:.0f}  route 
 print(f"   of 'inverse' (factor): constant blocks into LDS {v[2]/n:.0f} cyc/tick, border rows of R {v[31]/n:.0f} cyc/tick")
 for k, nme in enumerate(names):
     print(f"{k:2d} {nme:22s} {v[k]/n:12.0f} cyc/tick  {100*v[k]/tot:5.1f}%")
+    if k == 21 and v[35:39].sum() > 0:
+        for j, ph in enumerate(["state HBM -> LDS", "lane 0: support FSM, preview of the support states", "lane 0: orientation preview",
+                                "one instant per lane: selection, rotated references, hull edges"]):
+            print(f"      pre {ph:60s} {v[35+j]/n:10.0f} cyc/tick  {100*v[35+j]/tot:5.1f}%")
+    if k == 23 and v[39] > 0:
+        print(f"      post {'state fetched back, jerk, CoM samples, LIPM step':59s} {v[39]/n:10.0f} cyc/tick  {100*v[39]/tot:5.1f}%")
+        print(f"      post {'trunk (lane 0), feet (one lane per sample), state store':59s} {(v[23]-v[39])/n:10.0f} cyc/tick  {100*(v[23]-v[39])/tot:5.1f}%")
     if k == 12 and v[32:35].sum() > 0:                       # the compact view's sweep by phase (sweep_flat)
         for j, ph in enumerate(["phase 1: chain of rotation norms", "phase 2: ga / gb of every rotation, one lane each", "phase 3: lane i carries row i of Z through the rotations"]):
             print(f"      sweep {ph:58s} {v[32+j]/n:10.0f} cyc/tick  {100*v[32+j]/tot:5.1f}%")
