@@ -429,8 +429,17 @@ size_t wg_pldp_lds_bytes(void);
  * and SimilarConstraints; constraint sense A_j . zmp + B_j >= 0.  The caller supplies, per gait, the polytope of each
  * previewed instant (N entries) -- 2 KB per gait-tick instead of the 33 KB dense DPu. */
 #define WG_POLY_MAX_ROWS 8            /* "8 constraints per support foot", :771-772 */
+/* the QP back-end of the tick, m_FastFormulationMode (ZMPConstrainedQPFastFormulation.hh:263-265; the constructor takes PLDP, :55) */
+#define WG_DIMITROV_PLDP 0            /* PLDPSolver on the LQ-preconditioned problem (v = LQ u, Hessian = I), X <- iLQ' X            */
+#define WG_DIMITROV_QLD 1             /* "QLD" (:1297-1320): ql0001_ on the problem as it stands -- Q = OptA (:382-389), constraint  */
+                                      /* matrix from the triangular Pu' (:891-904), cost vector from OptB / OptC as built (:545-556), */
+                                      /* iwar[0] = 1, eps = 1e-8, bounds +-1e8 (:1280-1292); X is the jerk itself (:1383).  With the   */
+                                      /* reference's own OptA (alpha VPu' instead of alpha VPu'VPu, :524-527: not symmetric, its upper  */
+                                      /* triangle not positive definite) ql0001_ answers ifail = 2 on the first tick -- here as there. */
+#define WG_DIMITROV_QLDANDLQ 2        /* "QLDANDLQ": ql0001_ on the SAME preconditioned problem PLDP gets -- Q = I handed over as its   */
+                                      /* own Cholesky factor (iwar[0] = 0, :1288-1289), DPu from iLQ Pu' (:905-918), X <- iLQ' X        */
 typedef struct wg_dimitrov_model {
-  int N, pad_;                        /* m_QP_N = 16                                  :83  */
+  int N, solver;                      /* m_QP_N = 16 (:83); WG_DIMITROV_PLDP (0, the reference's default), _QLD or _QLDANDLQ */
   double T;                           /* m_QP_T = 0.1                                 :82  */
   double Tctrl;                       /* m_SamplingPeriod = 0.005 */
   double com_height;                  /* m_ComHeight = 0.80                           :87  */
@@ -451,18 +460,26 @@ typedef struct wg_dimitrov_state {
 } wg_dimitrov_state_t;
 typedef struct wg_dimitrov_out {
   double jerk_x, jerk_y;              /* ptX[0], ptX[N] */
-  int ret, n_iter, n_active, m;       /* PLDP return code (see wg_pldp_solve_batch), m_ItNb, active rows, rows */
+  int ret, n_iter, n_active, m;       /* PLDP return code (see wg_pldp_solve_batch), m_ItNb, active rows, rows;
+                                       * WG_DIMITROV_QLD: ql0001_'s ifail (0 = solved), its iteration count, active constraints, rows */
   /* what Interpolation writes for lk = 0..interval (21 samples; the last one is overwritten by the next tick) */
   double com_x[WG_SAMPLES_PER_TICK + 1][3], com_y[WG_SAMPLES_PER_TICK + 1][3];
   double zmp_x[WG_SAMPLES_PER_TICK + 1], zmp_y[WG_SAMPLES_PER_TICK + 1];
+  double X[2 * WG_PLDP_N];            /* ptX: the jerks over the horizon (x block, then y block), un-preconditioned (:1355-1383) */
 } wg_dimitrov_out_t;
 void wg_dimitrov_defaults(wg_dimitrov_model_t *model);
 int wg_dimitrov_configure(const wg_dimitrov_model_t *model);
 /* the constants InitConstants leaves behind, for inspection: iLQ, OptC 2N x 2N, OptB 2N x 6, Pu (= iLQ Pu'), iPu N x N,
  * Px N x 3, all row-major; any pointer may be NULL */
 int wg_dimitrov_get_constants(double *iLQ, double *OptB, double *OptC, double *Pu, double *iPu, double *Px);
+/* what mode QLD works with: Q = m_Q (2N x 2N, ql0001_'s column-major layout, :382-389), OptB (2N x 6) and OptC (2N x 2N) as
+ * BuildingConstantPartOfTheObjectiveFunction leaves them before the LQ step (:545-556), PuT = Pu' (N x N, [k N + i], :629-637);
+ * row-major unless said otherwise; any pointer may be NULL */
+int wg_dimitrov_get_qld_constants(double *Q, double *OptB, double *OptC, double *PuT);
 /* polys: B x N polytopes (instant-major per gait); outs may be NULL.  A gait whose solve returns ret != 0 keeps its
- * state (xk not advanced), like the reference which stops there (:1343-1347). */
+ * state (xk not advanced), like the reference which stops there (:1343-1347).  With model.solver == WG_DIMITROV_QLD / _QLDANDLQ the
+ * solve is the in-wave ql0002 of wg_qp_solve_batch -- the back-ends of this tick whose CPU counterpart is the reference's own
+ * compiled qld.cpp; the PLDP hot-start members of the state are carried along untouched, max_iter is ignored. */
 int wg_dimitrov_tick_batch(int B, const wg_zmp_polytope_t *polys, wg_dimitrov_state_t *states, wg_dimitrov_out_t *outs,
                            int max_iter);
 int wg_dimitrov_tick_batch_dev(int B, const wg_zmp_polytope_t *polys, wg_dimitrov_state_t *states,
@@ -632,6 +649,7 @@ int wg_pldp_solve_batch_ctx(wg_ctx_t *ctx, int B, int mcap, const int *m, const 
 int wg_dimitrov_configure_ctx(wg_ctx_t *ctx, const wg_dimitrov_model_t *model);
 int wg_dimitrov_get_constants_ctx(wg_ctx_t *ctx, double *iLQ, double *OptB, double *OptC, double *Pu, double *iPu,
                                   double *Px);
+int wg_dimitrov_get_qld_constants_ctx(wg_ctx_t *ctx, double *Q, double *OptB, double *OptC, double *PuT);
 int wg_dimitrov_tick_batch_dev_ctx(wg_ctx_t *ctx, int B, const wg_zmp_polytope_t *polys, wg_dimitrov_state_t *states,
                                    wg_dimitrov_out_t *outs, int max_iter, void *hip_stream);
 int wg_dimitrov_tick_batch_ctx(wg_ctx_t *ctx, int B, const wg_zmp_polytope_t *polys, wg_dimitrov_state_t *states,

@@ -206,7 +206,9 @@ int slot_mark(wg_ctx::SlotOrder &o, hipStream_t st) {
 // Dense batched QP kernel: one wavefront (= one workgroup) per QP.
 // Replaces ql0001_ (qld.hh:27-31) for B problems at once.
 // ---------------------------------------------------------------------------
-template <bool kALds, bool kGLds, bool kWLds = true>       // where A / G / wa | b live is known at compile time: ds_ or global_ accesses,
+// kFixN / kFixM > 0: the Herdt-sized boundary (nmax == kFixN, mmax == kFixM, A, G and wa | b out of the LDS) with the strides, the
+// LDS layout and the solver's loop bounds as compile-time constants (QlView::carve_fixed_dense, DenseProbT<false, kFixN>)
+template <bool kALds, bool kGLds, bool kWLds = true, int kFixN = 0, int kFixM = 0>   // where A / G / wa | b live is known at compile time: ds_ or global_ accesses,
 // Left to itself the compiler takes 256 VGPRs plus 3 AGPRs -- 259 registers, one wave per SIMD, four QPs per CU where the LDS
 // would admit five at n = 36, m = 75.  Forced to two waves per SIMD (-DWG_QLD_WPE=2: 256 registers, 2-3 spilled, 12-16 B of
 // scratch) it measured 5 % SLOWER on the Herdt workload's real QPs (1.73 against 1.82 M QPs/s, B = 4096): the fifth QP per CU
@@ -219,7 +221,7 @@ template <bool kALds, bool kGLds, bool kWLds = true>       // where A / G / wa |
 #define WG_QLD_ATTR __attribute__((amdgpu_waves_per_eu(kGLds ? 1 : 2, kGLds ? 8 : 2)))
 #endif
 __global__ __launch_bounds__(64) WG_QLD_ATTR void wg_ql_dense_kernel(   // never flat_ (those also count on lgkmcnt and stall the LDS waits)
-    int B, int nmax, int mmax, const int *__restrict__ n_arr, const int *__restrict__ m_arr,
+    int B, int nmax_arg, int mmax_arg, const int *__restrict__ n_arr, const int *__restrict__ m_arr,
     const int *__restrict__ me_arr, const double *__restrict__ C, const double *__restrict__ dvec,
     const double *__restrict__ A, const double *__restrict__ bvec, const double *__restrict__ xl,
     const double *__restrict__ xu, double eps, double *__restrict__ x, double *__restrict__ u,
@@ -228,6 +230,7 @@ __global__ __launch_bounds__(64) WG_QLD_ATTR void wg_ql_dense_kernel(   // never
   extern __shared__ __attribute__((aligned(16))) double wg_lds[];
   const int lane = threadIdx.x & 63;
   const int qp = blockIdx.x;                     // one QP per block (grid == B): nothing lane-dependent lives across QPs
+  const int nmax = kFixN > 0 ? kFixN : nmax_arg, mmax = kFixM > 0 ? kFixM : mmax_arg;   // the host checks the match
   if (qp < B) {
     const int n = n_arr ? n_arr[qp] : nmax;
     const int m = m_arr ? m_arr[qp] : mmax - 1;
@@ -236,7 +239,8 @@ __global__ __launch_bounds__(64) WG_QLD_ATTR void wg_ql_dense_kernel(   // never
     wg::QlView q;
     // kWLds = false: the constraint weights wa (m + n) and b (m) -- read lane-parallel once per iteration -- live in this
     // block's slot of global memory [wa (mmax + nmax) | b (mmax)]: 1.5 KB less LDS, the eighth QP on the CU at n = 36, m = 75
-    if constexpr (kWLds) q.carve(wg_lds, D, me);
+    if constexpr (kFixN > 0) q.template carve_fixed_dense<kFixN, kFixM>(wg_lds, n, m, me, wab_slots + (size_t)qp * (2 * kFixM + kFixN));
+    else if constexpr (kWLds) q.carve(wg_lds, D, me);
     else q.template carve<true, false, true>(wg_lds, D, me, wab_slots + (size_t)qp * (2 * (size_t)mmax + nmax), mmax + nmax);
 
     // ---- stage the problem into LDS (coalesced 8-byte lanes) ----
@@ -265,7 +269,7 @@ __global__ __launch_bounds__(64) WG_QLD_ATTR void wg_ql_dense_kernel(   // never
     for (int k = lane; k < m; k += 64) q.b[k] = -bvec[(size_t)qp * mmax + k];   // qld.cpp:469-475
     WG_WSYNC();
     // qld.cpp:442-444: c(nmax,nmax) == 0 -> eps (inside the n x n block only if nmax == n)
-    wg::DenseProbT<kGLds> prob;
+    wg::DenseProbT<kGLds, kFixN> prob;
     if (nmax == n && lane == 0 && fabs(prob.Gd(q, n - 1)) == 0.0) prob.setGd(q, n - 1, eps);
     WG_WSYNC();
 
@@ -297,7 +301,7 @@ __global__ __launch_bounds__(64) WG_QLD_ATTR void wg_ql_dense_kernel(   // never
 
 extern "C" {
 
-int wg_abi_version(void) { return 3; }
+int wg_abi_version(void) { return 4; }
 
 const char *wg_last_error(void) { return g_err.c_str(); }
 
@@ -353,9 +357,9 @@ void wg_shutdown(void) {
 
 #ifdef WG_PROFILE
 // diagnostic build only: read-and-reset the in-kernel phase timers (shader cycles)
-int wg_prof_read(unsigned long long *out40) {          // 40 counters (wg_ql_device.hpp, g_prof)
-  if (hipMemcpyFromSymbol(out40, HIP_SYMBOL(wg::g_prof), 40 * sizeof(unsigned long long)) != hipSuccess) return -1;
-  unsigned long long z[40] = {0};
+int wg_prof_read(unsigned long long *out48) {          // 48 counters (wg_ql_device.hpp, g_prof)
+  if (hipMemcpyFromSymbol(out48, HIP_SYMBOL(wg::g_prof), 48 * sizeof(unsigned long long)) != hipSuccess) return -1;
+  unsigned long long z[48] = {0};
   if (hipMemcpyToSymbol(HIP_SYMBOL(wg::g_prof), z, sizeof z) != hipSuccess) return -1;
   return 0;
 }
@@ -409,6 +413,17 @@ int wg_qp_solve_batch_dev_ctx(wg_ctx_t *ctx, int B, int nmax, int mmax, const in
       wab = static_cast<double *>(ctx->qp_slot.p);
       lds = lds_now;
     }
+  }
+  // the Herdt-sized boundary (what QPProblem::solve hands over at N = 16: nmax = 36, mmax = 76) has its own instantiation
+  bool fixed36 = wab && nmax == 36 && mmax == 76;
+  if (const char *e = getenv("WG_QL_FIXED")) fixed36 = fixed36 && atoi(e) != 0;
+  if (fixed36) {
+    lds = wg::QlView::fixed_dense_bytes<36>();
+    hipLaunchKernelGGL((wg_ql_dense_kernel<false, false, false, 36, 76>), dim3(B), dim3(64), lds, st, B, nmax, mmax, n, m, me, C, d, A, b,
+                       xl, xu, eps, x, u, ifail, n_iter, iact, nact, hist, hist_cap, hist_len, wab);
+    if (int rc = slot_mark(ctx->qp_order, st)) return rc;
+    HIP_TRY(hipGetLastError());
+    return WG_OK;
   }
   const void *kfn = a_in_lds ? reinterpret_cast<const void *>(wg_ql_dense_kernel<true, true>)
                              : (g_in_lds ? reinterpret_cast<const void *>(wg_ql_dense_kernel<false, true>)
@@ -1123,6 +1138,17 @@ wg_dimitrov_tick_kernel(int B, const wg::DimitrovConst *__restrict__ K, const wg
   if (g < B) wg::dimitrov_tick(*K, dim_lds, polys + (size_t)g * N, states + g, outs ? outs + g : nullptr, max_iter);
 }
 
+// modes QLD / QLDANDLQ: the same tick with the in-wave ql0002 as its back-end (wg_dimitrov_device.hpp, dimitrov_qld_tick)
+template <bool kLQ>
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
+wg_dimitrov_qld_tick_kernel(int B, const wg::DimitrovConst *__restrict__ K, const wg_zmp_polytope_t *__restrict__ polys,
+                            wg_dimitrov_state_t *states, wg_dimitrov_out_t *outs) {
+  extern __shared__ __attribute__((aligned(16))) double dimq_lds[];
+  const int N = K->N;
+  const int g = blockIdx.x;
+  if (g < B) wg::dimitrov_qld_tick<kLQ>(*K, dimq_lds, polys + (size_t)g * N, states + g, outs ? outs + g : nullptr);
+}
+
 namespace {
 inline size_t dimitrov_lds_bytes() {
   return wg::PldpLds::bytes(WG_PLDP_MMAX, wg::kDimitrovActiveCap, true) + (4 * 2 * WG_PLDP_N + 8) * 8 +
@@ -1144,6 +1170,8 @@ int wg_dimitrov_configure_ctx(wg_ctx_t *ctx, const wg_dimitrov_model_t *model) {
   if (model->N < 1 || model->N > WG_PLDP_N) return fail(WG_ERR_BAD_ARG, "N=%d outside [1,%d]", model->N, WG_PLDP_N);
   if (!(model->T > 0.0) || !(model->Tctrl > 0.0) || (int)(model->T / model->Tctrl) != WG_SAMPLES_PER_TICK)
     return fail(WG_ERR_BAD_ARG, "T/Tctrl must be %d", WG_SAMPLES_PER_TICK);
+  if (model->solver != WG_DIMITROV_PLDP && model->solver != WG_DIMITROV_QLD && model->solver != WG_DIMITROV_QLDANDLQ)
+    return fail(WG_ERR_BAD_ARG, "solver = %d: WG_DIMITROV_PLDP (0), WG_DIMITROV_QLD (1) or WG_DIMITROV_QLDANDLQ (2)", model->solver);
   {
     std::lock_guard<std::mutex> lk(ctx->mu);
     if (!ctx->dim_host) ctx->dim_host.reset(new wg::DimitrovConst);
@@ -1171,11 +1199,33 @@ int wg_dimitrov_get_constants_ctx(wg_ctx_t *ctx, double *iLQ, double *OptB, doub
   return WG_OK;
 }
 
+int wg_dimitrov_get_qld_constants_ctx(wg_ctx_t *ctx, double *Q, double *OptB, double *OptC, double *PuT) {
+  if (!ctx) return fail(WG_ERR_BAD_ARG, "null context");
+  if (!ctx->dim_set) return fail(WG_ERR_BAD_ARG, "wg_dimitrov_configure() has not been called on this context");
+  const size_t N = (size_t)(*ctx->dim_host).N, n = 2 * N;
+  if (Q) memcpy(Q, (*ctx->dim_host).Qq, 8 * n * n);
+  if (OptB) memcpy(OptB, (*ctx->dim_host).OptBq, 8 * n * 6);
+  if (OptC) memcpy(OptC, (*ctx->dim_host).OptCq, 8 * n * n);
+  if (PuT) memcpy(PuT, (*ctx->dim_host).PuTq, 8 * N * N);
+  return WG_OK;
+}
+
 int wg_dimitrov_tick_batch_dev_ctx(wg_ctx_t *ctx, int B, const wg_zmp_polytope_t *polys, wg_dimitrov_state_t *states, wg_dimitrov_out_t *outs, int max_iter, void *hip_stream) {
   if (int rc = use_ctx(ctx)) return rc;
   if (!ctx->dim_set) return fail(WG_ERR_BAD_ARG, "wg_dimitrov_configure() has not been called on this context");
   if (B < 0 || !polys || !states) return fail(WG_ERR_BAD_ARG, "bad arguments");
   if (B == 0) return WG_OK;
+  if ((*ctx->dim_host).solver != WG_DIMITROV_PLDP) {
+    const size_t ldsq = wg::dimitrov_qld_lds_bytes();
+    if ((*ctx->dim_host).solver == WG_DIMITROV_QLDANDLQ)
+      hipLaunchKernelGGL(wg_dimitrov_qld_tick_kernel<true>, dim3(B), dim3(64), ldsq, reinterpret_cast<hipStream_t>(hip_stream), B,
+                         ctx->dim_dev, polys, states, outs);
+    else
+      hipLaunchKernelGGL(wg_dimitrov_qld_tick_kernel<false>, dim3(B), dim3(64), ldsq, reinterpret_cast<hipStream_t>(hip_stream), B,
+                         ctx->dim_dev, polys, states, outs);
+    HIP_TRY(hipGetLastError());
+    return WG_OK;
+  }
   const size_t lds = dimitrov_lds_bytes();
   if (lds > 64 * 1024)
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(wg_dimitrov_tick_kernel),
@@ -1619,6 +1669,12 @@ int wg_dimitrov_get_constants(double *iLQ, double *OptB, double *OptC, double *P
   wg_ctx *c = nullptr;
   if (int rc = default_ctx(&c)) return rc;
   return wg_dimitrov_get_constants_ctx(c, iLQ, OptB, OptC, Pu, iPu, Px);
+}
+
+int wg_dimitrov_get_qld_constants(double *Q, double *OptB, double *OptC, double *PuT) {
+  wg_ctx *c = nullptr;
+  if (int rc = default_ctx(&c)) return rc;
+  return wg_dimitrov_get_qld_constants_ctx(c, Q, OptB, OptC, PuT);
 }
 
 int wg_dimitrov_tick_batch_dev(int B, const wg_zmp_polytope_t *polys, wg_dimitrov_state_t *states, wg_dimitrov_out_t *outs, int max_iter, void *hip_stream) {

@@ -9,10 +9,14 @@
 namespace wg {
 
 struct DimitrovConst {           // device-resident (wg_dimitrov_configure)
-  int N, pad_;
+  int N, solver;
   double T, Tctrl, h;
   double OptB[2 * WG_PLDP_N * 6], OptC[2 * WG_PLDP_N * 2 * WG_PLDP_N], iLQ[2 * WG_PLDP_N * 2 * WG_PLDP_N];
   PldpModel pldp;
+  // mode QLD (m_FastFormulationMode == QLD): the problem as InitConstants builds it without the LQ preconditioning --
+  // Qq = m_Q = OptA in ql0001_'s column-major layout (:382-389), OptBq / OptCq the cost terms before iLQ is applied (:545-556),
+  // PuTq = Pu' as :629-637 fills it (PuTq[k N + i], k <= i)
+  double Qq[2 * WG_PLDP_N * 2 * WG_PLDP_N], OptBq[2 * WG_PLDP_N * 6], OptCq[2 * WG_PLDP_N * 2 * WG_PLDP_N], PuTq[WG_PLDP_N * WG_PLDP_N];
 };
 
 // host: the constants of InitConstants (ZMPConstrainedQPFastFormulation.cpp:158-246, 384-560, 597-690), row-major.
@@ -122,7 +126,14 @@ struct DimitrovHost {
       iPu = inv;
     }
     memset(&K, 0, sizeof K);
-    K.N = (int)N; K.T = T; K.Tctrl = m.Tctrl; K.h = m.com_height;
+    K.N = (int)N; K.T = T; K.Tctrl = m.Tctrl; K.h = m.com_height; K.solver = m.solver;
+    // mode QLD: BuildingConstantPartOfTheObjectiveFunctionQLD (:382-389) stores m_Q[i 2N + j] = OptA(j, i), which ql0001_ reads as
+    // the column-major matrix C(j, i) = OptA(j, i); OptB / OptC stay as built; Pu' is the raw table
+    for (unsigned i = 0; i < n; i++)
+      for (unsigned j = 0; j < n; j++) K.Qq[i * n + j] = OptA[j * n + i];
+    memcpy(K.OptBq, OptB.data(), sizeof(double) * n * 6);
+    memcpy(K.OptCq, OptC.data(), sizeof(double) * n * n);
+    memcpy(K.PuTq, PuT.data(), sizeof(double) * N * N);
     memcpy(K.OptB, OptB2.data(), sizeof(double) * n * 6);
     memcpy(K.OptC, OptC2.data(), sizeof(double) * n * n);
     memcpy(K.iLQ, iLQ.data(), sizeof(double) * n * n);
@@ -205,6 +216,7 @@ __device__ void dimitrov_tick(const DimitrovConst &K, unsigned char *lds, const 
   }
   WG_WSYNC();
   const double jx = NewX[0], jy = NewX[N];
+  if (out && lane < 2 * WG_PLDP_N) out->X[lane] = lane < n ? NewX[lane] : 0.0;
   if (rc == 0) {
     // ---- LinearizedInvertedPendulum2D::Interpolation :157-227 (lk = 0..interval) ----
     if (out && lane <= WG_SAMPLES_PER_TICK) {
@@ -237,6 +249,170 @@ __device__ void dimitrov_tick(const DimitrovConst &K, unsigned char *lds, const 
     st->starting = 0;                                              // :1339
     st->n_removed = first_rows;                                    // :1340
     if (out) { out->jerk_x = jx; out->jerk_y = jy; out->ret = rc; out->n_iter = it; out->n_active = S; out->m = m; }
+  }
+  WG_WSYNC();
+}
+
+// ---- the same tick with ql0001_ as the back-end (m_FastFormulationMode == QLD / QLDANDLQ, :1297-1320) --------------------------
+// QLD: the problem as it stands -- Q = OptA (full matrix, iwar[0] = 1), D = OptB xk - OptC ZMPRef (constants as built: no LQ
+//   preconditioning), DPu(idx, k) = A_j0 Pu'[k N + i] and DPu(idx, k + N) = A_j1 Pu'[k N + i] for k <= i, zero beyond (:891-904:
+//   "In this case, Pu is triangular"), X[0], X[N] are the jerks (:1383).
+// QLDANDLQ: the preconditioned problem PLDP gets -- Q = I (handed to ql0001_ as its own Cholesky factor, iwar[0] = 0), D from the
+//   iLQ-premultiplied OptB / OptC, DPu(idx, k) = A_j0 (iLQ Pu')[k N + i] for every k (:905-918), X <- iLQ' X (:1355-1381).
+// DPx, the bounds -+1e8 and eps = 1e-8 are the same in every mode.
+// The in-wave ql0002 (wg_ql_device.hpp) solves it through a problem view that never materialises DPu: a row is its two polytope
+// coefficients and its instant, an element their product with one entry of the Pu table -- the value the dense matrix holds.
+// ql0002 is instantiated for a full Hessian (lql): on the identity the reference's factor-given branch (iwar[0] = 0) returns the
+// same bits -- held against the compiled qld.cpp called the driver's way by tests/test_dimitrov_gpu.py.
+template <bool kLQ>                                       // kLQ: mode QLDANDLQ (identity Hessian, full rows)
+struct DimitrovQldProb {
+  static constexpr bool kCompact = false;
+  static constexpr bool kHasFactor = false;
+  static constexpr bool kRowOps = false;
+  static constexpr bool kWideN = false;
+  static constexpr int kNM = 2 * WG_PLDP_N;               // n = 2N <= 32: the compile-time-bounded forms of the solver
+  const double *c0, *c1;                                  // LDS: polytope coefficients of every row
+  const int *slot;                                        // LDS: the row's instant
+  const double *PuT;                                      // LDS: the Pu table, N x N (entry [k N + i]; QLD: Pu', zero for k > i)
+  int N;
+  __device__ __forceinline__ double G(const QlView &q, int i, int j) const {
+    if constexpr (kLQ) return i == j ? q.Gdiag[i] : 0.0;    // m_Q = identity (:537-540)
+    else {
+      const double g = q.G[i + j * q.ldg], dg = q.Gdiag[i];   // Q read in place (a constant of the model), its diagonal in LDS
+      return i == j ? dg : g;
+    }
+  }
+  __device__ __forceinline__ double Gd(const QlView &q, int i) const { return q.Gdiag[i]; }
+  __device__ __forceinline__ void setGd(const QlView &q, int i, double v) const { q.Gdiag[i] = v; }
+  __device__ __forceinline__ double xl(const QlView &, int) const { return -1e8; }
+  __device__ __forceinline__ double xu(const QlView &, int) const { return 1e8; }
+  __device__ __forceinline__ double A(const QlView &, int k, int i) const {
+    const bool second = i >= N;
+    const int kk = second ? i - N : i;
+    const int inst = slot[k];
+    const double a = second ? c1[k] : c0[k];
+    if constexpr (kLQ) return a * PuT[kk * N + inst];
+    else {
+      const double pu = PuT[kk * N + (kk <= inst ? inst : kk)];      // clamped address, selected value
+      return kk <= inst ? a * pu : 0.0;                              // memset zero beyond the triangle (:782)
+    }
+  }
+};
+
+constexpr int kDimQldNsc = 2 * WG_PLDP_N;
+__host__ __device__ inline size_t dimitrov_qld_ql_bytes() {
+  return (QlDims(2 * WG_PLDP_N, WG_PLDP_MMAX, WG_PLDP_MMAX, true, false, kDimQldNsc, false, true, true, true, 0, false).bytes() + 15) & ~(size_t)15;
+}
+__host__ __device__ inline size_t dimitrov_qld_lds_bytes() {
+  // solver area | c0 c1 (mcap each) | Pu table (N x N) | zr (2N) | NewX (2N) | xk (8) | slot (mcap ints) | rowbase (N + 1 ints)
+  return dimitrov_qld_ql_bytes() + 8 * (size_t)(2 * WG_PLDP_MMAX + WG_PLDP_N * WG_PLDP_N + 4 * WG_PLDP_N + 8) +
+         4 * (size_t)(WG_PLDP_MMAX + ((WG_PLDP_N + 2) & ~1)) + 16;
+}
+
+template <bool kLQ>
+__device__ void dimitrov_qld_tick(const DimitrovConst &K, double *lds, const wg_zmp_polytope_t *__restrict__ polys,
+                                  wg_dimitrov_state_t *st, wg_dimitrov_out_t *out) {
+  const int lane = wg_lane();
+  const int N = K.N, n = 2 * N, mcap = WG_PLDP_MMAX;
+  double *t = reinterpret_cast<double *>(reinterpret_cast<char *>(lds) + dimitrov_qld_ql_bytes());
+  double *c0 = t; t += mcap; double *c1 = t; t += mcap;
+  double *PuT = t; t += WG_PLDP_N * WG_PLDP_N;
+  double *zr = t; t += 2 * WG_PLDP_N;
+  double *NewX = t; t += 2 * WG_PLDP_N;
+  double *xk = t; t += 8;
+  int *slot = reinterpret_cast<int *>(t);
+  int *rowbase = slot + mcap;
+  if (lane < 6) xk[lane] = st->xk[lane];
+  if (lane == 0) {
+    int idx = 0;
+    for (int i = 0; i < N; i++) { rowbase[i] = idx; int r = polys[i].nrows; r = r < 0 ? 0 : (r > WG_POLY_MAX_ROWS ? WG_POLY_MAX_ROWS : r); idx += r; }
+    rowbase[N] = idx;
+  }
+  WG_WSYNC();
+  const int m = uni(rowbase[N]);
+  // the solver's view: n = 2N variables, m rows; Q read in place (or the identity), wa | b in LDS
+  QlDims D(n, m, m, true, false, kDimQldNsc, false, true, true, true, 0, false);
+  QlView q;
+  q.template carve<false, true, true>(lds, D, 0);
+  q.G = const_cast<double *>(K.Qq);
+  q.ldg = n;
+  const double *OptB = kLQ ? K.OptB : K.OptBq, *OptC = kLQ ? K.OptC : K.OptCq, *PuSrc = kLQ ? K.pldp.Pu : K.PuTq;
+  // ---- BuildConstraintMatrices :759-1022 ----
+  for (int e = lane; e < N * WG_POLY_MAX_ROWS; e += 64) {
+    const int i = e / WG_POLY_MAX_ROWS, j = e % WG_POLY_MAX_ROWS;
+    const int nr = rowbase[i + 1] - rowbase[i];
+    if (j < nr) {
+      const int idx = rowbase[i] + j;
+      const double a0 = polys[i].A[j][0], a1 = polys[i].A[j][1];
+      const double *px = K.pldp.Px + i * 3;
+      const double dpx = (xk[0] * px[0] + xk[1] * px[1] + xk[2] * px[2]) * a0 + (xk[3] * px[0] + xk[4] * px[1] + xk[5] * px[2]) * a1 +
+                         polys[i].B[j];
+      q.b[idx] = -dpx;                                         // inner sign, qld.cpp:469-475
+      c0[idx] = a0; c1[idx] = a1; slot[idx] = i;
+    }
+  }
+  if (lane < N) { zr[lane] = polys[lane].centre[0]; zr[lane + N] = polys[lane].centre[1]; }
+  for (int e = lane; e < N * N; e += 64) PuT[e] = PuSrc[e];
+  if (lane < n) q.Gdiag[lane] = kLQ ? 1.0 : K.Qq[lane + lane * n];
+  WG_WSYNC();
+  // ---- D = OptB xk - OptC ZMPRef :1254-1262 ----
+  if (lane < n) {
+    double l1 = 0.0, od = 0.0;
+    for (int j = 0; j < n; j++) l1 += OptC[lane * n + j] * zr[j];
+    for (int j = 0; j < 6; j++) od += OptB[lane * 6 + j] * xk[j];
+    q.d[lane] = od - l1;
+  }
+  DimitrovQldProb<kLQ> prob;
+  prob.c0 = c0; prob.c1 = c1; prob.slot = slot; prob.PuT = PuT; prob.N = N;
+  if (lane == 0 && fabs(prob.Gd(q, n - 1)) == 0.0) prob.setGd(q, n - 1, 1e-8);    // qld.cpp:442-444 (nmax == n)
+  WG_WSYNC();
+  const QlResult r = ql_solve(q, prob, 1e-8, nullptr, 0);
+  WG_WSYNC();
+  if constexpr (kLQ) {
+    // ---- X <- iLQ' X :1355-1381 ----
+    if (lane < n) {
+      double s = 0.0;
+      for (int j = lane; j < n; j++) s += K.iLQ[j * n + lane] * q.x[j];
+      NewX[lane] = s;
+    }
+  } else if (lane < n) NewX[lane] = q.x[lane];
+  WG_WSYNC();
+  const double jx = NewX[0], jy = NewX[N];
+  if (out && lane < 2 * WG_PLDP_N) out->X[lane] = lane < n ? NewX[lane] : 0.0;
+  const int first_rows = rowbase[1] - rowbase[0];
+  WG_WSYNC();
+  if (r.ifail == 0) {
+    // ---- LinearizedInvertedPendulum2D::Interpolation :157-227 (lk = 0..interval) ----
+    if (out && lane <= WG_SAMPLES_PER_TICK) {
+      const double tt = (lane + 1) * K.Tctrl;
+      const double c02 = -K.h / 9.81;
+      const double cx0 = xk[0] + tt * xk[1] + 0.5 * tt * tt * xk[2] + tt * tt * tt * jx / 6.0;
+      const double cx1 = xk[1] + tt * xk[2] + 0.5 * tt * tt * jx;
+      const double cx2 = xk[2] + tt * jx;
+      const double cy0 = xk[3] + tt * xk[4] + 0.5 * tt * tt * xk[5] + tt * tt * tt * jy / 6.0;
+      const double cy1 = xk[4] + tt * xk[5] + 0.5 * tt * tt * jy;
+      const double cy2 = xk[5] + tt * jy;
+      out->com_x[lane][0] = cx0; out->com_x[lane][1] = cx1; out->com_x[lane][2] = cx2;
+      out->com_y[lane][0] = cy0; out->com_y[lane][1] = cy1; out->com_y[lane][2] = cy2;
+      out->zmp_x[lane] = 1.0 * cx0 + 0.0 * cx1 + c02 * cx2;
+      out->zmp_y[lane] = 1.0 * cy0 + 0.0 * cy1 + c02 * cy2;
+    }
+    // ---- OneIteration :230-264 ----
+    if (lane < 2) {
+      const double T = K.T;
+      const double A01 = T, A02 = T * T / 2.0, A12 = T, B0 = T * T * T / 6.0, B1 = T * T / 2.0, B2 = T;
+      const double u = lane == 0 ? jx : jy;
+      const double *c = xk + 3 * lane;
+      const double n0 = 0.0 + 1.0 * c[0] + A01 * c[1] + A02 * c[2];
+      const double n1 = 0.0 + 0.0 * c[0] + 1.0 * c[1] + A12 * c[2];
+      const double n2 = 0.0 + 0.0 * c[0] + 0.0 * c[1] + 1.0 * c[2];
+      st->xk[3 * lane + 0] = n0 + u * B0; st->xk[3 * lane + 1] = n1 + u * B1; st->xk[3 * lane + 2] = n2 + u * B2;
+    }
+  }
+  if (lane == 0) {
+    st->starting = 0;
+    st->n_removed = first_rows;
+    if (out) { out->jerk_x = jx; out->jerk_y = jy; out->ret = r.ifail; out->n_iter = r.n_iter; out->n_active = r.nact; out->m = m; }
   }
   WG_WSYNC();
 }

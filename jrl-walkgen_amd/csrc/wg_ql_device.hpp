@@ -230,6 +230,28 @@ struct QlView {
     R = p;
     Z = z_ext; wa = wa_ext; b = b_ext; d = d_ext; wd = wd_ext; wx = wx_ext; Rf = rf_ext;
   }
+  // The dense ql0001_ boundary at a size known at compile time (the Herdt QP: NMAX = 36, MMAX = 76): G and A are read in place
+  // (the caller points G / A at the problem's own arrays, leading dimensions NMAX / MMAX), wa | b live in the block's global
+  // slot; Z, R and the vectors sit at constant LDS offsets:  Z | R | x d ww wd wx lam | xl xu | diag(G) | sc0..sc3 | slot | iact
+  template <int NMAX, int MMAX>
+  __device__ __forceinline__ void carve_fixed_dense(double *base, int n_, int m_, int me_, double *ext_wab) {
+    n = n_; m = m_; me = me_; mn = m_ + n_; ldg = NMAX; ldz = NMAX | 1; lda = MMAX;
+    r_tail = n_ * (n_ + 1) / 2; nact_cap = 0;
+    double *p = base;
+    Z = p; p += NMAX * (NMAX | 1);
+    R = p; p += NMAX * (NMAX + 1) / 2 + NMAX; Rf = R;
+    x = p; p += NMAX; d = p; p += NMAX; ww = p; p += NMAX; wd = p; p += NMAX; wx = p; p += NMAX; lam = p; p += NMAX;
+    xl = p; p += NMAX; xu = p; p += NMAX;
+    Gdiag = p; p += NMAX;
+    wa = ext_wab; b = ext_wab + (MMAX + NMAX);
+    sc0 = p; p += NMAX; sc1 = p; p += NMAX; sc2 = p; p += NMAX; sc3 = p; p += NMAX;
+    slot = p; p += 8;
+    iact = reinterpret_cast<int *>(p);
+    G = nullptr; A = nullptr;
+  }
+  template <int NMAX> static constexpr size_t fixed_dense_bytes() {
+    return 8 * (size_t)(NMAX * (NMAX | 1) + NMAX * (NMAX + 1) / 2 + NMAX + 9 * NMAX + 4 * NMAX + 8) + 4 * (size_t)((NMAX + 1) & ~1);
+  }
   // doubles in front of sc0 in that layout (where the tick's overlay starts)
   template <int NMAX> static constexpr int fixed_elem_head() { return 3 * NMAX + 8 + ((NMAX + 1) & ~1) / 2; }
 };
@@ -240,12 +262,13 @@ struct QlView {
 #define Am(k, i) prob.A(q, (k), (i))
 
 struct QlView;
-template <bool kGLds>                       // where G lives is known at compile time (ds_ or global_ accesses, never flat_)
+template <bool kGLds, int kNMc = 0>         // where G lives is known at compile time (ds_ or global_ accesses, never flat_)
 struct DenseProbT {
   static constexpr bool kCompact = false;
   static constexpr bool kHasFactor = false;    // no structure to exploit: ql0002's own Cholesky and inverse
   static constexpr bool kRowOps = false;   // no structured row products: rows are read element by element
-  static constexpr int kNM = 0;        // no compile-time bound on n
+  static constexpr int kNM = kNMc;     // 0: no compile-time bound on n; > 0: n <= kNM (the Herdt-sized boundary kernel: the
+                                       // compile-time-bounded forms of the sweep, the back substitution and the ordered sums)
   static constexpr bool kWideN = false;  // 64 <= n <= 128 is not known at compile time: the wide (two rows / columns per lane) forms by test
   __device__ __forceinline__ double G(const QlView &q, int i, int j) const;
   __device__ __forceinline__ double A(const QlView &q, int k, int i) const;
@@ -273,7 +296,7 @@ typedef DenseProbT<true> DenseProb;
 
 // ---- optional in-kernel phase timers (diagnostic build only: -DWG_PROFILE) ----
 #ifdef WG_PROFILE
-__device__ unsigned long long g_prof[40];               // 32..34: the sweep's three phases (norm chain, coefficients, row rotations)
+__device__ unsigned long long g_prof[48];               // 32..34: the sweep's three phases (norm chain, coefficients, row rotations)
 #define PT_DECL unsigned long long pt_acc[28] = {0}; unsigned long long pt_cnt[4] = {0}; unsigned long long pt_sw[3] = {0}; unsigned long long pt_last = clock64();
 #define PT(k) do { unsigned long long t_ = clock64(); pt_acc[k] += t_ - pt_last; pt_last = t_; } while (0)
 #define PT_FLUSH do { if ((threadIdx.x & 63) == 0) { for (int k_ = 0; k_ < 28; ++k_) if (k_ < 21 || k_ > 23) atomicAdd(&g_prof[k_], pt_acc[k_]); \
@@ -313,22 +336,22 @@ struct QlResume {
   double xmag, vfact, res, ratio, diag;
 };
 
-template <bool kGLds> __device__ __forceinline__ double DenseProbT<kGLds>::G(const QlView &q, int i, int j) const {
+template <bool kGLds, int kNMc> __device__ __forceinline__ double DenseProbT<kGLds, kNMc>::G(const QlView &q, int i, int j) const {
   if constexpr (kGLds) return q.G[i + j * q.ldg];
   else {
     const double g = q.G[i + j * q.ldg], dg = q.Gdiag[i];  // both requested: the select costs no round trip
     return i == j ? dg : g;
   }
 }
-template <bool kGLds> __device__ __forceinline__ double DenseProbT<kGLds>::A(const QlView &q, int k, int i) const { return q.A[k + i * q.lda]; }
-template <bool kGLds> __device__ __forceinline__ double DenseProbT<kGLds>::Gd(const QlView &q, int i) const {
+template <bool kGLds, int kNMc> __device__ __forceinline__ double DenseProbT<kGLds, kNMc>::A(const QlView &q, int k, int i) const { return q.A[k + i * q.lda]; }
+template <bool kGLds, int kNMc> __device__ __forceinline__ double DenseProbT<kGLds, kNMc>::Gd(const QlView &q, int i) const {
   if constexpr (kGLds) return q.G[i + i * q.ldg]; else return q.Gdiag[i];
 }
-template <bool kGLds> __device__ __forceinline__ void DenseProbT<kGLds>::setGd(const QlView &q, int i, double v) const {
+template <bool kGLds, int kNMc> __device__ __forceinline__ void DenseProbT<kGLds, kNMc>::setGd(const QlView &q, int i, double v) const {
   if constexpr (kGLds) q.G[i + i * q.ldg] = v; else q.Gdiag[i] = v;
 }
-template <bool kGLds> __device__ __forceinline__ double DenseProbT<kGLds>::xl(const QlView &q, int i) const { return q.xl[i]; }
-template <bool kGLds> __device__ __forceinline__ double DenseProbT<kGLds>::xu(const QlView &q, int i) const { return q.xu[i]; }
+template <bool kGLds, int kNMc> __device__ __forceinline__ double DenseProbT<kGLds, kNMc>::xl(const QlView &q, int i) const { return q.xl[i]; }
+template <bool kGLds, int kNMc> __device__ __forceinline__ double DenseProbT<kGLds, kNMc>::xu(const QlView &q, int i) const { return q.xu[i]; }
 
 // ---- wave reductions on the DPP data path (gfx9 row shifts / row broadcasts: one VALU move per 32-bit half and step, no
 // LDS crossbar, no exec-mask branching).  max / min are idempotent, so lanes without a partner just keep their own value

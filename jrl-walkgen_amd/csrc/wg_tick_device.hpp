@@ -572,7 +572,7 @@ __device__ __forceinline__ TickDiag mpc_tick(const wg_model_t &m, const TickTabl
                                (NH == 16) ? ext16 + kExtWab : nullptr);
   wg_gait_state_t *s = L.st;
 #ifdef WG_PROFILE
-  unsigned long long tk0 = clock64(), tk1 = 0, tk2 = 0, tk3 = 0, tka = 0, tkb = 0, tkc = 0, tkd = 0;
+  unsigned long long tk0 = clock64(), tk1 = 0, tk2 = 0, tk3 = 0, tka = 0, tkb = 0, tkc = 0, tkd = 0, tke = 0, tkf = 0, tkg = 0;
 #endif
 
   // ---- state: HBM -> LDS (coalesced 8-byte lanes) ----
@@ -1088,6 +1088,9 @@ __device__ __forceinline__ TickDiag mpc_tick(const wg_model_t &m, const TickTabl
 
   }
   WG_WSYNC();
+#ifdef WG_PROFILE
+  tke = clock64();
+#endif
 
   // ---- feet: one lane per 5 ms sample (interpolate_feet_positions, OnLineFootTrajectoryGeneration.cpp:235-346) ----
   {
@@ -1181,6 +1184,9 @@ __device__ __forceinline__ TickDiag mpc_tick(const wg_model_t &m, const TickTabl
       backl = outl; backr = outr;
     }
     WG_WSYNC();
+#ifdef WG_PROFILE
+    tkf = clock64();
+#endif
     if (mine && out) { out->lf[lane] = outl; out->rf[lane] = outr; }
     if (lane == 0 && out) { out->lf_back = backl; out->rf_back = backr; }
     if (lane == 11) { s->lf[0] = outl; s->rf[0] = outr; }
@@ -1193,6 +1199,9 @@ __device__ __forceinline__ TickDiag mpc_tick(const wg_model_t &m, const TickTabl
     }
   }
   WG_WSYNC();
+#ifdef WG_PROFILE
+  tkg = clock64();
+#endif
 
   // ---- state: LDS -> HBM ----
   {
@@ -1210,6 +1219,9 @@ __device__ __forceinline__ TickDiag mpc_tick(const wg_model_t &m, const TickTabl
     atomicAdd(&g_prof[37], tkc - tkb);                 //        lane 0: orientation preview
     atomicAdd(&g_prof[38], tk1 - tkc);                 //        one instant per lane: selection, rotated references, hull edges
     atomicAdd(&g_prof[39], tkd - tk3);                 // of 23: state fetched back, jerk, CoM samples, LIPM step
+    atomicAdd(&g_prof[40], tke - tkd);                 //        lane 0: trunk
+    atomicAdd(&g_prof[41], tkf - tke);                 //        feet: polynomials, one lane per sample
+    atomicAdd(&g_prof[42], tkg - tkf);                 //        samples into the state's queue (LDS)
   }
 #endif
   TickDiag dg;

@@ -104,6 +104,8 @@ def lib():
         _lib.wg_dimitrov_tick_batch.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
         _lib.wg_dimitrov_tick_batch_dev.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
         _lib.wg_dimitrov_get_constants.argtypes = [C.c_void_p] * 6
+        if hasattr(_lib, "wg_dimitrov_get_qld_constants"):
+            _lib.wg_dimitrov_get_qld_constants.argtypes = [C.c_void_p] * 4
         _lib.wg_riccati_solve.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_double, C.c_int,
                                           C.c_int, C.c_void_p, C.c_void_p]
         _lib.wg_riccati_gains.argtypes = [C.c_double] * 4 + [C.c_int, C.c_int, C.c_void_p, C.c_void_p]
@@ -141,7 +143,7 @@ def lib():
 CTX_ENTRY_POINTS = ("wg_qp_solve_batch", "wg_qp_solve_batch_dev", "wg_mpc_configure", "wg_mpc_reserve", "wg_mpc_tick_lds_bytes", "wg_mpc_tick_batch",
                     "wg_mpc_tick_batch_dev", "wg_mpc_run_batch_dev", "wg_mpc_run_sched_dev", "wg_mpc_set_velref_dev", "wg_mpc_tick_pinned",
                     "wg_mpc_assemble_batch", "wg_mpc_assemble_batch_dev", "wg_pldp_configure",
-                    "wg_pldp_solve_batch", "wg_pldp_solve_batch_dev", "wg_dimitrov_configure", "wg_dimitrov_get_constants",
+                    "wg_pldp_solve_batch", "wg_pldp_solve_batch_dev", "wg_dimitrov_configure", "wg_dimitrov_get_constants", "wg_dimitrov_get_qld_constants",
                     "wg_dimitrov_tick_batch", "wg_dimitrov_tick_batch_dev", "wg_preview_configure", "wg_preview_window",
                     "wg_preview_run_batch", "wg_preview_run_batch_dev", "wg_gramian_batch", "wg_gramian_batch_dev",
                     "wg_zmpdisc_batch", "wg_zmpdisc_batch_dev", "wg_zmpdisc_full_batch_dev")
@@ -456,8 +458,8 @@ POLY_MAX_ROWS = 8
 
 
 class DimitrovModel(C.Structure):       # wg_dimitrov_model_t
-    _fields_ = [("N", C.c_int), ("pad_", C.c_int), ("T", C.c_double), ("Tctrl", C.c_double), ("com_height", C.c_double),
-                ("alpha", C.c_double), ("beta", C.c_double)]
+    _fields_ = [("N", C.c_int), ("solver", C.c_int), ("T", C.c_double), ("Tctrl", C.c_double), ("com_height", C.c_double),
+                ("alpha", C.c_double), ("beta", C.c_double)]       # solver: 0 = PLDP (the reference's default), 1 = QLD
 
 
 class ZmpPolytope(C.Structure):         # wg_zmp_polytope_t
@@ -473,7 +475,7 @@ class DimitrovOut(C.Structure):         # wg_dimitrov_out_t
     _fields_ = [("jerk_x", C.c_double), ("jerk_y", C.c_double), ("ret", C.c_int), ("n_iter", C.c_int),
                 ("n_active", C.c_int), ("m", C.c_int),
                 ("com_x", (C.c_double * 3) * 21), ("com_y", (C.c_double * 3) * 21),
-                ("zmp_x", C.c_double * 21), ("zmp_y", C.c_double * 21)]
+                ("zmp_x", C.c_double * 21), ("zmp_y", C.c_double * 21), ("X", C.c_double * 32)]
 
 
 def dimitrov_defaults():
@@ -492,6 +494,14 @@ def dimitrov_constants(N):
     Pu = np.zeros((N, N)); iPu = np.zeros((N, N)); Px = np.zeros((N, 3))
     _check(lib().wg_dimitrov_get_constants(_hp(iLQ), _hp(OptB), _hp(OptC), _hp(Pu), _hp(iPu), _hp(Px)))
     return dict(iLQ=iLQ, OptB=OptB, OptC=OptC, Pu=Pu, iPu=iPu, Px=Px)
+
+
+def dimitrov_qld_constants(N):
+    """what mode QLD hands to ql0001_ and builds its cost vector from: Q (column-major 2N x 2N), OptB / OptC as built, Pu'"""
+    n = 2 * N
+    Q = np.zeros((n, n)); OptB = np.zeros((n, 6)); OptC = np.zeros((n, n)); PuT = np.zeros((N, N))
+    _check(lib().wg_dimitrov_get_qld_constants(_hp(Q), _hp(OptB), _hp(OptC), _hp(PuT)))
+    return dict(Q=Q, OptB=OptB, OptC=OptC, PuT=PuT)
 
 
 def dimitrov_tick_batch(polys, states, want_out=True, max_iter=0):

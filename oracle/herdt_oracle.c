@@ -457,6 +457,35 @@ void wgo_solve_timer(int enable, double *seconds, long *count) {
 /* route the tick's QP through the reference's own compiled solver (NULL = this directory's restatement) */
 void wgo_set_reference_ql(void *ql0001_entry) { g_ref_ql = (wgo_ql0001_fn)ql0001_entry; }
 
+/* One ql0001_ call the way the reference's drivers make it (QPProblem::solve, qp-problem.cpp:256-279, and
+ * ZMPConstrainedQPFastFormulation.cpp:1280-1307): iwar[0] = lql (1: C is the Hessian; 0: C is its upper-triangular Cholesky
+ * factor, what mode QLDANDLQ says of its identity), eps = 1e-8, lwar = 3 nmax^2/2 + 10 nmax + 2 mmax + 20000 -- by the reference's
+ * COMPILED ql0001_ when wgo_set_reference_ql gave one (then *n_iter = -1: it does not report iterations), by the restatement
+ * otherwise.  The restatement has the lql branch only (ql_oracle.c); it is handed C as a Hessian either way -- for the identity
+ * the same matrix, and the compiled reference returns the same bits on it with iwar[0] = 0 and 1 (tests/test_dimitrov_gpu.py
+ * runs the compiled one the driver's way).  *nact = number of non-zero multipliers (compiled) / active constraints (restated). */
+int wgo_ql_call(int lql, int m, int me, int mmax, int n, int nmax, double *C, double *d, double *A, double *b, double *xl, double *xu,
+                double *x, double *u, int *ifail, int *n_iter, int *nact) {
+  int *iact = (int *)calloc((size_t)n + 1, sizeof(int));
+  *nact = 0;
+  if (g_ref_ql) {
+    int m_ = m, me_ = me, mmax_ = mmax, n_ = n, nmax_ = nmax, mnn_ = m + 2 * n, iout_ = 0, iprint_ = 1, liwar_ = n;
+    int lwar_ = 3 * nmax * nmax / 2 + 10 * nmax + 2 * mmax + 20000;
+    double eps_ = 1e-8;
+    double *war = (double *)calloc((size_t)lwar_, sizeof(double));
+    iact[0] = lql ? 1 : 0;
+    g_ref_ql(&m_, &me_, &mmax_, &n_, &nmax_, &mnn_, C, d, A, b, xl, xu, x, u, &iout_, ifail, &iprint_, war, &lwar_, iact, &liwar_, &eps_);
+    free(war);
+    *n_iter = -1;
+    for (int i = 0; i < m + 2 * n; i++) *nact += (u[i] != 0.0);
+  } else {
+    int hlen = 0;
+    wgo_ql_solve(m, me, mmax, n, nmax, C, d, A, b, xl, xu, 1e-8, x, u, ifail, iact, nact, n_iter, NULL, 0, &hlen);
+  }
+  free(iact);
+  return *ifail;
+}
+
 int wgo_mpc_tick(const wg_model_t *m, wg_gait_state_t *s, wg_tick_out_t *out, wgo_qp_dump_t *dump) {
   const int N = m->N;
   const double T = m->T;

@@ -360,6 +360,101 @@ int wgo_dimitrov_tick(const wgo_pldp_model_t *M, const double *OptB, const doubl
   }
   st->starting = 0;
   st->n_removed = polys[0].nrows;
-  if (out) { out->jerk_x = jx; out->jerk_y = jy; out->ret = rc; out->n_iter = nit; out->n_active = nact; out->m = m; }
+  if (out) {
+    out->jerk_x = jx; out->jerk_y = jy; out->ret = rc; out->n_iter = nit; out->n_active = nact; out->m = m;
+    for (int i = 0; i < 2 * WG_PLDP_N; i++) out->X[i] = i < n ? NewX[i] : 0.0;
+  }
   return rc;
+}
+
+/* ---- the Dimitrov-2008 tick in modes QLD and QLDANDLQ ------------------------------------------------------------------
+ * ZMPConstrainedQPFastFormulation::BuildZMPTrajectoryFromFootTrajectory with m_FastFormulationMode == QLD / QLDANDLQ
+ * (/root/reference/src/ZMPRefTrajectoryGeneration/ZMPConstrainedQPFastFormulation.cpp): BuildConstraintMatrices :759-1022 with the
+ * triangular fill of :891-904 (QLD) or the full one of :905-918 (QLDANDLQ), D :1254-1262, XL / XU = -+1e8 and X = 0 (:1280-1286),
+ * iwar[0] = 1 / 0 (:1288-1291), ql0001_ (:1297-1307) on m_Q = OptA (:382-389) / the identity (:537-540), X used as it is (QLD,
+ * :1383) or un-preconditioned (QLDANDLQ, :1355-1381), Interpolation + OneIteration.
+ * The arithmetic core -- the solve -- is the reference's own compiled qld.cpp when the harness sets it (wgo_ql_call); the dense
+ * arrays are built here exactly as the driver builds them (DPu column-major with leading dimension m + 1, zero-filled). */
+int wgo_dimitrov_qld_tick(int mode, int N, const double *Q, const double *OptB, const double *OptC, const double *PuT,
+                          const double *Px, const double *iLQ, double T, double Tctrl, double com_height,
+                          const wg_zmp_polytope_t *polys, wg_dimitrov_state_t *st, wg_dimitrov_out_t *out) {
+  const int n = 2 * N;
+  const int lq = mode == 2;
+  static double A[(WG_PLDP_MMAX + 1) * 2 * WG_PLDP_N], Cq[4 * WG_PLDP_N * WG_PLDP_N], U[WG_PLDP_MMAX + 1 + 4 * WG_PLDP_N];
+  double b[WG_PLDP_MMAX + 1], zr[2 * WG_PLDP_N], D[2 * WG_PLDP_N], X[2 * WG_PLDP_N], XL[2 * WG_PLDP_N], XU[2 * WG_PLDP_N];
+  double NewX[2 * WG_PLDP_N];
+  const double *xk = st->xk;
+  int m = 0;
+  for (int i = 0; i < N; i++) m += polys[i].nrows;
+  if (m > WG_PLDP_MMAX) return -100;
+  const int mmax = m + 1;
+  memset(A, 0, sizeof(double) * (size_t)mmax * n);
+  memset(b, 0, sizeof b);
+  int idx = 0;
+  for (int i = 0; i < N; i++) {
+    zr[i] = polys[i].centre[0];
+    zr[i + N] = polys[i].centre[1];
+    for (int j = 0; j < polys[i].nrows; j++) {
+      b[idx] = (xk[0] * Px[i * 3 + 0] + xk[1] * Px[i * 3 + 1] + xk[2] * Px[i * 3 + 2]) * polys[i].A[j][0] +
+               (xk[3] * Px[i * 3 + 0] + xk[4] * Px[i * 3 + 1] + xk[5] * Px[i * 3 + 2]) * polys[i].A[j][1] +
+               polys[i].B[j];
+      const int kend = lq ? N - 1 : i;                    /* QLD: "Pu is triangular" (:891-904); QLDANDLQ: it is not (:905-918) */
+      for (int k = 0; k <= kend; k++) {
+        A[idx + k * mmax] = polys[i].A[j][0] * PuT[k * N + i];
+        A[idx + (k + N) * mmax] = polys[i].A[j][1] * PuT[k * N + i];
+      }
+      idx++;
+    }
+  }
+  for (int i = 0; i < n; i++) {
+    double l1 = 0.0, od = 0.0;
+    for (int j = 0; j < n; j++) l1 += OptC[i * n + j] * zr[j];
+    for (int j = 0; j < 6; j++) od += OptB[i * 6 + j] * xk[j];
+    D[i] = od - l1;
+    XL[i] = -1e8; XU[i] = 1e8; X[i] = 0.0;
+  }
+  if (lq) { memset(Cq, 0, sizeof(double) * (size_t)n * n); for (int i = 0; i < n; i++) Cq[i * n + i] = 1.0; }
+  else memcpy(Cq, Q, sizeof(double) * (size_t)n * n);
+  int ifail = 0, nit = 0, nact = 0;
+  wgo_ql_call(lq ? 0 : 1, m, 0, mmax, n, n, Cq, D, A, b, XL, XU, X, U, &ifail, &nit, &nact);
+  for (int i = 0; i < n; i++) {
+    if (!lq) { NewX[i] = X[i]; continue; }
+    double s = 0.0;
+    for (int j = i; j < n; j++) s += iLQ[j * n + i] * X[j];
+    NewX[i] = s;
+  }
+  const double jx = NewX[0], jy = NewX[N];
+  if (ifail == 0) {
+    const double c02 = -com_height / 9.81;
+    if (out)
+      for (int lk = 0; lk <= WG_SAMPLES_PER_TICK; lk++) {
+        const double t = (lk + 1) * Tctrl;
+        const double cx0 = xk[0] + t * xk[1] + 0.5 * t * t * xk[2] + t * t * t * jx / 6.0;
+        const double cx1 = xk[1] + t * xk[2] + 0.5 * t * t * jx;
+        const double cx2 = xk[2] + t * jx;
+        const double cy0 = xk[3] + t * xk[4] + 0.5 * t * t * xk[5] + t * t * t * jy / 6.0;
+        const double cy1 = xk[4] + t * xk[5] + 0.5 * t * t * jy;
+        const double cy2 = xk[5] + t * jy;
+        out->com_x[lk][0] = cx0; out->com_x[lk][1] = cx1; out->com_x[lk][2] = cx2;
+        out->com_y[lk][0] = cy0; out->com_y[lk][1] = cy1; out->com_y[lk][2] = cy2;
+        out->zmp_x[lk] = 1.0 * cx0 + 0.0 * cx1 + c02 * cx2;
+        out->zmp_y[lk] = 1.0 * cy0 + 0.0 * cy1 + c02 * cy2;
+      }
+    const double A01 = T, A02 = T * T / 2.0, A12 = T, B0 = T * T * T / 6.0, B1 = T * T / 2.0, B2 = T;
+    for (int a = 0; a < 2; a++) {
+      const double u = a == 0 ? jx : jy;
+      double *c = st->xk + 3 * a;
+      const double n0 = 0.0 + 1.0 * c[0] + A01 * c[1] + A02 * c[2];
+      const double n1 = 0.0 + 0.0 * c[0] + 1.0 * c[1] + A12 * c[2];
+      const double n2 = 0.0 + 0.0 * c[0] + 0.0 * c[1] + 1.0 * c[2];
+      c[0] = n0 + u * B0; c[1] = n1 + u * B1; c[2] = n2 + u * B2;
+    }
+  }
+  st->starting = 0;
+  st->n_removed = polys[0].nrows;
+  if (out) {
+    out->jerk_x = jx; out->jerk_y = jy; out->ret = ifail; out->n_iter = nit; out->n_active = nact; out->m = m;
+    for (int i = 0; i < 2 * WG_PLDP_N; i++) out->X[i] = i < n ? NewX[i] : 0.0;
+  }
+  return ifail;
 }

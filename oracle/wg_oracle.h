@@ -54,6 +54,10 @@ int wgo_invariant_hessian(const wg_model_t *model, double *Qb);
 /* NULL (default): the tick solves with wgo_ql_solve; otherwise with the given ql0001_ entry point (the reference's own
  * compiled qld.cpp from oracle/_ref/libqld_ref.so) */
 void wgo_set_reference_ql(void *ql0001_entry);
+/* one ql0001_ call as the reference's drivers make it (iwar[0] = lql): by the compiled reference when one was set, else by the
+ * restatement */
+int wgo_ql_call(int lql, int m, int me, int mmax, int n, int nmax, double *C, double *d, double *A, double *b, double *xl, double *xu,
+                double *x, double *u, int *ifail, int *n_iter, int *nact);
 /* enable / disable and read-and-reset the wall time spent inside the reference's ql0001_ (solve only) */
 void wgo_solve_timer(int enable, double *seconds, long *count);
 /* the benchmark workload on the CPU, loop in C (see herdt_oracle.c) */
@@ -78,6 +82,16 @@ int wgo_pldp_solve(const wgo_pldp_model_t *M, wg_pldp_state_t *st, const double 
 int wgo_dimitrov_tick(const wgo_pldp_model_t *M, const double *OptB, const double *OptC, const double *iLQ, double T,
                       double Tctrl, double com_height, const wg_zmp_polytope_t *polys, wg_dimitrov_state_t *st,
                       wg_dimitrov_out_t *out, int max_iter);
+/* the same tick in the reference's modes QLD (mode = 1) and QLDANDLQ (mode = 2) (ZMPConstrainedQPFastFormulation.cpp:1297-1320):
+ *   QLD       ql0001_ on (Q = OptA, D, DPu, DPx) without the LQ preconditioning, iwar[0] = 1: Q = ql0001_'s column-major 2N x 2N,
+ *             OptB (2N x 6) / OptC (2N x 2N) row-major AS BUILT, PuT = Pu' (N x N, :629-637); iLQ unused
+ *   QLDANDLQ  ql0001_ on the preconditioned problem, Q = identity handed over as its own factor (iwar[0] = 0): OptB / OptC
+ *             premultiplied by iLQ, PuT = iLQ Pu' (full), X <- iLQ' X; Q unused
+ * Px N x 3.  The solve goes through wgo_ql_call: PINNED to the compiled reference when wgo_set_reference_ql was given oracle/_ref's
+ * entry point. */
+int wgo_dimitrov_qld_tick(int mode, int N, const double *Q, const double *OptB, const double *OptC, const double *PuT,
+                          const double *Px, const double *iLQ, double T, double Tctrl, double com_height,
+                          const wg_zmp_polytope_t *polys, wg_dimitrov_state_t *st, wg_dimitrov_out_t *out);
 
 /* ---- Kajita stage-1 preview-control iteration (preview_oracle.c); arguments as wg_preview_run_batch ---------------- */
 int wgo_preview_run(const wg_preview_gains_t *g, const double *F, int B, int L, const double *zmp_x, const double *zmp_y,

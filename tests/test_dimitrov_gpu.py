@@ -193,3 +193,139 @@ def test_step_sequences_to_com_through_zmpdisc_footconstraints_and_the_tick():
         i_end = int(round(lived[b] * model.T / zm.T))
         feet_mid = 0.5 * (r["left"][b, i_end, :2] + r["right"][b, i_end, :2])
         assert np.hypot(so[b].xk[0] - feet_mid[0], so[b].xk[3] - feet_mid[1]) < 0.15, b
+
+
+def _qld_setup(mode):
+    wg.init(0)
+    model = wg.dimitrov_defaults()
+    model.solver = mode                                        # 1 = WG_DIMITROV_QLD, 2 = WG_DIMITROV_QLDANDLQ
+    wg.dimitrov_configure(model)
+    return model, wg.dimitrov_constants(model.N), wg.dimitrov_qld_constants(model.N)
+
+
+@pytest.mark.parametrize("mode,ql", [(2, "reference"), (2, "restated"), (1, "reference"), (1, "restated")])
+def test_fused_tick_with_the_ql_back_ends_bit_exact(mode, ql):
+    """The reference's modes QLDANDLQ (2) and QLD (1) (ZMPConstrainedQPFastFormulation.cpp:1297-1320): ql0001_ as the tick's
+    solver.  The GPU tick solves with the in-wave ql0002 through a structured view of DPu; the oracle tick builds the dense arrays
+    as the driver does and calls ql0001_ -- the reference's own COMPILED qld.cpp called the driver's way, iwar[0] = 0 / 1
+    ("reference": oracle/_ref; states, jerk sequences, return codes and samples bit for bit), or the restatement ("restated":
+    iteration and active-set counts as well).  These are the back-ends of this tick whose CPU counterpart is pinned to the
+    reference.  Mode QLDANDLQ walks; mode QLD is the reference's, literally: its OptA carries alpha VPu' instead of alpha VPu'VPu
+    (:524-527), not symmetric, upper triangle not positive definite -- ql0001_ answers ifail = 2 ("accuracy insufficient") on
+    the first tick there (the driver prints IFAIL and stops, :1348-1352) and here."""
+    model, K, Kq = _qld_setup(mode)
+    N = model.N
+    lib = ol.oracle()
+    if ql == "reference":
+        if not ol.have_ref():
+            pytest.skip("oracle/_ref not built")
+        lib.wgo_set_reference_ql(C.cast(getattr(ol.ref(), ol.REF_SYM), C.c_void_p))
+    else:
+        lib.wgo_set_reference_ql(None)
+    try:
+        dp = lambda a: a.ctypes.data_as(C.POINTER(C.c_double))  # noqa: E731
+        B, T = 20, 40
+        plans = [dv.plan(np.random.default_rng(500 + g), n_steps=3 + g % 6) for g in range(B)]
+        offs = [(5 * g) % 11 for g in range(B)]
+        sg = (wg.DimitrovState * B)(); so = (wg.DimitrovState * B)()
+        for g in range(B):
+            for s in (sg[g], so[g]):
+                s.starting = 1
+                s.xk[0] = 0.002 * g; s.xk[4] = 0.001 * (g % 5 - 2)
+        n_ok = 0; max_act = 0; iters = []; rets = set()
+        OB, OC, PU = (K["OptB"], K["OptC"], K["Pu"]) if mode == 2 else (Kq["OptB"], Kq["OptC"], Kq["PuT"])
+        for it in range(T):
+            polys = (wg.ZmpPolytope * (B * N))()
+            for g in range(B):
+                for i, p in enumerate(dv.polys_at(plans[g], it + offs[g], N)):
+                    _fill(polys[g * N + i], p)
+            outs = wg.dimitrov_tick_batch(polys, sg)
+            for g in range(B):
+                oo = wg.DimitrovOut()
+                rc = lib.wgo_dimitrov_qld_tick(C.c_int(mode), C.c_int(N), dp(Kq["Q"]), dp(OB), dp(OC), dp(PU), dp(K["Px"]), dp(K["iLQ"]),
+                                               C.c_double(model.T), C.c_double(model.Tctrl), C.c_double(model.com_height),
+                                               C.byref(polys, g * N * C.sizeof(wg.ZmpPolytope)), C.byref(so[g]), C.byref(oo))
+                assert outs[g].ret == rc, (it, g, outs[g].ret, rc)
+                rets.add(rc)
+                assert bytes(sg[g]) == bytes(so[g]), (it, g)
+                assert (outs[g].jerk_x, outs[g].jerk_y, outs[g].m) == (oo.jerk_x, oo.jerk_y, oo.m), (it, g)
+                assert bytes(outs[g].X) == bytes(oo.X), (it, g)
+                if rc == 0:
+                    assert bytes(outs[g].com_x) == bytes(oo.com_x) and bytes(outs[g].zmp_y) == bytes(oo.zmp_y), (it, g)
+                    n_ok += 1
+                if ql == "restated":
+                    assert (outs[g].n_iter, outs[g].n_active) == (oo.n_iter, oo.n_active), (it, g)
+                max_act = max(max_act, outs[g].n_active); iters.append(outs[g].n_iter)
+        if mode == 2:
+            # a plan that ends inside the preview window poses inconsistent constraints: ql0001_ says so (ifail = 10 + row), the gait
+            # stops there like the reference's driver does (:1348-1352) -- the same code from the GPU and from the reference
+            assert all(r == 0 or r > 10 for r in rets) and n_ok > 0.6 * B * T and max_act >= 6 and np.mean(iters) > 3, (rets, n_ok)
+            x_end = np.array([so[g].xk[0] for g in range(B)])
+            assert x_end.max() > 0.2                              # the gaits did walk
+        else:
+            assert 2 in rets                                      # the reference's QLD mode: "IFAIL: 2" (see the docstring)
+    finally:
+        lib.wgo_set_reference_ql(None)
+        wg.dimitrov_configure(wg.dimitrov_defaults())
+
+
+def test_pldp_against_qldandlq_objective_gap_per_tick():
+    """The same gaits through PLDP and through ql0001_ on the SAME preconditioned problem (mode QLDANDLQ), both from the same state
+    at every tick.  In jerk coordinates u the common objective is 1/2 u' H u + D' u with H = LQ LQ' (the lower triangle of OptA,
+    mirrored: what the LQ factor factors) and D = OptB xk - OptC ZMPRef as built; v = LQ' u turns it into 1/2 |v|^2 + (iLQ D)' v.
+    ql0001_ returns the minimiser over the polytopes; PLDP stops on a face (it never drops a constraint inside a solve) -- feasible,
+    objective at least QL's.  The gap per tick is reported (pytest -s) and bounded."""
+    wg.init(0)
+    mp = wg.dimitrov_defaults()
+    mq = wg.dimitrov_defaults(); mq.solver = 2
+    N = mp.N; n = 2 * N
+    B, T = 16, 30
+    plans = [dv.plan(np.random.default_rng(900 + g), n_steps=4 + g % 5) for g in range(B)]
+    sp = (wg.DimitrovState * B)(); sq = (wg.DimitrovState * B)()
+    for g in range(B):
+        for s in (sp[g], sq[g]):
+            s.starting = 1; s.xk[0] = 0.002 * g
+    with wg.Context(0) as cp, wg.Context(0) as cq:
+        assert cp.call("wg_dimitrov_configure", C.byref(mp)) == 0 and cq.call("wg_dimitrov_configure", C.byref(mq)) == 0
+        Q = np.zeros((n, n)); OB = np.zeros((n, 6)); OC = np.zeros((n, n)); PuT = np.zeros((N, N)); Px = np.zeros((N, 3))
+        hp = lambda a: a.ctypes.data_as(C.c_void_p)  # noqa: E731
+        assert cq.call("wg_dimitrov_get_qld_constants", hp(Q), hp(OB), hp(OC), hp(PuT)) == 0
+        assert cq.call("wg_dimitrov_get_constants", None, None, None, None, None, hp(Px)) == 0
+        OptA = Q.T                                               # Q is ql0001_'s column-major layout of OptA
+        H = np.tril(OptA) + np.tril(OptA, -1).T                  # what OptCholesky factors (lower triangle)
+        rel, worst = [], 0.0
+        for it in range(T):
+            polys = (wg.ZmpPolytope * (B * N))()
+            for g in range(B):
+                for i, p in enumerate(dv.polys_at(plans[g], it, N)):
+                    _fill(polys[g * N + i], p)
+            for g in range(B):                                   # the same state for both solvers; PLDP cold-started on it (its
+                for k in range(6):                               # hot-start members describe ITS previous tick, not this state)
+                    sp[g].xk[k] = sq[g].xk[k]
+                sp[g].starting = 1
+            xk = np.array([[sq[g].xk[k] for k in range(6)] for g in range(B)])
+            op = (wg.DimitrovOut * B)(); oq = (wg.DimitrovOut * B)()
+            assert cp.call("wg_dimitrov_tick_batch", B, C.addressof(polys), C.addressof(sp), C.addressof(op), 0) == 0
+            assert cq.call("wg_dimitrov_tick_batch", B, C.addressof(polys), C.addressof(sq), C.addressof(oq), 0) == 0
+            for g in range(B):
+                if op[g].ret != 0 or oq[g].ret != 0:
+                    continue
+                zr = np.array([polys[g * N + i].centre[0] for i in range(N)] + [polys[g * N + i].centre[1] for i in range(N)])
+                D = OB @ xk[g] - OC @ zr
+                f = lambda X: 0.5 * X @ H @ X + D @ X             # noqa: E731
+                Xp, Xq = np.array(op[g].X[:n]), np.array(oq[g].X[:n])
+                fp, fq = f(Xp), f(Xq)
+                rel.append((fp - fq) / max(abs(fq), 1e-12))
+                for X in (Xp, Xq):                               # feasibility: A (Px xk + Pu X) + B >= 0
+                    for i in range(N):
+                        pu = np.zeros(N); pu[:i + 1] = PuT[:i + 1, i]
+                        zx = Px[i] @ xk[g][:3] + pu @ X[:N]; zy = Px[i] @ xk[g][3:] + pu @ X[N:]
+                        for j in range(polys[g * N + i].nrows):
+                            worst = min(worst, polys[g * N + i].A[j][0] * zx + polys[g * N + i].A[j][1] * zy + polys[g * N + i].B[j])
+        rel = np.array(rel)
+        assert len(rel) > 100
+        print("PLDP vs QLDANDLQ objective over %d ticks: relative gap mean %.3g, median %.3g, max %.3g, min %.3g; PLDP reaches the "
+              "optimum (gap < 1e-9) on %.0f %% of the ticks; worst constraint value %.3g"
+              % (len(rel), rel.mean(), np.median(rel), rel.max(), rel.min(), 100.0 * (np.abs(rel) < 1e-9).mean(), worst))
+        assert rel.min() > -1e-7                                   # ql0001_'s solution is the minimiser
+        assert worst > -1e-6                                       # both are feasible (PLDP's own 1e-8 slack, rows of norm ~1e-3)

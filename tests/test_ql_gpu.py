@@ -74,13 +74,17 @@ def test_herdt_shape_uniform_batch():
     assert not bad, bad[:5]
 
 
-@pytest.mark.parametrize("a_in_lds,g_in_lds,w_in_lds", [("1", "1", "1"), ("0", "1", "1"), ("0", "0", "1"), ("0", "0", "0")])
+@pytest.mark.parametrize("a_in_lds,g_in_lds,w_in_lds", [("1", "1", "1"), ("0", "1", "1"), ("0", "0", "1"), ("0", "0", "0"), ("0", "0", "0-generic")])
 def test_matrices_in_lds_or_read_in_place(a_in_lds, g_in_lds, w_in_lds, monkeypatch):
     """A is staged in LDS only while that does not cost a resident QP (Herdt-sized QPs read it in place, from L2), and G -- cold
     once Z = R^-1 exists, its diagonal kept in LDS for ql0002's shift -- follows it out when that buys two more resident QPs,
     the constraint weights wa | b (a slot of global memory per QP) when that buys the eighth;
     every placement is the same arithmetic and is held to the oracle, on Herdt-shaped QPs and on small dense ones, on QPs whose
-    Hessian needs the diagonal shift (singular) and on the c(nmax, nmax) == 0 patch"""
+    Hessian needs the diagonal shift (singular) and on the c(nmax, nmax) == 0 patch.  With everything out of the LDS a batch of
+    exactly the Herdt size (nmax = 36, mmax = 76) takes the kernel instantiated for that size (strides, LDS layout and the solver's
+    loop bounds compile-time constants); "0-generic" (WG_QL_FIXED=0) keeps the any-size kernel on the same batch."""
+    if w_in_lds.endswith("-generic"):
+        monkeypatch.setenv("WG_QL_FIXED", "0"); w_in_lds = "0"
     monkeypatch.setenv("WG_QL_A_IN_LDS", a_in_lds)
     monkeypatch.setenv("WG_QL_G_IN_LDS", g_in_lds)
     monkeypatch.setenv("WG_QL_W_IN_LDS", w_in_lds)

@@ -16,7 +16,7 @@ if fam == "herdt_like":
 else:
     qps = [qpgen.FAMILIES[fam](np.random.default_rng(5 + s)) for s in range(B)]
 pk = wm.pack_qps(qps)
-buf = (C.c_ulonglong * 40)()
+buf = (C.c_ulonglong * 48)()
 wm.lib().wg_prof_read(buf)
 res = wm.qp_solve_batch(pk)
 wm.lib().wg_prof_read(buf)

@@ -14,7 +14,7 @@ s0 = wg.gait_init(model, [0.0316055, 0.0, 0.7116911], [0.0, 0.09, 0.0], [0.0, -0
 for g in range(B): C.memmove(C.byref(states[g]), C.byref(s0), C.sizeof(wg.GaitState))
 dev = torch.frombuffer(bytearray(bytes(memoryview(states).cast("B"))), dtype=torch.uint8).cuda()
 diag = torch.zeros(B, 6, dtype=torch.int32, device="cuda")
-buf = (C.c_ulonglong * 40)()
+buf = (C.c_ulonglong * 48)()
 its = 0
 for tick in range(WARM + MEAS):
     if tick % 50 == 0:
@@ -41,7 +41,10 @@ for k, nme in enumerate(names):
             print(f"      pre {ph:60s} {v[35+j]/n:10.0f} cyc/tick  {100*v[35+j]/tot:5.1f}%")
     if k == 23 and v[39] > 0:
         print(f"      post {'state fetched back, jerk, CoM samples, LIPM step':59s} {v[39]/n:10.0f} cyc/tick  {100*v[39]/tot:5.1f}%")
-        print(f"      post {'trunk (lane 0), feet (one lane per sample), state store':59s} {(v[23]-v[39])/n:10.0f} cyc/tick  {100*(v[23]-v[39])/tot:5.1f}%")
+        for j, ph in enumerate(["lane 0: trunk", "feet: polynomials, one lane per sample", "samples into the state's queue (LDS)"]):
+            print(f"      post {ph:59s} {v[40+j]/n:10.0f} cyc/tick  {100*v[40+j]/tot:5.1f}%")
+        rest = v[23] - v[39] - v[40:43].sum()
+        print(f"      post {'state LDS -> HBM':59s} {rest/n:10.0f} cyc/tick  {100*rest/tot:5.1f}%")
     if k == 12 and v[32:35].sum() > 0:                       # the compact view's sweep by phase (sweep_flat)
         for j, ph in enumerate(["phase 1: chain of rotation norms", "phase 2: ga / gb of every rotation, one lane each", "phase 3: lane i carries row i of Z through the rotations"]):
             print(f"      sweep {ph:58s} {v[32+j]/n:10.0f} cyc/tick  {100*v[32+j]/tot:5.1f}%")
