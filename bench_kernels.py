@@ -72,43 +72,55 @@ def dimitrov_and_pldp(wg, dev, stream, B=4096):
     lib = wg.lib()
     res = {}
 
-    # ---- the fused Dimitrov tick: polytope windows in, jerk + state out ----
+    # ---- the fused Dimitrov tick: polytope windows in, jerk + state out; with PLDP, then with ql0001_ (mode QLDANDLQ) ----
     ST = np.dtype([("xk", "f8", 6), ("pldp", "u1", C.sizeof(wg.PldpState)), ("n_removed", "i4"), ("starting", "i4")])
     assert ST.itemsize == C.sizeof(wg.DimitrovState)
-    st = np.zeros(B, ST); st["starting"] = 1
-    dst = torch.from_numpy(st.view(np.uint8)).to(dev)
     OUT = C.sizeof(wg.DimitrovOut)
-    dout = torch.zeros(B * OUT, dtype=torch.uint8, device=dev)
     odt = np.dtype([("jerk", "f8", 2), ("ret", "i4"), ("n_iter", "i4"), ("n_active", "i4"), ("m", "i4"), ("rest", "u1", OUT - 32)])
-    WARM, MEAS = 3, 20
-    ms, iters, failed = [], [], 0
-    for it in range(WARM + MEAS):
-        win = table[plan_id[:, None], (it + offs)[:, None] + np.arange(N)[None, :]]
-        dpoly = torch.from_numpy(np.ascontiguousarray(win).view(np.uint8)).to(dev)
-        torch.cuda.synchronize(dev)
-        e0, e1 = _ev()
-        with torch.cuda.stream(stream):
-            e0.record(stream)
-            rc = lib.wg_dimitrov_tick_batch_dev(B, dpoly.data_ptr(), dst.data_ptr(), dout.data_ptr(), 0, sh)
-            e1.record(stream)
-        assert rc == 0, wg.lib().wg_last_error()
-        torch.cuda.synchronize(dev)
-        o = np.frombuffer(dout.cpu().numpy().tobytes(), dtype=odt)
-        if it >= WARM:
-            ms.append(e0.elapsed_time(e1)); iters.append(float(o["n_iter"].mean())); failed += int((o["ret"] != 0).sum())
-        bad = o["ret"] != 0
-        if bad.any():                                  # the reference would have exited there: those gaits restart from rest
-            h = np.frombuffer(dst.cpu().numpy().tobytes(), dtype=ST).copy()
-            h["xk"][bad] = 0.0; h["starting"][bad] = 1; h["n_removed"][bad] = 0; h["pldp"][bad] = 0
-            offs = offs.copy(); offs[bad] = -it - 1 + (offs[bad] % 5)
-            dst = torch.from_numpy(h.view(np.uint8)).to(dev)
-    sec = float(np.sum(ms)) * 1e-3
-    per_tick = N * C.sizeof(wg.ZmpPolytope) + 2 * C.sizeof(wg.DimitrovState) + OUT      # windows in, state in + out, outputs
-    res["dimitrov_tick"] = {"value": B * MEAS / sec, "unit": "ticks/s", "batch": B, "launches": MEAS, "kernel": "wg_dimitrov_tick_kernel",
-                            "kernel_ms": float(np.mean(ms)), "mean_pldp_iterations": float(np.mean(iters)),
-                            "solves_ended_by_the_references_exit_condition": failed,
-                            "roofline": _roof(per_tick, B * MEAS, sec),
-                            "bytes_are": "N polytopes (248 B each) + state in and out + outputs per gait-tick"}
+
+    def tick_leg(solver, kernel, iter_key):
+        mdl = wg.dimitrov_defaults(); mdl.solver = solver; wg.dimitrov_configure(mdl)
+        offs_l = offs.copy()
+        st = np.zeros(B, ST); st["starting"] = 1
+        dst = torch.from_numpy(st.view(np.uint8)).to(dev)
+        dout = torch.zeros(B * OUT, dtype=torch.uint8, device=dev)
+        WARM, MEAS = 3, 20
+        ms, iters, failed = [], [], 0
+        for it in range(WARM + MEAS):
+            win = table[plan_id[:, None], (it + offs_l)[:, None] + np.arange(N)[None, :]]
+            dpoly = torch.from_numpy(np.ascontiguousarray(win).view(np.uint8)).to(dev)
+            torch.cuda.synchronize(dev)
+            e0, e1 = _ev()
+            with torch.cuda.stream(stream):
+                e0.record(stream)
+                rc = lib.wg_dimitrov_tick_batch_dev(B, dpoly.data_ptr(), dst.data_ptr(), dout.data_ptr(), 0, sh)
+                e1.record(stream)
+            assert rc == 0, wg.lib().wg_last_error()
+            torch.cuda.synchronize(dev)
+            o = np.frombuffer(dout.cpu().numpy().tobytes(), dtype=odt)
+            if it >= WARM:
+                ms.append(e0.elapsed_time(e1)); iters.append(float(o["n_iter"].mean())); failed += int((o["ret"] != 0).sum())
+            bad = o["ret"] != 0
+            if bad.any():                              # the reference would have stopped there: those gaits restart from rest
+                h = np.frombuffer(dst.cpu().numpy().tobytes(), dtype=ST).copy()
+                h["xk"][bad] = 0.0; h["starting"][bad] = 1; h["n_removed"][bad] = 0; h["pldp"][bad] = 0
+                offs_l = offs_l.copy(); offs_l[bad] = -it - 1 + (offs_l[bad] % 5)
+                dst = torch.from_numpy(h.view(np.uint8)).to(dev)
+        sec = float(np.sum(ms)) * 1e-3
+        per_tick = N * C.sizeof(wg.ZmpPolytope) + 2 * C.sizeof(wg.DimitrovState) + OUT      # windows in, state in + out, outputs
+        return {"value": B * MEAS / sec, "unit": "ticks/s", "batch": B, "launches": MEAS, "kernel": kernel,
+                "kernel_ms": float(np.mean(ms)), iter_key: float(np.mean(iters)),
+                "solves_ended_by_the_references_exit_condition": failed,
+                "roofline": _roof(per_tick, B * MEAS, sec),
+                "bytes_are": "N polytopes (248 B each) + state in and out + outputs per gait-tick"}
+
+    res["dimitrov_tick"] = tick_leg(0, "wg_dimitrov_tick_kernel", "mean_pldp_iterations")
+    try:
+        res["dimitrov_tick_qldandlq"] = tick_leg(2, "wg_dimitrov_qld_tick_kernel<true>", "mean_ql_iterations")
+        res["dimitrov_tick_qldandlq"]["solver"] = ("ql0001_ on the preconditioned problem (m_FastFormulationMode == QLDANDLQ): the in-wave "
+                                                   "ql0002, bit-exact against the reference's compiled qld.cpp")
+    finally:
+        wg.dimitrov_configure(model)
 
     # ---- PLDP alone, hot-started, on the dense arguments PLDPSolver::SolveProblem takes ----
     Pu, Px, OptB, OptC, iLQ = k["Pu"], k["Px"], k["OptB"], k["OptC"], k["iLQ"]

@@ -517,6 +517,37 @@ __device__ __forceinline__ void zt_times_ww(const QlView &q, double *s, int lane
   WG_WSYNC();
 }
 
+// The same product for a constraint normal whose entries are known to be exact zeros outside the row ranges [0, r], [NH, NH + r]
+// and [2 NH, n) (a CoP row of instant r of the Herdt QP; r = -1: a foot-placement row, nothing in the jerk columns): the rows of
+// Z in between are not read.  Their products are +-0.0 and the sums -- started from +0.0, never -0.0 -- do not change when they
+// are left out: the same bits for 2 (NH - 1 - r) / n fewer bytes of Z, on average 46 % of the walk at NH = 32, which is what
+// this kernel is bound by (Z lives in global memory).  Ranges are wave-uniform and end on multiples of GRP (NH is one): no
+// ragged tails; entries of a chunk beyond r meet their zero coefficients.
+template <int NH, int GRP>
+__device__ __forceinline__ void zt_times_ww_cop(const QlView &q, double *s, int lane, int r) {
+  static_assert(NH % GRP == 0, "the row ranges must end on whole chunks");
+  const int n = q.n;
+  const int i0 = lane, i1 = lane + 64 < n ? lane + 64 : lane;      // surplus lanes shadow their first column
+  const double *z0 = q.Z + (size_t)i0 * q.ldz, *z1 = q.Z + (size_t)i1 * q.ldz;
+  double a0 = 0.0, a1 = 0.0;
+  const int len = r + 1;                                        // rows of each jerk block that carry an entry
+#pragma unroll 1
+  for (int blk = 0; blk < 2; ++blk) {
+    const int base = blk * NH;
+    for (int j = base; j < base + len; j += GRP) {
+      double u0[GRP], u1[GRP], w[GRP];
+#pragma unroll
+      for (int e = 0; e < GRP; ++e) { u0[e] = WG_ZLD(z0 + j + e); u1[e] = WG_ZLD(z1 + j + e); w[e] = q.ww[j + e]; }
+#pragma unroll
+      for (int e = 0; e < GRP; ++e) { a0 += u0[e] * w[e]; a1 += u1[e] * w[e]; }
+    }
+  }
+  for (int j = 2 * NH; j < n; ++j) { const double w = q.ww[j]; a0 += WG_ZLD(z0 + j) * w; a1 += WG_ZLD(z1 + j) * w; }
+  s[i0] = a0;
+  if (lane + 64 < n) s[i1] = a1;
+  WG_WSYNC();
+}
+
 // r0 = sum_{j0 <= j < j1} Z(i0, j) * s[j], r1 the same for row i1 (j ascending, from +0.0): rows i0 = lane and i1 = lane + 64
 // of a matrix of 64 < n <= 128 rows in ONE pass, the entries of eight columns requested together ahead of the two add chains
 // (with Z in global memory an exposed entry is an L2 round trip; one register set only: this sits where many values are live).
@@ -1828,6 +1859,12 @@ __device__ __forceinline__ QlResult ql_solve(const QlView &q, P &prob, double vs
         else for (int i = lane; i < n; i += 64) q.ww[i] = Am(knext - 1, i);
         WG_WSYNC();
         if constexpr (P::kCompact) prob.zt_row(q, s, knext - 1, lane);
+        else if constexpr (P::kWideN && P::kRowOps) {
+          // the Herdt QP at a horizon known at compile time: a CoP row of instant r has no entry in rows (r, N) and (N + r, 2N)
+          constexpr int kNHc = P::kHorizon;
+          const int k = knext - 1;
+          zt_times_ww_cop<kNHc, WG_ELEM_GRP>(q, s, lane, (k >= 1 && k <= 4 * kNHc) ? ((k - 1) >> 2) : -1);
+        }
         else zt_times_ww<P::kNM, (P::kRowOps ? WG_ELEM_GRP : 8), P::kWideN>(q, s, lane);
       } else {
         int k1 = knext - m;

@@ -664,6 +664,7 @@ struct HerdtElemProbT {
   static constexpr bool kRowOps = true;        // row products walk the row's structure instead of calling A() per element
   static constexpr int kNM = 0;
   static constexpr bool kWideN = NHC >= 32;    // 64 <= n <= 128 for every problem of the model
+  static constexpr int kHorizon = NHC;         // (> 0: the compile-time horizon; rows 1 + 4 i + e are the CoP rows of instant i)
   struct NConst { static constexpr int v = NHC; __device__ __forceinline__ NConst &operator=(int) { return *this; } __device__ __forceinline__ operator int() const { return v; } };
   typename std::conditional<(NHC > 0), NConst, int>::type N;   // assigning to the constant form is a no-op
   int ns;
