@@ -522,7 +522,8 @@ inline bool tick_compact(const wg_model_t &m) {
 }
 // element view (-1: any horizon; 32: BASELINE config 5's horizon as a compile-time constant -- same LDS bytes, same slot, a fixed
 // layout): Z in a per-block slot of global memory instead of LDS (decided at compile time: mpc_tick<-1>, mpc_tick<32>)
-inline bool tick_elem(int view) { return view == -1 || view == 32; }
+inline bool tick_elem(int view) { return view == -1 || view == 32 || view == 33; }   // 33: N = 32 with Z in registers
+inline int tick_waves_per_simd(int view) { return view == 33 ? WG_ZR_WPS : (tick_elem(view) ? WG_TICK32_WPE : WG_TICK_WPE_MAX); }
 inline bool tick_z_global(int view) { return tick_elem(view); }
 // compact view (N = 16): wa, b and the border block Gv in a per-block slot of global memory (decided at compile time: mpc_tick<16>)
 inline bool tick16_ext(int view) { return view == 16; }
@@ -541,6 +542,7 @@ inline size_t tick_lds_with_cap(const wg_model_t &m, int view, int r_cols) {
   // element view, short horizons: the pre-solve overlay does not fit over R; it gets its own bytes behind the tick's arrays
   if (view == -1 && wg::TickLds::elem_overlay_apart(m.N, sizeof(wg_gait_state_t)))
     tick = ((tick + 15) & ~(size_t)15) + wg::TickLds::elem_overlay_need(m.N, sizeof(wg_gait_state_t));
+  if (view == 33) tick += ((size_t)wg::kZrTile * wg::kZrTs + (size_t)wg::kZrTail * tick_max_n(m)) * 8;   // Z^T a tile + Z's tail rows (behind R)
   return ql + tick;
 }
 // Element view: how many columns of R the LDS holds (0: all of them).  R is the operand that decides the residency at N = 32
@@ -565,7 +567,8 @@ inline int tick_elem_cap(const wg_model_t &m, int view) {
     return (c < n && fits(c)) ? c : 0;
   }
   // waves a CU holds by the registers the element view's kernels are compiled for (WG_TICK32_WPE per SIMD, four SIMDs)
-  auto per_cu = [&](int c) { const size_t g = (tick_lds_with_cap(m, view, c) + 1279) / 1280; size_t k = 128 / g; return k > (size_t)(4 * WG_TICK32_WPE) ? (size_t)(4 * WG_TICK32_WPE) : k; };
+  const size_t wcap = 4 * (size_t)tick_waves_per_simd(view);
+  auto per_cu = [&](int c) { const size_t g = (tick_lds_with_cap(m, view, c) + 1279) / 1280; size_t k = 128 / g; return k > wcap ? wcap : k; };
   const size_t full = per_cu(0);
   int best = 0;
   size_t best_k = full;
@@ -587,7 +590,7 @@ inline size_t tick_z_slot_doubles(const wg_model_t &m, int view) {
   if (view == 16) return (n + 2 * mm) + n * wg::kGvLd;       // wa | b | Gv
   // element view: Z | wa | b | Gv | rowA | rowB | rowK | gd | d | wd | wx | R in full (mpc_tick<-1>)
   // (the fixed N = 32 view keeps Z with leading dimension n: whole cache lines per column; slots are multiples of 64 bytes)
-  const size_t zd = view == 32 ? n * n : n * (n | 1);
+  const size_t zd = (view == 32 || view == 33) ? n * n : n * (n | 1);
   return (zd + (n + 2 * mm) + n * wg::kGvLdElem + 2 * mm + (mm + 1) / 2 + 2 + 4 * n + (n * (n + 1) / 2 + n) + 7) & ~(size_t)7;
 }
 inline size_t tick_lds_for(const wg_model_t &m, int view) { return tick_lds_with_cap(m, view, tick_elem_cap(m, view)); }
@@ -602,7 +605,15 @@ inline int tick_view(const wg_model_t &m) {
   // N = 32 (BASELINE config 5) has an instantiation with the horizon as a compile-time constant (mpc_tick<32>: every slot and
   // LDS offset a constant, only the two-rows-per-lane forms of the solver); WG_TICK_ELEM_GENERIC=1 keeps the any-horizon
   // kernel there too (tests run both: same bytes)
-  if (m.N == 32) { const char *g = getenv("WG_TICK_ELEM_GENERIC"); if (!(g && atoi(g) != 0)) return 32; }
+  if (m.N == 32) {
+    const char *g = getenv("WG_TICK_ELEM_GENERIC");
+    if (g && atoi(g) != 0) return -1;
+#ifdef WG_WITH_REGZ
+    const char *z = getenv("WG_TICK_REGZ");              // experiment builds: Z in registers, four gaits per CU (mpc_tick<33>)
+    if (z && atoi(z) != 0) return 33;
+#endif
+    return 32;
+  }
   return -1;
 }
 inline size_t tick_ql_bytes(const wg_model_t &m) { return tick_ql_bytes_for(m, tick_view(m), tick_elem_cap(m, tick_view(m))); }
@@ -731,7 +742,7 @@ int tick_launch(wg_ctx_t *ctx, int B, wg_gait_state_t *states, wg_tick_out_t *ou
   int *order = nullptr, *iters_out = nullptr;
   {
     int per_cu = 128 / (int)((lds + 1279) / 1280);
-    const int max_waves = 4 * (tick_elem(view) ? WG_TICK32_WPE : WG_TICK_WPE_MAX);
+    const int max_waves = 4 * tick_waves_per_simd(view);
     if (per_cu > max_waves) per_cu = max_waves;
     bool lpt = B > ctx->num_cu * per_cu && !host_states;
     if (const char *e = getenv("WG_TICK_LPT")) lpt = lpt && atoi(e) != 0;
@@ -926,7 +937,7 @@ int wg_mpc_run_sched_dev_ctx(wg_ctx_t *ctx, int B, wg_gait_state_t *states, int 
   }
   // as many blocks as the device keeps resident: LDS granules (1280 B, 128 per CU), at most 8 waves of 256 registers per CU
   int per_cu = 128 / (int)((lds + 1279) / 1280);
-  const int max_waves = 4 * (tick_elem(view) ? WG_TICK32_WPE : WG_TICK_WPE_MAX);   // what the kernel's register budget admits per CU
+  const int max_waves = 4 * tick_waves_per_simd(view);   // what the kernel's register budget admits per CU
   if (per_cu > max_waves) per_cu = max_waves;
   if (per_cu < 1) per_cu = 1;
   int grid = ctx->num_cu * per_cu;

@@ -155,6 +155,7 @@ struct QlView {
                                                            // afterwards): R itself, or a full-size array when R is capped
   double *x, *d, *ww, *wd, *wx, *lam, *xl, *xu, *wa, *b;
   double *sc0, *sc1, *sc2, *sc3, *slot;
+  double *ztile = nullptr;                                 // Z in registers (ZRegs): the LDS tile of zr_zt_times_ww
   int *iact;
   // kBounds / kWabLds mirror QlDims::bounds / wab_lds at compile time (a run-time choice between an LDS and a global array
   // would make the pointer generic and every access through it a flat_ instruction); ext_wab: [wa (mmax + nmax) | b (mmax)]
@@ -934,6 +935,246 @@ __device__ __forceinline__ void sweep_flat(const QlView &q, double *s, int nu, i
   PT_SW(2);
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// Z in REGISTERS (the N = 32 element view's "Z on chip" form): lane L carries row L of Z in z0[], every access with a
+// compile-time column index (fully unrolled loops with wave-uniform predicates), so the array lives in the register file (144
+// of the 256 registers a lane has at one wave per SIMD).  The rows beyond the 64th (n <= 72: at most eight) live in LDS (zt, 8 x
+// NMAX, 4.6 KB): every lane works on tail row 64 + (L & 7) -- eight lanes compute the same values and store them to the same
+// place, no lane-dependent branch.  Z never moves through global memory inside the active-set loop: the sweep and the deletions
+// rotate registers (and the LDS tail), x and the dependence sums read the column the last sweep left, and the one operation that
+// goes against the layout -- Z^T a, a sum over ROWS in row order for every column -- passes the per-lane products through an LDS
+// tile of kZrTile columns and lets the column's owner add them in row order: the same additions in the same order as the column
+// walk it replaces.
+template <int NMAX>
+struct ZRegs {
+  double z0[NMAX];
+  double *zt;                                               // LDS: rows 64 .. 71, [row - 64][NMAX]
+  double c0, c1;                                            // column nact as the last sweep left it (rows L, 64 + (L & 7))
+};
+struct NoZRegs {};
+#ifndef WG_ZR_TILE
+#define WG_ZR_TILE 24
+#endif
+#ifndef WG_ZR_WPS
+#define WG_ZR_WPS 1                                         // waves per SIMD the register-Z kernels are compiled for (experiment: 2)
+#endif
+constexpr int kZrTile = WG_ZR_TILE;                         // columns of Z^T a per pass through the tile (a divisor of NMAX)
+constexpr int kZrTs = 73;                                   // tile row stride (doubles): [column][row]
+constexpr int kZrTail = 8;                                  // rows kept in LDS
+
+// f(integral_constant<K * STEP>) for the K with c0 == K * STEP (wave-uniform c0)
+template <int NP, int STEP, class F>
+__device__ __forceinline__ void zr_dispatch(int c0, F &&f) {
+  if constexpr (NP == 1) f(std::integral_constant<int, 0>{});
+  else {
+    constexpr int kH = NP / 2;
+    if (c0 < kH * STEP) zr_dispatch<kH, STEP>(c0, f);
+    else zr_dispatch<NP - kH, STEP>(c0 - kH * STEP, [&](auto b) { f(std::integral_constant<int, decltype(b)::value + kH * STEP>{}); });
+  }
+}
+// rows of Z from the global slot (where factor() / the generic inverse leave them) into the registers / the LDS tail
+template <int NMAX>
+__device__ __forceinline__ void zr_load(const QlView &q, ZRegs<NMAX> &zr, int lane) {
+  const int n = q.n;
+  const double *r0 = q.Z + lane;
+#pragma unroll
+  for (int j = 0; j < NMAX; ++j) {
+    const int jc = j < n ? j : n - 1;                       // columns past n: a valid address, a value nobody uses
+    zr.z0[j] = r0[(size_t)jc * q.ldz];
+  }
+  for (int e = lane; e < kZrTail * NMAX; e += 64) {
+    const int r = 64 + e / NMAX, j = e % NMAX;
+    const bool in = r < n && j < n;
+    const double v = q.Z[(size_t)(in ? r : 0) + (size_t)(in ? j : 0) * q.ldz];
+    zr.zt[e] = in ? v : 0.0;
+  }
+  zr.c0 = 0.0; zr.c1 = 0.0;
+  WG_WSYNC();
+}
+// column j (wave-uniform, < n) of the rows
+template <int NMAX>
+__device__ __forceinline__ void zr_col(const ZRegs<NMAX> &zr, int j, int lane, double &c0, double &c1) {
+  c0 = 0.0;
+#pragma unroll
+  for (int k = 0; k < NMAX; ++k)
+    if (k == j) c0 = zr.z0[k];
+  c1 = zr.zt[(lane & 7) * NMAX + j];
+}
+// s[j] = sum_i Z(i, j) ww[i], i ascending from +0.0 (qld.cpp:2071-2085): products per lane, sums per column through the tile
+template <int NMAX>
+__device__ __forceinline__ void zr_zt_times_ww(const QlView &q, const ZRegs<NMAX> &zr, double *s, int lane) {
+  const int n = q.n;
+  const int tr = 64 + (lane & 7);                           // the lane's tail row (rows >= n: products nobody adds)
+  const double w0 = q.ww[lane], w1 = q.ww[tr < n ? tr : n - 1];
+  double *tile = q.ztile;
+  const double *ztr = zr.zt + (lane & 7) * NMAX;
+#pragma unroll 1
+  for (int c0 = 0; c0 < NMAX; c0 += kZrTile) {
+    // which slice of the columns: a wave-uniform dispatch over compile-time register indices
+    auto put = [&](auto base) {
+      constexpr int kB = decltype(base)::value;
+      double tv[kZrTile];
+#pragma unroll
+      for (int t = 0; t < kZrTile; ++t) tv[t] = ztr[kB + t];
+#pragma unroll
+      for (int t = 0; t < kZrTile; ++t) tile[t * kZrTs + lane] = zr.z0[kB + t] * w0;
+#pragma unroll
+      for (int t = 0; t < kZrTile; ++t) tile[t * kZrTs + tr] = tv[t] * w1;
+    };
+    static_assert(NMAX % kZrTile == 0, "whole passes");
+    zr_dispatch<NMAX / kZrTile, kZrTile>(c0, put);
+    WG_WSYNC();
+    {
+      const int t = lane < kZrTile ? lane : kZrTile - 1;    // surplus lanes shadow the last column of the pass
+      const double *col = tile + t * kZrTs;
+      double acc = 0.0;
+      int i = 0;
+      for (; i + 8 <= n; i += 8) {
+        double v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = col[i + e];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc += v[e];
+      }
+      for (; i < n; ++i) acc += col[i];
+      const int j = c0 + t;
+      if (lane < kZrTile && j < n) s[j] = acc;
+    }
+    WG_WSYNC();
+  }
+}
+// r0 = sum_{j0 <= j < j1} Z(L, j) s[j] (j ascending from +0.0), r1 the same for row 64 + (L & 7)
+template <int NMAX>
+__device__ __forceinline__ void zr_rows_times(const QlView &q, const ZRegs<NMAX> &zr, const double *s, int j0, int j1, int lane, double &r0,
+                                              double &r1) {
+  const int n = q.n;
+  double a0 = 0.0, a1 = 0.0;
+  const double *ztr = zr.zt + (lane & 7) * NMAX;
+#pragma unroll
+  for (int jc = 0; jc < NMAX; jc += 8) {
+    double sv[8], tv[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { sv[e] = s[jc + e < n ? jc + e : n - 1]; tv[e] = ztr[jc + e]; }
+#pragma unroll
+    for (int e = 0; e < 8; ++e)
+      if (jc + e >= j0 && jc + e < j1) { a0 += zr.z0[jc + e] * sv[e]; a1 += tv[e] * sv[e]; }
+  }
+  r0 = a0; r1 = a1;
+}
+// Givens sweep (qld.cpp:1992-2030) on register rows.  Phase 1 (the chain of norms) as in sweep(); phase 2: lane c & 63 turns
+// its rotation into (ga, gb) and KEEPS the pair (gb == 0 marks a skipped rotation); phase 3: every lane carries its rows through
+// the rotations, the coefficients of rotation c read from lane c's registers (v_readlane with a compile-time lane): no global
+// memory access at all in the rotation loop.
+template <int NMAX>
+__device__ __forceinline__ void zr_sweep(const QlView &q, ZRegs<NMAX> &zr, double *s, int nu, int nact, int lane) {
+  if (nu - 1 <= nact) { zr_col(zr, nact, lane, zr.c0, zr.c1); return; }
+  double *chain = q.sc3;
+  if (sweep_range_ok(s, nact, nu, lane)) {
+    double cur = s[nu - 1];
+    double pa = s[nu - 2], pb;
+    int c = nu - 1;
+    if (WG_UBOOL(cur != 0.0)) {
+      for (;;) {
+        pb = s[(c - 2 >= 0) ? c - 2 : 0];
+        cur = givens_norm_fast(pa, cur); chain[c - 1] = cur;
+        if (--c <= nact) break;
+        pa = s[(c - 2 >= 0) ? c - 2 : 0];
+        cur = givens_norm_fast(pb, cur); chain[c - 1] = cur;
+        if (--c <= nact) break;
+      }
+    } else
+    for (;;) {
+      pb = s[(c - 2 >= 0) ? c - 2 : 0];
+      { const double nrmc = givens_norm_fast(pa, cur); cur = (cur == 0.0) ? pa : nrmc; chain[c - 1] = cur; }
+      if (--c <= nact) break;
+      pa = s[(c - 2 >= 0) ? c - 2 : 0];
+      { const double nrmc = givens_norm_fast(pb, cur); cur = (cur == 0.0) ? pb : nrmc; chain[c - 1] = cur; }
+      if (--c <= nact) break;
+    }
+  } else {
+    double cur = s[nu - 1];
+    double p = s[nu - 2];
+    for (int c = nu - 1; c > nact; --c) {
+      const double p_next = s[(c - 2 >= 0) ? c - 2 : 0];
+      const double nrmc = givens_norm(p, cur);
+      cur = (cur == 0.0) ? p : nrmc;
+      chain[c - 1] = cur;
+      p = p_next;
+    }
+  }
+  WG_WSYNC();
+  // phase 2: rotation c lives in lane c & 63 (set 0: c < 64, set 1: c >= 64)
+  double ga0 = 1.0, gb0 = 0.0, ga1 = 1.0, gb1 = 0.0;
+  {
+    const int ca = lane, cb = lane + 64;
+    const bool ma = ca > nact && ca < nu, mb = cb > nact && cb < nu;
+    const int cca = ma ? ca : nu - 1, ccb = mb ? cb : nu - 1;
+    const double Pa = s[cca - 1], Qa = (cca == nu - 1) ? s[nu - 1] : chain[cca], Na = (Qa == 0.0) ? 0.0 : chain[cca - 1];
+    const double Pb = s[ccb - 1], Qb = (ccb == nu - 1) ? s[nu - 1] : chain[ccb], Nb = (Qb == 0.0) ? 0.0 : chain[ccb - 1];
+    const bool ra = ma && Na != 0.0, rb = mb && Nb != 0.0;
+    const double da = ra ? Na : 1.0, db = rb ? Nb : 1.0;
+    ga0 = ra ? Pa / da : 1.0; gb0 = ra ? Qa / da : 0.0;
+    ga1 = rb ? Pb / db : 1.0; gb1 = rb ? Qb / db : 0.0;
+    WG_WSYNC();                                             // every lane has read s[] before any lane rewrites it
+    if (ra) s[ca - 1] = Na;
+    if (rb) s[cb - 1] = Nb;
+  }
+  WG_WSYNC();
+  // phase 3
+  double carry0 = 0.0, carry1 = 0.0;
+  double *ztr = zr.zt + (lane & 7) * NMAX;
+#pragma unroll
+  for (int c = NMAX - 1; c >= 1; --c) {
+    if (c == nu - 1) { carry0 = zr.z0[c]; carry1 = ztr[c]; }
+    if (c <= nu - 1 && c > nact) {
+      const double ga = (c < 64) ? rl(ga0, c & 63) : rl(ga1, c & 63);
+      const double gb = (c < 64) ? rl(gb0, c & 63) : rl(gb1, c & 63);
+      const double zl0 = zr.z0[c - 1], zl1 = ztr[c - 1];
+      if (gb == 0.0) {                                      // a skipped rotation (q was 0): wave-uniform
+        zr.z0[c] = carry0; ztr[c] = carry1;
+        carry0 = zl0; carry1 = zl1;
+      } else {
+        const double t0 = ga * zl0 + gb * carry0, t1 = ga * zl1 + gb * carry1;
+        zr.z0[c] = ga * carry0 - gb * zl0; ztr[c] = ga * carry1 - gb * zl1;
+        carry0 = t0; carry1 = t1;
+      }
+      if (c - 1 == nact) { zr.z0[c - 1] = carry0; ztr[c - 1] = carry1; }
+    }
+  }
+  zr.c0 = carry0; zr.c1 = carry1;
+  WG_WSYNC();
+}
+// the Z part of a constraint deletion (qld.cpp:1903-1982): columns k, k + 1 rotated for k = kdrop .. nact - 2 with the
+// coefficients the R pass left in sc0 (ga) / sc1 (gb)
+template <int NMAX>
+__device__ __forceinline__ void zr_drop_rotations(const QlView &q, ZRegs<NMAX> &zr, int kdrop, int nact_old, int lane) {
+  double *ztr = zr.zt + (lane & 7) * NMAX;
+#pragma unroll
+  for (int k = 0; k < NMAX - 1; ++k) {
+    if (k >= kdrop && k < nact_old - 1) {
+      const double ga = q.sc0[k], gb = q.sc1[k];
+      const double a0 = zr.z0[k], b0 = zr.z0[k + 1], a1 = ztr[k], b1 = ztr[k + 1];
+      zr.z0[k + 1] = ga * b0 - gb * a0; zr.z0[k] = ga * a0 + gb * b0;
+      ztr[k + 1] = ga * b1 - gb * a1; ztr[k] = ga * a1 + gb * b1;
+    }
+  }
+  WG_WSYNC();
+}
+// s[i] = sg * Z(row, i), i < n (the normal of a bound constraint, qld.cpp:1461-1470): the lane that owns the row writes it out
+template <int NMAX>
+__device__ __forceinline__ void zr_row_to(const QlView &q, const ZRegs<NMAX> &zr, int row, double sg, double *s, int lane) {
+  const int n = q.n;
+  if (row < 64) {
+    if (lane == row) {
+#pragma unroll
+      for (int j = 0; j < NMAX; ++j)
+        if (j < n) { const double z = zr.z0[j]; s[j] = (sg > 0.0) ? z : -z; }
+    }
+  } else {
+    for (int j = lane; j < n; j += 64) { const double z = zr.zt[(row - 64) * NMAX + j]; s[j] = (sg > 0.0) ? z : -z; }
+  }
+}
+
 // qld.cpp:1861-1889.  Returns kdrop (0-based) or -1; ratio updated when found.
 template <bool kOnePass = false>                          // kOnePass: nact <= 64 known at compile time (n <= 64)
 __device__ __forceinline__ int pick_drop(const QlView &q, int nact, double res, double &ratio, int lane) {
@@ -1205,7 +1446,11 @@ __device__ __forceinline__ void sweep(const QlView &q, double *s, int nu, int na
 
 // qld.cpp:1903-1982.  nu = number of R columns taking part (nact, or nact+1
 // when the S column rides along).  Returns the new nact.
-__device__ __forceinline__ int drop_constraint(const QlView &q, int kdrop, int nu, int nact, int lane) {
+// ZR = ZRegs: Z lives in registers -- the rotations are recorded (sc0 / sc1) while R is updated and applied to the register rows
+// afterwards (the R updates never read Z: the same arithmetic, the Z part in one unrolled pass).
+template <class ZR = NoZRegs>
+__device__ __forceinline__ int drop_constraint(const QlView &q, int kdrop, int nu, int nact, int lane, ZR *zr = nullptr) {
+  constexpr bool kRegs = !std::is_same<ZR, NoZRegs>::value;
   const int n = q.n;
   if (lane == 0) {
     int code = q.iact[kdrop];
@@ -1232,6 +1477,8 @@ __device__ __forceinline__ int drop_constraint(const QlView &q, int kdrop, int n
       Rp(k + 1, c) = ga * rk1 - gb * rk;
       Rp(k, c) = t;
     }
+    if constexpr (kRegs) { if (lane == 0) { q.sc0[k] = ga; q.sc1[k] = gb; } }
+    else
     for (int i = lane; i < n; i += 64) {
       double zk = Zm(i, k), zk1 = Zm(i, k + 1);
       double t = ga * zk + gb * zk1;
@@ -1241,6 +1488,7 @@ __device__ __forceinline__ int drop_constraint(const QlView &q, int kdrop, int n
     if (lane == 0) { q.iact[k] = q.iact[k + 1]; q.lam[k] = q.lam[k + 1]; }
     WG_WSYNC();
   }
+  if constexpr (kRegs) zr_drop_rotations(q, *zr, kdrop, nact, lane);
   return nact - 1;
 }
 
@@ -1295,10 +1543,13 @@ __device__ __forceinline__ bool independent_coordinate(const QlView &q, const P 
 // one row of Z per lane (n <= 64): the branch-free, prefetching form -- the compact view always, the dense view by size (the
 // element view is built for n > 64: it keeps the one form it needs, its kernel is large enough as it is)
 #define WG_SWEEP(q, s, nu, nact, lane) \
-  do { if (P::kNM > 0 || (!P::kRowOps && q.n <= 64)) sweep_flat(q, s, nu, nact, lane PT_SW_ARG); else sweep<(P::kRowOps ? WG_ELEM_GRP : 8), P::kWideN>(q, s, nu, nact, lane); } while (0)
+  do { if constexpr (kRegs) zr_sweep(q, *zr, s, nu, nact, lane); else \
+       if (P::kNM > 0 || (!P::kRowOps && q.n <= 64)) sweep_flat(q, s, nu, nact, lane PT_SW_ARG); else sweep<(P::kRowOps ? WG_ELEM_GRP : 8), P::kWideN>(q, s, nu, nact, lane); } while (0)
 
-template <class P>
-__device__ __forceinline__ QlResult ql_solve(const QlView &q, P &prob, double vsmall, int *hist, int hist_cap, QlResume *rs = nullptr) {
+template <class P, class ZR = NoZRegs>
+__device__ __forceinline__ QlResult ql_solve(const QlView &q, P &prob, double vsmall, int *hist, int hist_cap, QlResume *rs = nullptr,
+                                             ZR *zr = nullptr) {
+  constexpr bool kRegs = !std::is_same<ZR, NoZRegs>::value;   // Z in registers (ZRegs): see zr_* above
   int lane = wg_lane();
   const int n = q.n, m = q.m, me = q.me, mn = q.mn;
   QlResult out;
@@ -1464,6 +1715,10 @@ __device__ __forceinline__ QlResult ql_solve(const QlView &q, P &prob, double vs
   }
 
   PT(3);
+  if constexpr (kRegs) {
+    // Z = R^-1 as factor() (or the generic inverse above) left it in the global slot: its rows into the registers, where Z stays
+    if (!early_exit && !resuming) { WG_WSYNC(); zr_load(q, *zr, lane); }
+  }
   enum { ST_RESET, ST_RESID, ST_SCAN, ST_CONVERGED, ST_FINISH };
   int st = early_exit ? ST_FINISH : ST_RESET;
   if (resuming) st = rs->st;
@@ -1551,7 +1806,8 @@ __device__ __forceinline__ QlResult ql_solve(const QlView &q, P &prob, double vs
         PT(26);
         if (P::kWideN || (P::kNM == 0 && n > 64 && n <= 128)) {
           double r0, r1;
-          z_rows_times<(P::kRowOps ? WG_ELEM_GRP : 8)>(q, s, 0, nact, lane, r0, r1);
+          if constexpr (kRegs) zr_rows_times(q, *zr, s, 0, nact, lane, r0, r1);
+          else z_rows_times<(P::kRowOps ? WG_ELEM_GRP : 8)>(q, s, 0, nact, lane, r0, r1);
           q.x[lane] += r0; q.sc0[lane] = r0;
           if (lane + 64 < n) { q.x[lane + 64] += r1; q.sc0[lane + 64] = r1; }
         } else
@@ -1575,12 +1831,14 @@ __device__ __forceinline__ QlResult ql_solve(const QlView &q, P &prob, double vs
         WG_WSYNC();
       }
       PT(4);
-      zt_times_ww<P::kNM, (P::kRowOps ? WG_ELEM_GRP : 8), P::kWideN>(q, s, lane);                      // :1175-1177
+      if constexpr (kRegs) zr_zt_times_ww(q, *zr, s, lane);
+      else zt_times_ww<P::kNM, (P::kRowOps ? WG_ELEM_GRP : 8), P::kWideN>(q, s, lane);                      // :1175-1177
       PT(5);
       if (nact != n) {                                      // :1186-1201
         if (P::kWideN || (P::kNM == 0 && n > 64 && n <= 128)) {
           double r0, r1;
-          z_rows_times<(P::kRowOps ? WG_ELEM_GRP : 8)>(q, s, nact, n, lane, r0, r1);
+          if constexpr (kRegs) zr_rows_times(q, *zr, s, nact, n, lane, r0, r1);
+          else z_rows_times<(P::kRowOps ? WG_ELEM_GRP : 8)>(q, s, nact, n, lane, r0, r1);
           q.x[lane] -= r0;
           if (lane + 64 < n) q.x[lane + 64] -= r1;
         } else
@@ -1610,7 +1868,7 @@ __device__ __forceinline__ QlResult ql_solve(const QlView &q, P &prob, double vs
       kd = uni(wave_min_int(kd));
       if (kd != 0x7fffffff) {
         LOG_EVENT(-q.iact[kd]);
-        nact = drop_constraint(q, kd, nact, nact, lane);
+        nact = drop_constraint<ZR>(q, kd, nact, nact, lane, zr);
         st = ST_RESID;
         continue;
       }
@@ -1859,6 +2117,7 @@ __device__ __forceinline__ QlResult ql_solve(const QlView &q, P &prob, double vs
         else for (int i = lane; i < n; i += 64) q.ww[i] = Am(knext - 1, i);
         WG_WSYNC();
         if constexpr (P::kCompact) prob.zt_row(q, s, knext - 1, lane);
+        else if constexpr (kRegs) zr_zt_times_ww(q, *zr, s, lane);
         else if constexpr (P::kWideN && P::kRowOps) {
           // the Herdt QP at a horizon known at compile time: a CoP row of instant r has no entry in rows (r, N) and (N + r, 2N)
           constexpr int kNHc = P::kHorizon;
@@ -1870,6 +2129,10 @@ __device__ __forceinline__ QlResult ql_solve(const QlView &q, P &prob, double vs
         int k1 = knext - m;
         double sg = 1.0;
         if (k1 > n) { k1 = knext - mn; sg = -1.0; }
+        if constexpr (kRegs) {
+          for (int i = lane; i < n; i += 64) q.ww[i] = (i == k1 - 1) ? sg : 0.0;
+          zr_row_to(q, *zr, k1 - 1, sg, s, lane);
+        } else
         for (int i = lane; i < n; i += 64) {
           q.ww[i] = (i == k1 - 1) ? sg : 0.0;
           double z = Zm(k1 - 1, i);
@@ -1914,6 +2177,10 @@ __device__ __forceinline__ QlResult ql_solve(const QlView &q, P &prob, double vs
           } else {
             // column nact of Z is read once, lane-parallel (with Z in global memory: two coalesced loads instead of n
             // broadcast ones in a row); the three ordered sums then run from LDS, one per lane, as in the compact view
+            if constexpr (kRegs) {                            // column nact: what the sweep just left in zr.c0 / c1
+              { const double zi = zr->c0, wi = q.ww[lane]; q.sc0[lane] = wi * zi; q.sc1[lane] = fabs(wi * zi); q.sc2[lane] = zi * zi; }
+              if (lane + 64 < n) { const double zi = zr->c1, wi = q.ww[lane + 64]; q.sc0[lane + 64] = wi * zi; q.sc1[lane + 64] = fabs(wi * zi); q.sc2[lane + 64] = zi * zi; }
+            } else
             for (int i = lane; i < n; i += 64) {
               const double zi = Zm(i, nact), wi = q.ww[i];
               q.sc0[i] = wi * zi; q.sc1[i] = fabs(wi * zi); q.sc2[i] = zi * zi;
@@ -1988,6 +2255,9 @@ __device__ __forceinline__ QlResult ql_solve(const QlView &q, P &prob, double vs
           if constexpr (P::kNM > 0) {                       // :1749-1755; surplus lanes shadow lane n - 1 (same address, same value)
             const int il = lane < n ? lane : n - 1;
             q.x[il] = q.x[il] + step * Zm(il, nact);
+          } else if constexpr (kRegs) {
+            q.x[lane] += step * zr->c0;
+            if (lane + 64 < n) q.x[lane + 64] += step * zr->c1;
           } else
           for (int i = lane; i < n; i += 64) q.x[i] += step * Zm(i, nact);
           parnew += parinc;
@@ -2013,7 +2283,7 @@ __device__ __forceinline__ QlResult ql_solve(const QlView &q, P &prob, double vs
         {                                                   // :1697-1711
           int nu = nact + 1;
           LOG_EVENT(-q.iact[kdrop]);
-          nact = drop_constraint(q, kdrop, nu, nact, lane);
+          nact = drop_constraint<ZR>(q, kdrop, nu, nact, lane, zr);
           double *snew = s - (nact + 1);
           if (nu > n) nu = n;
           // ascending copy, source ahead of destination: lanes in index order

@@ -515,12 +515,16 @@ struct QpDumpOut {
   int nmax, mmax;
 };
 
-template <int NH>
+// NHP == 33: NH = 32 with Z in REGISTERS (wg_ql_device.hpp, ZRegs): one wave per SIMD (512 registers), four gaits per CU, the
+//            wave's LDS also holds the Z^T a tile; the global slot keeps Z only between the factorisation and the load
+template <int NHP>
 __device__ __forceinline__ TickDiag mpc_tick(const wg_model_t &m, const TickTables *__restrict__ tb, wg_gait_state_t *gstate,
                                     wg_tick_out_t *out, double *lds_ql, char *lds_tick, int *hist, int hist_cap,
                                     int *hist_len, double *zglobal = nullptr, int elem_nact_cap = 0,
                                     const QpDumpOut *dump = nullptr) {
   const int lane = wg_lane();
+  constexpr bool kRegZ = (NHP == 33);
+  constexpr int NH = kRegZ ? 32 : NHP;
   constexpr bool kElem = (NH == -1 || NH == 32);  // element view: any horizon (-1), or the horizon as a constant (32)
   // compact view: the horizon is a compile-time constant everywhere (checked by the host).  Fixed element view: a constant where
   // it decides ADDRESSES (kNC below: slot and LDS offsets, table strides), but the trip count of the assembly's loops stays a
@@ -737,6 +741,10 @@ __device__ __forceinline__ TickDiag mpc_tick(const wg_model_t &m, const TickTabl
                                                                               extE + eCold + eNmax, extE + eCold + 2 * eNmax, extE + eCold + 3 * eNmax,
                                                                               extE + eRfull);
       if (q.nact_cap > 0 && (elem_nact_cap >> 16) > 0 && (elem_nact_cap >> 16) < q.nact_cap) q.nact_cap = elem_nact_cap >> 16;   // tests
+      if constexpr (kRegZ) {                                // the Z^T a tile behind R's LDS part (the layout's cap, not the tests')
+        const int rc = elem_nact_cap & 0xffff, nn = 2 * 32 + 2 * kSMax;
+        q.ztile = q.R + ((rc > 0 && rc < nn) ? rc * (rc + 1) / 2 : nn * (nn + 1) / 2) + nn;
+      }
     }
     else if constexpr (kElemView) {
       q.template carve<false, false, false>(lds_ql, D, 0, extE, eMmax + eNmax, extE + eCold + eNmax, eNmax);
@@ -935,11 +943,13 @@ __device__ __forceinline__ TickDiag mpc_tick(const wg_model_t &m, const TickTabl
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // gd / d (global slot) written above are read by other lanes below
     }
     HerdtElemProbT<(NH == 32) ? 32 : -1> prob;
+    typename std::conditional<kRegZ, ZRegs<2 * 32 + 2 * kSMax>, NoZRegs>::type zregs;
+    if constexpr (kRegZ) zregs.zt = q.ztile + kZrTile * kZrTs;       // the LDS tail rows behind the tile
     prob.N = N; prob.ns = ns; prob.Qb = &tb->Qb[0][0]; prob.u = L.uvec; prob.Gv = L.Gv; prob.gd = L.gd;
     prob.rowA = L.rowA; prob.rowB = L.rowB; prob.rowK = L.rowK; prob.stepidx = L.stepidx; prob.V_f = L.V_f;
     prob.R2 = tb->R2; prob.Z2 = tb->Z2; prob.z2sign = tb->z2_cross_sign; prob.blocks_ok = tb->blocks_ok;
     QlResume rs;
-    qr = ql_solve(q, prob, 1e-8, hist, hist_cap, &rs);
+    qr = ql_solve(q, prob, 1e-8, hist, hist_cap, &rs, &zregs);
     if (WG_UBOOL(qr.ifail == kQlCapHit)) {
       // the active set outgrew the columns of R the LDS holds: the finished columns (packed, qr.nact of them: the capped part
       // and the working column behind it are one contiguous triangle) move to the full-size R of the per-block global slot
@@ -954,7 +964,7 @@ __device__ __forceinline__ TickDiag mpc_tick(const wg_model_t &m, const TickTabl
       q.r_tail = n * (n + 1) / 2;
       q.nact_cap = 0;
       rs.valid = 1;
-      qr = ql_solve(q, prob, 1e-8, hist, hist_cap, &rs);
+      qr = ql_solve(q, prob, 1e-8, hist, hist_cap, &rs, &zregs);
     }
     {
       WG_WSYNC();

@@ -33,17 +33,28 @@
 // LDS reads, so each LDS wait behind one turns into lgkmcnt(0) -- a global round trip.  Pinned as address-space-1 pointers
 // they stay global_ accesses (kernel arguments are global memory).
 constexpr bool wg_tick_is_elem(int NH) { return NH == -1 || NH == 32; }
-#define WG_TICK_WAVES(NH) __attribute__((amdgpu_waves_per_eu(wg_tick_is_elem(NH) ? WG_TICK32_WPE : WG_TICK_WPE_MIN, wg_tick_is_elem(NH) ? WG_TICK32_WPE : WG_TICK_WPE_MAX)))
+// view 33 (N = 32 with Z in registers): one wave per SIMD, 512 registers
+#define WG_TICK_WAVES(NH) __attribute__((amdgpu_waves_per_eu((NH) == 33 ? WG_ZR_WPS : wg_tick_is_elem(NH) ? WG_TICK32_WPE : WG_TICK_WPE_MIN, (NH) == 33 ? WG_ZR_WPS : wg_tick_is_elem(NH) ? WG_TICK32_WPE : WG_TICK_WPE_MAX)))
+// View 33 (N = 32 with Z in registers, DESIGN 3.2 "Z on chip": measured, slower than view 32) is an EXPERIMENT: its three kernels are
+// only compiled into builds made with -DWG_WITH_REGZ (make lib/libwg_mpc_xregz.so EXTRA=-DWG_WITH_REGZ; tools/regz_probe.sh)
+#ifdef WG_WITH_REGZ
+#define WG_REGZ_KERNEL(KERN, view) (view) == 33 ? reinterpret_cast<const void *>(KERN<33>) :
+#define WG_REGZ_CASE(KERN, grid, lds, st, ...) case 33: hipLaunchKernelGGL(KERN<33>, dim3(grid), dim3(64), lds, st, __VA_ARGS__); break;
+#else
+#define WG_REGZ_KERNEL(KERN, view)
+#define WG_REGZ_CASE(KERN, grid, lds, st, ...)
+#endif
 // one kernel instantiation per problem view of the tick (16 compact, 0 dense, -1 element, 32 element with N = 32 fixed)
 #define WG_KERNEL_BY_VIEW(KERN, view)                                                                                              \
   ((view) == 16 ? reinterpret_cast<const void *>(KERN<16>) : (view) == 0 ? reinterpret_cast<const void *>(KERN<0>)                 \
-   : (view) == 32 ? reinterpret_cast<const void *>(KERN<32>) : reinterpret_cast<const void *>(KERN<-1>))
+   : (view) == 32 ? reinterpret_cast<const void *>(KERN<32>) : WG_REGZ_KERNEL(KERN, view) reinterpret_cast<const void *>(KERN<-1>))
 #define WG_LAUNCH_BY_VIEW(KERN, view, grid, lds, st, ...)                                                                           \
   do {                                                                                                                             \
     switch (view) {                                                                                                                \
       case 16: hipLaunchKernelGGL(KERN<16>, dim3(grid), dim3(64), lds, st, __VA_ARGS__); break;                                     \
       case 0: hipLaunchKernelGGL(KERN<0>, dim3(grid), dim3(64), lds, st, __VA_ARGS__); break;                                       \
       case 32: hipLaunchKernelGGL(KERN<32>, dim3(grid), dim3(64), lds, st, __VA_ARGS__); break;                                     \
+      WG_REGZ_CASE(KERN, grid, lds, st, __VA_ARGS__)                                                                                \
       default: hipLaunchKernelGGL(KERN<-1>, dim3(grid), dim3(64), lds, st, __VA_ARGS__); break;                                     \
     }                                                                                                                              \
   } while (0)
