@@ -269,7 +269,8 @@ __global__ __launch_bounds__(64) WG_QLD_ATTR void wg_ql_dense_kernel(   // never
     for (int k = lane; k < m; k += 64) q.b[k] = -bvec[(size_t)qp * mmax + k];   // qld.cpp:469-475
     WG_WSYNC();
     // qld.cpp:442-444: c(nmax,nmax) == 0 -> eps (inside the n x n block only if nmax == n)
-    wg::DenseProbT<kGLds, kFixN> prob;
+    typename std::conditional<(kFixN > 0), wg::DenseRegProb<(kFixN > 0 ? kFixN : 1), (kFixM > 0 ? kFixM : 1)>, wg::DenseProbT<kGLds, kFixN>>::type prob;
+    if constexpr (kFixN > 0) prob.load_rows(q, lane);       // A's rows into registers (m <= kFixM <= 128: two rows per lane)
     if (nmax == n && lane == 0 && fabs(prob.Gd(q, n - 1)) == 0.0) prob.setGd(q, n - 1, eps);
     WG_WSYNC();
 

@@ -279,6 +279,32 @@ struct DenseProbT {
   __device__ __forceinline__ double xu(const QlView &q, int i) const;
 };
 typedef DenseProbT<true> DenseProb;
+// The dense boundary at a size known at compile time (n <= NM, m <= MM <= 128) with the constraint matrix kept as REGISTER ROWS:
+// lane k carries row k (ar0) and row 64 + k (ar1) of A, loaded once per QP -- the violation scan, which walks every row in every
+// iteration, then reads no memory but x (LDS broadcasts); the new normal is written out by the lane that owns the row.  Every
+// other access to A (once per solve, or in the residual refresh) still reads it in place.
+template <int NM, int MM>
+struct DenseRegProb : DenseProbT<false, NM> {
+  static constexpr bool kRegRows = true;
+  double ar0[NM], ar1[NM];
+  __device__ __forceinline__ void load_rows(const QlView &q, int lane) {
+    const int m = q.m;
+    const int k0 = lane < m ? lane : m - 1, k1 = lane + 64 < m ? lane + 64 : m - 1;
+#pragma unroll
+    for (int i = 0; i < NM; ++i) { ar0[i] = q.A[k0 + i * q.lda]; ar1[i] = q.A[k1 + i * q.lda]; }
+  }
+  // ww[i] = A(k, i), i < n: the owner of row k writes it (compile-time column indices: the rows stay in registers)
+  __device__ __forceinline__ void row_to(const QlView &q, int k, double *dst, int lane) const {
+    const int n = q.n;
+    if (lane == (k & 63)) {
+#pragma unroll
+      for (int i = 0; i < NM; ++i)
+        if (i < n) dst[i] = k < 64 ? ar0[i] : ar1[i];
+    }
+  }
+};
+template <class P, class = void> struct HasRegRows { static constexpr bool value = false; };
+template <class P> struct HasRegRows<P, typename std::enable_if<P::kRegRows>::type> { static constexpr bool value = true; };
 #define Rp(i, j) q.R[(j) * ((j) + 1) / 2 + (i)]
 #define Rf(i, j) q.Rf[(j) * ((j) + 1) / 2 + (i)]        // the same packing, in the factorisation's array
 
@@ -1962,6 +1988,43 @@ __device__ __forceinline__ QlResult ql_solve(const QlView &q, P &prob, double vs
           if (temp <= tempa) continue;
           bestv = sumx; bestres = sum; bestw = wak; bidx = k + 1;
         }
+      } else if constexpr (HasRegRows<P>::value) {
+        // dense rows in registers: no memory access but x (LDS broadcasts, eight at a time); both of the lane's rows (lane,
+        // 64 + lane) are walked together, then the reference's tests in its order -- row lane first, row 64 + lane second
+        constexpr int NMr = P::kNM;
+        const int ka = lane, kb = lane + 64;
+        const bool ina = ka < m, inb = kb < m;
+        const int kca = ina ? ka : m - 1, kcb = inb ? kb : m - 1;
+        const double waka = ina ? q.wa[kca] : 0.0, bka = q.b[kca], wakb = inb ? q.wa[kcb] : 0.0, bkb = q.b[kcb];
+        double suma = -bka, tempa_ = fabs(bka), sumb = -bkb, tempb_ = fabs(bkb);
+#pragma unroll
+        for (int i0 = 0; i0 < NMr; i0 += 8) {
+          double xs[8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) xs[e] = q.x[(i0 + e < n) ? i0 + e : n - 1];
+#pragma unroll
+          for (int e = 0; e < 8; ++e)
+            if (i0 + e < NMr && i0 + e < n) {
+              const double ta = xs[e] * prob.ar0[i0 + e]; suma += ta; tempa_ += fabs(ta);
+              const double tb = xs[e] * prob.ar1[i0 + e]; sumb += tb; tempb_ += fabs(tb);
+            }
+        }
+#pragma unroll
+        for (int pp = 0; pp < 2; ++pp) {
+          const int k = pp == 0 ? ka : kb;
+          const double wak = pp == 0 ? waka : wakb, sum = pp == 0 ? suma : sumb;
+          double temp = pp == 0 ? tempa_ : tempb_;
+          if (wak <= 0.0) continue;
+          double sumx = -sum * wak;
+          if (k + 1 <= me) sumx = fabs(sumx);
+          if (sumx <= 0.0) continue;
+          if (bidx >= 0 && sumx <= bestv) continue;
+          double tempa = temp + fabs(sum);
+          if (tempa <= temp) continue;
+          temp += onha * fabs(sum);
+          if (temp <= tempa) continue;
+          bestv = sumx; bestres = sum; bestw = wak; bidx = k + 1;
+        }
       } else
       // dense rows: ONE walk of the row for both sums (sum += x_i a_ki, temp += |x_i a_ki|, i ascending: the same values the
       // serial code forms in two walks, the second only for candidates), the row's entries of eight columns requested while the
@@ -2114,6 +2177,7 @@ __device__ __forceinline__ QlResult ql_solve(const QlView &q, P &prob, double vs
       WG_REP(2)
       if (knext <= m) {
         if constexpr (P::kCompact) prob.fill_row(q, knext - 1, q.ww, lane);
+        else if constexpr (HasRegRows<P>::value) prob.row_to(q, knext - 1, q.ww, lane);
         else for (int i = lane; i < n; i += 64) q.ww[i] = Am(knext - 1, i);
         WG_WSYNC();
         if constexpr (P::kCompact) prob.zt_row(q, s, knext - 1, lane);
