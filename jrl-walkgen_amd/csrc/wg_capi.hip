@@ -270,7 +270,7 @@ __global__ __launch_bounds__(64) WG_QLD_ATTR void wg_ql_dense_kernel(   // never
     WG_WSYNC();
     // qld.cpp:442-444: c(nmax,nmax) == 0 -> eps (inside the n x n block only if nmax == n)
     typename std::conditional<(kFixN > 0), wg::DenseRegProb<(kFixN > 0 ? kFixN : 1), (kFixM > 0 ? kFixM : 1)>, wg::DenseProbT<kGLds, kFixN>>::type prob;
-    if constexpr (kFixN > 0) prob.load_rows(q, lane);       // A's rows into registers (m <= kFixM <= 128: two rows per lane)
+    // (kFixN > 0: A's rows go into registers inside ql_solve, once R and Z exist -- m <= kFixM <= 128: two rows per lane)
     if (nmax == n && lane == 0 && fabs(prob.Gd(q, n - 1)) == 0.0) prob.setGd(q, n - 1, eps);
     WG_WSYNC();
 

@@ -1550,6 +1550,76 @@ __device__ __forceinline__ bool independent_coordinate(const QlView &q, const P 
   return __any(found) != 0;
 }
 
+// Cholesky factor of G (qld.cpp:859-890) and Z = R^-1 (:937-975) for n <= NM <= 64 with one COLUMN of R / one ROW of Z per
+// lane, in registers, the loops over rows and columns unrolled (compile-time register indices): entry (i, j) of the factor is
+// temp = G(i, j) - sum_{k < i} R(k, j) R(k, i), k ascending -- lane j holds R(., j), R(k, i) comes from lane i's registers
+// (v_readlane, both indices known at compile time) -- then R(i, j) = temp / R(i, i); row i of the inverse is
+// Z(i, c) = -(sum_{k < c} Z(i, k) R(k, c)) / R(c, c), k ascending, with the exact zeros Z(i, k < i) = +0.0 left in (their
+// products are +-0.0 and the sum, started from +0.0, does not move).  The same operations in the same order as the loops they
+// replace, without their two LDS hand-overs per row: 27 k cycles instead of 240 k at n = 36.
+// Returns false -- R and Z untouched -- when a pivot falls below vsmall: the caller then takes the generic path, which finds
+// the same pivot and applies ql0002's diagonal shift.
+template <int NM, class P>
+__device__ __forceinline__ bool chol_inverse_regs(const QlView &q, const P &prob, double vsmall, int lane) {
+  const int n = q.n;
+  const int j = lane < n ? lane : n - 1;                    // surplus lanes shadow the last column / row
+  double r[NM];
+#pragma unroll
+  for (int k = 0; k < NM; ++k) r[k] = 0.0;
+  bool ok = true;
+#pragma unroll
+  for (int i = 0; i < NM; ++i) {
+    if (i < n) {
+      const int jj = j > i ? j : i;                         // finished columns (j < i) walk column i along: unused
+      double temp = prob.G(q, i, jj);
+#pragma unroll
+      for (int k = 0; k < i; ++k) temp -= r[k] * rl(r[k], i);
+      const double tpiv = rl(temp, i);
+      ok = ok && !(tpiv < vsmall);
+      const double rii = sqrt(tpiv);
+      const double quo = temp / rii;
+      r[i] = (j == i) ? rii : ((j > i) ? quo : r[i]);
+    }
+  }
+  if (!WG_UBOOL(ok)) return false;
+  if (lane < n) {
+#pragma unroll
+    for (int k = 0; k < NM; ++k)
+      if (k <= j) Rf(k, j) = r[k];
+  }
+  WG_WSYNC();
+  // ---- Z = R^-1: lane i owns row i ----
+  const int i = j;
+  double z[NM];
+#pragma unroll
+  for (int k = 0; k < NM; ++k) z[k] = 0.0;
+  {
+    double rdiag = 0.0;
+#pragma unroll
+    for (int k = 0; k < NM; ++k) rdiag = (k == i) ? r[k] : rdiag;     // R(i, i): the lane's own diagonal
+    const double zd = 1.0 / rdiag;
+#pragma unroll
+    for (int k = 0; k < NM; ++k) z[k] = (k == i) ? zd : z[k];
+  }
+#pragma unroll
+  for (int c = 1; c < NM; ++c) {
+    if (c < n) {
+      double sum = 0.0;
+#pragma unroll
+      for (int k = 0; k < c; ++k) sum += z[k] * Rf(k, c);
+      const double zc = -sum / Rf(c, c);
+      z[c] = (i < c) ? zc : z[c];
+    }
+  }
+  if (lane < n) {
+#pragma unroll
+    for (int k = 0; k < NM; ++k)
+      if (k < n) Zm(i, k) = z[k];
+  }
+  WG_WSYNC();
+  return true;
+}
+
 // The solver.  Problem data must already be in LDS: G (copy of C, patched per
 // qld.cpp:442-444), A, d, b (INNER sign: b = -b_user, qld.cpp:469-475), xl, xu.
 // hist: optional global add(+code)/drop(-code) log written by lane 0.
@@ -1658,7 +1728,13 @@ __device__ __forceinline__ QlResult ql_solve(const QlView &q, P &prob, double vs
     PT(1);
     bool factored = false;
     if constexpr (P::kHasFactor) {
+      WG_REP(8)
       if (!need_shift && prob.blocks_ok) factored = WG_UBOOL(prob.factor(q, vsmall, lane));
+    }
+    if constexpr (P::kNM > 0 && P::kNM <= 64 && !kRegs) {
+      // compile-time-bounded views without a structured factor of their own (the dense boundary at a known size, the Dimitrov
+      // tick's QL back-end; the compact view when its blocks do not apply): R and Z through registers
+      if (!factored && !need_shift) factored = chol_inverse_regs<P::kNM>(q, prob, vsmall, lane);
     }
     if (!factored) {
     for (;;) {
@@ -1741,6 +1817,8 @@ __device__ __forceinline__ QlResult ql_solve(const QlView &q, P &prob, double vs
   }
 
   PT(3);
+  // register rows of A (DenseRegProb) are loaded here, after the factorisation has given its registers back
+  if constexpr (HasRegRows<P>::value) { if (!early_exit && !resuming) prob.load_rows(q, lane); }
   if constexpr (kRegs) {
     // Z = R^-1 as factor() (or the generic inverse above) left it in the global slot: its rows into the registers, where Z stays
     if (!early_exit && !resuming) { WG_WSYNC(); zr_load(q, *zr, lane); }
@@ -1773,6 +1851,7 @@ __device__ __forceinline__ QlResult ql_solve(const QlView &q, P &prob, double vs
         PT(24);
       } else {                                              // :1031-1099
         iflag = 2;
+        WG_REP(11) {                                        // gradient and residuals of the refresh: reads x, lam; writes ww, s
         typename ActiveParamsOf<P>::type ap;
         if constexpr (P::kCompact) ap = prob.active_params(q, nact, lane);
         for (int i = lane; i < n; i += 64) {
@@ -1813,6 +1892,7 @@ __device__ __forceinline__ QlResult ql_solve(const QlView &q, P &prob, double vs
           s[k] = sk;
         }
         WG_WSYNC();
+        }   // WG_REP(11)
         PT(25);
       }
       if (nact > 0) {                                       // :1104-1170

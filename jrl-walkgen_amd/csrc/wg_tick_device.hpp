@@ -755,6 +755,7 @@ __device__ __forceinline__ TickDiag mpc_tick(const wg_model_t &m, const TickTabl
     else q.carve(lds_ql, D, 0);
   }
 
+  WG_REP(9) {                                               // attribution builds: the QP assembly twice (it only reads the state)
   // ---- S*c products (MV2_ = prod(S, CoM), generator-vel-ref.cpp:780-787) ----
   for (int i = lane; i < N; i += 64) {
     double ax = 0.0, ay = 0.0, bx = 0.0, by = 0.0;
@@ -899,6 +900,7 @@ __device__ __forceinline__ TickDiag mpc_tick(const wg_model_t &m, const TickTabl
     q.b[r] = -bacc;                 // inner sign, qld.cpp:469-475
   }
   WG_WSYNC();
+  }   // WG_REP(9)
 
   // ---- QPProblem::solve -> ql0001_ (eps = 1e-8, qp-problem.cpp:260) ----
 #ifdef WG_PROFILE

@@ -9,7 +9,10 @@ D = os.path.join(ROOT, "gpurun_out", "attr")
 B, TICKS = 4096, 10 + 3 * 100                      # probe_elem.py: one 10-tick warm-up launch + PR = 3 launches of PT = 100 ticks
 NAMES = {0: "(plain: nothing repeated)", 1: "violation scan, qld.cpp:1255-1331", 2: "Z^T a of the new normal, :1421-1470",
          3: "sweep: chain of rotation norms, :1992-2030 (phase 1)", 4: "back substitution of the step, :1824-1851",
-         5: "linear-dependence sums, :1491-1532", 6: "xmag ordered sums (both sites), :2039-2058", 7: "pick_drop, :1861-1889"}
+         5: "linear-dependence sums, :1491-1532", 6: "xmag ordered sums (both sites), :2039-2058", 7: "pick_drop, :1861-1889",
+         8: "factor(): constant blocks, border rows of R and Z (once per tick)", 9: "QP assembly of the tick (S c, gradient, tables, rhs)",
+         11: "residual refresh: gradient and residuals, :1031-1099 (once per tick)"}
+PHASES = [k for k in (1, 2, 3, 4, 5, 6, 7, 8, 9, 11) if os.path.isdir(os.path.join(D, "pmc_%d" % k))]
 CNT = ["SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_INSTS_VMEM", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_VALU"]
 
 
@@ -36,7 +39,7 @@ print("# plain build: %.0f ticks/s; VALU %.0f, SALU %.0f, LDS %.0f, VMEM %.0f in
                                                                    100 * base["SQ_WAIT_INST_ANY"] / base["SQ_WAVE_CYCLES"]))
 print("%-58s %8s %8s %7s %10s %9s %9s %8s %7s" % ("phase", "VALU", "SALU", "LDS", "wave cyc", "parked", "stalled", "time %", "SALU/VALU"))
 acc = collections.Counter()
-for k in range(1, 8):
+for k in PHASES:
     c, rate, chk = load(k)
     assert chk == sum0, (k, chk, sum0)
     d = {n: c[n] - base[n] for n in CNT}
@@ -48,7 +51,7 @@ for k in range(1, 8):
                                                                       d["SQ_WAVE_CYCLES"], d["SQ_WAIT_ANY"], d["SQ_WAIT_INST_ANY"], share,
                                                                       d["SQ_INSTS_SALU"] / max(1.0, d["SQ_INSTS_VALU"])))
 rest = {n: base[n] - acc[n] for n in CNT}
-print("%-58s %8.0f %8.0f %7.0f %10.0f %9.0f %9.0f %7.1f%% %7.2f" % ("everything else (sweep phases 2-3, drops, x / lambda updates,", rest["SQ_INSTS_VALU"], rest["SQ_INSTS_SALU"],
+print("%-58s %8.0f %8.0f %7.0f %10.0f %9.0f %9.0f %7.1f%% %7.2f" % ("everything else (see the timer table below for its split):", rest["SQ_INSTS_VALU"], rest["SQ_INSTS_SALU"],
                                                                   rest["SQ_INSTS_LDS"], rest["SQ_WAVE_CYCLES"], rest["SQ_WAIT_ANY"], rest["SQ_WAIT_INST_ANY"],
                                                                   100 - acc["share"], rest["SQ_INSTS_SALU"] / max(1.0, rest["SQ_INSTS_VALU"])))
-print("%-58s" % "   factor(), residual refresh, the tick around the solve)")
+print("%-58s" % "   sweep phases 2-3, drops, x / lambda updates, the refresh's substitutions, lane-0 bookkeeping, feet, state in / out")

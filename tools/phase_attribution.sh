@@ -2,7 +2,8 @@
 # Per-phase attribution of the N = 16 tick's instruction streams and wait cycles (run on the GPU box via gpurun).
 # Builds lib/libwg_mpc_xr<k>.so = -DWG_REPEAT_PHASE=k (csrc/wg_ql_device.hpp: the idempotent phase k of every active-set
 # iteration is executed twice; k = 0: no phase repeated, same compiler barriers) must exist:
-#   for k in 0 1 2 3 4 5 6 7; do make -C jrl-walkgen_amd lib/libwg_mpc_xr$k.so EXTRA=-DWG_REPEAT_PHASE=$k; done
+#   for k in 0 1 2 3 4 5 6 7 8 9 11; do make -C jrl-walkgen_amd lib/libwg_mpc_xr$k.so EXTRA=-DWG_REPEAT_PHASE=$k; done
+# (8: factor(), 9: the tick's QP assembly, 11: gradient + residuals of the residual refresh -- idempotent as well)
 # For each build: the multi-tick kernel's rate (no profiler), then ONE rocprofv3 --pmc pass of eight SQ counters.
 # tools/phase_attribution.py turns the differences against k = 0 into the per-phase table.
 set -u
@@ -12,7 +13,7 @@ O=$R/gpurun_out/attr
 rm -rf $O; mkdir -p $O
 export PN=16 PB=4096 PT=100 PR=3
 cd /tmp
-for k in 0 1 2 3 4 5 6 7; do
+for k in 0 1 2 3 4 5 6 7 8 9 11; do
   export WG_LIB_PATH=$R/jrl-walkgen_amd/lib/libwg_mpc_xr$k.so
   python3 $R/tools/probe_elem.py 2>&1 | grep -v amdgpu.ids > $O/time_$k.txt
   rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU \

@@ -11,7 +11,7 @@
 set -u
 export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-BENCH="bench.py --steps 200 --warmup 50 --no-cpu-baseline --no-parity --no-per-tick-leg --no-config5 --no-kernels"
+BENCH="bench.py --steps 200 --warmup 50 --no-cpu-baseline --no-parity --no-per-tick-leg --no-config5 --no-kernels --no-outs-leg"
 bash $R/tools/prof.sh tick $BENCH > $R/gpurun_out/prof_tick.log 2>&1
 echo "tick done"
 # the same with the tick's deliverable stored in the timed launch (wg_tick_out_t per gait-tick): the WRITE_SIZE of the outs-on leg
@@ -36,6 +36,9 @@ echo "elem done"
 $R/tools/micro/fetchcal > $R/gpurun_out/fetchcal.txt 2>&1
 bash $R/tools/pmc_traffic.sh fetchcal $R/tools/micro/fetchcal > $R/gpurun_out/fetchcal_pmc.txt 2>&1
 echo "calibration done"
+# one robot: what one wave alone on a CU spends its cycles on
+bash $R/tools/prof.sh b1 tools/probe_b1.py > $R/gpurun_out/prof_b1.log 2>&1
+echo "b1 done"
 # one robot: the tick's latency split
 $R/jrl-walkgen_amd/bin/latency_b1 > $R/gpurun_out/latency_b1.json 2> $R/gpurun_out/latency_b1.err
 echo "latency done"

@@ -22,7 +22,7 @@ def launch_plan(t0, t1, per_tick=False, redraw=REDRAW):            # bench.launc
     return out
 
 
-names = ["tick", "ticko", "tickg", "pertick", "config5", "elem", "gramian", "dimitrov", "pldp", "preview", "zmpdisc"]
+names = ["tick", "ticko", "tickg", "pertick", "config5", "elem", "b1", "gramian", "dimitrov", "pldp", "preview", "zmpdisc"]
 summ = {}
 for k in names:
     d = os.path.join(ROOT, "gpurun_out", "prof_" + k)
@@ -68,7 +68,7 @@ n_run = sum(1 for _, n in PLAN if n > 1)
 plan_txt = ", ".join(str(n) for _, n in PLAN if n > 1)
 out = {"tag": tag,
        "how": "rocprofv3 passes of `python3 bench.py --steps 200 --warmup 50 --no-cpu-baseline --no-parity --no-per-tick-leg "
-              "--no-config5 --no-kernels` (tools/prof_round.sh): kernel trace + stats, then the counters in separate --pmc passes (FETCH_SIZE and "
+              "--no-config5 --no-kernels --no-outs-leg` (tools/prof_round.sh): kernel trace + stats, then the counters in separate --pmc passes (FETCH_SIZE and "
               "WRITE_SIZE each in its own).  Units and gfx950 correction per MI355X_MICROARCH.md (HBM / rocprofv3): KiB x 1024, "
               "FETCH_SIZE doubled.  Totals over ALL launches of the kernel divided by the gait-ticks those launches ran "
               "(B = 4096; bench.py runs 100 pre-roll + 50 warm-up ticks untimed, then the timed 200; multi-tick launches: " + plan_txt + " ticks, "
@@ -98,7 +98,7 @@ if "pertick" in summ:
 if "elem" in summ:
     # the N = 32 element-view run kernel: probe_elem.py runs one 10-tick warm-up launch and PR = 3 launches of PT = 50 ticks
     EB, ET, ER, EW = 8192, 50, 3, 10
-    kern = "wg_mpc_run_xcd_kernel<-1>"
+    kern = "wg_mpc_run_xcd_kernel<32>"                     # N = 32 has its own instantiation since round 4 (<-1>: any horizon)
     c = summ["elem"]["counters"][kern]
     gt = EB * (ET * ER + EW)
     tot = lambda n: c[n]["mean_per_launch"] * c[n]["launches"]       # noqa: E731
@@ -124,9 +124,22 @@ if "elem" in summ:
         "calibration": cal,
         "valu_insts_per_gait_tick": tot("SQ_INSTS_VALU") / gt, "salu_insts_per_gait_tick": tot("SQ_INSTS_SALU") / gt,
         "lds_insts_per_gait_tick": tot("SQ_INSTS_LDS") / gt, "vmem_insts_per_gait_tick": tot("SQ_INSTS_VMEM") / gt,
-        "valu_busy": 2 * tot("SQ_ACTIVE_INST_VALU") / tot("SQ_WAVE_CYCLES"),
+        "valu_busy": 3 * tot("SQ_ACTIVE_INST_VALU") / tot("SQ_WAVE_CYCLES"),        # three waves per SIMD
         "wait_any_frac_per_wave": tot("SQ_WAIT_ANY") / tot("SQ_WAVE_CYCLES"),
         "avg_kernel_ns_rocprofv3": summ["elem"]["kernels"][kern]["avg_ns"], "kernel_calls_rocprofv3": summ["elem"]["kernels"][kern]["calls"]}
+if "b1" in summ:
+    # one robot: one wave alone on a CU, one launch per tick (tools/probe_b1.py): what the wave's cycles are spent on
+    kern = "wg_mpc_tick_kernel<16>"
+    c = summ["b1"]["counters"][kern]
+    m_ = lambda n: c[n]["mean_per_launch"]                           # noqa: E731
+    out["one_robot_kernel"] = {
+        "kernel": kern, "command": "python3 tools/probe_b1.py (B = 1, 200 launches of one tick)", "avg_kernel_ns_rocprofv3": summ["b1"]["kernels"][kern]["avg_ns"],
+        "wave_cycles_per_tick": 4 * m_("SQ_WAVE_CYCLES"), "valu_insts_per_tick": m_("SQ_INSTS_VALU"), "salu_insts_per_tick": m_("SQ_INSTS_SALU"),
+        "lds_insts_per_tick": m_("SQ_INSTS_LDS"), "vmem_insts_per_tick": m_("SQ_INSTS_VMEM"),
+        "executing_frac": m_("SQ_ACTIVE_INST_ANY") / m_("SQ_WAVE_CYCLES"), "valu_executing_frac": m_("SQ_ACTIVE_INST_VALU") / m_("SQ_WAVE_CYCLES"),
+        "lds_executing_frac": m_("SQ_ACTIVE_INST_LDS") / m_("SQ_WAVE_CYCLES"), "parked_in_waitcnt_frac": m_("SQ_WAIT_ANY") / m_("SQ_WAVE_CYCLES"),
+        "issue_stalled_frac": m_("SQ_WAIT_INST_ANY") / m_("SQ_WAVE_CYCLES"),
+        "note": "SQ_WAVE_CYCLES and the SQ_ACTIVE / SQ_WAIT counters are in quad-cycles; fractions are of the wave's lifetime"}
 json.dump(out, open(os.path.join(ROOT, "profiles", "current_tick_pmc.json"), "w"), indent=1)
 lat = os.path.join(ROOT, "gpurun_out", "latency_b1.json")
 if os.path.exists(lat) and os.path.getsize(lat) > 0:
@@ -151,12 +164,16 @@ Everything named `{tag}_*` was produced by ONE run of `tools/prof_round.sh` on a
 
 | files | command profiled | what to read there |
 |---|---|---|
-| `{tag}_tick_*` | `python3 bench.py --steps 200 --warmup 50 --no-cpu-baseline --no-parity --no-per-tick-leg --no-config5 --no-kernels` | the benchmarked kernel `wg_mpc_run_xcd_kernel<16>` alone: B = 4096, the untimed launches (pre-roll + warm-up: 48 and 100 ticks) and the timed one of 200 ticks with the velocity references of its four stretches staged on the device (plus the two single-tick launches of the control loop's first ticks under their own kernel name); kernel-trace stats and the PMC passes |
+| `{tag}_tick_*` | `python3 bench.py --steps 200 --warmup 50 --no-cpu-baseline --no-parity --no-per-tick-leg --no-config5 --no-kernels --no-outs-leg` | the benchmarked kernel `wg_mpc_run_xcd_kernel<16>` alone: B = 4096, the untimed launches (pre-roll + warm-up: 48 and 100 ticks) and the timed one of 200 ticks with the velocity references of its four stretches staged on the device (plus the two single-tick launches of the control loop's first ticks under their own kernel name); kernel-trace stats and the PMC passes |
 | `{tag}_tickg_*` | the same with `WG_RUN_QUEUE=global` | the device-wide queue of round 1 (`wg_mpc_run_kernel<16>`): the L2 write-back traffic the XCD-local hand-over removed |
 | `{tag}_pertick_*` | the same with `--per-tick-launch` | `wg_mpc_tick_kernel<16>`, 350 launches of one tick |
 | `{tag}_config5_*` | `PN=32 PB=8192 PT=50 python3 tools/probe_run.py` | BASELINE configs[4]'s size: N = 32, B = 8192 (element view), per-tick and multi-tick launches |
-| `{tag}_elem_*` | `PN=32 PB=8192 PT=50 PR=3 python3 tools/probe_elem.py` | the element-view run kernel `wg_mpc_run_xcd_kernel<-1>` alone (what `bench.py`'s `config5` leg times): kernel trace and all PMC passes; `current_tick_pmc.json` -> `elem_run_kernel` holds its HBM-side traffic per gait-tick (FETCH_SIZE x 2 and uncorrected, WRITE_SIZE) |
+| `{tag}_elem_*` | `PN=32 PB=8192 PT=50 PR=3 python3 tools/probe_elem.py` | the element-view run kernel `wg_mpc_run_xcd_kernel<32>` alone (what `bench.py`'s `config5` leg times): kernel trace and all PMC passes; `current_tick_pmc.json` -> `elem_run_kernel` holds its HBM-side traffic per gait-tick (FETCH_SIZE x 2 and uncorrected, WRITE_SIZE) |
 | `{tag}_fetchcal_*` | `tools/micro/fetchcal` (plain, then `tools/pmc_traffic.sh`) | FETCH_SIZE / WRITE_SIZE against known byte counts: 4 / 8 / 16 B per lane coalesced, the Z^T a column walk and the sweep's row walk of a 72 x 73 slot |
+| `{tag}_ticko_*` | the same with `--outs-on` | the timed launch stores every gait-tick's `wg_tick_out_t`: WRITE_SIZE of the `outs_on` leg (`current_tick_pmc.json` -> `run_kernel_outs`) |
+| `{tag}_b1_*` | `python3 tools/probe_b1.py` | one robot, one wave alone on a CU: the counters behind DESIGN 4's "one robot" paragraph (`current_tick_pmc.json` -> `one_robot_kernel`) |
+| `{tag}_regz_*` | `bash tools/regz_probe.sh` (experiment builds, `-DWG_WITH_REGZ`) | the "Z on chip" experiment at N = 32: parity, rate at four and eight gaits per CU, all counters of the four-per-CU build |
+| `{tag}_phase_attribution.txt` | `bash tools/phase_attribution.sh` + `python tools/phase_attribution.py`, then the timer table of `{tag}_tick_phase_timers.txt` | per-phase counters of the N = 16 run kernel (phases executed twice, differences against the plain build) and the shader-clock split of everything the counters cannot repeat |
 | `{tag}_latency_b1.json` | `jrl-walkgen_amd/bin/latency_b1` | one robot (B = 1): host-pointer call, its split (copy in / launch / kernel / copy out) and the host-mapped call |
 | `{tag}_resource_usage.txt` | `python tools/isa_audit.py` (no GPU) | registers, spills, scratch, occupancy of every kernel; where the spill code sits by loop depth; instruction mix of the inner loops |
 | `{tag}_gramian_*` | `python3 tools/probe_gramian.py` | `wg_gramian_kernel`: SQ_INSTS_VALU_MFMA_MOPS_F64 / _F32, SQ_VALU_MFMA_BUSY_CYCLES, duration against the dense MFMA peak (`*_probe_output.txt`) |
