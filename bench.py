@@ -280,8 +280,10 @@ def config5_leg(dev, flags, ticks=40, warm=10):
     alg = float(algorithmic_bytes(d[:, 3].astype(np.float64), d[:, 4].astype(np.float64)).sum())
     # HBM-side traffic of this kernel from the rocprofv3 --pmc passes filed in profiles/ (per gait-tick there, per step here)
     traffic = {"traffic": None}
+    kern_name = "wg_mpc_run_xcd_kernel<32>"                   # N = 32 has its own instantiation (the any-horizon one is <-1>)
     try:
         e = json.load(open(PMC_SUMMARY))["elem_run_kernel"]
+        kern_name = e.get("kernel", kern_name)
         traffic = {"traffic": e["hbm_bytes_per_gait_tick"] * B, "traffic_read": e["hbm_read_bytes_per_gait_tick"] * B,
                    "traffic_read_uncorrected": e["hbm_read_bytes_per_gait_tick_uncorrected"] * B,
                    "traffic_write": e["hbm_write_bytes_per_gait_tick"] * B,
@@ -303,7 +305,7 @@ def config5_leg(dev, flags, ticks=40, warm=10):
             "n_hist": {str(int(k)): int(v) for k, v in zip(*np.unique(d[:, 3], return_counts=True))},
             "roofline": dict({"bound": "hbm", "achieved": alg / kern_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                               "frac": alg / kern_s / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes_per_step": alg / ticks,
-                              "kernel": "wg_mpc_run_xcd_kernel<-1>"}, **traffic)}
+                              "kernel": kern_name}, **traffic)}
 
 
 def main():

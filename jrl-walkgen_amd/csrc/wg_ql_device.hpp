@@ -1731,9 +1731,10 @@ __device__ __forceinline__ QlResult ql_solve(const QlView &q, P &prob, double vs
       WG_REP(8)
       if (!need_shift && prob.blocks_ok) factored = WG_UBOOL(prob.factor(q, vsmall, lane));
     }
-    if constexpr (P::kNM > 0 && P::kNM <= 64 && !kRegs) {
+    if constexpr (P::kNM > 0 && P::kNM <= 64 && !kRegs && !P::kHasFactor) {
       // compile-time-bounded views without a structured factor of their own (the dense boundary at a known size, the Dimitrov
-      // tick's QL back-end; the compact view when its blocks do not apply): R and Z through registers
+      // tick's QL back-end): R and Z through registers.  The compact view keeps the generic loops for the rare tick whose blocks
+      // do not apply: unrolled into the tick kernels this body doubled their spilled SGPRs (260 -> 552) for a path they almost never take
       if (!factored && !need_shift) factored = chol_inverse_regs<P::kNM>(q, prob, vsmall, lane);
     }
     if (!factored) {

@@ -47,6 +47,7 @@ for k in PHASES:
     for n in CNT:
         acc[n] += d[n]
     acc["share"] += share
+    acc["share_%d" % k] = share
     print("%-58s %8.0f %8.0f %7.0f %10.0f %9.0f %9.0f %7.1f%% %7.2f" % (NAMES[k][:58], d["SQ_INSTS_VALU"], d["SQ_INSTS_SALU"], d["SQ_INSTS_LDS"],
                                                                       d["SQ_WAVE_CYCLES"], d["SQ_WAIT_ANY"], d["SQ_WAIT_INST_ANY"], share,
                                                                       d["SQ_INSTS_SALU"] / max(1.0, d["SQ_INSTS_VALU"])))
@@ -55,3 +56,43 @@ print("%-58s %8.0f %8.0f %7.0f %10.0f %9.0f %9.0f %7.1f%% %7.2f" % ("everything 
                                                                   rest["SQ_INSTS_LDS"], rest["SQ_WAVE_CYCLES"], rest["SQ_WAIT_ANY"], rest["SQ_WAIT_INST_ANY"],
                                                                   100 - acc["share"], rest["SQ_INSTS_SALU"] / max(1.0, rest["SQ_INSTS_VALU"])))
 print("%-58s" % "   sweep phases 2-3, drops, x / lambda updates, the refresh's substitutions, lane-0 bookkeeping, feet, state in / out")
+
+# ---- the lump, split by the shader-clock timers (tools/probe_tick_phases.py on lib/libwg_mpc_prof.so, one launch per tick) ----
+# The phases below cannot be executed twice (they rotate Z, move x, advance the state), so their cost comes from s_memtime
+# brackets instead.  Timer cycles are not the counters' wave cycles (another build, one launch per tick, the reads themselves cost):
+# each row's share = its timer cycles / the timer cycles of ALL rows listed here x the share the counters leave for the lump.
+TIMERS = os.path.join(ROOT, "gpurun_out", "phases_tick.txt")
+if os.path.exists(TIMERS):
+    top, sub = {}, {}
+    for ln in open(TIMERS):
+        m = re.match(r"^\s*(\d+) (.*?)\s+(\d+) cyc/tick", ln)
+        if m:
+            top[int(m.group(1))] = float(m.group(3)); continue
+        m = re.match(r"^\s+(sweep|pre|post) (.*?)\s+(\d+) cyc/tick", ln)
+        if m:
+            sub[(m.group(1), m.group(2).strip())] = float(m.group(3))
+    sw = {k[1][:7]: v for k, v in sub.items() if k[0] == "sweep"}
+    rows = [("sweep phase 2: (ga, gb) of every rotation, one lane each, :2011-2014", sw.get("phase 2", 0.0)),
+            ("sweep phase 3: lane i carries row i of Z through the rotations, :2015-2029", sw.get("phase 3", 0.0)),
+            ("step direction and lengths before the back substitution (z, ww := Z s, ratios), :1715-1823", top.get(14, 0.0)),
+            ("route of the new normal besides the dependence sums (counter row above), :1471-1560", max(0.0, top.get(13, 0.0) - acc["share_5"] / 100.0 * sum(top.get(k, 0.0) for k in range(24)))),
+            ("x / lambda update, constraint drop (:1903-1982), bookkeeping of the iteration", top.get(17, 0.0) + top.get(18, 0.0) + top.get(10, 0.0) + top.get(20, 0.0)),
+            ("residual refresh besides its gradient (counter row above): reset, Z^T ww, x shift, substitutions, lambda", max(0.0, top.get(4, 0.0) - top.get(25, 0.0) - top.get(27, 0.0)) + top.get(5, 0.0) + top.get(6, 0.0) + top.get(7, 0.0)),
+            ("start of the solve: norms of the rows, diagonal test", top.get(0, 0.0) + top.get(1, 0.0))]
+    for (grp, name), v in sub.items():
+        if grp in ("pre", "post"):
+            rows.append(("tick, %s the solve: %s" % ("before" if grp == "pre" else "after", name), v))
+    if top.get(23) and not any(g == "post" for g, _ in sub):
+        rows.append(("tick, after the solve", top[23]))
+    tot_t = sum(top.get(k, 0.0) for k in range(24))
+    lump = 100 - acc["share"]
+    tsum = sum(v for _, v in rows)
+    print()
+    print("# the lump by shader-clock timers (%s; %.0f timer cycles per gait-tick in all, %.0f of them in the rows below = %.1f %% there," %
+          (os.path.relpath(TIMERS, ROOT), tot_t, tsum, 100 * tsum / tot_t))
+    print("# against %.1f %% by the counters: the timers' own reads weigh on short phases); share = row / sum of these rows x %.1f %%" % (lump, lump))
+    print("%-112s %10s %8s" % ("phase (not repeatable: timed)", "timer cyc", "time %"))
+    for name, v in sorted(rows, key=lambda r: -r[1]):
+        print("%-112s %10.0f %7.1f%%" % (name[:112], v, lump * v / tsum))
+    big = max(lump * v / tsum for _, v in rows)
+    print("# rows above (counters) + rows here (timers) = 100 %% of the tick; largest row of the former lump: %.1f %%" % big)

@@ -59,4 +59,8 @@ done
 PB=4096 python3 $R/tools/probe_tick_phases.py 2>&1 | grep -v amdgpu.ids > $R/gpurun_out/phases_tick.txt
 PN=32 PB=3072 python3 $R/tools/probe_tick_phases.py 2>&1 | grep -v amdgpu.ids > $R/gpurun_out/phases_tick32.txt
 echo "phases done"
+# duration of a multi-tick launch against its length: the steady rate and what every launch pays once (ramp + idle tail)
+python3 $R/tools/probe_launch_fit.py 2>&1 | grep -v amdgpu.ids > $R/gpurun_out/launch_fit.txt
+PTS=1,2,4,8,12,20 PN=32 PB=8192 python3 $R/tools/probe_launch_fit.py 2>&1 | grep -v amdgpu.ids >> $R/gpurun_out/launch_fit.txt
+echo "launch fit done"
 tail -25 $R/gpurun_out/prof_tick.log

@@ -144,7 +144,7 @@ json.dump(out, open(os.path.join(ROOT, "profiles", "current_tick_pmc.json"), "w"
 lat = os.path.join(ROOT, "gpurun_out", "latency_b1.json")
 if os.path.exists(lat) and os.path.getsize(lat) > 0:
     shutil.copy(lat, os.path.join(ROOT, "profiles", f"{tag}_latency_b1.json"))
-for src, dst in (("phases_tick.txt", "tick_phase_timers.txt"), ("phases_tick32.txt", "tick32_phase_timers.txt")):
+for src, dst in (("phases_tick.txt", "tick_phase_timers.txt"), ("phases_tick32.txt", "tick32_phase_timers.txt"), ("launch_fit.txt", "launch_fit.txt")):
     ph = os.path.join(ROOT, "gpurun_out", src)
     if os.path.exists(ph):
         shutil.copy(ph, os.path.join(ROOT, "profiles", f"{tag}_{dst}"))
@@ -179,6 +179,7 @@ Everything named `{tag}_*` was produced by ONE run of `tools/prof_round.sh` on a
 | `{tag}_gramian_*` | `python3 tools/probe_gramian.py` | `wg_gramian_kernel`: SQ_INSTS_VALU_MFMA_MOPS_F64 / _F32, SQ_VALU_MFMA_BUSY_CYCLES, duration against the dense MFMA peak (`*_probe_output.txt`) |
 | `{tag}_dimitrov_*`, `{tag}_pldp_*`, `{tag}_preview_*`, `{tag}_zmpdisc_*` | `tools/probe_<name>.py` | the other kernels of the path |
 | `{tag}_tick_phase_timers.txt`, `{tag}_tick32_phase_timers.txt` | `PB=4096 python3 tools/probe_tick_phases.py`, `PN=32 PB=3072 ...` (diagnostic build `lib/libwg_mpc_prof.so`) | in-kernel phase timers of the tick at N = 16 and N = 32 (shader cycles per gait-tick, one launch per tick) |
+| `{tag}_launch_fit.txt` | `python3 tools/probe_launch_fit.py` (N = 16, B = 4096; then N = 32, B = 8192) | duration of a multi-tick launch against its length, least squares: the steady rate and what every launch pays once (ramp and the idle tail in which the last gait-ticks finish) -- the difference between the 200-step figure and the driver's 20-step window |
 | `{tag}_soak_parity.txt` | `python tools/soak_parity.py` | every gait of the benchmark workload (4096 x 250 ticks at N = 16, 8192 x 50 at N = 32) advanced as `bench.py` does it, final states byte for byte against the CPU checker on the host cores |
 | `{tag}_soak_parity_long.txt` | `SOAK_LONG=1 python tools/soak_parity.py` | the same at four times the length (4096 x 1000 ticks at N = 16) and through the element view at N = 20, 24, 28, 32: 5.0 M MPC ticks byte for byte |
 | `current_tick_pmc.json` | derived from `{tag}_tick_*`, `{tag}_tickg_*`, `{tag}_pertick_*` | per gait-tick: HBM bytes read / written (FETCH_SIZE x 2 and WRITE_SIZE, KiB units, separate passes), VALU / SALU / LDS / VMEM instructions, VALU busy; `bench.py` scales `roofline.traffic` and its second axis from this file |
