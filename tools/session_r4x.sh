@@ -1,0 +1,5 @@
+cd $GRAFT_REPO_ROOT
+mkdir -p gpurun_out
+timeout -k 10 900 python3 bench.py > gpurun_out/bench_full.json 2> gpurun_out/bench_full.err; echo "bench rc=$?"
+timeout -k 10 600 python3 bench.py --steps 20 --warmup 5 > gpurun_out/bench_window.json 2> gpurun_out/bench_window.err; echo "window rc=$?"
+SOAK_LONG=1 timeout -k 10 900 python3 tools/soak_parity.py > gpurun_out/soak_parity_long.txt 2>&1; echo "soak rc=$?"; tail -3 gpurun_out/soak_parity_long.txt
