@@ -378,7 +378,7 @@ def main():
     lo, hi = rank * B, (rank + 1) * B                         # weak scaling: B gaits per GPU
     K, W0 = args.steps, args.warmup
     W = W0 + max(0, args.preroll)                             # pre-roll + warm-up: all untimed, same launch plan
-    n_seg = (K + W + min(K, 100) + K + REDRAW_TICKS - 1) // REDRAW_TICKS
+    n_seg = (K + W + min(K, 100) + K + 2 * REDRAW_TICKS - 1) // REDRAW_TICKS    # + one period: the outs leg starts at the timed region's phase
     vtab = torch.from_numpy(velocity_table(lo, hi, n_seg)).to(dev)
     states = start_states(model, B).to(dev)
     diag = torch.zeros(K + W, B, 6, dtype=torch.int32, device=dev)
@@ -464,7 +464,16 @@ def main():
     # secondary figure: the same launches with the deliverable stored (outs non-NULL), on the following ticks of the same gaits
     outs_leg = None
     if outs_buf is not None and not args.outs_on:
-        t_first = W + K + (min(K, 100) if alt is not None else 0)
+        t_now = W + K + (min(K, 100) if alt is not None else 0)
+        # same position relative to the reference redraws as the timed region (so that the leg is the same launch plan: a window
+        # that straddles a redraw is two launches, and every launch pays its ramp and tail once): the ticks in between run untimed
+        t_first = t_now + (W - t_now) % REDRAW_TICKS
+        if (t_first + K + REDRAW_TICKS - 1) // REDRAW_TICKS > vtab.shape[0]:
+            t_first = t_now
+        with torch.cuda.stream(stream):
+            for t, n in launches(t_now, t_first):
+                redraw(t, n)
+                fire(t, n, diag_ptr=False)
         plan = launches(t_first, t_first + K)
         shard.barrier(); torch.cuda.synchronize(dev)
         t1 = time.perf_counter()
@@ -477,7 +486,8 @@ def main():
         outs_leg = {"value": shard.sum_over_ranks(B * K, dev) / e3, "unit": "ticks/s", "steps": K, "ms_per_step": 1e3 * e3 / K,
                     "launches": len(plan), "out_bytes_per_gait_tick": out_bytes,
                     "stored_gb": B * K * out_bytes / 1e9, "store_rate_gbs": B * K * out_bytes / e3 / 1e9,
-                    "note": "the same launches on the following %d ticks with outs non-NULL: every gait-tick stores its wg_tick_out_t (20 "
+                    "first_tick": t_first,
+                    "note": "the same launch plan on %d later ticks (same position relative to the reference redraws) with outs non-NULL: every gait-tick stores its wg_tick_out_t (20 "
                             "CoM / ZMP / feet / trunk samples, what ZMPVelocityReferencedQP::OnLine pushes on its deques, "
                             "ZMPVelocityReferencedQP.cpp:405-442), tick-major, K x B structs" % K}
 
