@@ -1,7 +1,4 @@
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
-bash tools/phase_attribution.sh
-cd $GRAFT_REPO_ROOT
 timeout -k 10 900 python3 bench.py > gpurun_out/bench_full.json 2> gpurun_out/bench_full.err; echo "bench rc=$?"
 timeout -k 10 600 python3 bench.py --steps 20 --warmup 5 > gpurun_out/bench_window.json 2> gpurun_out/bench_window.err; echo "window rc=$?"
-timeout -k 10 600 python3 tools/soak_parity.py > gpurun_out/soak_parity.txt 2>&1; echo "soak rc=$?"; tail -3 gpurun_out/soak_parity.txt
