@@ -133,7 +133,7 @@ def dimitrov_and_pldp(wg, dev, stream, B=4096):
     nit = torch.zeros(B, dtype=torch.int32, device=dev); nact = torch.zeros(B, dtype=torch.int32, device=dev)
     n_removed = np.zeros(B, np.int32); starting = np.ones(B, np.int32)
     karr = np.arange(N)
-    WARM, MEAS = 2, 3
+    WARM, MEAS = 6, 8                                        # hot-start state settles over the first ticks of a plan (tools/probe_pldp.py: 30)
     ms, iters, mrows, bytes_tot = [], [], [], 0.0
     for it in range(WARM + MEAS):
         win = table[plan_id[:, None], (it + offs)[:, None] + np.arange(N)[None, :]]              # B x N polytopes
