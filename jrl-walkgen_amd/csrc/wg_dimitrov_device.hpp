@@ -271,10 +271,15 @@ struct DimitrovQldProb {
   static constexpr bool kRowOps = false;
   static constexpr bool kWideN = false;
   static constexpr int kNM = 2 * WG_PLDP_N;               // n = 2N <= 32: the compile-time-bounded forms of the solver
-  const double *c0, *c1;                                  // LDS: polytope coefficients of every row
+  // Read-only operands stay where they are (global memory, L1-resident: the polytopes of the gait, the model's Pu table): the
+  // rows the scan walks are in registers (below), so these are read once per solve (row norms, load_rows, residual refresh) --
+  // and the 4 KB of LDS they took as copies are what separates six from eight gaits per CU.
+  const wg_zmp_polytope_t *polys;                         // global: the gait's N polytopes (row k = face k - rowbase[i] of instant i)
   const int *slot;                                        // LDS: the row's instant
-  const double *PuT;                                      // LDS: the Pu table, N x N (entry [k N + i]; QLD: Pu', zero for k > i)
+  const int *rowbase;                                     // LDS: first row of every instant
+  const double *PuT;                                      // global: the Pu table, N x N (entry [k N + i]; QLD: Pu', zero for k > i)
   int N;
+  __device__ __forceinline__ double coef(int k, int inst, int axis) const { return polys[inst].A[k - rowbase[inst]][axis]; }
   __device__ __forceinline__ double G(const QlView &q, int i, int j) const {
     if constexpr (kLQ) return i == j ? q.Gdiag[i] : 0.0;    // m_Q = identity (:537-540)
     else {
@@ -290,11 +295,33 @@ struct DimitrovQldProb {
     const bool second = i >= N;
     const int kk = second ? i - N : i;
     const int inst = slot[k];
-    const double a = second ? c1[k] : c0[k];
+    const double a = coef(k, inst, second ? 1 : 0);
     if constexpr (kLQ) return a * PuT[kk * N + inst];
     else {
       const double pu = PuT[kk * N + (kk <= inst ? inst : kk)];      // clamped address, selected value
       return kk <= inst ? a * pu : 0.0;                              // memset zero beyond the triangle (:782)
+    }
+  }
+  // m <= WG_PLDP_MMAX = 128: the two rows a lane owns (lane, 64 + lane) as their n <= 32 entries in registers, formed ONCE per solve
+  // from the same expression as A() -- the violation scan then reads nothing but x, the new normal is written out by its owner
+  // (the register-row interface of the solver, like DenseRegProb)
+  static constexpr bool kRegRows = true;
+  double ar0[kNM], ar1[kNM];
+  __device__ __forceinline__ void load_rows(const QlView &q, int lane) {
+    const int m = q.m;
+    const int k0 = lane < m ? lane : m - 1, k1 = lane + 64 < m ? lane + 64 : m - 1;
+#pragma unroll
+    for (int i = 0; i < kNM; ++i) {
+      const int ic = i < q.n ? i : q.n - 1;
+      ar0[i] = A(q, k0, ic); ar1[i] = A(q, k1, ic);
+    }
+  }
+  __device__ __forceinline__ void row_to(const QlView &q, int k, double *dst, int lane) const {
+    const int n = q.n;
+    if (lane == (k & 63)) {
+#pragma unroll
+      for (int i = 0; i < kNM; ++i)
+        if (i < n) dst[i] = k < 64 ? ar0[i] : ar1[i];
     }
   }
 };
@@ -304,8 +331,8 @@ __host__ __device__ inline size_t dimitrov_qld_ql_bytes() {
   return (QlDims(2 * WG_PLDP_N, WG_PLDP_MMAX, WG_PLDP_MMAX, true, false, kDimQldNsc, false, true, true, true, 0, false).bytes() + 15) & ~(size_t)15;
 }
 __host__ __device__ inline size_t dimitrov_qld_lds_bytes() {
-  // solver area | c0 c1 (mcap each) | Pu table (N x N) | zr (2N) | NewX (2N) | xk (8) | slot (mcap ints) | rowbase (N + 1 ints)
-  return dimitrov_qld_ql_bytes() + 8 * (size_t)(2 * WG_PLDP_MMAX + WG_PLDP_N * WG_PLDP_N + 4 * WG_PLDP_N + 8) +
+  // solver area | zr (2N) | NewX (2N) | xk (8) | slot (mcap ints) | rowbase (N + 1 ints)
+  return dimitrov_qld_ql_bytes() + 8 * (size_t)(4 * WG_PLDP_N + 8) +
          4 * (size_t)(WG_PLDP_MMAX + ((WG_PLDP_N + 2) & ~1)) + 16;
 }
 
@@ -315,8 +342,6 @@ __device__ void dimitrov_qld_tick(const DimitrovConst &K, double *lds, const wg_
   const int lane = wg_lane();
   const int N = K.N, n = 2 * N, mcap = WG_PLDP_MMAX;
   double *t = reinterpret_cast<double *>(reinterpret_cast<char *>(lds) + dimitrov_qld_ql_bytes());
-  double *c0 = t; t += mcap; double *c1 = t; t += mcap;
-  double *PuT = t; t += WG_PLDP_N * WG_PLDP_N;
   double *zr = t; t += 2 * WG_PLDP_N;
   double *NewX = t; t += 2 * WG_PLDP_N;
   double *xk = t; t += 8;
@@ -348,11 +373,10 @@ __device__ void dimitrov_qld_tick(const DimitrovConst &K, double *lds, const wg_
       const double dpx = (xk[0] * px[0] + xk[1] * px[1] + xk[2] * px[2]) * a0 + (xk[3] * px[0] + xk[4] * px[1] + xk[5] * px[2]) * a1 +
                          polys[i].B[j];
       q.b[idx] = -dpx;                                         // inner sign, qld.cpp:469-475
-      c0[idx] = a0; c1[idx] = a1; slot[idx] = i;
+      slot[idx] = i;
     }
   }
   if (lane < N) { zr[lane] = polys[lane].centre[0]; zr[lane + N] = polys[lane].centre[1]; }
-  for (int e = lane; e < N * N; e += 64) PuT[e] = PuSrc[e];
   if (lane < n) q.Gdiag[lane] = kLQ ? 1.0 : K.Qq[lane + lane * n];
   WG_WSYNC();
   // ---- D = OptB xk - OptC ZMPRef :1254-1262 ----
@@ -363,7 +387,7 @@ __device__ void dimitrov_qld_tick(const DimitrovConst &K, double *lds, const wg_
     q.d[lane] = od - l1;
   }
   DimitrovQldProb<kLQ> prob;
-  prob.c0 = c0; prob.c1 = c1; prob.slot = slot; prob.PuT = PuT; prob.N = N;
+  prob.polys = polys; prob.slot = slot; prob.rowbase = rowbase; prob.PuT = PuSrc; prob.N = N;
   if (lane == 0 && fabs(prob.Gd(q, n - 1)) == 0.0) prob.setGd(q, n - 1, 1e-8);    // qld.cpp:442-444 (nmax == n)
   WG_WSYNC();
   const QlResult r = ql_solve(q, prob, 1e-8, nullptr, 0);
