@@ -308,12 +308,24 @@ struct DimitrovQldProb {
   static constexpr bool kRegRows = true;
   double ar0[kNM], ar1[kNM];
   __device__ __forceinline__ void load_rows(const QlView &q, int lane) {
-    const int m = q.m;
+    const int m = q.m, n = q.n;
     const int k0 = lane < m ? lane : m - 1, k1 = lane + 64 < m ? lane + 64 : m - 1;
+    const int i0 = slot[k0], i1 = slot[k1];
+    const double a00 = coef(k0, i0, 0), a01 = coef(k0, i0, 1), a10 = coef(k1, i1, 0), a11 = coef(k1, i1, 1);
+    // the element expression of A(), with the row's (instant, coefficients) fetched once
 #pragma unroll
     for (int i = 0; i < kNM; ++i) {
-      const int ic = i < q.n ? i : q.n - 1;
-      ar0[i] = A(q, k0, ic); ar1[i] = A(q, k1, ic);
+      const int ic = i < n ? i : n - 1;
+      const bool second = ic >= N;
+      const int kk = second ? ic - N : ic;
+      if constexpr (kLQ) {
+        ar0[i] = (second ? a01 : a00) * PuT[kk * N + i0];
+        ar1[i] = (second ? a11 : a10) * PuT[kk * N + i1];
+      } else {
+        const double p0 = PuT[kk * N + (kk <= i0 ? i0 : kk)], p1 = PuT[kk * N + (kk <= i1 ? i1 : kk)];
+        ar0[i] = kk <= i0 ? (second ? a01 : a00) * p0 : 0.0;
+        ar1[i] = kk <= i1 ? (second ? a11 : a10) * p1 : 0.0;
+      }
     }
   }
   __device__ __forceinline__ void row_to(const QlView &q, int k, double *dst, int lane) const {
