@@ -195,15 +195,17 @@ def test_step_sequences_to_com_through_zmpdisc_footconstraints_and_the_tick():
         assert np.hypot(so[b].xk[0] - feet_mid[0], so[b].xk[3] - feet_mid[1]) < 0.15, b
 
 
-def _qld_setup(mode):
+def _qld_setup(mode, N=None):
     wg.init(0)
     model = wg.dimitrov_defaults()
+    if N:
+        model.N = N                                            # n = 2N < 32: the register rows' unused tail
     model.solver = mode                                        # 1 = WG_DIMITROV_QLD, 2 = WG_DIMITROV_QLDANDLQ
     wg.dimitrov_configure(model)
     return model, wg.dimitrov_constants(model.N), wg.dimitrov_qld_constants(model.N)
 
 
-@pytest.mark.parametrize("mode,ql", [(2, "reference"), (2, "restated"), (1, "reference"), (1, "restated")])
+@pytest.mark.parametrize("mode,ql", [(2, "reference"), (2, "restated"), (1, "reference"), (1, "restated"), (2, "restated-N12"), (2, "reference-N10")])
 def test_fused_tick_with_the_ql_back_ends_bit_exact(mode, ql):
     """The reference's modes QLDANDLQ (2) and QLD (1) (ZMPConstrainedQPFastFormulation.cpp:1297-1320): ql0001_ as the tick's
     solver.  The GPU tick solves with the in-wave ql0002 through a structured view of DPu; the oracle tick builds the dense arrays
@@ -213,7 +215,8 @@ def test_fused_tick_with_the_ql_back_ends_bit_exact(mode, ql):
     reference.  Mode QLDANDLQ walks; mode QLD is the reference's, literally: its OptA carries alpha VPu' instead of alpha VPu'VPu
     (:524-527), not symmetric, upper triangle not positive definite -- ql0001_ answers ifail = 2 ("accuracy insufficient") on
     the first tick there (the driver prints IFAIL and stops, :1348-1352) and here."""
-    model, K, Kq = _qld_setup(mode)
+    ql, _, small = ql.partition("-N")
+    model, K, Kq = _qld_setup(mode, int(small) if small else None)
     N = model.N
     lib = ol.oracle()
     if ql == "reference":
