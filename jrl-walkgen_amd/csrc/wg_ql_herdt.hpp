@@ -785,21 +785,25 @@ struct HerdtElemProbT {
       const int klast = (k0 + 63 < 4 * N) ? k0 + 63 : 4 * N;
       const int rmax = (klast - 1) >> 2;                    // instant of the pass's last CoP row
       const double ac = cop ? a : 0.0, bc = cop ? b : 0.0;
+#ifndef WG_SCAN_CH
+#define WG_SCAN_CH 4
+#endif
+      constexpr int CH = WG_SCAN_CH;                         // terms whose operands are requested together, ahead of the two add chains
 #pragma unroll 1
-      for (int c0 = 0; c0 <= rmax; c0 += 4) {
-        double vv[4], uu[4];
+      for (int c0 = 0; c0 <= rmax; c0 += CH) {
+        double vv[CH], uu[CH];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) { const int d = r - c0 - e, ci = c0 + e < N ? c0 + e : N - 1; vv[e] = v[ci]; uu[e] = u[d > -1 ? d : -1]; }
+        for (int e = 0; e < CH; ++e) { const int d = r - c0 - e, ci = c0 + e < N ? c0 + e : N - 1; vv[e] = v[ci]; uu[e] = u[d > -1 ? d : -1]; }
 #pragma unroll
-        for (int e = 0; e < 4; ++e) { const double t = vv[e] * (0.0 - ac * uu[e]); sum += t; asum += fabs(t); }
+        for (int e = 0; e < CH; ++e) { const double t = vv[e] * (0.0 - ac * uu[e]); sum += t; asum += fabs(t); }
       }
 #pragma unroll 1
-      for (int c0 = 0; c0 <= rmax; c0 += 4) {
-        double vv[4], uu[4];
+      for (int c0 = 0; c0 <= rmax; c0 += CH) {
+        double vv[CH], uu[CH];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) { const int d = r - c0 - e, ci = c0 + e < N ? c0 + e : N - 1; vv[e] = v[N + ci]; uu[e] = u[d > -1 ? d : -1]; }
+        for (int e = 0; e < CH; ++e) { const int d = r - c0 - e, ci = c0 + e < N ? c0 + e : N - 1; vv[e] = v[N + ci]; uu[e] = u[d > -1 ? d : -1]; }
 #pragma unroll
-        for (int e = 0; e < 4; ++e) { const double t = vv[e] * (0.0 - bc * uu[e]); sum += t; asum += fabs(t); }
+        for (int e = 0; e < CH; ++e) { const double t = vv[e] * (0.0 - bc * uu[e]); sum += t; asum += fabs(t); }
       }
       const int j = (r >= 0) ? stepidx[r] - 1 : -1;
       const bool st = j >= 0 && j < ns;
