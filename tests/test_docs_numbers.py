@@ -22,3 +22,22 @@ def test_every_profile_file_the_documents_cite_exists():
             if not os.path.exists(os.path.join(ROOT, "profiles", m.group(1))):
                 missing.append((doc, m.group(1)))
     assert not missing, missing
+
+
+def test_filed_resource_audit_keeps_the_headline_kernels_budget():
+    """VERDICT r3 item 3, as a standing check on the FILED audit (tools/isa_audit.py regenerates it in minutes, without a GPU): the
+    multi-tick kernel of the benchmark spills at most 56 B of scratch per lane and none of its scratch traffic sits inside the
+    active-set iteration (depth >= 2); the N = 32 instantiation keeps its scratch traffic out of the inner loops (depth >= 3)."""
+    import re
+    txt = open(os.path.join(ROOT, "profiles", "round4_resource_usage.txt")).read()
+    m = re.search(r"^wg_mpc_run_xcd_kernel<16>\s+(\d+)\s+(\d+)\s+(\d+)\s+(\d+)\s+(\d+)\s+(\d+)\s+(\d+)\s*$", txt, re.M)
+    assert m, "no row for wg_mpc_run_xcd_kernel<16>"
+    vgpr, agpr, sgpr, vspill, sspill, scratch, occ = (int(x) for x in m.groups())
+    assert scratch <= 56 and vspill <= 17 and occ == 2, (vspill, scratch, occ)
+
+    def scratch_by_depth(kernel):
+        blk = txt[txt.index(kernel + ":"):]
+        line = re.search(r"scratch\s+total\s+(\d+)\s+by depth: (.*)", blk)
+        return {int(a): int(b) for a, b in re.findall(r"d(\d+): (\d+)", line.group(2))}
+    assert sum(n for d, n in scratch_by_depth("wg_mpc_run_xcd_kernel<16>").items() if d >= 2) == 0
+    assert sum(n for d, n in scratch_by_depth("wg_mpc_run_xcd_kernel<32>").items() if d >= 3) == 0
