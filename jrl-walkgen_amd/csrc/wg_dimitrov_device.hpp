@@ -270,6 +270,7 @@ struct DimitrovQldProb {
   static constexpr bool kHasFactor = false;
   static constexpr bool kRowOps = false;
   static constexpr bool kWideN = false;
+  static constexpr int kFixedLdz = 0;                     // run-time carve (n = 2N varies with the model)
   static constexpr int kNM = 2 * WG_PLDP_N;               // n = 2N <= 32: the compile-time-bounded forms of the solver
   // Read-only operands stay where they are (global memory, L1-resident: the polytopes of the gait, the model's Pu table): the
   // rows the scan walks are in registers (below), so these are read once per solve (row norms, load_rows, residual refresh) --

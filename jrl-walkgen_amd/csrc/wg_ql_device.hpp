@@ -271,6 +271,7 @@ struct DenseProbT {
   static constexpr int kNM = kNMc;     // 0: no compile-time bound on n; > 0: n <= kNM (the Herdt-sized boundary kernel: the
                                        // compile-time-bounded forms of the sweep, the back substitution and the ordered sums)
   static constexpr bool kWideN = false;  // 64 <= n <= 128 is not known at compile time: the wide (two rows / columns per lane) forms by test
+  static constexpr int kFixedLdz = kNMc > 0 ? (kNMc | 1) : 0;   // > 0: Z in LDS with this leading dimension (carve_fixed_dense)
   __device__ __forceinline__ double G(const QlView &q, int i, int j) const;
   __device__ __forceinline__ double A(const QlView &q, int k, int i) const;
   __device__ __forceinline__ double Gd(const QlView &q, int i) const;
@@ -650,7 +651,7 @@ __device__ __forceinline__ void backsub(const QlView &q, const double *s, int na
 // buf: 2 * kBsLen doubles of LDS (the four scratch vectors are contiguous).
 // one row of backsub_lds: P = {terms k = j+2 .. j+9, R(j, j+1)} prefetched by the previous row, Nx receives the same for
 // row j-1.  Two copies of this body with P / Nx swapped make the hand-over a renaming instead of nine register moves.
-struct BsState { double w, wprev, rr, sreg, dreg; int col, nact, lane; bool mine; };
+struct BsState { double w, wprev, rr, sreg, dreg, rsd; int col, nact, lane; bool mine; };   // rsd: R(lane, lane + 1), the first term's coefficient of row `lane`
 // kHead: what is known about the row's length at compile time (the rows go from the bottom up, so the r-th row from the bottom has
 // r terms): -1 nothing (three uniform branches per row), 0 no term, 4 / 8 at most so many (the prefetched head only: entries
 // past the row are +0.0), 9 more than eight (head and tail loop, no test) -- backsub_lds unrolls the first nine rows that way
@@ -671,9 +672,20 @@ __device__ __forceinline__ void bs_row(const QlView &q, double *buf, int j, BsSt
     S.rr = Rp(jnn, S.col);
   }
   __builtin_amdgcn_wave_barrier();
+  if constexpr (kBsLen <= 64) {
+    // the eight terms through ONE address register with constant offsets (the scalar address arithmetic and the move into a vector
+    // register were repeated for every pair), the superdiagonal entry from the register its row's lane loaded before the first row
+    typedef __attribute__((address_space(3))) double lds_f64;
+    const lds_f64 *np = (const lds_f64 *)(bn + j + 1);
+    asm volatile("" : "+v"(np));
 #pragma unroll
-  for (int e = 0; e < 8; ++e) Nx[e] = bn[j + 1 + e];        // prefetch: the next row's first terms
-  Nx[8] = Rp(jn, jn + 1);
+    for (int e = 0; e < 8; ++e) Nx[e] = np[e];              // prefetch: the next row's first terms
+    Nx[8] = rl(S.rsd, jn);
+  } else {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) Nx[e] = bn[j + 1 + e];      // prefetch: the next row's first terms
+    Nx[8] = Rp(jn, jn + 1);
+  }
   const double sj = rl(S.sreg, j), dj = rl(S.dreg, j);
   double sum = 0.0;
   if constexpr (kHead >= 4) {
@@ -725,7 +737,11 @@ __device__ __forceinline__ void backsub_lds(const QlView &q, const double *s, in
     S.sreg = S.mine ? s[lane] : 0.0;
     S.dreg = S.mine ? Rp(lane, lane) : 1.0;
   }
-  if constexpr (kBsLen <= 64) { const int zl = lane < kBsLen ? lane : kBsLen - 1; buf[zl] = 0.0; buf[kBsLen + zl] = 0.0; }
+  if constexpr (kBsLen <= 64) {
+    const int zl = lane < kBsLen ? lane : kBsLen - 1; buf[zl] = 0.0; buf[kBsLen + zl] = 0.0;
+    const int rlc = lane + 1 < nact ? lane : 0;              // rows without a first term (the last one, lanes past it) read R(0, 1): unused
+    S.rsd = Rp(rlc, rlc + 1);
+  }
   else { for (int e = lane; e < kBsLen; e += 64) { buf[e] = 0.0; buf[kBsLen + e] = 0.0; } }
   S.col = S.mine ? lane : 0;
   S.w = 0.0; S.wprev = 0.0;
@@ -800,6 +816,7 @@ __device__ __forceinline__ double ordered_sum_lds(double term, double *scratch, 
 //   phase 1  chain of rotation norms (all lanes redundantly; s[c-1] prefetched); lane c records its rotation;
 //   phase 2  lane c turns (p, q, norm) into (ga, gb) and publishes the pair in LDS;
 //   phase 3  lane i carries row i of Z through the rotations.
+template <int kLdzC = 0>                                     // > 0: Z lives in LDS with this leading dimension (every compile-time-bounded view)
 __device__ __forceinline__ void sweep_flat(const QlView &q, double *s, int nu, int nact, int lane PT_SW_PARAM) {
   const int n = q.n;
   if (nu - 1 <= nact) return;
@@ -811,29 +828,39 @@ __device__ __forceinline__ void sweep_flat(const QlView &q, double *s, int nu, i
   double *chain = q.sc2;                                    // nu <= n entries
   WG_REP(3)
   if (sweep_range_ok<true>(s, nact, nu, lane)) {
-    // the usual case: the shorter norm; unrolled by two so that handing the prefetched operand on is a renaming
+    // the usual case: the shorter norm; unrolled by two so that handing the prefetched operand on is a renaming.  The operand
+    // and the record are reached through two walking pointers kept in vector registers (constant offsets in the ds instructions,
+    // one v_add per pair of rotations) instead of clamped indices rebuilt from the scalar counter for every access; the operand
+    // fetched ahead of the LAST rotation may lie one or two entries below s (nact = 0): in the wave's LDS (s is never the first
+    // array of a view; an out-of-range LDS read returns zero anyway), and never used.
     double cur = s[nu - 1];
     double pa = s[nu - 2], pb;
     int c = nu - 1;
+    typedef __attribute__((address_space(3))) double lds_f64;  // s (R's working column) and the scratch vectors are LDS in every view that sweeps here
+    const lds_f64 *sp = (const lds_f64 *)(s + (nu - 4));      // sp[1] = s[c - 2], sp[0] = s[c - 3]
+    lds_f64 *cp = (lds_f64 *)(chain + (nu - 3));              // cp[1] = chain[c - 1], cp[0] = chain[c - 2]
+    asm volatile("" : "+v"(sp), "+v"(cp));
     if (WG_UBOOL(cur != 0.0)) {
       // a norm is at least its larger operand: once cur is non-zero it stays non-zero, no rotation is skipped and the
       // "cur == 0 ? p : norm" select of the general form below always takes the norm
       for (;;) {
-        pb = s[(c - 2 >= 0) ? c - 2 : 0];                   // operand of the next rotation, off the chain
-        cur = givens_norm_fast(pa, cur); chain[c - 1] = cur;
+        pb = sp[1];                                         // operand of the next rotation, off the chain
+        cur = givens_norm_fast(pa, cur); cp[1] = cur;
         if (--c <= nact) break;
-        pa = s[(c - 2 >= 0) ? c - 2 : 0];
-        cur = givens_norm_fast(pb, cur); chain[c - 1] = cur;
+        pa = sp[0];
+        cur = givens_norm_fast(pb, cur); cp[0] = cur;
         if (--c <= nact) break;
+        sp -= 2; cp -= 2;
       }
     } else
     for (;;) {
-      pb = s[(c - 2 >= 0) ? c - 2 : 0];
-      { const double nrmc = givens_norm_fast(pa, cur); cur = (cur == 0.0) ? pa : nrmc; chain[c - 1] = cur; }
+      pb = sp[1];
+      { const double nrmc = givens_norm_fast(pa, cur); cur = (cur == 0.0) ? pa : nrmc; cp[1] = cur; }
       if (--c <= nact) break;
-      pa = s[(c - 2 >= 0) ? c - 2 : 0];
-      { const double nrmc = givens_norm_fast(pb, cur); cur = (cur == 0.0) ? pb : nrmc; chain[c - 1] = cur; }
+      pa = sp[0];
+      { const double nrmc = givens_norm_fast(pb, cur); cur = (cur == 0.0) ? pb : nrmc; cp[0] = cur; }
       if (--c <= nact) break;
+      sp -= 2; cp -= 2;
     }
   } else {
     double cur = s[nu - 1];
@@ -921,7 +948,49 @@ __device__ __forceinline__ void sweep_flat(const QlView &q, double *s, int nu, i
       // operands through two walking pointers with constant offsets (no clamp, no index arithmetic), the three register sets
       // handed on where the loop closes -- the stepping loop below (clamped fetches, a test per rotation, and the moves the
       // compiler needs to make its three exits agree) took 23 instructions per rotation for 6 of arithmetic and 3 of LDS
-      {
+      if constexpr (kLdzC > 0) {
+        // Z in LDS with a constant leading dimension: every operand and every store of a group through THREE address registers
+        // (the group's lowest column of operands, of pairs, of stores) with constant offsets -- a v_add, or a scalar add and a move
+        // into a vector register, per access otherwise
+        typedef __attribute__((address_space(3))) double lds_f64;
+        constexpr int L = kLdzC;
+        while (c - 8 > nact) {                              // six at a time: the two register sets swap roles, no moves
+          const lds_f64 *zlo = (const lds_f64 *)(q.Z + i + (c - 9) * L);      // Z(i, c - 9): operand of rotation c - 8
+          const lds_f64 *glo = (const lds_f64 *)(gab + 2 * (c - 8));
+          lds_f64 *zst = (lds_f64 *)(q.Z + i + (c - 5) * L);                   // Z(i, c - 5): the group's last store
+          asm volatile("" : "+v"(zlo), "+v"(glo), "+v"(zst));
+          Op n0, n1, n2;
+          n0.zl = zlo[5 * L]; n0.ga = glo[10]; n0.gb = glo[11];
+          n1.zl = zlo[4 * L]; n1.ga = glo[8];  n1.gb = glo[9];
+          n2.zl = zlo[3 * L]; n2.ga = glo[6];  n2.gb = glo[7];
+          { const double t = s0.ga * s0.zl + s0.gb * carry; zst[5 * L] = s0.ga * carry - s0.gb * s0.zl; carry = t; }
+          { const double t = s1.ga * s1.zl + s1.gb * carry; zst[4 * L] = s1.ga * carry - s1.gb * s1.zl; carry = t; }
+          { const double t = s2.ga * s2.zl + s2.gb * carry; zst[3 * L] = s2.ga * carry - s2.gb * s2.zl; carry = t; }
+          s0.zl = zlo[2 * L]; s0.ga = glo[4]; s0.gb = glo[5];
+          s1.zl = zlo[L];     s1.ga = glo[2]; s1.gb = glo[3];
+          s2.zl = zlo[0];     s2.ga = glo[0]; s2.gb = glo[1];
+          { const double t = n0.ga * n0.zl + n0.gb * carry; zst[2 * L] = n0.ga * carry - n0.gb * n0.zl; carry = t; }
+          { const double t = n1.ga * n1.zl + n1.gb * carry; zst[L] = n1.ga * carry - n1.gb * n1.zl; carry = t; }
+          { const double t = n2.ga * n2.zl + n2.gb * carry; zst[0] = n2.ga * carry - n2.gb * n2.zl; carry = t; }
+          c -= 6;
+        }
+        while (c - 5 > nact) {
+          const lds_f64 *zlo = (const lds_f64 *)(q.Z + i + (c - 6) * L);      // Z(i, c - 6): operand of rotation c - 5
+          const lds_f64 *glo = (const lds_f64 *)(gab + 2 * (c - 5));
+          lds_f64 *zst = (lds_f64 *)(q.Z + i + (c - 2) * L);
+          asm volatile("" : "+v"(zlo), "+v"(glo), "+v"(zst));
+          Op n0, n1, n2;
+          n0.zl = zlo[2 * L]; n0.ga = glo[4]; n0.gb = glo[5];
+          n1.zl = zlo[L];     n1.ga = glo[2]; n1.gb = glo[3];
+          n2.zl = zlo[0];     n2.ga = glo[0]; n2.gb = glo[1];
+          { const double t = s0.ga * s0.zl + s0.gb * carry; zst[2 * L] = s0.ga * carry - s0.gb * s0.zl; carry = t; }
+          { const double t = s1.ga * s1.zl + s1.gb * carry; zst[L] = s1.ga * carry - s1.gb * s1.zl; carry = t; }
+          { const double t = s2.ga * s2.zl + s2.gb * carry; zst[0] = s2.ga * carry - s2.gb * s2.zl; carry = t; }
+          s0 = n0; s1 = n1; s2 = n2;
+          c -= 3;
+        }
+        zp = q.Z + i + c * ldz;                              // where the stepping loop goes on
+      } else {
         const double *zq = q.Z + i + (c - 4) * ldz;          // Z(i, c - 4): operand of rotation c - 3
         const double *gq = gab + 2 * (c - 3);
         while (c - 8 > nact) {                              // six at a time: the two register sets swap roles, no moves
@@ -1640,7 +1709,7 @@ __device__ __forceinline__ bool chol_inverse_regs(const QlView &q, const P &prob
 // element view is built for n > 64: it keeps the one form it needs, its kernel is large enough as it is)
 #define WG_SWEEP(q, s, nu, nact, lane) \
   do { if constexpr (kRegs) zr_sweep(q, *zr, s, nu, nact, lane); else \
-       if (P::kNM > 0 || (!P::kRowOps && q.n <= 64)) sweep_flat(q, s, nu, nact, lane PT_SW_ARG); else sweep<(P::kRowOps ? WG_ELEM_GRP : 8), P::kWideN>(q, s, nu, nact, lane); } while (0)
+       if (P::kNM > 0 || (!P::kRowOps && q.n <= 64)) sweep_flat<P::kFixedLdz>(q, s, nu, nact, lane PT_SW_ARG); else sweep<(P::kRowOps ? WG_ELEM_GRP : 8), P::kWideN>(q, s, nu, nact, lane); } while (0)
 
 template <class P, class ZR = NoZRegs>
 __device__ __forceinline__ QlResult ql_solve(const QlView &q, P &prob, double vsmall, int *hist, int hist_cap, QlResume *rs = nullptr,

@@ -240,6 +240,7 @@ struct HerdtProb {
   static constexpr bool kRowOps = false;       // the compact view has its own register-row paths
   static constexpr int kNM = 2 * NH + 2 * 2;   // n <= 2N + 2*2: at most two previewed steps (checked by wg_mpc_configure)
   static constexpr bool kWideN = false;
+  static constexpr int kFixedLdz = kNM | 1;    // Z in LDS, leading dimension of carve_fixed<kNM, ...>
   static_assert(4 * NH == 64, "one CoP row per lane needs 4N == 64");
   // ---- LDS / global tables (wave-uniform pointers) ----
   const double *Qb;       // global (L1/L2-resident constant of the model), NH x kQbLd
@@ -664,6 +665,7 @@ struct HerdtElemProbT {
   static constexpr bool kRowOps = true;        // row products walk the row's structure instead of calling A() per element
   static constexpr int kNM = 0;
   static constexpr bool kWideN = NHC >= 32;    // 64 <= n <= 128 for every problem of the model
+  static constexpr int kFixedLdz = 0;          // Z lives in the global slot
   static constexpr int kHorizon = NHC;         // (> 0: the compile-time horizon; rows 1 + 4 i + e are the CoP rows of instant i)
   struct NConst { static constexpr int v = NHC; __device__ __forceinline__ NConst &operator=(int) { return *this; } __device__ __forceinline__ operator int() const { return v; } };
   typename std::conditional<(NHC > 0), NConst, int>::type N;   // assigning to the constant form is a no-op
