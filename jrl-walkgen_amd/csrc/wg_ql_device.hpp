@@ -692,7 +692,19 @@ __device__ __forceinline__ void bs_row(const QlView &q, double *buf, int j, BsSt
     sum += P[8] * S.wprev;
     sum += P[0]; sum += P[1]; sum += P[2]; sum += P[3];
     if constexpr (kHead >= 8) { sum += P[4]; sum += P[5]; sum += P[6]; sum += P[7]; }
-    if constexpr (kHead >= 9) {
+    if constexpr (kHead >= 9 && kBsLen <= 64) {
+      // the tail through one walking address register: entries up to nact + 6 <= kBsLen - 6 are read (nact <= kBsLen - 12), no clamp
+      typedef __attribute__((address_space(3))) double lds_f64;
+      const lds_f64 *tp = (const lds_f64 *)(bj + j + 10);
+      asm volatile("" : "+v"(tp));
+      double a0 = tp[0], a1 = tp[1], a2 = tp[2], a3 = tp[3];
+      for (int k = j + 10; k < nact; k += 4) {
+        const double b0 = tp[4], b1 = tp[5], b2 = tp[6], b3 = tp[7];
+        sum += a0; sum += a1; sum += a2; sum += a3;
+        a0 = b0; a1 = b1; a2 = b2; a3 = b3;
+        tp += 4;
+      }
+    } else if constexpr (kHead >= 9) {
       double a0 = bj[j + 10], a1 = bj[j + 11], a2 = bj[j + 12], a3 = bj[j + 13];
       for (int k = j + 10; k < nact; k += 4) {
         const int kn = k + 4 < kBsLen - 4 ? k + 4 : kBsLen - 4;                    // clamped: unused past the end
@@ -1015,6 +1027,30 @@ __device__ __forceinline__ void sweep_flat(const QlView &q, double *s, int nu, i
           zq -= 3 * ldz; gq -= 6; c -= 3;
         }
       }
+      if constexpr (kLdzC > 0) {
+        // the last one to five rotations, straight-line per count: columns relative to nact through two address registers with
+        // constant offsets, the operands of the first three rotations are in s0 / s1 / s2 already, the others are requested
+        // together before the first rotation; ends with Z(i, nact) = carry
+        typedef __attribute__((address_space(3))) double lds_f64;
+        constexpr int L = kLdzC;
+        lds_f64 *zb = (lds_f64 *)(q.Z + i + nact * L);        // Z(i, nact)
+        const lds_f64 *gb_ = (const lds_f64 *)(gab + 2 * nact);
+        asm volatile("" : "+v"(zb), "+v"(gb_));
+        auto rot = [&](const Op &o, int k) {                  // rotation nact + k: stores Z(i, nact + k)
+          const double t = o.ga * o.zl + o.gb * carry;
+          zb[k * L] = o.ga * carry - o.gb * o.zl;
+          carry = t;
+        };
+        auto ld = [&](int k) -> Op { Op o; o.zl = zb[(k - 1) * L]; o.ga = gb_[2 * k]; o.gb = gb_[2 * k + 1]; return o; };
+        switch (c - nact) {
+          case 5: { const Op o2 = ld(2), o1 = ld(1); rot(s0, 5); rot(s1, 4); rot(s2, 3); rot(o2, 2); rot(o1, 1); break; }
+          case 4: { const Op o1 = ld(1); rot(s0, 4); rot(s1, 3); rot(s2, 2); rot(o1, 1); break; }
+          case 3: rot(s0, 3); rot(s1, 2); rot(s2, 1); break;
+          case 2: rot(s0, 2); rot(s1, 1); break;
+          default: rot(s0, 1); break;
+        }
+        zb[0] = carry;                                        // Z(i, nact)
+      } else {
       for (;;) {                                            // the last (at most five) rotations
         { const Op nx = fetch(c - 3); rotate_all(s0); s0 = nx; }
         if (--c <= nact) break;
@@ -1023,8 +1059,10 @@ __device__ __forceinline__ void sweep_flat(const QlView &q, double *s, int nu, i
         { const Op nx = fetch(c - 3); rotate_all(s2); s2 = nx; }
         if (--c <= nact) break;
       }
+      zp[0] = carry;                                         // Z(i, nact)
+      }
     }
-    zp[0] = carry;                                           // Z(i, nact)
+    if (any_skip) zp[0] = carry;                             // Z(i, nact)
   }
   WG_WSYNC();
   PT_SW(2);
