@@ -672,7 +672,7 @@ __device__ __forceinline__ void bs_row(const QlView &q, double *buf, int j, BsSt
     S.rr = Rp(jnn, S.col);
   }
   __builtin_amdgcn_wave_barrier();
-  if constexpr (kBsLen <= 64) {
+  {
     // the eight terms through ONE address register with constant offsets (the scalar address arithmetic and the move into a vector
     // register were repeated for every pair), the superdiagonal entry from the register its row's lane loaded before the first row
     typedef __attribute__((address_space(3))) double lds_f64;
@@ -681,10 +681,6 @@ __device__ __forceinline__ void bs_row(const QlView &q, double *buf, int j, BsSt
 #pragma unroll
     for (int e = 0; e < 8; ++e) Nx[e] = np[e];              // prefetch: the next row's first terms
     Nx[8] = rl(S.rsd, jn);
-  } else {
-#pragma unroll
-    for (int e = 0; e < 8; ++e) Nx[e] = bn[j + 1 + e];      // prefetch: the next row's first terms
-    Nx[8] = Rp(jn, jn + 1);
   }
   const double sj = rl(S.sreg, j), dj = rl(S.dreg, j);
   double sum = 0.0;
@@ -692,7 +688,7 @@ __device__ __forceinline__ void bs_row(const QlView &q, double *buf, int j, BsSt
     sum += P[8] * S.wprev;
     sum += P[0]; sum += P[1]; sum += P[2]; sum += P[3];
     if constexpr (kHead >= 8) { sum += P[4]; sum += P[5]; sum += P[6]; sum += P[7]; }
-    if constexpr (kHead >= 9 && kBsLen <= 64) {
+    if constexpr (kHead >= 9) {
       // the tail through one walking address register: entries up to nact + 6 <= kBsLen - 6 are read (nact <= kBsLen - 12), no clamp
       typedef __attribute__((address_space(3))) double lds_f64;
       const lds_f64 *tp = (const lds_f64 *)(bj + j + 10);
@@ -704,14 +700,6 @@ __device__ __forceinline__ void bs_row(const QlView &q, double *buf, int j, BsSt
         a0 = b0; a1 = b1; a2 = b2; a3 = b3;
         tp += 4;
       }
-    } else if constexpr (kHead >= 9) {
-      double a0 = bj[j + 10], a1 = bj[j + 11], a2 = bj[j + 12], a3 = bj[j + 13];
-      for (int k = j + 10; k < nact; k += 4) {
-        const int kn = k + 4 < kBsLen - 4 ? k + 4 : kBsLen - 4;                    // clamped: unused past the end
-        const double b0 = bj[kn], b1 = bj[kn + 1], b2 = bj[kn + 2], b3 = bj[kn + 3];
-        sum += a0; sum += a1; sum += a2; sum += a3;
-        a0 = b0; a1 = b1; a2 = b2; a3 = b3;
-      }
     }
   } else if constexpr (kHead == 0) {
   } else
@@ -721,12 +709,15 @@ __device__ __forceinline__ void bs_row(const QlView &q, double *buf, int j, BsSt
     if (j + 6 < nact) {
       sum += P[4]; sum += P[5]; sum += P[6]; sum += P[7];
       if (j + 10 < nact) {
-        double a0 = bj[j + 10], a1 = bj[j + 11], a2 = bj[j + 12], a3 = bj[j + 13];
+        typedef __attribute__((address_space(3))) double lds_f64;
+        const lds_f64 *tp = (const lds_f64 *)(bj + j + 10);
+        asm volatile("" : "+v"(tp));
+        double a0 = tp[0], a1 = tp[1], a2 = tp[2], a3 = tp[3];
         for (int k = j + 10; k < nact; k += 4) {
-          const int kn = k + 4 < kBsLen - 4 ? k + 4 : kBsLen - 4;                  // clamped: unused past the end
-          const double b0 = bj[kn], b1 = bj[kn + 1], b2 = bj[kn + 2], b3 = bj[kn + 3];
+          const double b0 = tp[4], b1 = tp[5], b2 = tp[6], b3 = tp[7];
           sum += a0; sum += a1; sum += a2; sum += a3;
           a0 = b0; a1 = b1; a2 = b2; a3 = b3;
+          tp += 4;
         }
       }
     }
@@ -754,7 +745,11 @@ __device__ __forceinline__ void backsub_lds(const QlView &q, const double *s, in
     const int rlc = lane + 1 < nact ? lane : 0;              // rows without a first term (the last one, lanes past it) read R(0, 1): unused
     S.rsd = Rp(rlc, rlc + 1);
   }
-  else { for (int e = lane; e < kBsLen; e += 64) { buf[e] = 0.0; buf[kBsLen + e] = 0.0; } }
+  else {
+    for (int e = lane; e < kBsLen; e += 64) { buf[e] = 0.0; buf[kBsLen + e] = 0.0; }
+    const int rlc = lane + 1 < nact ? lane : 0;
+    S.rsd = Rp(rlc, rlc + 1);
+  }
   S.col = S.mine ? lane : 0;
   S.w = 0.0; S.wprev = 0.0;
   S.rr = Rp(nact >= 2 ? nact - 2 : 0, S.col);               // R(j-1, lane) of the row whose products are formed next
