@@ -1420,25 +1420,32 @@ __device__ __forceinline__ void sweep(const QlView &q, double *s, int nu, int na
     double cur = s[nu - 1];
     double pa = s[nu - 2], pb;
     int c = nu - 1;
+    // operand and record through ONE index kept in a vector register (s may be LDS or, once a solve went on in the global slot,
+    // global memory: the address space follows the caller, so an index, not a typed pointer): constant offsets in the loads and
+    // stores, one v_add per pair of rotations instead of a clamp, a shift, an add and a move per access.  The operand fetched
+    // ahead of the last rotation may lie one entry below s (nact = 0): inside the view's memory, never used.
+    int iv = nu - 4;                                        // s[iv + 1] = s[c - 2], chain[iv + 2] = chain[c - 1]
+    asm volatile("" : "+v"(iv));
     if (WG_UBOOL(cur != 0.0)) {                             // cur stays non-zero: no select (see sweep_flat)
       for (;;) {
-        pb = s[(c - 2 >= 0) ? c - 2 : 0];
-        cur = givens_norm_fast(pa, cur); chain[c - 1] = cur;
+        pb = s[iv + 1];
+        cur = givens_norm_fast(pa, cur); chain[iv + 2] = cur;
         if (--c <= nact) break;
-        pa = s[(c - 2 >= 0) ? c - 2 : 0];
-        cur = givens_norm_fast(pb, cur); chain[c - 1] = cur;
+        pa = s[iv];
+        cur = givens_norm_fast(pb, cur); chain[iv + 1] = cur;
         if (--c <= nact) break;
+        iv -= 2;
       }
     } else
     for (;;) {
-      pb = s[(c - 2 >= 0) ? c - 2 : 0];
-      { const double nrmc = givens_norm_fast(pa, cur); cur = (cur == 0.0) ? pa : nrmc; chain[c - 1] = cur; }
+      pb = s[iv + 1];
+      { const double nrmc = givens_norm_fast(pa, cur); cur = (cur == 0.0) ? pa : nrmc; chain[iv + 2] = cur; }
       if (--c <= nact) break;
-      pa = s[(c - 2 >= 0) ? c - 2 : 0];
-      { const double nrmc = givens_norm_fast(pb, cur); cur = (cur == 0.0) ? pb : nrmc; chain[c - 1] = cur; }
+      pa = s[iv];
+      { const double nrmc = givens_norm_fast(pb, cur); cur = (cur == 0.0) ? pb : nrmc; chain[iv + 1] = cur; }
       if (--c <= nact) break;
+      iv -= 2;
     }
-    WG_WSYNC();
   } else {
     double cur = s[nu - 1];
     double p = s[nu - 2];
