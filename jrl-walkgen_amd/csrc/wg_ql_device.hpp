@@ -847,27 +847,28 @@ __device__ __forceinline__ void sweep_flat(const QlView &q, double *s, int nu, i
     const lds_f64 *sp = (const lds_f64 *)(s + (nu - 4));      // sp[1] = s[c - 2], sp[0] = s[c - 3]
     lds_f64 *cp = (lds_f64 *)(chain + (nu - 3));              // cp[1] = chain[c - 1], cp[0] = chain[c - 2]
     asm volatile("" : "+v"(sp), "+v"(cp));
+    // pairs in a counted loop with ONE exit (the two-exit form cost a flag and a trampoline block per rotation), then the odd one
+    const int rots = c - nact;                              // >= 1
     if (WG_UBOOL(cur != 0.0)) {
       // a norm is at least its larger operand: once cur is non-zero it stays non-zero, no rotation is skipped and the
       // "cur == 0 ? p : norm" select of the general form below always takes the norm
-      for (;;) {
+      for (int k = rots >> 1; k > 0; --k) {
         pb = sp[1];                                         // operand of the next rotation, off the chain
         cur = givens_norm_fast(pa, cur); cp[1] = cur;
-        if (--c <= nact) break;
         pa = sp[0];
         cur = givens_norm_fast(pb, cur); cp[0] = cur;
-        if (--c <= nact) break;
         sp -= 2; cp -= 2;
       }
-    } else
-    for (;;) {
-      pb = sp[1];
-      { const double nrmc = givens_norm_fast(pa, cur); cur = (cur == 0.0) ? pa : nrmc; cp[1] = cur; }
-      if (--c <= nact) break;
-      pa = sp[0];
-      { const double nrmc = givens_norm_fast(pb, cur); cur = (cur == 0.0) ? pb : nrmc; cp[0] = cur; }
-      if (--c <= nact) break;
-      sp -= 2; cp -= 2;
+      if (rots & 1) { cur = givens_norm_fast(pa, cur); cp[1] = cur; }
+    } else {
+      for (int k = rots >> 1; k > 0; --k) {
+        pb = sp[1];
+        { const double nrmc = givens_norm_fast(pa, cur); cur = (cur == 0.0) ? pa : nrmc; cp[1] = cur; }
+        pa = sp[0];
+        { const double nrmc = givens_norm_fast(pb, cur); cur = (cur == 0.0) ? pb : nrmc; cp[0] = cur; }
+        sp -= 2; cp -= 2;
+      }
+      if (rots & 1) { const double nrmc = givens_norm_fast(pa, cur); cur = (cur == 0.0) ? pa : nrmc; cp[1] = cur; }
     }
   } else {
     double cur = s[nu - 1];
@@ -1426,25 +1427,25 @@ __device__ __forceinline__ void sweep(const QlView &q, double *s, int nu, int na
     // ahead of the last rotation may lie one entry below s (nact = 0): inside the view's memory, never used.
     int iv = nu - 4;                                        // s[iv + 1] = s[c - 2], chain[iv + 2] = chain[c - 1]
     asm volatile("" : "+v"(iv));
+    const int rots = c - nact;                              // >= 1: pairs in a counted loop with one exit, then the odd one (sweep_flat)
     if (WG_UBOOL(cur != 0.0)) {                             // cur stays non-zero: no select (see sweep_flat)
-      for (;;) {
+      for (int k = rots >> 1; k > 0; --k) {
         pb = s[iv + 1];
         cur = givens_norm_fast(pa, cur); chain[iv + 2] = cur;
-        if (--c <= nact) break;
         pa = s[iv];
         cur = givens_norm_fast(pb, cur); chain[iv + 1] = cur;
-        if (--c <= nact) break;
         iv -= 2;
       }
-    } else
-    for (;;) {
-      pb = s[iv + 1];
-      { const double nrmc = givens_norm_fast(pa, cur); cur = (cur == 0.0) ? pa : nrmc; chain[iv + 2] = cur; }
-      if (--c <= nact) break;
-      pa = s[iv];
-      { const double nrmc = givens_norm_fast(pb, cur); cur = (cur == 0.0) ? pb : nrmc; chain[iv + 1] = cur; }
-      if (--c <= nact) break;
-      iv -= 2;
+      if (rots & 1) { cur = givens_norm_fast(pa, cur); chain[iv + 2] = cur; }
+    } else {
+      for (int k = rots >> 1; k > 0; --k) {
+        pb = s[iv + 1];
+        { const double nrmc = givens_norm_fast(pa, cur); cur = (cur == 0.0) ? pa : nrmc; chain[iv + 2] = cur; }
+        pa = s[iv];
+        { const double nrmc = givens_norm_fast(pb, cur); cur = (cur == 0.0) ? pb : nrmc; chain[iv + 1] = cur; }
+        iv -= 2;
+      }
+      if (rots & 1) { const double nrmc = givens_norm_fast(pa, cur); cur = (cur == 0.0) ? pa : nrmc; chain[iv + 2] = cur; }
     }
   } else {
     double cur = s[nu - 1];
