@@ -519,7 +519,9 @@ __device__ __forceinline__ void zt_times_ww(const QlView &q, double *s, int lane
     // two columns per lane in ONE pass (the second pass of the strided form has n - 64 useful lanes), loads in groups of
     // eight ahead of the two add chains: at this size Z may live in global memory (L2), where every exposed round trip
     // costs hundreds of cycles
-    const int i0 = lane, i1 = lane + 64 < n ? lane + 64 : lane;      // surplus lanes shadow their first column
+    // surplus lanes all shadow column 0: one address per load instruction (it coalesces to a single request on a line lane 0 has
+    // just fetched) instead of 56 more scattered ones -- the column walk is bound by the address path, not by the bytes
+    const int i0 = lane, i1 = lane + 64 < n ? lane + 64 : 0;
     const double *z0 = q.Z + (size_t)i0 * q.ldz, *z1 = q.Z + (size_t)i1 * q.ldz;
     double a0 = 0.0, a1 = 0.0;
     int j = 0;
@@ -555,7 +557,7 @@ template <int NH, int GRP>
 __device__ __forceinline__ void zt_times_ww_cop(const QlView &q, double *s, int lane, int r) {
   static_assert(NH % GRP == 0, "the row ranges must end on whole chunks");
   const int n = q.n;
-  const int i0 = lane, i1 = lane + 64 < n ? lane + 64 : lane;      // surplus lanes shadow their first column
+  const int i0 = lane, i1 = lane + 64 < n ? lane + 64 : 0;         // surplus lanes all shadow column 0 (one coalesced request: see zt_times_ww)
   const double *z0 = q.Z + (size_t)i0 * q.ldz, *z1 = q.Z + (size_t)i1 * q.ldz;
   double a0 = 0.0, a1 = 0.0;
   const int len = r + 1;                                        // rows of each jerk block that carry an entry
@@ -583,7 +585,8 @@ __device__ __forceinline__ void zt_times_ww_cop(const QlView &q, double *s, int 
 template <int GRP = 8>
 __device__ __forceinline__ void z_rows_times(const QlView &q, const double *s, int j0, int j1, int lane, double &r0, double &r1) {
   const int n = q.n, ldz = q.ldz;
-  const int i0 = lane < n ? lane : n - 1, i1 = lane + 64 < n ? lane + 64 : i0;
+  // lanes without a second row all shadow row 64 (n > 64 here; one coalesced request per load instead of a second copy of the first set's)
+  const int i0 = lane < n ? lane : n - 1, i1 = lane + 64 < n ? lane + 64 : (n > 64 ? 64 : i0);
   const double *z0 = q.Z + i0, *z1 = q.Z + i1;
   constexpr int kG = GRP;
   double a0 = 0.0, a1 = 0.0;
@@ -1493,7 +1496,9 @@ __device__ __forceinline__ void sweep(const QlView &q, double *s, int nu, int na
     // without the selects.
     constexpr int kSwC = GRP;
     const int i0 = lane;
-    const int i1 = lane + 64 < n ? lane + 64 : lane;
+    // lanes without a second row all mirror row 64 when there is one (ONE address per load and per store -- the same value to the
+    // same place as lane 0's second row -- instead of a second copy of the first set's 56); with n <= 64 they mirror their own first row
+    const int i1 = lane + 64 < n ? lane + 64 : (n > 64 ? 64 : lane);
     const int ldz = q.ldz;
     double *z0 = q.Z + i0, *z1 = q.Z + i1;
     double carry0 = WG_ZLD(z0 + (nu - 1) * ldz), carry1 = WG_ZLD(z1 + (nu - 1) * ldz);

@@ -5,8 +5,10 @@ that phase's own VALU / SALU / LDS instruction counts, its parked cycles (SQ_WAI
 (SQ_WAIT_INST_ANY), its wave cycles and its share of the tick time.     python tools/phase_attribution.py [> profiles/...]"""
 import collections, csv, glob, os, re, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-D = os.path.join(ROOT, "gpurun_out", "attr")
-B, TICKS = 4096, 10 + 3 * 100                      # probe_elem.py: one 10-tick warm-up launch + PR = 3 launches of PT = 100 ticks
+D = os.path.join(ROOT, "gpurun_out", os.environ.get("ATTR_DIR", "attr"))
+NH = int(os.environ.get("PN", "16"))
+B = int(os.environ.get("PB", "4096"))
+TICKS = 10 + int(os.environ.get("PR", "3")) * int(os.environ.get("PT", "100"))   # probe_elem.py: one 10-tick warm-up launch + PR launches of PT ticks
 NAMES = {0: "(plain: nothing repeated)", 1: "violation scan, qld.cpp:1255-1331", 2: "Z^T a of the new normal, :1421-1470",
          3: "sweep: chain of rotation norms, :1992-2030 (phase 1)", 4: "back substitution of the step, :1824-1851",
          5: "linear-dependence sums, :1491-1532", 6: "xmag ordered sums (both sites), :2039-2058", 7: "pick_drop, :1861-1889",
@@ -29,9 +31,9 @@ def load(k):
 
 
 base, rate0, sum0 = load(0)
-print("# N = 16 tick, B = 4096, multi-tick launches (wg_mpc_run_xcd_kernel<16>): per gait-tick, measured by rocprofv3 --pmc.")
+print("# N = %d tick, B = %d, multi-tick launches (wg_mpc_run_xcd_kernel<%d>): per gait-tick, measured by rocprofv3 --pmc." % (NH, B, NH))
 print("# Row k = counters of the build that runs phase k twice MINUS the plain build = what one execution of that phase costs per")
-print("# gait-tick (%.1f active-set iterations on average).  Same state checksum in every build (the repeated phases are idempotent)." % 22.5)
+print("# gait-tick (%.1f active-set iterations on average).  Same state checksum in every build (the repeated phases are idempotent)." % (22.5 if NH == 16 else 44.2))
 print("# plain build: %.0f ticks/s; VALU %.0f, SALU %.0f, LDS %.0f, VMEM %.0f instructions, %.0f wave cycles per gait-tick of which parked"
       " (s_waitcnt) %.0f = %.1f %%, issue-stalled %.0f = %.1f %%" % (rate0, base["SQ_INSTS_VALU"], base["SQ_INSTS_SALU"], base["SQ_INSTS_LDS"],
                                                                    base["SQ_INSTS_VMEM"], base["SQ_WAVE_CYCLES"], base["SQ_WAIT_ANY"],
@@ -61,7 +63,7 @@ print("%-58s" % "   sweep phases 2-3, drops, x / lambda updates, the refresh's s
 # The phases below cannot be executed twice (they rotate Z, move x, advance the state), so their cost comes from s_memtime
 # brackets instead.  Timer cycles are not the counters' wave cycles (another build, one launch per tick, the reads themselves cost):
 # each row's share = its timer cycles / the timer cycles of ALL rows listed here x the share the counters leave for the lump.
-TIMERS = os.path.join(ROOT, "gpurun_out", "phases_tick.txt")
+TIMERS = os.path.join(ROOT, "gpurun_out", "phases_tick.txt" if NH == 16 else "phases_tick32.txt")
 if os.path.exists(TIMERS):
     top, sub = {}, {}
     for ln in open(TIMERS):

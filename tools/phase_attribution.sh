@@ -9,9 +9,10 @@
 set -u
 export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-O=$R/gpurun_out/attr
+O=$R/gpurun_out/${ATTR_DIR:-attr}
 rm -rf $O; mkdir -p $O
-export PN=16 PB=4096 PT=100 PR=3
+# ATTR_DIR=attr32 PN=32 PB=8192 PT=50 PR=2 bash tools/phase_attribution.sh  does the same for the N = 32 kernel
+export PN=${PN:-16} PB=${PB:-4096} PT=${PT:-100} PR=${PR:-3}
 cd /tmp
 for k in 0 1 2 3 4 5 6 7 8 9 11; do
   export WG_LIB_PATH=$R/jrl-walkgen_amd/lib/libwg_mpc_xr$k.so
