@@ -36,6 +36,9 @@ namespace wg {
 // Eight is what a 256-register kernel carries (the dense boundary kernel); the element view is compiled for 168 registers --
 // three waves per SIMD -- and takes groups of four: measured 7 % slower per wave and, with twelve gaits on a CU instead of eight,
 // 7 % faster overall.
+#ifndef WG_ELEM_ZT_GRP
+#define WG_ELEM_ZT_GRP 8                // rows of the Z^T a column walk requested together (its own knob: that walk is bound by the address path)
+#endif
 #ifndef WG_ELEM_GRP
 #define WG_ELEM_GRP 4
 #endif
@@ -2382,7 +2385,7 @@ __device__ __forceinline__ QlResult ql_solve(const QlView &q, P &prob, double vs
           // the Herdt QP at a horizon known at compile time: a CoP row of instant r has no entry in rows (r, N) and (N + r, 2N)
           constexpr int kNHc = P::kHorizon;
           const int k = knext - 1;
-          zt_times_ww_cop<kNHc, WG_ELEM_GRP>(q, s, lane, (k >= 1 && k <= 4 * kNHc) ? ((k - 1) >> 2) : -1);
+          zt_times_ww_cop<kNHc, WG_ELEM_ZT_GRP>(q, s, lane, (k >= 1 && k <= 4 * kNHc) ? ((k - 1) >> 2) : -1);
         }
         else zt_times_ww<P::kNM, (P::kRowOps ? WG_ELEM_GRP : 8), P::kWideN>(q, s, lane);
       } else {
