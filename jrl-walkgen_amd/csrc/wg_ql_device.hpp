@@ -1423,6 +1423,7 @@ __device__ __forceinline__ void sweep(const QlView &q, double *s, int nu, int na
   // chain[c - 1]); p = s[c - 1] is fetched one rotation ahead, off the chain.  Phase 2 rebuilds each rotation from it:
   // sc0[c] = ga, sc1[c] = gb, sc2[c] = norm (0 marks "skipped").
   double *chain = q.sc3;
+  WG_REP(3)
   if (sweep_range_ok(s, nact, nu, lane)) {                  // the usual case: the shorter norm, as in sweep_flat
     double cur = s[nu - 1];
     double pa = s[nu - 2], pb;
