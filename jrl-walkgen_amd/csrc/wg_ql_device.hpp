@@ -761,7 +761,10 @@ __device__ __forceinline__ void backsub_lds(const QlView &q, const double *s, in
   S.rr = Rp(nact >= 2 ? nact - 2 : 0, S.col);               // R(j-1, lane) of the row whose products are formed next
   double A9[9] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0}, B9[9];
   int j = nact - 1;
-  if constexpr (kBsLen <= 64) {
+#ifndef WG_BS_UNROLL_WIDE
+#define WG_BS_UNROLL_WIDE 0
+#endif
+  if constexpr (kBsLen <= 64 || WG_BS_UNROLL_WIDE) {
     // the first nine rows unrolled with their lengths known (one uniform test per row instead of three), the rest in pairs
     if (nact > 0) { bs_row<kBsLen, 0>(q, buf, nact - 1, S, A9, B9);
     if (nact > 1) { bs_row<kBsLen, 4>(q, buf, nact - 2, S, B9, A9);
