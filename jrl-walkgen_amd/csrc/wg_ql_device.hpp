@@ -581,6 +581,85 @@ __device__ __forceinline__ void zt_times_ww_cop(const QlView &q, double *s, int 
   WG_WSYNC();
 }
 
+#ifndef WG_ZT_TILED
+#define WG_ZT_TILED 2                  // 0: one column per lane (zt_times_ww_cop), 1: four lanes per column, 2: that with the next block requested ahead
+#endif
+// The same product for the fixed N = 32 view (Z global, leading dimension NH * 2 + 8 = 72) with FOUR lanes per column: lane L
+// owns column 16 p + L / 4 in pass p and the two rows j0 + 2 (L & 3), + 1 of every eight-row block -- the four lanes of a column
+// read 64 contiguous bytes, so a load instruction touches 16 cache lines instead of 64 and an eight-row block of all 72 columns
+// costs 80 line requests instead of 288 (the column walk is bound by its requests).  The eight products of a block
+// reach every lane of the quad by DPP (quad_perm broadcasts, no LDS) and are added in row order: the same adds in the same
+// order as zt_times_ww_cop with groups of eight (whole blocks: the rows past the row's instant carry exact zeros; rows past n --
+// block 8 only -- are masked to +0.0, which never changes a sum that cannot be -0.0).
+template <int K>
+__device__ __forceinline__ double wg_quad_bcast(double v) {   // lane K of every quad to the whole quad
+  constexpr int ctrl = K * 0x55;                              // quad_perm:[K,K,K,K]
+  const int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), ctrl, 0xf, 0xf, true);
+  const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), ctrl, 0xf, 0xf, true);
+  return __hiloint2double(hi, lo);
+}
+template <int NH>
+__device__ __forceinline__ void zt_times_ww_cop_tiled(const QlView &q, double *s, int lane, int r, bool tail) {
+  constexpr int L = 2 * NH + 8;                               // q.ldz of carve_fixed_elem
+  constexpr int NP = (L + 15) / 16;                           // passes of sixteen columns
+  const int n = q.n;
+  const int h = lane & 3, cq = lane >> 2;
+  const double2 *zb[NP];
+  bool colok[NP];
+#pragma unroll
+  for (int p = 0; p < NP; ++p) {
+    const int c = 16 * p + cq;
+    colok[p] = c < n;
+    zb[p] = reinterpret_cast<const double2 *>(q.Z + (size_t)(colok[p] ? c : 0) * L + 2 * h);   // lanes without a column: column 0
+  }
+  double acc[NP];
+#pragma unroll
+  for (int p = 0; p < NP; ++p) acc[p] = 0.0;
+  struct Blk { double2 u[NP]; double w0, w1; };
+  auto load = [&](Blk &B, int j0) {                           // rows j0 .. j0 + 7 (j0 a multiple of 8): requested, not waited for
+#pragma unroll
+    for (int p = 0; p < NP; ++p) B.u[p] = zb[p][j0 >> 1];
+    B.w0 = q.ww[j0 + 2 * h]; B.w1 = q.ww[j0 + 2 * h + 1];
+  };
+  auto sum = [&](const Blk &B, bool last) {
+    const int jr = 2 * NH + 2 * h;                            // the last block's rows (the only one that can reach past n)
+    const bool ok0 = !last || jr < n, ok1 = !last || jr + 1 < n;
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+      double p0 = B.u[p].x * B.w0, p1 = B.u[p].y * B.w1;
+      if (last) { p0 = ok0 ? p0 : 0.0; p1 = ok1 ? p1 : 0.0; }
+      double a = acc[p];
+      a += wg_quad_bcast<0>(p0); a += wg_quad_bcast<0>(p1);
+      a += wg_quad_bcast<1>(p0); a += wg_quad_bcast<1>(p1);
+      a += wg_quad_bcast<2>(p0); a += wg_quad_bcast<2>(p1);
+      a += wg_quad_bcast<3>(p0); a += wg_quad_bcast<3>(p1);
+      acc[p] = a;
+    }
+  };
+  const int nb = (r >> 3) + 1;                                // blocks of each jerk range that carry entries (r = -1: none)
+  // x blocks, y blocks, then the step columns' rows 2 NH .. n - 1 -- unless the normal has no entry there (a CoP row of an instant in
+  // the current support phase: exact zeros, whose products leave the sums unchanged)
+  const int total = 2 * nb + (tail ? 1 : 0);
+  auto start = [&](int idx) { return idx < nb ? 8 * idx : (idx < 2 * nb ? NH + 8 * (idx - nb) : 2 * NH); };
+#if WG_ZT_TILED == 2
+  // the next block is requested before the current one is summed (two register sets taking turns)
+  Blk A, B;
+  load(A, start(0));
+  for (int idx = 0;;) {
+    if (idx + 1 >= total) { sum(A, tail); break; }
+    load(B, start(idx + 1)); sum(A, false); ++idx;
+    if (idx + 1 >= total) { sum(B, tail); break; }
+    load(A, start(idx + 1)); sum(B, false); ++idx;
+  }
+#else
+  for (int idx = 0; idx < total; ++idx) { Blk A; load(A, start(idx)); sum(A, tail && idx == total - 1); }
+#endif
+#pragma unroll
+  for (int p = 0; p < NP; ++p)
+    if (h == 0 && colok[p]) s[16 * p + cq] = acc[p];
+  WG_WSYNC();
+}
+
 // r0 = sum_{j0 <= j < j1} Z(i0, j) * s[j], r1 the same for row i1 (j ascending, from +0.0): rows i0 = lane and i1 = lane + 64
 // of a matrix of 64 < n <= 128 rows in ONE pass, the entries of eight columns requested together ahead of the two add chains
 // (with Z in global memory an exposed entry is an L2 round trip; one register set only: this sits where many values are live).
@@ -2389,6 +2468,13 @@ __device__ __forceinline__ QlResult ql_solve(const QlView &q, P &prob, double vs
           // the Herdt QP at a horizon known at compile time: a CoP row of instant r has no entry in rows (r, N) and (N + r, 2N)
           constexpr int kNHc = P::kHorizon;
           const int k = knext - 1;
+          if constexpr (WG_ZT_TILED != 0) {
+            const bool cop = k >= 1 && k <= 4 * kNHc;
+            const int rr = cop ? ((k - 1) >> 2) : -1;
+            const int si = cop ? prob.stepidx[rr] : 1;       // the previewed step the instant belongs to (0: the current support phase)
+            zt_times_ww_cop_tiled<kNHc>(q, s, lane, rr, !cop || (si >= 1 && si <= prob.ns));
+          }
+          else
           zt_times_ww_cop<kNHc, WG_ELEM_ZT_GRP>(q, s, lane, (k >= 1 && k <= 4 * kNHc) ? ((k - 1) >> 2) : -1);
         }
         else zt_times_ww<P::kNM, (P::kRowOps ? WG_ELEM_GRP : 8), P::kWideN>(q, s, lane);
