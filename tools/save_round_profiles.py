@@ -174,7 +174,7 @@ Everything named `{tag}_*` was produced by ONE run of `tools/prof_round.sh` on a
 | `{tag}_b1_*` | `python3 tools/probe_b1.py` | one robot, one wave alone on a CU: the counters behind DESIGN 4's "one robot" paragraph (`current_tick_pmc.json` -> `one_robot_kernel`) |
 | `{tag}_regz_*` | `bash tools/regz_probe.sh` (experiment builds, `-DWG_WITH_REGZ`) | the "Z on chip" experiment at N = 32: parity, rate at four and eight gaits per CU, all counters of the four-per-CU build |
 | `{tag}_phase_attribution.txt` | `bash tools/phase_attribution.sh` + `python tools/phase_attribution.py`, then the timer table of `{tag}_tick_phase_timers.txt` | per-phase counters of the N = 16 run kernel (phases executed twice, differences against the plain build) and the shader-clock split of everything the counters cannot repeat |
-| `{tag}_phase_attribution_n32.txt` | `ATTR_DIR=attr32 PN=32 PB=8192 PT=50 PR=2 bash tools/phase_attribution.sh` + `... python tools/phase_attribution.py` | the same counter attribution for the N = 32 kernel `wg_mpc_run_xcd_kernel<32>` at the benchmark's residency (Z^T a 20.5 %, back substitution 10.6 %, scan 9.6 %, norm chain 9.6 %) |
+| `{tag}_phase_attribution_n32.txt` | `ATTR_DIR=attr32 PN=32 PB=8192 PT=50 PR=2 bash tools/phase_attribution.sh` + `... python tools/phase_attribution.py` | the same counter attribution for the N = 32 kernel `wg_mpc_run_xcd_kernel<32>` at the benchmark's residency (back substitution 12.1 %, norm chain 11.6 %, scan 11.0 %, Z^T a 10.4 %) |
 | `{tag}_latency_b1.json` | `jrl-walkgen_amd/bin/latency_b1` | one robot (B = 1): host-pointer call, its split (copy in / launch / kernel / copy out) and the host-mapped call |
 | `{tag}_resource_usage.txt` | `python tools/isa_audit.py` (no GPU) | registers, spills, scratch, occupancy of every kernel; where the spill code sits by loop depth; instruction mix of the inner loops |
 | `{tag}_gramian_*` | `python3 tools/probe_gramian.py` | `wg_gramian_kernel`: SQ_INSTS_VALU_MFMA_MOPS_F64 / _F32, SQ_VALU_MFMA_BUSY_CYCLES, duration against the dense MFMA peak (`*_probe_output.txt`) |
