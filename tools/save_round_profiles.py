@@ -187,6 +187,13 @@ Everything named `{tag}_*` was produced by ONE run of `tools/prof_round.sh` on a
 
 {agree}
 
+How the set is regenerated (≈ 25 minutes, 8 of them on the GPU): build `lib/libwg_mpc_prof.so` and the eleven
+`lib/libwg_mpc_xr<k>.so` (`EXTRA=-DWG_REPEAT_PHASE=k`); `gpurun -- bash tools/gpu_round_a.sh` (GPU tests, then `tools/prof_round.sh`);
+`python tools/save_round_profiles.py {tag}`; `gpurun -- bash tools/gpu_round_b.sh` (both attributions, both bench lines, both soaks);
+`python tools/phase_attribution.py > profiles/{tag}_phase_attribution.txt` (and with `ATTR_DIR=attr32 PN=32 PB=8192 PT=50 PR=2` for
+`_n32`), copy the soaks, `python tools/file_bench.py {tag}`, `python tools/isa_audit.py --out profiles/{tag}_resource_usage.txt`,
+`python tools/doc_numbers.py {tag}` (the documents' generated blocks; `tests/test_docs_numbers.py` fails while they disagree).
+
 Each `*_rocprofv3_summary.txt/json` = per-kernel averages of the trace (`kernels`) and per-launch means of every counter
 (`counters`); `*_kernel_stats.csv` = rocprofv3's own `--stats` table of the same run.
 """
