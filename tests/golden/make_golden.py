@@ -3,7 +3,10 @@
 
   herdt_emergency_stop_datref.npz : the reference's own golden file
         /root/reference/tests/TestHerdt2010EmergencyStopTestFGPI.datref.cmake  (4508 x 38), as data.
-  ql_golden.npz : QPs (inputs) + the COMPILED REFERENCE qld.cpp's outputs (x, u, ifail, final active set)
+  ql_golden.npz : QPs (inputs) + the COMPILED REFERENCE qld.cpp's outputs (x, u, ifail, final active set, and the
+        add/drop HISTORY: +k = code k added, -k = dropped, in order -- from a throw-away build of the reference's qld.cpp
+        with one log call at its add site (qld.cpp:1766) and one at its drop site (:1903), tests/oraclelib.py:ref_hist;
+        x, u, ifail and the final set are taken from the UNPATCHED oracle/_ref build and must agree with the patched one)
         - 24 QPs per family of tests/qpgen.py (branch coverage of ql0002), and
         - the 225 QPs the Herdt oracle assembles while replaying the EmergencyStop scenario.
   preview_control_parameters.npz : the reference's precomputed Kajita gains
@@ -21,6 +24,7 @@ import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.dirname(HERE))
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))   # repo root: herdt_replay takes the POD layouts from the package
 import herdt_replay as hr  # noqa: E402
 import oraclelib as ol  # noqa: E402
 import qpgen  # noqa: E402
@@ -68,9 +72,16 @@ def main():
 
     def add(tag, q):
         r = ol.ref_ql(q)
-        o = ol.oracle_ql(q)   # only to learn nact (a static local inside the reference)
+        h = ol.ref_ql_hist(q)   # the instrumented build: same arithmetic, plus the add/drop log
+        assert h["ifail"] == r["ifail"] and ol.same_bits(h["x"], r["x"]) and ol.same_bits(h["u"], r["u"])
+        assert np.array_equal(h["iwar"], r["iwar"])
+        # nact is a static local inside the reference: it is the history's balance (adds minus drops)
+        nact = int((h["hist"] > 0).sum() - (h["hist"] < 0).sum())
+        o = ol.oracle_ql(q)
+        assert r["ifail"] != 0 or nact == o["nact"]
         recs.append(dict(tag=tag, n=q["n"], m=q["m"], me=q["me"], mmax=q["mmax"], C=q["C"], d=q["d"], A=q["A"], b=q["b"],
-                         xl=q["xl"], xu=q["xu"], x=r["x"], u=r["u"], ifail=r["ifail"], iact=r["iwar"][:o["nact"]]))
+                         xl=q["xl"], xu=q["xu"], x=r["x"], u=r["u"], ifail=r["ifail"], iact=r["iwar"][:o["nact"]],
+                         hist=h["hist"]))
 
     for fam in sorted(qpgen.FAMILIES):
         for s in range(24):

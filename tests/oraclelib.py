@@ -78,7 +78,7 @@ def oracle_ql(q, eps=1e-8, hist_cap=4096):
                 n_iter=nit.value, hist=hist[:min(hlen.value, hist_cap)].copy(), hist_len=hlen.value)
 
 
-def ref_ql(q, eps=1e-8):
+def ref_ql(q, eps=1e-8, lib=None):
     """Run the compiled reference ql0001_ (argument order of qld.hh:27-31;
     workspace sizes as qp-problem.cpp:256-263).  Not re-entrant (static locals)."""
     n, m = q["n"], q["m"]
@@ -93,7 +93,7 @@ def ref_ql(q, eps=1e-8):
     iwar[0] = 1
     ci = lambda v: C.byref(C.c_int(v))
     ifail = C.c_int(-99)
-    fn = getattr(ref(), REF_SYM)
+    fn = getattr(lib if lib is not None else ref(), REF_SYM)
     d = q["d"].copy()
     A = q["A"].copy(order="F")
     b = q["b"].copy()
@@ -105,6 +105,67 @@ def ref_ql(q, eps=1e-8):
     # the final ordered active set is left in iwar[0..nact); nact itself is a
     # static local, so recover it from the non-zero multipliers' count bound
     return dict(x=x, u=u, ifail=ifail.value, iwar=iwar[:n].copy(), C_after=Cc)
+
+
+# ---- add/drop history of the REFERENCE itself -------------------------------------------------------------------
+# ql0002 keeps nact / iact in static locals and returns only the final ordered set, so the history needs a
+# throw-away build of the reference's qld.cpp with one log call at the add site (qld.cpp:1766, `iact[*nact] = knext;`)
+# and one at the drop site (qld.cpp:1903, label L800).  The patched text exists only in a temp dir outside the repo and
+# is deleted with it; nothing of it is committed or travels.  Event codes as oracle/ql_oracle.c:log_event:
+# +k = constraint k (1-based QL code) added, -k = dropped.
+REF_QLD_SRC = "/root/reference/src/Mathematics/qld.cpp"
+HIST_CAP = 1 << 16
+_LOGGER = """
+extern "C" {
+__attribute__((visibility("default"))) int wg_hist_len = 0;
+__attribute__((visibility("default"))) int wg_hist_buf[%d];
+}
+static inline void wg_hist_log(int code) { if (wg_hist_len < %d) wg_hist_buf[wg_hist_len] = code; ++wg_hist_len; }
+""" % (HIST_CAP, HIST_CAP)
+_ref_hist = None
+_ref_hist_dir = None
+
+
+def have_ref_source():
+    return os.path.exists(REF_QLD_SRC)
+
+
+def ref_hist():
+    """The reference's qld.cpp with the two log calls, built -O3 -DNDEBUG (oracle/Makefile's flags) in a temp dir."""
+    global _ref_hist, _ref_hist_dir
+    if _ref_hist is None:
+        import atexit
+        import re
+        import shutil
+        import tempfile
+        lines = open(REF_QLD_SRC).read().split("\n")
+        add = [i for i, l in enumerate(lines) if re.match(r"^\s*iact\[\*nact\] = knext;\s*$", l)]
+        drop = [i for i, l in enumerate(lines) if re.match(r"^L800:\s*$", l)]
+        assert len(add) == 1 and len(drop) == 1, (add, drop)
+        lines[add[0]] += " wg_hist_log(knext);"
+        lines[drop[0]] += " wg_hist_log(-iact[kdrop]);"
+        _ref_hist_dir = tempfile.mkdtemp(prefix="wg_qld_hist_")
+        atexit.register(shutil.rmtree, _ref_hist_dir, True)
+        open(os.path.join(_ref_hist_dir, "logger.h"), "w").write(_LOGGER)
+        open(os.path.join(_ref_hist_dir, "qld_hist.cpp"), "w").write("\n".join(lines))
+        so = os.path.join(_ref_hist_dir, "libqld_hist.so")
+        subprocess.check_call(["g++", "-O3", "-DNDEBUG", "-fPIC", "-shared", "-include",
+                               os.path.join(_ref_hist_dir, "logger.h"), os.path.join(_ref_hist_dir, "qld_hist.cpp"),
+                               "-o", so])
+        _ref_hist = C.CDLL(so)
+    return _ref_hist
+
+
+def ref_ql_hist(q, eps=1e-8):
+    """ref_ql on the instrumented build: the same outputs plus the reference's own add/drop history."""
+    lib = ref_hist()
+    hlen = C.c_int.in_dll(lib, "wg_hist_len")
+    hlen.value = 0
+    r = ref_ql(q, eps, lib=lib)
+    assert hlen.value <= HIST_CAP
+    buf = (C.c_int * HIST_CAP).in_dll(lib, "wg_hist_buf")
+    r["hist"] = np.array(buf[:hlen.value], dtype=np.int32)
+    return r
 
 
 def same_bits(a, b):

@@ -62,6 +62,34 @@ def test_family_bit_exact(family):
     assert not bad, bad[:5]
 
 
+def test_golden_vectors_and_reference_history_through_the_gpu():
+    """The committed fixture of the COMPILED REFERENCE (tests/golden/ql_golden.npz: x, u, ifail, final set and the reference's
+    own add/drop history) against the HIP solver directly, no oracle in between: "bit-exact active-set index sequences"."""
+    import test_ql_oracle as tqo
+    wg = _wg()
+    gold = list(tqo._golden())
+    groups = {}
+    for tag, q, ref in gold:      # one launch per problem shape family keeps the padding (nmax, mmax) as the fixture's
+        groups.setdefault((q["n"], q["mmax"]), []).append((tag, q, ref))
+    n_checked = 0
+    for (n, mmax), items in sorted(groups.items()):
+        qps = [q for _, q, _ in items]
+        pk = wg.pack_qps(qps)
+        assert pk["nmax"] == n and pk["mmax"] == mmax
+        res = wg.qp_solve_batch(pk, hist_cap=512)
+        for k, (tag, q, ref) in enumerate(items):
+            m = q["m"]
+            assert int(res["ifail"][k]) == ref["ifail"], tag
+            assert ol.same_bits(res["x"][k, :n], ref["x"]), tag
+            assert int(res["hist_len"][k]) == len(ref["hist"]), tag
+            assert np.array_equal(res["hist"][k, :len(ref["hist"])], ref["hist"]), tag
+            if ref["ifail"] == 0:
+                assert ol.same_bits(res["u"][k, :m + 2 * n], ref["u"]), tag
+                assert np.array_equal(res["iact"][k, :len(ref["iact"])], ref["iact"]), tag
+            n_checked += 1
+    assert n_checked >= 400
+
+
 def test_herdt_shape_uniform_batch():
     """Uniform n/m batch through the NULL-size-array convention (m = mmax-1)."""
     wg = _wg()

@@ -22,7 +22,7 @@ def _golden():
         q = dict(n=int(g("n")), m=int(g("m")), me=int(g("me")), mmax=int(g("mmax")), nmax=int(g("n")),
                  C=np.asfortranarray(g("C")), d=g("d").copy(), A=np.asfortranarray(g("A")), b=g("b").copy(),
                  xl=g("xl").copy(), xu=g("xu").copy())
-        yield str(g("tag")), q, dict(x=g("x"), u=g("u"), ifail=int(g("ifail")), iact=g("iact"))
+        yield str(g("tag")), q, dict(x=g("x"), u=g("u"), ifail=int(g("ifail")), iact=g("iact"), hist=g("hist"))
 
 
 def test_oracle_matches_reference_golden_vectors_bit_for_bit():
@@ -39,6 +39,34 @@ def test_oracle_matches_reference_golden_vectors_bit_for_bit():
         n_checked += 1
     assert n_checked >= 400
     assert {0, 2, 11} <= fails     # success, "accuracy insufficient" and "inconsistent" exits all covered
+
+
+def test_oracle_history_matches_reference_golden():
+    """north_star: "bit-exact active-set index sequences".  The golden history is the REFERENCE's own (its qld.cpp with a
+    log call at the add site :1766 and the drop site :1903, tests/golden/make_golden.py); every add and every drop of the
+    restatement, in order, for successful and failed solves alike."""
+    n_events = n_drops = longest = 0
+    for tag, q, ref in _golden():
+        o = ol.oracle_ql(q)
+        assert o["hist_len"] == len(ref["hist"]), tag
+        assert np.array_equal(o["hist"], ref["hist"]), tag
+        n_events += len(ref["hist"])
+        n_drops += int((ref["hist"] < 0).sum())
+        longest = max(longest, len(ref["hist"]))
+    assert n_events >= 7000 and n_drops >= 500 and longest >= 100   # the fixture does exercise drops and long solves
+
+
+@pytest.mark.skipif(not ol.have_ref_source(), reason="reference source not present (development container only)")
+@pytest.mark.parametrize("family", sorted(qpgen.FAMILIES))
+def test_oracle_history_matches_instrumented_reference_live(family, capfd):
+    gen = qpgen.FAMILIES[family]
+    for s in range(60):
+        q = gen(np.random.default_rng(77000 + 13 * s))
+        r = ol.ref_ql_hist(q)
+        o = ol.oracle_ql(q)
+        assert r["ifail"] == o["ifail"] and ol.same_bits(r["x"], o["x"]), (family, s)
+        assert o["hist_len"] == len(r["hist"]) and np.array_equal(o["hist"], r["hist"]), (family, s)
+    capfd.readouterr()
 
 
 @pytest.mark.skipif(not ol.have_ref(), reason="compiled reference qld not present")
