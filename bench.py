@@ -38,6 +38,7 @@ REDRAW_TICKS = 50            # 5 s of walking
 PREROLL_TICKS = 100          # untimed ticks before the warm-up: every timed window, however short, sees the de-synchronised batch
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 FP64_VECTOR_PEAK_TFLOPS = 78.6   # MI355X FP64 vector peak (spec): 256 CUs x 4 SIMDs x 16 lanes x 2 flop x 2.4 GHz
+BOX_CPU_SHARE = 16           # host cores that go with one GPU of the pool's boxes (used only when the OS shows no limit)
 CONFIG5_BATCH = 8192         # BASELINE configs[4]: N = 32 with foot-placement variables, batch = 8192
 # counters of the timed kernel measured by rocprofv3 --pmc passes of this very command (tools/prof_round.sh files them)
 PMC_SUMMARY = os.path.join(ROOT, "profiles", "current_tick_pmc.json")
@@ -116,29 +117,115 @@ def _cpu_run(args):
     return ng * n_ticks, dt, kind, (sec.value if kind == "reference" else None), cnt.value
 
 
+def usable_cores():
+    """(cores this process may really use, what the OS shows, why): the affinity mask cut down by the cgroup CPU quota.
+    os.cpu_count() is the host's core count -- on a shared GPU box most of them belong to somebody else."""
+    visible = os.cpu_count() or 1
+    try:
+        affinity = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        affinity = visible
+    quota = None
+    dirs = ["/sys/fs/cgroup"]
+    try:                                                           # cgroup v2: this process's own group and every ancestor
+        for l in open("/proc/self/cgroup"):
+            if l.startswith("0::"):
+                rel = l.strip()[3:].strip("/")
+                while rel:
+                    dirs.append(os.path.join("/sys/fs/cgroup", rel))
+                    rel = os.path.dirname(rel)
+    except OSError:
+        pass
+    for d in dirs:
+        try:                                                       # "<quota|max> <period>"
+            q, per = open(os.path.join(d, "cpu.max")).read().split()
+            if q != "max":
+                quota = min(quota or 1e9, float(q) / float(per))
+        except (OSError, ValueError):
+            pass
+    if quota is None:
+        try:                                                       # cgroup v1
+            q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                quota = q / per
+        except (OSError, ValueError):
+            pass
+    used = affinity if quota is None else max(1, min(affinity, int(quota + 1e-9)))
+    note = None
+    if quota is None and affinity == visible and visible > BOX_CPU_SHARE:
+        # nothing the process can read limits it, yet a one-GPU lease of a many-core host owns a share of it
+        used = BOX_CPU_SHARE
+        note = "no affinity mask / cgroup quota visible on a %d-core host: the one-GPU lease's share (%d) assumed" % (visible, BOX_CPU_SHARE)
+    cap = os.environ.get("WG_BENCH_CPU_CORES")                     # explicit override for boxes whose limits are not visible
+    if cap:
+        used = max(1, min(used, int(cap)))
+    return used, {"os_cpu_count": visible, "affinity": affinity, "cgroup_quota": quota, "note": note}
+
+
+def _cpu_worker(w, per, n_ticks, barrier, q):
+    try:
+        barrier.wait(120)                                          # every worker starts its timed loop together
+        q.put((w,) + tuple(_cpu_run((w * per, per, n_ticks, True))))
+    except Exception as e:                                         # noqa: BLE001
+        q.put((w, 0, 1.0, "error: %s" % e, None, 0))
+
+
+def cpu_model_name():
+    try:
+        for l in open("/proc/cpuinfo"):
+            if l.startswith("model name"):
+                return l.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return None
+
+
 def cpu_baseline(n_gaits, n_ticks):
     """The CPU checker on the first `n_gaits` gaits of the same workload: tick assembly = oracle/ C restatement,
     QP solve = the reference's own qld.cpp compiled -O3 -DNDEBUG (oracle/_ref, ~all of the CPU time) when it was built,
-    else the restated solver.  Timed on one core, then on every host core (one process per core, QLD keeps statics).
+    else the restated solver.  Timed on one core, then on every core this process may use (affinity mask and cgroup quota, not
+    os.cpu_count(); one process per core, QLD keeps statics; >= 2 s of work per worker, all started behind one barrier).
     Checker code timed as a baseline -- never part of the measured GPU path."""
     import multiprocessing as mp
     ticks, dt, kind, solve_s, solves = _cpu_run((0, n_gaits, n_ticks, True))
     one = dict(value=ticks / dt, seconds=dt, kind=kind,
                solve_only=(solves / solve_s if solve_s else None))
-    cores = os.cpu_count() or 1
-    per = max(8, n_gaits // 32)
+    cores, seen = usable_cores()
+    # >= 2 s per worker at the one-core rate just measured (more when the cores are slower under load), <= ~6 s
+    per = int(min(max(8, np.ceil(2.5 * one["value"] / n_ticks)), 4 * n_gaits))
     try:
-        with mp.get_context("fork").Pool(cores) as pool:
-            t0 = time.perf_counter()
-            res = pool.map(_cpu_run, [(w * per, per, n_ticks, True) for w in range(cores)])
-            wall = time.perf_counter() - t0
-        allc = dict(value=sum(r[0] for r in res) / max(r[1] for r in res), cores=cores, wall_seconds=wall,
-                    sample="%d gaits x %d ticks per core" % (per, n_ticks))
+        ctx = mp.get_context("fork")
+        barrier, q = ctx.Barrier(cores), ctx.Queue()
+        procs = [ctx.Process(target=_cpu_worker, args=(w, per, n_ticks, barrier, q)) for w in range(cores)]
+        t0 = time.perf_counter()
+        for p in procs:
+            p.start()
+        res = [q.get(timeout=600) for _ in procs]
+        for p in procs:
+            p.join()
+        wall = time.perf_counter() - t0
+        res = [r[1:] for r in sorted(res)]
+        bad = [r[2] for r in res if isinstance(r[2], str) and r[2].startswith("error")]
+        if bad:
+            raise RuntimeError(bad[0])
+        rates = [r[0] / r[1] for r in res]
+        value = sum(r[0] for r in res) / max(r[1] for r in res)
+        eff = value / (cores * one["value"])
+        allc = dict(value=value, cores=cores, cores_used=cores, cores_visible=seen["os_cpu_count"], cores_affinity=seen["affinity"],
+                    cgroup_cpu_quota=seen["cgroup_quota"], cores_note=seen["note"], wall_seconds=wall,
+                    worker_seconds_min=min(r[1] for r in res), worker_seconds_max=max(r[1] for r in res),
+                    worker_rate_min=min(rates), worker_rate_max=max(rates), parallel_efficiency=eff,
+                    cpu_model=cpu_model_name(),
+                    sample="%d gaits x %d ticks per core, %d workers started together" % (per, n_ticks, cores))
+        if eff < 0.5:
+            allc["warning"] = ("parallel efficiency %.2f: %d workers deliver %.1f x one core -- the cores this process was told it may "
+                               "use are shared or throttled; WG_BENCH_CPU_CORES sets the worker count by hand" % (eff, cores, value / one["value"]))
         if all(r[3] for r in res):
             # every core's solves at that core's own solve-only rate
             allc["solve_only"] = sum(r[4] / r[3] for r in res)
     except Exception as e:                                        # noqa: BLE001 -- a baseline, never fatal
-        allc = dict(value=None, cores=cores, error=str(e))
+        allc = dict(value=None, cores=cores, cores_visible=seen["os_cpu_count"], error=str(e))
     return one, allc
 
 
@@ -349,7 +436,7 @@ def main():
         cpu_line = {"value": one["value"], "unit": "ticks/s", "cores": 1, "kind": one["kind"],
                     "sample": f"first {ng} gaits x {nt} ticks of the same workload ({ng * nt} ticks, "
                               f"{one['seconds']:.1f} s); tick assembly by the oracle/ C restatement, {solver}; "
-                              f"1 core of {os.cpu_count()} host cores",
+                              f"1 core of {allc.get('cores_used', allc['cores'])} usable ({os.cpu_count()} visible) host cores",
                     "value_is": "assemble + solve (the whole tick)",
                     "solve_only": one["solve_only"],          # ticks/s counting only the time inside ql0001_ (qp-problem.cpp:275-279)
                     "all_cores": allc}

@@ -50,3 +50,18 @@ def test_velocity_table_is_per_gait_deterministic():
     c = b.velocity_table(4, 12, 3)
     assert np.array_equal(a[:, 4:8], c[:, 0:4])                   # gait g draws the same references in any shard
     assert (a[..., 0] >= -0.1).all() and (a[..., 0] <= 0.3).all() and (np.abs(a[..., 1]) <= 0.1).all() and (np.abs(a[..., 2]) <= 0.2).all()
+
+
+def test_cpu_baseline_worker_count_is_what_the_process_may_use(monkeypatch):
+    """"1 core and all host cores; the harness prints the core count" -- the count is the affinity mask
+    cut down by the cgroup quota (or, with no limit visible on a many-core host, one GPU lease's share), never os.cpu_count()
+    of a shared host; the line reports what was seen, what was used and the parallel efficiency."""
+    b = _bench()
+    used, seen = b.usable_cores()
+    assert 1 <= used <= len(os.sched_getaffinity(0)) <= seen["os_cpu_count"]
+    assert used <= max(b.BOX_CPU_SHARE, int(seen["cgroup_quota"] or 0)) or seen["affinity"] < seen["os_cpu_count"]
+    monkeypatch.setenv("WG_BENCH_CPU_CORES", "2")
+    assert b.usable_cores()[0] == min(2, used)
+    one, allc = b.cpu_baseline(8, 4)                                # a token sample: the bookkeeping, not a measurement
+    assert allc["cores_used"] == min(2, used) and allc["value"] > 0 and 0 < allc["parallel_efficiency"]
+    assert allc["worker_rate_min"] <= allc["worker_rate_max"] and allc["cores_visible"] == seen["os_cpu_count"]

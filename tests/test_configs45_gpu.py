@@ -206,6 +206,19 @@ def test_config5_full_size_sample_followed_by_the_oracle(config5_run):
         assert _oracle_follow(pt, model, g, T) == fin[g].tobytes(), g
 
 
+def test_config5_bench_plan_at_the_timed_size(config5_run):
+    """bench.py's config5 leg as it issues it (B = 8192, N = 32: warm-up = ticks [0, 10), timed = ONE launch of ticks
+    [10, 50) through wg_mpc_run_batch_dev): same bytes and the same ifail / iterations / n / m per QP as the fixture's run."""
+    import test_fullsize_gpu as tf
+    model, B, T, fin, diag = config5_run
+    bench = tf._bench_module()
+    assert B == bench.CONFIG5_BATCH and T == 50
+    fin2, diag2, names = tf.bench_plan_run(wg, model, B, T, 10, bench)
+    assert names == ["wg_mpc_tick_batch_dev", "wg_mpc_tick_batch_dev", "wg_mpc_run_batch_dev", "wg_mpc_run_batch_dev"]
+    assert np.array_equal(diag2, diag)
+    assert b"".join(fin2) == fin.tobytes()
+
+
 def test_config5_determinism_and_batch_composition_invariance(config5_run):
     model, B, T, fin, diag = config5_run
     fin_again, diag_again = _run_dev(model, list(range(B)), T)

@@ -99,6 +99,70 @@ def test_full_size_sample_followed_by_the_oracle(full_run):
         assert bytes(memoryview(s).cast("B")) == fin[g], g
 
 
+def _bench_module():
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("wg_bench", os.path.join(root, "bench.py"))
+    mod = importlib.util.module_from_spec(spec)
+    sys.modules["wg_bench"] = mod
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def bench_plan_run(ctx, model, B, t_end, timed_from, bench):
+    """bench.py's own launch sequence on device-resident states (its launch_plan, its velocity_table, its entry points:
+    wg_mpc_tick_batch_dev for the control loop's first two ticks, wg_mpc_set_velref_dev + wg_mpc_run_batch_dev for a stretch
+    that does not start on a redraw, wg_mpc_run_sched_dev with the references of every later stretch staged for one that
+    does): ticks [0, timed_from) as its pre-roll + warm-up, [timed_from, t_end) as its timed region.  Returns the final states
+    (host bytes per gait), the per-tick diagnostics and the entry point of every launch."""
+    import torch
+    n_seg = (t_end + bench.REDRAW_TICKS - 1) // bench.REDRAW_TICKS
+    vtab = torch.from_numpy(bench.velocity_table(0, B, n_seg)).cuda()
+    states = bench.start_states(model, B).cuda()
+    diag = torch.zeros(t_end, B, 6, dtype=torch.int32, device="cuda")
+    sp, dp, dstride = states.data_ptr(), diag.data_ptr(), B * 6 * 4
+    stream = torch.cuda.Stream()
+    sh = stream.cuda_stream
+    names = []
+    with torch.cuda.stream(stream):
+        for t, n in bench.launch_plan(0, timed_from) + bench.launch_plan(timed_from, t_end):
+            staged = n > 1 and t % bench.REDRAW_TICKS == 0
+            if t % bench.REDRAW_TICKS == 0 and not staged:
+                ctx.mpc_set_velref_dev(B, sp, vtab[t // bench.REDRAW_TICKS].data_ptr(), sh)
+            adv = 1 if t == 0 else (19 if t == 1 else 20)
+            if n == 1 and t < 2:
+                names.append("wg_mpc_tick_batch_dev")
+                ctx.mpc_tick_batch_dev(B, sp, None, dp + t * dstride, adv, stream=sh)
+            elif staged:
+                names.append("wg_mpc_run_sched_dev")
+                ctx.mpc_run_sched_dev(B, sp, n, vtab[t // bench.REDRAW_TICKS].data_ptr(), bench.REDRAW_TICKS, adv, None,
+                                      dp + t * dstride, stream=sh)
+            else:
+                names.append("wg_mpc_run_batch_dev")
+                ctx.mpc_run_batch_dev(B, sp, n, adv, None, dp + t * dstride, stream=sh)
+    torch.cuda.synchronize()
+    raw = states.cpu().numpy().tobytes()
+    sz = C.sizeof(wg.GaitState)
+    return [raw[k * sz:(k + 1) * sz] for k in range(B)], diag.cpu().numpy(), names
+
+
+def test_bench_plan_at_the_timed_size_ends_in_the_per_tick_runs_bytes(full_run):
+    """The entry point bench.py times (wg_mpc_run_sched_dev, B = 4096, one launch from a redraw boundary with the later
+    stretches' references staged) at the size it times it: bench.py's own pre-roll / warm-up / timed launch sequence over the
+    first 200 ticks must leave every gait in the bytes the one-launch-per-tick host-pointer run left it in (which a sample of
+    the oracle follows, test above), with the same ifail / iteration count / active-set size for every one of the 819 200
+    QPs.  tools/soak_parity.py is the longer soak with the oracle on every gait."""
+    model, B, T, fin, st, fails, iters = full_run
+    bench = _bench_module()
+    assert B == bench.BATCH_PER_GPU and bench.PREROLL_TICKS + 50 == 150       # the default W: timed region starts at tick 150
+    fin2, diag, names = bench_plan_run(wg, model, B, T, 150, bench)
+    assert names == ["wg_mpc_tick_batch_dev", "wg_mpc_tick_batch_dev", "wg_mpc_run_batch_dev", "wg_mpc_run_sched_dev",
+                     "wg_mpc_run_sched_dev"]                                  # ticks 0 | 1 | 2-49 | 50-149 (staged) | 150-199 (timed)
+    assert int((diag[:, :, 0] != 0).sum()) == 0
+    assert np.array_equal(diag[:, :, 1], iters)
+    assert fin2 == fin
+
+
 def test_determinism_and_batch_composition_invariance(full_run):
     model, B, T, fin, st, fails, iters = full_run
     # same gaits in another order, other batch size, other neighbours -> identical bytes per gait
