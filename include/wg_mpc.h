@@ -69,13 +69,24 @@ int wg_shard_range(long long total, int rank, int world, long long *lo, long lon
  *   - contexts are independent: two contexts may hold different models (N = 16 and N = 32, two robots, two preview
  *     windows) and their launches may overlap on different streams;
  *   - launches on ONE context share its workspaces: keep them on one stream (or order them with events).  Host-pointer
- *     entry points are synchronous and serialised per context;
+ *     entry points are synchronous and serialised per context: each context owns one non-blocking stream on which they copy
+ *     in, launch and copy out, and they wait for THAT stream only -- never for the device: a host call on one context does
+ *     not stall, and is not stalled by, the launches of another context or of the caller's own streams (two
+ *     PatternGeneratorInterface objects, or a facade object beside a fleet, run side by side).  The same holds for the
+ *     *_configure entry points: re-configuring waits for this context's earlier launches (their events), nobody else's;
  *   - a context belongs to one device; its entry points make that device current for the calling thread;
  *   - wg_ctx_destroy waits for the device, then frees everything the context owns. */
 typedef struct wg_ctx wg_ctx_t;
 int wg_ctx_create(int device_ordinal, wg_ctx_t **ctx);
 void wg_ctx_destroy(wg_ctx_t *ctx);
 int wg_ctx_device(const wg_ctx_t *ctx);
+/* Launches of one context that arrive on different streams are ordered by the library (see wg_mpc_tick_batch_dev).  `on` != 0
+ * makes the context refuse them instead (WG_ERR_BUSY); the initial value is WG_OVERLAP_STRICT of the environment, read once when
+ * the context is created.  wg_overlap_serialised: how many launches of this context were ordered behind a launch of another
+ * stream so far -- a caller that expected two streams to overlap reads its lost concurrency here (WG_OVERLAP_NOTE=1 in the
+ * environment also prints one line to stderr at the first occurrence). */
+int wg_set_overlap_strict(int on);
+long long wg_overlap_serialised(void);
 
 /* Batched dense QP solve -------------------------------------------------
  *
@@ -224,7 +235,8 @@ typedef struct wg_gait_state {
 
 #define WG_SAMPLES_PER_TICK 20   /* QP_T_ / m_SamplingPeriod */
 
-/* What one tick appends to the four deques + solver diagnostics. */
+/* What one tick appends to the four deques + solver diagnostics.  Arrays of it should start on a 128-byte boundary
+ * (hipMalloc / wg_host_alloc do). */
 typedef struct wg_tick_out {
   double jerk_x, jerk_y;                       /* control applied to the LIPM */
   int ifail, n_iter, nact, n, m, nb_prw_steps; /* QP dimensions: n = 2N+2s, m = 1+4N+5s */
@@ -235,6 +247,10 @@ typedef struct wg_tick_out {
   /* the newest sample ALREADY in the feet queues before this tick: the double-support branch of
    * interpolate_feet_positions rewrites it (OnLineFootTrajectoryGeneration.cpp:333-336, k = 0) */
   wg_foot_sample_t lf_back, rf_back;
+  /* sizeof == 7808 = 61 cache lines of 128 B (ABI 5; it was 7688, 8 B past 60 lines): in an array of these no line is shared
+   * by two gaits' structs -- two waves finishing at different times no longer write the shared line back twice (measured
+   * 10.7 KB written per 7688-B struct stored).  Never written, never read. */
+  double pad_[15];
 } wg_tick_out_t;
 
 /* Defaults of every constant the reference hard-codes; robot part = jrl-dynamics' sample robot. */
@@ -273,8 +289,9 @@ int wg_mpc_reserve(int max_gaits);
  * sees to that itself: a launch that arrives on a different stream while the context's previous tick / run launch has not
  * completed is enqueued BEHIND it (hipStreamWaitEvent on an event the previous launch left) -- a pipeline that orders its
  * streams with events of its own is accepted as it is, an unordered one is serialised instead of corrupted.  Streams that
- * are meant to overlap take one context each (wg_ctx_create).  With WG_OVERLAP_STRICT=1 in the environment such a launch is
- * refused instead (WG_ERR_BUSY, nothing launched): a way to find serialisation that was not intended.  The ordering test, the
+ * are meant to overlap take one context each (wg_ctx_create).  With WG_OVERLAP_STRICT=1 in the environment when the context is
+ * created (or after wg_set_overlap_strict(1)) such a launch is refused instead (WG_ERR_BUSY, nothing launched): a way to find
+ * serialisation that was not intended; wg_overlap_serialised() counts the launches that were ordered.  The ordering test, the
  * launch and the event record are one critical section per context (host threads may share a context).
  * With more gaits than the device keeps resident, a call that follows another one on the same `states` array starts the gaits
  * in the order of decreasing QL iteration count of that previous tick (scheduling only: no result depends on it). */
@@ -619,6 +636,8 @@ int wg_qp_solve_batch_ctx(wg_ctx_t *ctx, int B, int nmax, int mmax, const int *n
                           const double *C, const double *d, const double *A, const double *b, const double *xl,
                           const double *xu, double eps, double *x, double *u, int *ifail, int *n_iter, int *iact,
                           int *nact, int *hist, int hist_cap, int *hist_len);
+int wg_set_overlap_strict_ctx(wg_ctx_t *ctx, int on);
+long long wg_overlap_serialised_ctx(wg_ctx_t *ctx);
 int wg_mpc_configure_ctx(wg_ctx_t *ctx, const wg_model_t *model);
 size_t wg_mpc_tick_lds_bytes_ctx(wg_ctx_t *ctx);
 int wg_mpc_reserve_ctx(wg_ctx_t *ctx, int max_gaits);

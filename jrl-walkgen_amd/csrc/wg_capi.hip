@@ -99,6 +99,15 @@ struct wg_ctx {
   SlotOrder guard_order;
   // wg_mpc_assemble_batch_dev runs the tick on scratch copies of the states kept per context (asm_state): same ordering
   SlotOrder asm_order;
+  // launches of the other back-ends (PLDP, Dimitrov tick, preview): they read constants a re-configuration overwrites, so they
+  // leave an event for it to wait on (marked, never claimed: they keep nothing per launch in the context)
+  SlotOrder aux_order;
+  // The host-pointer entry points stage, launch and copy back on THIS stream (non-blocking: no implicit ordering against the
+  // legacy stream or anybody else's) and wait for it alone -- never for the device: another context's launches, or a caller's
+  // own streams, keep running while this context's host call waits for its own work.
+  hipStream_t host_stream = nullptr;
+  bool overlap_strict = false;           // WG_OVERLAP_STRICT at wg_ctx_create / wg_init, wg_set_overlap_strict afterwards
+  long long serialised = 0;              // launches that were ordered behind one of another stream (wg_overlap_serialised)
   // one-robot path (wg_mpc_tick_pinned): its own stream, a completion counter in host-mapped memory
   hipStream_t pin_stream = nullptr;
   int *pin_flag = nullptr;               // host-mapped; the kernel adds 1 per gait when its outputs are visible
@@ -128,12 +137,14 @@ struct wg_ctx {
     model_set = false; pldp_N = 0; dim_set = false; prev_set = false;
     for (DevBuf *b : {&tick_state, &tick_out, &tick_aux, &run_buf, &tick_z, &asm_state, &lpt_buf, &qp_slot, &pldp_buf, &dim_buf, &prev_buf, &in, &out, &gram_buf, &zd_buf})
       b->release();
-    for (SlotOrder *o : {&guard_order, &qp_order, &asm_order}) {
+    for (SlotOrder *o : {&guard_order, &qp_order, &asm_order, &aux_order}) {
       if (o->ev) (void)hipEventDestroy(o->ev);
       o->ev = nullptr; o->armed = false; o->stream = nullptr;
     }
     lpt_states = nullptr; lpt_B = 0;
     if (pin_stream) (void)hipStreamDestroy(pin_stream);
+    if (host_stream) (void)hipStreamDestroy(host_stream);
+    host_stream = nullptr;
     if (pin_flag) (void)hipHostFree(pin_flag);
     pin_stream = nullptr; pin_flag = nullptr; pin_seq = 0;
   }
@@ -158,6 +169,11 @@ int make_ctx(int device_ordinal, wg_ctx **out) {
   wg_ctx *c = new wg_ctx();
   c->device = device_ordinal;
   c->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  if (hipStreamCreateWithFlags(&c->host_stream, hipStreamNonBlocking) != hipSuccess) {
+    delete c;
+    return fail(WG_ERR_HIP, "hipStreamCreateWithFlags failed for the context's host stream");
+  }
+  if (const char *e = getenv("WG_OVERLAP_STRICT")) c->overlap_strict = atoi(e) != 0;   // read once per context, not per launch
   *out = c;
   return WG_OK;
 }
@@ -180,18 +196,39 @@ int use_ctx(wg_ctx *ctx) {
 
 // Both with ctx->launch_mu held, around the launch.
 // before a launch that uses device state of the context (`o`): behind the previous such launch, whatever stream that was on
-inline bool overlap_strict() { const char *e = getenv("WG_OVERLAP_STRICT"); return e && atoi(e) != 0; }
-inline bool slot_pending_elsewhere(const wg_ctx::SlotOrder &o, hipStream_t st) {
-  return o.armed && o.stream != st && hipEventQuery(o.ev) == hipErrorNotReady;
-}
-int slot_claim(wg_ctx::SlotOrder &o, hipStream_t st, const char *what) {
-  if (!slot_pending_elsewhere(o, st)) return WG_OK;
-  if (overlap_strict())
-    return fail(WG_ERR_BUSY, "a %s launch of this context is still in flight on another stream (WG_OVERLAP_STRICT: launches of one "
-                             "context are refused instead of ordered; give each stream its own wg_ctx to overlap them)", what);
+inline bool slot_pending(const wg_ctx::SlotOrder &o) { return o.armed && hipEventQuery(o.ev) == hipErrorNotReady; }
+inline bool slot_pending_elsewhere(const wg_ctx::SlotOrder &o, hipStream_t st) { return o.stream != st && slot_pending(o); }
+int slot_claim(wg_ctx *ctx, wg_ctx::SlotOrder &o, hipStream_t st, const char *what) {
+  if (!slot_pending(o)) return WG_OK;
+  // the handle alone does not identify a stream (one destroyed and re-created at the same address counts as the same): the wait
+  // is issued whenever the previous launch is pending -- behind a launch of the same stream it costs nothing
+  if (o.stream != st) {
+    if (ctx->overlap_strict)
+      return fail(WG_ERR_BUSY, "a %s launch of this context is still in flight on another stream (WG_OVERLAP_STRICT: launches of one "
+                               "context are refused instead of ordered; give each stream its own wg_ctx to overlap them)", what);
+    if (ctx->serialised++ == 0 && getenv("WG_OVERLAP_NOTE"))
+      fprintf(stderr, "wg_mpc: a %s launch was ordered behind one of another stream of the same context (first occurrence; "
+                      "wg_overlap_serialised() counts them, one wg_ctx per stream overlaps them)\n", what);
+  }
   HIP_TRY(hipStreamWaitEvent(st, o.ev, 0));
   return WG_OK;
 }
+// a re-configuration overwrites tables that launches of THIS context may still be reading: wait for those launches (their events,
+// the context's own streams) -- not for the device
+int ctx_wait_own(wg_ctx *ctx) {
+  std::lock_guard<std::mutex> launch_lk(ctx->launch_mu);
+  for (wg_ctx::SlotOrder *o : {&ctx->guard_order, &ctx->qp_order, &ctx->asm_order, &ctx->aux_order})
+    if (o->armed) HIP_TRY(hipEventSynchronize(o->ev));
+  if (ctx->host_stream) HIP_TRY(hipStreamSynchronize(ctx->host_stream));
+  if (ctx->pin_stream) HIP_TRY(hipStreamSynchronize(ctx->pin_stream));
+  return WG_OK;
+}
+// staging copies of the host-pointer entry points: on the context's stream; the caller of these waits for that stream before it
+// returns (pageable host memory: the runtime stages the copy, the stream synchronise below covers both directions)
+#define WG_H2D(dst, src, bytes) HIP_TRY(hipMemcpyAsync((dst), (src), (bytes), hipMemcpyHostToDevice, ctx->host_stream))
+#define WG_D2H(dst, src, bytes) HIP_TRY(hipMemcpyAsync((dst), (src), (bytes), hipMemcpyDeviceToHost, ctx->host_stream))
+#define WG_ZERO(dst, bytes) HIP_TRY(hipMemsetAsync((dst), 0, (bytes), ctx->host_stream))
+#define WG_HOST_WAIT() HIP_TRY(hipStreamSynchronize(ctx->host_stream))
 // after it: the event later launches are ordered behind
 int slot_mark(wg_ctx::SlotOrder &o, hipStream_t st) {
   if (!o.ev) HIP_TRY(hipEventCreateWithFlags(&o.ev, hipEventDisableTiming));
@@ -302,7 +339,8 @@ __global__ __launch_bounds__(64) WG_QLD_ATTR void wg_ql_dense_kernel(   // never
 
 extern "C" {
 
-int wg_abi_version(void) { return 4; }
+static_assert(sizeof(wg_tick_out_t) == 61 * 128, "wg_tick_out_t: whole 128-byte lines (include/wg_mpc.h)");
+int wg_abi_version(void) { return 5; }
 
 const char *wg_last_error(void) { return g_err.c_str(); }
 
@@ -326,6 +364,19 @@ void wg_ctx_destroy(wg_ctx_t *ctx) {
 }
 
 int wg_ctx_device(const wg_ctx_t *ctx) { return ctx ? ctx->device : -1; }
+
+int wg_set_overlap_strict_ctx(wg_ctx_t *ctx, int on) {
+  if (!ctx) return fail(WG_ERR_BAD_ARG, "null context");
+  std::lock_guard<std::mutex> launch_lk(ctx->launch_mu);
+  ctx->overlap_strict = on != 0;
+  return WG_OK;
+}
+
+long long wg_overlap_serialised_ctx(wg_ctx_t *ctx) {
+  if (!ctx) return -1;
+  std::lock_guard<std::mutex> launch_lk(ctx->launch_mu);
+  return ctx->serialised;
+}
 
 int wg_shard_range(long long total, int rank, int world, long long *lo, long long *hi) {
   if (total < 0 || world < 1 || rank < 0 || rank >= world || !lo || !hi)
@@ -468,7 +519,7 @@ int wg_qp_solve_batch_ctx(wg_ctx_t *ctx, int B, int nmax, int mmax, const int *n
   if (int rc = ctx->in.reserve(tot)) return rc;
   char *din = static_cast<char *>(ctx->in.p);
   for (auto &s : in)
-    if (s.bytes) HIP_TRY(hipMemcpy(din + s.off, s.h, s.bytes, hipMemcpyHostToDevice));
+    if (s.bytes) WG_H2D(din + s.off, s.h, s.bytes);
   struct OSeg { void *h; size_t bytes; size_t off; };
   std::vector<OSeg> out = {{x, sB * nmax * 8, 0},
                            {u, u ? sB * (mmax + 2 * (size_t)nmax) * 8 : 0, 0},
@@ -482,18 +533,18 @@ int wg_qp_solve_batch_ctx(wg_ctx_t *ctx, int B, int nmax, int mmax, const int *n
   for (auto &s : out) { s.off = otot; otot += (s.bytes + 255) & ~(size_t)255; }
   if (int rc = ctx->out.reserve(otot)) return rc;
   char *dout = static_cast<char *>(ctx->out.p);
-  HIP_TRY(hipMemset(dout, 0, otot));
+  WG_ZERO(dout, otot);
   auto ip = [&](int k) { return in[k].bytes ? din + in[k].off : nullptr; };
   auto op = [&](int k) { return out[k].bytes ? dout + out[k].off : nullptr; };
   int rc = wg_qp_solve_batch_dev_ctx(ctx, B, nmax, mmax, (const int *)ip(6), (const int *)ip(7), (const int *)ip(8),
                                  (const double *)ip(0), (const double *)ip(1), (const double *)ip(2),
                                  (const double *)ip(3), (const double *)ip(4), (const double *)ip(5), eps,
                                  (double *)op(0), (double *)op(1), (int *)op(2), (int *)op(3), (int *)op(4),
-                                 (int *)op(5), (int *)op(6), hist_cap, (int *)op(7), nullptr);
+                                 (int *)op(5), (int *)op(6), hist_cap, (int *)op(7), ctx->host_stream);
   if (rc) return rc;
-  HIP_TRY(hipDeviceSynchronize());
   for (auto &s : out)
-    if (s.bytes) HIP_TRY(hipMemcpy(s.h, dout + s.off, s.bytes, hipMemcpyDeviceToHost));
+    if (s.bytes) WG_D2H(s.h, dout + s.off, s.bytes);
+  WG_HOST_WAIT();
   return WG_OK;
 }
 
@@ -673,11 +724,13 @@ int wg_mpc_configure_ctx(wg_ctx_t *ctx, const wg_model_t *model) {
   if (!host_tables.blocks_ok && !qb.empty())
     return fail(WG_ERR_BAD_ARG, "the matrix-core Gramian is not positive definite enough for ql0002's factorisation");
   if (!ctx->tables_dev) HIP_TRY(hipMalloc(reinterpret_cast<void **>(&ctx->tables_dev), sizeof(wg::TickTables)));
-  // a launch of an earlier configuration may still be reading the tables
-  HIP_TRY(hipDeviceSynchronize());
-  HIP_TRY(hipMemcpy(ctx->tables_dev, &host_tables, sizeof host_tables, hipMemcpyHostToDevice));
+  // a launch of an earlier configuration may still be reading the tables: this context's own launches, on whatever stream they
+  // went (every tick / run / assemble launch leaves an event) -- other contexts and other work on the device are not waited for
+  if (int rc = ctx_wait_own(ctx)) return rc;
+  WG_H2D(ctx->tables_dev, &host_tables, sizeof host_tables);
   if (!ctx->model_dev) HIP_TRY(hipMalloc(reinterpret_cast<void **>(&ctx->model_dev), sizeof(wg_model_t)));
-  HIP_TRY(hipMemcpy(ctx->model_dev, model, sizeof(wg_model_t), hipMemcpyHostToDevice));
+  WG_H2D(ctx->model_dev, model, sizeof(wg_model_t));
+  WG_HOST_WAIT();
   ctx->model = *model;
   ctx->model_set = true;
   // The queue and the per-block solver slots of the tick / run kernels are sized by the launches themselves, for the grid they have
@@ -728,7 +781,7 @@ int tick_launch(wg_ctx_t *ctx, int B, wg_gait_state_t *states, wg_tick_out_t *ou
   const int grid = B;                             // one gait per block; the dispatcher balances uneven iteration counts
   hipStream_t st = reinterpret_cast<hipStream_t>(hip_stream);
   std::lock_guard<std::mutex> launch_lk(ctx->launch_mu);   // ordering test, launch and event record are one critical section
-  if (int rc = slot_claim(ctx->guard_order, st, "tick / run")) return rc;
+  if (int rc = slot_claim(ctx, ctx->guard_order, st, "tick / run")) return rc;
   const int ecap = tick_elem_cap_arg(ctx->model, view);
   double *zs = nullptr;
   const size_t zslot = tick_z_slot_doubles(ctx->model, view);
@@ -841,7 +894,7 @@ int wg_mpc_assemble_batch_dev_ctx(wg_ctx_t *ctx, int B, const wg_gait_state_t *s
   // the scratch copies of the states are the context's: assemble launches of one context are ordered like its tick / run launches
   hipStream_t st = reinterpret_cast<hipStream_t>(hip_stream);
   std::lock_guard<std::mutex> launch_lk(ctx->launch_mu);
-  if (int rc = slot_claim(ctx->asm_order, st, "assemble")) return rc;
+  if (int rc = slot_claim(ctx, ctx->asm_order, st, "assemble")) return rc;
   if (int rc = ctx->asm_state.reserve((size_t)B * sizeof(wg_gait_state_t))) return rc;
   hipLaunchKernelGGL(wg_mpc_assemble_kernel, dim3(B), dim3(64), lds, st, B, ctx->model,
                      ctx->tables_dev, states, static_cast<wg_gait_state_t *>(ctx->asm_state.p), advance_calls, (unsigned)qlb, nmax, mmax,
@@ -861,22 +914,22 @@ int wg_mpc_assemble_batch_ctx(wg_ctx_t *ctx, int B, const wg_gait_state_t *state
                off_m = off_n + sB * 4, tot = off_m + sB * 4;
   if (int rc = ctx->in.reserve(tot)) return rc;
   char *base = static_cast<char *>(ctx->in.p);
-  HIP_TRY(hipMemcpy(base, states, sB * sizeof(wg_gait_state_t), hipMemcpyHostToDevice));
+  WG_H2D(base, states, sB * sizeof(wg_gait_state_t));
   int rc = wg_mpc_assemble_batch_dev_ctx(ctx, B, reinterpret_cast<const wg_gait_state_t *>(base), advance_calls, nmax, mmax,
                                          reinterpret_cast<double *>(base + off_C), reinterpret_cast<double *>(base + off_d),
                                          reinterpret_cast<double *>(base + off_A), reinterpret_cast<double *>(base + off_b),
                                          reinterpret_cast<double *>(base + off_xl), reinterpret_cast<double *>(base + off_xu),
-                                         reinterpret_cast<int *>(base + off_n), reinterpret_cast<int *>(base + off_m), nullptr);
+                                         reinterpret_cast<int *>(base + off_n), reinterpret_cast<int *>(base + off_m), ctx->host_stream);
   if (rc) return rc;
-  HIP_TRY(hipStreamSynchronize(nullptr));   // the stream the launch went to, not every stream of the device
-  HIP_TRY(hipMemcpy(C, base + off_C, sB * sn * sn * 8, hipMemcpyDeviceToHost));
-  HIP_TRY(hipMemcpy(d, base + off_d, sB * sn * 8, hipMemcpyDeviceToHost));
-  HIP_TRY(hipMemcpy(A, base + off_A, sB * sm * sn * 8, hipMemcpyDeviceToHost));
-  HIP_TRY(hipMemcpy(b, base + off_b, sB * sm * 8, hipMemcpyDeviceToHost));
-  HIP_TRY(hipMemcpy(xl, base + off_xl, sB * sn * 8, hipMemcpyDeviceToHost));
-  HIP_TRY(hipMemcpy(xu, base + off_xu, sB * sn * 8, hipMemcpyDeviceToHost));
-  HIP_TRY(hipMemcpy(n, base + off_n, sB * 4, hipMemcpyDeviceToHost));
-  HIP_TRY(hipMemcpy(m, base + off_m, sB * 4, hipMemcpyDeviceToHost));
+  WG_D2H(C, base + off_C, sB * sn * sn * 8);
+  WG_D2H(d, base + off_d, sB * sn * 8);
+  WG_D2H(A, base + off_A, sB * sm * sn * 8);
+  WG_D2H(b, base + off_b, sB * sm * 8);
+  WG_D2H(xl, base + off_xl, sB * sn * 8);
+  WG_D2H(xu, base + off_xu, sB * sn * 8);
+  WG_D2H(n, base + off_n, sB * 4);
+  WG_D2H(m, base + off_m, sB * 4);
+  WG_HOST_WAIT();
   return WG_OK;
 }
 
@@ -907,7 +960,7 @@ int wg_mpc_run_sched_dev_ctx(wg_ctx_t *ctx, int B, wg_gait_state_t *states, int 
   const int total = B * n_ticks;
   hipStream_t st = reinterpret_cast<hipStream_t>(hip_stream);
   std::lock_guard<std::mutex> launch_lk(ctx->launch_mu);   // ordering test, launch and event record are one critical section
-  if (int rc = slot_claim(ctx->guard_order, st, "tick / run")) return rc;
+  if (int rc = slot_claim(ctx, ctx->guard_order, st, "tick / run")) return rc;
   // hand-over inside one XCD (default) or through one device-wide queue (WG_RUN_QUEUE=global: A/B tests)
   bool xcd_mode = true;
   if (const char *e = getenv("WG_RUN_QUEUE")) xcd_mode = e[0] != 'g';
@@ -974,23 +1027,23 @@ int wg_mpc_tick_batch_ctx(wg_ctx_t *ctx, int B, wg_gait_state_t *states, wg_tick
   if (outs) if (int rc = ctx->tick_out.reserve(sB * sizeof(wg_tick_out_t))) return rc;
   const size_t aux_bytes = sB * 6 * 4 + (hist ? sB * hist_cap * 4 + sB * 4 : 0);
   if (int rc = ctx->tick_aux.reserve(aux_bytes)) return rc;
-  HIP_TRY(hipMemcpy(ctx->tick_state.p, states, sB * sizeof(wg_gait_state_t), hipMemcpyHostToDevice));
+  WG_H2D(ctx->tick_state.p, states, sB * sizeof(wg_gait_state_t));
   int *d_diag = static_cast<int *>(ctx->tick_aux.p);
   int *d_hist = hist ? d_diag + sB * 6 : nullptr;
   int *d_hlen = hist ? d_hist + sB * hist_cap : nullptr;
-  HIP_TRY(hipMemset(ctx->tick_aux.p, 0, aux_bytes));
+  WG_ZERO(ctx->tick_aux.p, aux_bytes);
   int rc = wg_mpc_tick_batch_dev_ctx(ctx, B, static_cast<wg_gait_state_t *>(ctx->tick_state.p),
                                  outs ? static_cast<wg_tick_out_t *>(ctx->tick_out.p) : nullptr, d_diag, advance_calls,
-                                 d_hist, hist_cap, d_hlen, nullptr);
+                                 d_hist, hist_cap, d_hlen, ctx->host_stream);
   if (rc) return rc;
-  HIP_TRY(hipDeviceSynchronize());
-  HIP_TRY(hipMemcpy(states, ctx->tick_state.p, sB * sizeof(wg_gait_state_t), hipMemcpyDeviceToHost));
-  if (outs) HIP_TRY(hipMemcpy(outs, ctx->tick_out.p, sB * sizeof(wg_tick_out_t), hipMemcpyDeviceToHost));
-  if (diag) HIP_TRY(hipMemcpy(diag, d_diag, sB * 6 * 4, hipMemcpyDeviceToHost));
+  WG_D2H(states, ctx->tick_state.p, sB * sizeof(wg_gait_state_t));
+  if (outs) WG_D2H(outs, ctx->tick_out.p, sB * sizeof(wg_tick_out_t));
+  if (diag) WG_D2H(diag, d_diag, sB * 6 * 4);
   if (hist) {
-    HIP_TRY(hipMemcpy(hist, d_hist, sB * hist_cap * 4, hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(hist_len, d_hlen, sB * 4, hipMemcpyDeviceToHost));
+    WG_D2H(hist, d_hist, sB * hist_cap * 4);
+    WG_D2H(hist_len, d_hlen, sB * 4);
   }
+  WG_HOST_WAIT();
   return WG_OK;
 }
 
@@ -1057,7 +1110,9 @@ int wg_pldp_configure_ctx(wg_ctx_t *ctx, int N, const double *iPu, const double 
       host.iPuPx[(i + N) * 6 + j + 3] = s;
     }
   if (!ctx->pldp_dev) HIP_TRY(hipMalloc(reinterpret_cast<void **>(&ctx->pldp_dev), sizeof(wg::PldpModel)));
-  HIP_TRY(hipMemcpy(ctx->pldp_dev, &host, sizeof host, hipMemcpyHostToDevice));
+  if (int rc = ctx_wait_own(ctx)) return rc;             // a solve of the previous model may still be reading it
+  WG_H2D(ctx->pldp_dev, &host, sizeof host);
+  WG_HOST_WAIT();
   ctx->pldp_N = N;
   return WG_OK;
 }
@@ -1090,7 +1145,8 @@ int wg_pldp_solve_batch_dev_ctx(wg_ctx_t *ctx, int B, int mcap, const int *m, co
                        ctx->pldp_dev, m, D, A, b, zmpref, xkyk, similar, n_removed, starting, max_iter, states, X, ret, n_iter,
                        active, n_active);
   HIP_TRY(hipGetLastError());
-  return WG_OK;
+  std::lock_guard<std::mutex> launch_lk(ctx->launch_mu);
+  return slot_mark(ctx->aux_order, reinterpret_cast<hipStream_t>(hip_stream));
 }
 
 int wg_pldp_solve_batch_ctx(wg_ctx_t *ctx, int B, int mcap, const int *m, const double *D, const double *A, const double *b, const double *zmpref, const double *xkyk, const int *similar, const int *n_removed, const int *starting, int max_iter, wg_pldp_state_t *states, double *X, int *ret, int *n_iter, int *active, int *n_active) {
@@ -1113,27 +1169,27 @@ int wg_pldp_solve_batch_ctx(wg_ctx_t *ctx, int B, int mcap, const int *m, const 
   wg_pldp_state_t *dst = reinterpret_cast<wg_pldp_state_t *>(dX + sB * n);
   int *dm = reinterpret_cast<int *>(dst + sB), *dsim = dm + sB, *dnr = dsim + sB * mcap, *dstart = dnr + sB,
       *dret = dstart + sB, *dit = dret + sB, *dact = dit + sB, *dnact = dact + sB * mcap;
-  HIP_TRY(hipMemcpy(dD, D, sB * n * 8, hipMemcpyHostToDevice));
-  HIP_TRY(hipMemcpy(dA, A, sB * aslot * 8, hipMemcpyHostToDevice));
-  HIP_TRY(hipMemcpy(db, b, sB * mcap * 8, hipMemcpyHostToDevice));
-  HIP_TRY(hipMemcpy(dz, zmpref, sB * n * 8, hipMemcpyHostToDevice));
-  HIP_TRY(hipMemcpy(dx, xkyk, sB * 6 * 8, hipMemcpyHostToDevice));
-  HIP_TRY(hipMemcpy(dst, states, sB * sizeof(wg_pldp_state_t), hipMemcpyHostToDevice));
-  HIP_TRY(hipMemcpy(dm, m, sB * 4, hipMemcpyHostToDevice));
-  HIP_TRY(hipMemcpy(dsim, similar, sB * mcap * 4, hipMemcpyHostToDevice));
-  HIP_TRY(hipMemcpy(dnr, n_removed, sB * 4, hipMemcpyHostToDevice));
-  HIP_TRY(hipMemcpy(dstart, starting, sB * 4, hipMemcpyHostToDevice));
-  HIP_TRY(hipMemset(dret, 0, sB * (3 + mcap) * 4));
+  WG_H2D(dD, D, sB * n * 8);
+  WG_H2D(dA, A, sB * aslot * 8);
+  WG_H2D(db, b, sB * mcap * 8);
+  WG_H2D(dz, zmpref, sB * n * 8);
+  WG_H2D(dx, xkyk, sB * 6 * 8);
+  WG_H2D(dst, states, sB * sizeof(wg_pldp_state_t));
+  WG_H2D(dm, m, sB * 4);
+  WG_H2D(dsim, similar, sB * mcap * 4);
+  WG_H2D(dnr, n_removed, sB * 4);
+  WG_H2D(dstart, starting, sB * 4);
+  WG_ZERO(dret, sB * (3 + mcap) * 4);
   int rc = wg_pldp_solve_batch_dev_ctx(ctx, B, mcap, dm, dD, dA, db, dz, dx, dsim, dnr, dstart, max_iter, dst, dX, dret, dit, dact,
-                                   dnact, nullptr);
+                                   dnact, ctx->host_stream);
   if (rc) return rc;
-  HIP_TRY(hipDeviceSynchronize());
-  HIP_TRY(hipMemcpy(states, dst, sB * sizeof(wg_pldp_state_t), hipMemcpyDeviceToHost));
-  HIP_TRY(hipMemcpy(X, dX, sB * n * 8, hipMemcpyDeviceToHost));
-  HIP_TRY(hipMemcpy(ret, dret, sB * 4, hipMemcpyDeviceToHost));
-  if (n_iter) HIP_TRY(hipMemcpy(n_iter, dit, sB * 4, hipMemcpyDeviceToHost));
-  if (active) HIP_TRY(hipMemcpy(active, dact, sB * mcap * 4, hipMemcpyDeviceToHost));
-  if (n_active) HIP_TRY(hipMemcpy(n_active, dnact, sB * 4, hipMemcpyDeviceToHost));
+  WG_D2H(states, dst, sB * sizeof(wg_pldp_state_t));
+  WG_D2H(X, dX, sB * n * 8);
+  WG_D2H(ret, dret, sB * 4);
+  if (n_iter) WG_D2H(n_iter, dit, sB * 4);
+  if (active) WG_D2H(active, dact, sB * mcap * 4);
+  if (n_active) WG_D2H(n_active, dnact, sB * 4);
+  WG_HOST_WAIT();
   return WG_OK;
 }
 
@@ -1191,7 +1247,9 @@ int wg_dimitrov_configure_ctx(wg_ctx_t *ctx, const wg_dimitrov_model_t *model) {
     if (!wg::DimitrovHost::build(*model, (*ctx->dim_host)))
       return fail(WG_ERR_BAD_ARG, "the LQ factor or the inverse of Pu does not exist for this model");
     if (!ctx->dim_dev) HIP_TRY(hipMalloc(reinterpret_cast<void **>(&ctx->dim_dev), sizeof(wg::DimitrovConst)));
-    HIP_TRY(hipMemcpy(ctx->dim_dev, &(*ctx->dim_host), sizeof (*ctx->dim_host), hipMemcpyHostToDevice));
+    if (int rc = ctx_wait_own(ctx)) return rc;           // a tick of the previous model may still be reading the constants
+    WG_H2D(ctx->dim_dev, &(*ctx->dim_host), sizeof (*ctx->dim_host));
+    WG_HOST_WAIT();
     ctx->dim_set = true;
   }
   // the PLDPSolver constructor of the reference (:104-109): same iPu, Px, Pu
@@ -1236,7 +1294,8 @@ int wg_dimitrov_tick_batch_dev_ctx(wg_ctx_t *ctx, int B, const wg_zmp_polytope_t
       hipLaunchKernelGGL(wg_dimitrov_qld_tick_kernel<false>, dim3(B), dim3(64), ldsq, reinterpret_cast<hipStream_t>(hip_stream), B,
                          ctx->dim_dev, polys, states, outs);
     HIP_TRY(hipGetLastError());
-    return WG_OK;
+    std::lock_guard<std::mutex> launch_lk(ctx->launch_mu);
+    return slot_mark(ctx->aux_order, reinterpret_cast<hipStream_t>(hip_stream));
   }
   const size_t lds = dimitrov_lds_bytes();
   if (lds > 64 * 1024)
@@ -1246,7 +1305,8 @@ int wg_dimitrov_tick_batch_dev_ctx(wg_ctx_t *ctx, int B, const wg_zmp_polytope_t
   hipLaunchKernelGGL(wg_dimitrov_tick_kernel, dim3(grid), dim3(64), lds, reinterpret_cast<hipStream_t>(hip_stream), B,
                      ctx->dim_dev, polys, states, outs, max_iter);
   HIP_TRY(hipGetLastError());
-  return WG_OK;
+  std::lock_guard<std::mutex> launch_lk(ctx->launch_mu);
+  return slot_mark(ctx->aux_order, reinterpret_cast<hipStream_t>(hip_stream));
 }
 
 int wg_dimitrov_tick_batch_ctx(wg_ctx_t *ctx, int B, const wg_zmp_polytope_t *polys, wg_dimitrov_state_t *states, wg_dimitrov_out_t *outs, int max_iter) {
@@ -1263,14 +1323,14 @@ int wg_dimitrov_tick_batch_ctx(wg_ctx_t *ctx, int B, const wg_zmp_polytope_t *po
   wg_zmp_polytope_t *dp = reinterpret_cast<wg_zmp_polytope_t *>(base);
   wg_dimitrov_state_t *ds = reinterpret_cast<wg_dimitrov_state_t *>(base + pb);
   wg_dimitrov_out_t *dout = outs ? reinterpret_cast<wg_dimitrov_out_t *>(base + pb + sb) : nullptr;
-  HIP_TRY(hipMemcpy(dp, polys, pb, hipMemcpyHostToDevice));
-  HIP_TRY(hipMemcpy(ds, states, sb, hipMemcpyHostToDevice));
-  if (dout) HIP_TRY(hipMemset(dout, 0, ob));
-  int rc = wg_dimitrov_tick_batch_dev_ctx(ctx, B, dp, ds, dout, max_iter, nullptr);
+  WG_H2D(dp, polys, pb);
+  WG_H2D(ds, states, sb);
+  if (dout) WG_ZERO(dout, ob);
+  int rc = wg_dimitrov_tick_batch_dev_ctx(ctx, B, dp, ds, dout, max_iter, ctx->host_stream);
   if (rc) return rc;
-  HIP_TRY(hipDeviceSynchronize());
-  HIP_TRY(hipMemcpy(states, ds, sb, hipMemcpyDeviceToHost));
-  if (dout) HIP_TRY(hipMemcpy(outs, dout, ob, hipMemcpyDeviceToHost));
+  WG_D2H(states, ds, sb);
+  if (dout) WG_D2H(outs, dout, ob);
+  WG_HOST_WAIT();
   return WG_OK;
 }
 
@@ -1287,7 +1347,9 @@ int wg_preview_configure_ctx(wg_ctx_t *ctx, const wg_preview_gains_t *gains, con
   if (!(gains->T > 0.0)) return fail(WG_ERR_BAD_ARG, "sampling period must be positive");
   std::lock_guard<std::mutex> lk(ctx->mu);
   if (!ctx->prev_F) HIP_TRY(hipMalloc(reinterpret_cast<void **>(&ctx->prev_F), sizeof(double) * WG_PREVIEW_NL_MAX));
-  HIP_TRY(hipMemcpy(ctx->prev_F, F, sizeof(double) * gains->nl, hipMemcpyHostToDevice));
+  if (int rc = ctx_wait_own(ctx)) return rc;             // a run with the previous window may still be reading the gains
+  WG_H2D(ctx->prev_F, F, sizeof(double) * gains->nl);
+  WG_HOST_WAIT();
   const double T = gains->T;                                   // PreviewControl.cpp:203-214
   ctx->prev.A01 = T; ctx->prev.A02 = T * T / 2.0; ctx->prev.A12 = T;
   ctx->prev.B0 = T * T * T / 6.0; ctx->prev.B1 = T * T / 2.0; ctx->prev.B2 = T;
@@ -1356,7 +1418,8 @@ int wg_preview_run_batch_dev_ctx(wg_ctx_t *ctx, int B, int L, const double *zmp_
                        ctx->prev_F, zmp_x_tm, zmp_y_tm, state, com_tm, zmp2_tm, simulation);
   }
   HIP_TRY(hipGetLastError());
-  return WG_OK;
+  std::lock_guard<std::mutex> launch_lk(ctx->launch_mu);
+  return slot_mark(ctx->aux_order, st);
 }
 
 int wg_preview_run_batch_ctx(wg_ctx_t *ctx, int B, int L, const double *zmp_x, const double *zmp_y, double *state, double *com, double *zmp2, int simulation) {
@@ -1373,31 +1436,29 @@ int wg_preview_run_batch_ctx(wg_ctx_t *ctx, int B, int L, const double *zmp_x, c
   double *d_stage = static_cast<double *>(ctx->prev_buf.p), *d_zx = d_stage + stage, *d_zy = d_zx + sB * Lz,
          *d_com = d_zy + sB * Lz, *d_z2 = d_com + sB * sL * 6, *d_st = d_z2 + sB * sL * 2;
   auto transpose = [&](int rows, int cols, const double *in, double *out) {
-    hipLaunchKernelGGL(wg::wg_transpose_kernel, dim3((cols + 31) / 32, (rows + 31) / 32), dim3(32, 8), 0, nullptr, rows,
+    hipLaunchKernelGGL(wg::wg_transpose_kernel, dim3((cols + 31) / 32, (rows + 31) / 32), dim3(32, 8), 0, ctx->host_stream, rows,
                        cols, in, out);
   };
-  HIP_TRY(hipMemcpy(d_stage, zmp_x, sB * Lz * 8, hipMemcpyHostToDevice));
+  // everything below is in order on the context's stream: the staging buffer is reused only behind the transpose that read it
+  WG_H2D(d_stage, zmp_x, sB * Lz * 8);
   transpose(B, (int)Lz, d_stage, d_zx);
-  HIP_TRY(hipDeviceSynchronize());
-  HIP_TRY(hipMemcpy(d_stage, zmp_y, sB * Lz * 8, hipMemcpyHostToDevice));
+  WG_H2D(d_stage, zmp_y, sB * Lz * 8);
   transpose(B, (int)Lz, d_stage, d_zy);
-  HIP_TRY(hipMemcpy(d_st, state, sB * 8 * 8, hipMemcpyHostToDevice));
+  WG_H2D(d_st, state, sB * 8 * 8);
   int rc = wg_preview_run_batch_dev_ctx(ctx, B, L, d_zx, d_zy, d_st, com ? d_com : nullptr, zmp2 ? d_z2 : nullptr, simulation,
-                                    nullptr);
+                                    ctx->host_stream);
   if (rc) return rc;
-  HIP_TRY(hipDeviceSynchronize());
-  HIP_TRY(hipMemcpy(state, d_st, sB * 8 * 8, hipMemcpyDeviceToHost));
+  WG_D2H(state, d_st, sB * 8 * 8);
   if (com) {                                                   // [L*6][B] -> [B][L*6]
     transpose(L * 6, B, d_com, d_stage);
-    HIP_TRY(hipDeviceSynchronize());
-    HIP_TRY(hipMemcpy(com, d_stage, sB * sL * 6 * 8, hipMemcpyDeviceToHost));
+    WG_D2H(com, d_stage, sB * sL * 6 * 8);
   }
   if (zmp2) {
     transpose(L * 2, B, d_z2, d_stage);
-    HIP_TRY(hipDeviceSynchronize());
-    HIP_TRY(hipMemcpy(zmp2, d_stage, sB * sL * 2 * 8, hipMemcpyDeviceToHost));
+    WG_D2H(zmp2, d_stage, sB * sL * 2 * 8);
   }
   HIP_TRY(hipGetLastError());
+  WG_HOST_WAIT();
   return WG_OK;
 }
 
@@ -1429,11 +1490,11 @@ int wg_gramian_batch_ctx(wg_ctx_t *ctx, int B, int N, const double *T, const dou
   const size_t sB = (size_t)B, nq = sB * N * N;
   if (int rc = ctx->gram_buf.reserve((2 * sB + nq) * 8)) return rc;
   double *dT = static_cast<double *>(ctx->gram_buf.p), *dh = dT + sB, *dQ = dh + sB;
-  HIP_TRY(hipMemcpy(dT, T, sB * 8, hipMemcpyHostToDevice));
-  HIP_TRY(hipMemcpy(dh, h, sB * 8, hipMemcpyHostToDevice));
-  if (int rc = wg_gramian_batch_dev_ctx(ctx, B, N, dT, dh, alpha, beta, gamma, precision, dQ, nullptr)) return rc;
-  HIP_TRY(hipDeviceSynchronize());
-  HIP_TRY(hipMemcpy(Qb, dQ, nq * 8, hipMemcpyDeviceToHost));
+  WG_H2D(dT, T, sB * 8);
+  WG_H2D(dh, h, sB * 8);
+  if (int rc = wg_gramian_batch_dev_ctx(ctx, B, N, dT, dh, alpha, beta, gamma, precision, dQ, ctx->host_stream)) return rc;
+  WG_D2H(Qb, dQ, nq * 8);
+  WG_HOST_WAIT();
   return WG_OK;
 }
 
@@ -1542,9 +1603,9 @@ int wg_zmpdisc_batch_ctx(wg_ctx_t *ctx, const wg_zmpdisc_model_t *model, int B, 
          *d_r = d_l + 6 * row;
   int *d_ns = reinterpret_cast<int *>(d_r + 6 * row), *d_len = d_ns + sB, *d_zty = d_len + sB, *d_lty = d_zty + row,
       *d_rty = d_lty + row;
-  HIP_TRY(hipMemcpy(d_steps, steps, sB * smax * sizeof(wg_rel_step_t), hipMemcpyHostToDevice));
-  HIP_TRY(hipMemcpy(d_feet, init_feet, sB * 6 * 8, hipMemcpyHostToDevice));
-  HIP_TRY(hipMemcpy(d_ns, n_steps, sB * 4, hipMemcpyHostToDevice));
+  WG_H2D(d_steps, steps, sB * smax * sizeof(wg_rel_step_t));
+  WG_H2D(d_feet, init_feet, sB * 6 * 8);
+  WG_H2D(d_ns, n_steps, sB * 4);
   wg::ZdOut O;
   memset(&O, 0, sizeof O);
   if (zmp) { O.zx = d_zx; O.zy = d_zy; }
@@ -1554,15 +1615,16 @@ int wg_zmpdisc_batch_ctx(wg_ctx_t *ctx, const wg_zmpdisc_model_t *model, int B, 
   if (left_type) O.ltype = d_lty;
   if (right) O.right = d_r;
   if (right_type) O.rtype = d_rty;
-  if (int rc = zd_launch(K, B, smax, d_steps, d_ns, d_feet, lcap, O, d_len, nullptr)) return rc;
-  HIP_TRY(hipDeviceSynchronize());
-  HIP_TRY(hipMemcpy(length, d_len, sB * 4, hipMemcpyDeviceToHost));
+  if (int rc = zd_launch(K, B, smax, d_steps, d_ns, d_feet, lcap, O, d_len, ctx->host_stream)) return rc;
+  WG_D2H(length, d_len, sB * 4);
+  WG_HOST_WAIT();
   // time-major device arrays -> the caller's gait-major arrays, samples below each gait's length only
   std::vector<double> hd;
   std::vector<int> hi;
   auto fetch_d = [&](const double *dev, int comps, double *dst, int dst_stride, int dst_off) -> int {
     hd.resize(row * comps);
-    HIP_TRY(hipMemcpy(hd.data(), dev, row * comps * 8, hipMemcpyDeviceToHost));
+    WG_D2H(hd.data(), dev, row * comps * 8);
+    WG_HOST_WAIT();
     for (size_t b = 0; b < sB; b++)
       for (int l = 0; l < length[b]; l++)
         for (int c = 0; c < comps; c++)
@@ -1571,7 +1633,8 @@ int wg_zmpdisc_batch_ctx(wg_ctx_t *ctx, const wg_zmpdisc_model_t *model, int B, 
   };
   auto fetch_i = [&](const int *dev, int *dst) -> int {
     hi.resize(row);
-    HIP_TRY(hipMemcpy(hi.data(), dev, row * 4, hipMemcpyDeviceToHost));
+    WG_D2H(hi.data(), dev, row * 4);
+    WG_HOST_WAIT();
     for (size_t b = 0; b < sB; b++)
       for (int l = 0; l < length[b]; l++) dst[b * sL + l] = hi[(size_t)l * sB + b];
     return WG_OK;
@@ -1604,6 +1667,18 @@ int wg_qp_solve_batch(int B, int nmax, int mmax, const int *n, const int *m, con
   wg_ctx *c = nullptr;
   if (int rc = default_ctx(&c)) return rc;
   return wg_qp_solve_batch_ctx(c, B, nmax, mmax, n, m, me, C, d, A, b, xl, xu, eps, x, u, ifail, n_iter, iact, nact, hist, hist_cap, hist_len);
+}
+
+int wg_set_overlap_strict(int on) {
+  wg_ctx *c = nullptr;
+  if (int rc = default_ctx(&c)) return rc;
+  return wg_set_overlap_strict_ctx(c, on);
+}
+
+long long wg_overlap_serialised(void) {
+  wg_ctx *c = nullptr;
+  if (default_ctx(&c)) return -1;
+  return wg_overlap_serialised_ctx(c);
 }
 
 int wg_mpc_configure(const wg_model_t *model) {

@@ -310,6 +310,11 @@ struct DimitrovQldProb {
   double ar0[kNM], ar1[kNM];
   __device__ __forceinline__ void load_rows(const QlView &q, int lane) {
     const int m = q.m, n = q.n;
+    if (m <= 0) {                              // every polytope empty: no row to form (slot[] holds nothing: not even slot[0])
+#pragma unroll
+      for (int i = 0; i < kNM; ++i) { ar0[i] = 0.0; ar1[i] = 0.0; }
+      return;
+    }
     const int k0 = lane < m ? lane : m - 1, k1 = lane + 64 < m ? lane + 64 : m - 1;
     const int i0 = slot[k0], i1 = slot[k1];
     const double a00 = coef(k0, i0, 0), a01 = coef(k0, i0, 1), a10 = coef(k1, i1, 0), a11 = coef(k1, i1, 1);

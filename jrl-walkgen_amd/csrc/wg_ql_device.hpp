@@ -293,7 +293,8 @@ struct DenseRegProb : DenseProbT<false, NM> {
   double ar0[NM], ar1[NM];
   __device__ __forceinline__ void load_rows(const QlView &q, int lane) {
     const int m = q.m;
-    const int k0 = lane < m ? lane : m - 1, k1 = lane + 64 < m ? lane + 64 : m - 1;
+    const int mc = m > 0 ? m - 1 : 0;          // a bounds-only QP (m == 0) must not read row -1: row 0 of the caller's buffer exists (mmax >= 1)
+    const int k0 = lane < m ? lane : mc, k1 = lane + 64 < m ? lane + 64 : mc;
 #pragma unroll
     for (int i = 0; i < NM; ++i) { ar0[i] = q.A[k0 + i * q.lda]; ar1[i] = q.A[k1 + i * q.lda]; }
   }
@@ -2276,7 +2277,8 @@ __device__ __forceinline__ QlResult ql_solve(const QlView &q, P &prob, double vs
         constexpr int NMr = P::kNM;
         const int ka = lane, kb = lane + 64;
         const bool ina = ka < m, inb = kb < m;
-        const int kca = ina ? ka : m - 1, kcb = inb ? kb : m - 1;
+        const int mc = m > 0 ? m - 1 : 0;      // m == 0: entry 0 of b exists (mmax >= 1), its value is masked below
+        const int kca = ina ? ka : mc, kcb = inb ? kb : mc;
         const double waka = ina ? q.wa[kca] : 0.0, bka = q.b[kca], wakb = inb ? q.wa[kcb] : 0.0, bkb = q.b[kcb];
         double suma = -bka, tempa_ = fabs(bka), sumb = -bkb, tempb_ = fabs(bkb);
 #pragma unroll

@@ -1201,6 +1201,9 @@ __device__ __forceinline__ TickDiag mpc_tick(const wg_model_t &m, const TickTabl
 #endif
     if (mine && out) { out->lf[lane] = outl; out->rf[lane] = outr; }
     if (lane == 0 && out) { out->lf_back = backl; out->rf_back = backr; }
+    // the tail that rounds the struct up to whole cache lines: written (zeros) so that the last line leaves the L2 whole and the
+    // struct's bytes do not depend on what the caller's buffer held
+    if (out && lane >= 32 && lane < 32 + (int)(sizeof(out->pad_) / sizeof(double))) out->pad_[lane - 32] = 0.0;
     if (lane == 11) { s->lf[0] = outl; s->rf[0] = outr; }
     if (lane == 18) { s->lf[1] = outl; s->rf[1] = outr; }
     if (lane == 19) { s->lf[2] = outl; s->rf[2] = outr; }

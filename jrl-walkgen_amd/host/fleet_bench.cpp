@@ -37,13 +37,14 @@
 static int env_int(const char *k, int dflt) { const char *e = getenv(k); return e ? atoi(e) : dflt; }
 
 // rank 0 publishes the RCCL unique id through a file named after the job; the other ranks take it only if it IS this job's
-// (host/wg_rendezvous.hpp: a file older than the job's launcher is a previous job's and is ignored)
-static int exchange_id(const std::string &path, int rank, ncclUniqueId *id) {
+// (host/wg_rendezvous.hpp: the name comes from the launcher's environment, a file whose writer is no longer alive is a previous
+// job's and is ignored)
+static int exchange_id(const std::string &path, int rank, int world, ncclUniqueId *id) {
   if (rank == 0) {
     CHECK_NCCL(ncclGetUniqueId(id));
-    return wg_rdv::publish(path, id, sizeof *id);
+    return wg_rdv::publish(path, id, sizeof *id, world);
   }
-  return wg_rdv::fetch(path, id, sizeof *id, wg_rdv::job_not_before());
+  return wg_rdv::fetch(path, id, sizeof *id, world);
 }
 
 int main(int argc, char **argv) {
@@ -112,9 +113,9 @@ int main(int argc, char **argv) {
   ncclComm_t comm = nullptr;
   double *d_red = nullptr;                                      // one double for the barriers / the max over ranks
   if (use_rccl) {
-    const std::string idpath = wg_rdv::id_path();            // WG_NCCL_ID_FILE, or named after port, run id and launcher
+    const std::string idpath = wg_rdv::id_path();            // WG_NCCL_ID_FILE, or named after port and the launcher's job identity
     ncclUniqueId id;
-    if (exchange_id(idpath, rank, &id)) return 1;
+    if (exchange_id(idpath, rank, world, &id)) return 1;
     CHECK_NCCL(ncclCommInitRank(&comm, world, id, rank));
     wg_model_t *d_model = nullptr;
     CHECK_HIP(hipMalloc((void **)&d_model, sizeof model));

@@ -49,7 +49,8 @@ class TickOut(C.Structure):             # wg_tick_out_t
                 ("com_yaw", (C.c_double * 2) * SAMPLES),
                 ("zmp_x", C.c_double * SAMPLES), ("zmp_y", C.c_double * SAMPLES),
                 ("lf", FootSample * SAMPLES), ("rf", FootSample * SAMPLES),
-                ("lf_back", FootSample), ("rf_back", FootSample)]
+                ("lf_back", FootSample), ("rf_back", FootSample),
+                ("pad_", C.c_double * 15)]          # sizeof == 7808 = 61 x 128 B (ABI 5)
 
 
 _dp = C.POINTER(C.c_double)
@@ -129,6 +130,10 @@ def lib():
         _lib.wg_ctx_destroy.restype = None
         _lib.wg_ctx_device.argtypes = [C.c_void_p]
         _lib.wg_mpc_configure.argtypes = [C.c_void_p]
+        if hasattr(_lib, "wg_set_overlap_strict"):          # absent from older experiment builds
+            _lib.wg_set_overlap_strict.argtypes = [C.c_int]
+            _lib.wg_overlap_serialised.argtypes = []
+            _lib.wg_overlap_serialised.restype = C.c_longlong
         if hasattr(_lib, "wg_mpc_reserve"):                 # absent from older experiment builds (WG_LIB_PATH, A/B runs)
             _lib.wg_mpc_reserve.argtypes = [C.c_int]
         for name in CTX_ENTRY_POINTS:
@@ -140,7 +145,7 @@ def lib():
     return _lib
 
 
-CTX_ENTRY_POINTS = ("wg_qp_solve_batch", "wg_qp_solve_batch_dev", "wg_mpc_configure", "wg_mpc_reserve", "wg_mpc_tick_lds_bytes", "wg_mpc_tick_batch",
+CTX_ENTRY_POINTS = ("wg_set_overlap_strict", "wg_overlap_serialised", "wg_qp_solve_batch", "wg_qp_solve_batch_dev", "wg_mpc_configure", "wg_mpc_reserve", "wg_mpc_tick_lds_bytes", "wg_mpc_tick_batch",
                     "wg_mpc_tick_batch_dev", "wg_mpc_run_batch_dev", "wg_mpc_run_sched_dev", "wg_mpc_set_velref_dev", "wg_mpc_tick_pinned",
                     "wg_mpc_assemble_batch", "wg_mpc_assemble_batch_dev", "wg_pldp_configure",
                     "wg_pldp_solve_batch", "wg_pldp_solve_batch_dev", "wg_dimitrov_configure", "wg_dimitrov_get_constants", "wg_dimitrov_get_qld_constants",

@@ -866,7 +866,8 @@ int wgo_mpc_tick(const wg_model_t *m, wg_gait_state_t *s, wg_tick_out_t *out, wg
     } else {
       for (int k = 1; k <= K; k++) { memset(&L[k], 0, sizeof L[k]); memset(&R[k], 0, sizeof R[k]); }
     }
-    if (out) { for (int k = 0; k < K; k++) { out->lf[k] = L[k + 1]; out->rf[k] = R[k + 1]; } out->lf_back = L[0]; out->rf_back = R[0]; }
+    if (out) { for (int k = 0; k < K; k++) { out->lf[k] = L[k + 1]; out->rf[k] = R[k + 1]; } out->lf_back = L[0]; out->rf_back = R[0];
+               for (size_t k = 0; k < sizeof(out->pad_) / sizeof(double); k++) out->pad_[k] = 0.0; }
     /* the back sample itself may have been rewritten (DS branch): it is still in
      * the queue and will be consumed later, so callers replaying the queue need it */
     if (dump) { dump->lf_back_rewritten = L[0]; dump->rf_back_rewritten = R[0]; }

@@ -150,8 +150,9 @@ def test_overlapping_launches_of_one_context_are_ordered(monkeypatch):
         other.mpc_run_batch_dev(B, ref.data_ptr(), 59, 20, None, None, None)
         torch.cuda.synchronize()
         assert torch.equal(a, ref)
-        # ---- strict mode: refused
-        monkeypatch.setenv("WG_OVERLAP_STRICT", "1")
+        assert ctx.call("wg_overlap_serialised") == 2 and other.call("wg_overlap_serialised") == 0   # the library says what it ordered
+        # ---- strict mode: refused (WG_OVERLAP_STRICT is read when a context is created; wg_set_overlap_strict toggles a live one)
+        assert ctx.call("wg_set_overlap_strict", 1) == 0
         a2, b2 = mk(), mk()
         torch.cuda.synchronize()
         ctx.mpc_run_batch_dev(B, a2.data_ptr(), 60, 20, None, None, s1.cuda_stream)
@@ -160,6 +161,7 @@ def test_overlapping_launches_of_one_context_are_ordered(monkeypatch):
         assert b"in flight" in wg.lib().wg_last_error()
         rc = ctx.call("wg_mpc_run_batch_dev", B, C.c_void_p(b2.data_ptr()), 2, 20, None, None, C.c_void_p(s2.cuda_stream))
         assert rc == -5, rc
+        assert ctx.call("wg_overlap_serialised") == 2                                   # refused launches are not counted as ordered
         ctx.mpc_tick_batch_dev(B, a2.data_ptr(), None, None, 20, stream=s1.cuda_stream)     # the same stream queues behind it
         torch.cuda.synchronize()
         ctx.mpc_tick_batch_dev(B, b2.data_ptr(), None, None, 20, stream=s2.cuda_stream)     # first launch done: accepted

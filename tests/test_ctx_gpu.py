@@ -138,3 +138,51 @@ def test_context_argument_checks():
         assert lib.wg_mpc_tick_batch_ctx(c.handle, 1, C.addressof(st), None, None, 0, None, 0, None) == -2   # not configured
         assert b"not been called on this context" in lib.wg_last_error()
         assert c.mpc_tick_lds_bytes() == 0
+
+
+def test_host_calls_of_one_context_do_not_wait_for_another_contexts_launch():
+    """The host-pointer entry points stage, launch and copy back on their context's own non-blocking stream and wait for that
+    stream alone (they used to end in hipDeviceSynchronize: one facade object's tick waited for a fleet's whole launch, two
+    PatternGeneratorInterface objects serialised on each other).  A long multi-tick launch of context A is in flight on a stream
+    -- half of the device's wave slots, so that there is room beside it -- while context B ticks ONE robot through host pointers:
+    every one of B's calls returns while A's launch is still running, at a latency within 2 x what it has on an idle device (+ a
+    fixed 150 us for sharing the chip), and with the bytes of the same ticks made alone.  So does a re-configuration of B."""
+    import time
+    wg.init(0)
+    model = wg.model_defaults()
+    with wg.Context(0) as ca, wg.Context(0) as cb:
+        ca.mpc_configure(model); cb.mpc_configure(model)
+        fleet = _dev(_fleet(model, 1024, 11))
+        ca.mpc_tick_batch_dev(1024, fleet.data_ptr(), None, None, 1)
+        ca.mpc_tick_batch_dev(1024, fleet.data_ptr(), None, None, 19)
+        torch.cuda.synchronize()
+
+        def robot_ticks(n):
+            st = _fleet(model, 1, 12)
+            cb.mpc_tick_batch(st, want_out=True, advance_calls=1)
+            cb.mpc_tick_batch(st, want_out=True, advance_calls=19)
+            lat = []
+            for _ in range(n):
+                t0 = time.perf_counter()
+                cb.mpc_tick_batch(st, want_out=True, advance_calls=20)
+                lat.append(time.perf_counter() - t0)
+            return lat, bytes(memoryview(st).cast("B"))
+
+        robot_ticks(5)                                             # warm: buffers sized, kernels loaded
+        alone, ref_bytes = robot_ticks(40)
+        s1 = torch.cuda.Stream()
+        done = torch.cuda.Event()
+        t0 = time.perf_counter()
+        ca.mpc_run_batch_dev(1024, fleet.data_ptr(), 600, 20, None, None, s1.cuda_stream)       # ~ 0.2 s of device time
+        done.record(s1)
+        beside, got_bytes = robot_ticks(40)
+        cb.mpc_configure(model)                                    # waits for B's own launches only
+        t_host = time.perf_counter() - t0
+        still_running = not done.query()
+        torch.cuda.synchronize()
+        t_all = time.perf_counter() - t0
+        assert still_running, "context A's launch ended before B's 42 host ticks did (%.1f ms): nothing was measured" % (1e3 * t_host)
+        assert t_all > 2.0 * t_host                                 # B's calls took a fraction of A's launch, not all of it
+        med_alone, med_beside = float(np.median(alone)), float(np.median(beside))
+        assert med_beside < 2.0 * med_alone + 150e-6, (med_alone, med_beside)
+        assert got_bytes == ref_bytes

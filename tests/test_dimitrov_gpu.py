@@ -272,6 +272,36 @@ def test_fused_tick_with_the_ql_back_ends_bit_exact(mode, ql):
         wg.dimitrov_configure(wg.dimitrov_defaults())
 
 
+def test_qld_tick_with_empty_polytopes():
+    """Every polytope of the window without a row (m = 0): the QL back-end's register-row loader has no row to clamp its surplus
+    lanes to (it indexed slot[-1]); the tick is the unconstrained minimiser, the same bytes as the oracle tick's."""
+    model, K, Kq = _qld_setup(2)
+    N = model.N
+    lib = ol.oracle()
+    lib.wgo_set_reference_ql(None)
+    try:
+        dp = lambda a: a.ctypes.data_as(C.POINTER(C.c_double))  # noqa: E731
+        B, T = 3, 4
+        sg = (wg.DimitrovState * B)(); so = (wg.DimitrovState * B)()
+        for g in range(B):
+            for s in (sg[g], so[g]):
+                s.starting = 1
+                s.xk[0] = 0.01 * g; s.xk[3] = -0.02 * g
+        for it in range(T):
+            polys = (wg.ZmpPolytope * (B * N))()                  # zero-initialised: nrows = 0 everywhere
+            outs = wg.dimitrov_tick_batch(polys, sg)
+            for g in range(B):
+                oo = wg.DimitrovOut()
+                rc = lib.wgo_dimitrov_qld_tick(C.c_int(2), C.c_int(N), dp(Kq["Q"]), dp(K["OptB"]), dp(K["OptC"]), dp(K["Pu"]), dp(K["Px"]),
+                                               dp(K["iLQ"]), C.c_double(model.T), C.c_double(model.Tctrl), C.c_double(model.com_height),
+                                               C.byref(polys, g * N * C.sizeof(wg.ZmpPolytope)), C.byref(so[g]), C.byref(oo))
+                assert outs[g].ret == rc == 0, (it, g, outs[g].ret, rc)
+                assert outs[g].m == 0 and outs[g].n_active == 0
+                assert bytes(sg[g]) == bytes(so[g]) and bytes(outs[g].X) == bytes(oo.X), (it, g)
+    finally:
+        wg.dimitrov_configure(wg.dimitrov_defaults())
+
+
 def test_pldp_against_qldandlq_objective_gap_per_tick():
     """The same gaits through PLDP and through ql0001_ on the SAME preconditioned problem (mode QLDANDLQ), both from the same state
     at every tick.  In jerk coordinates u the common objective is 1/2 u' H u + D' u with H = LQ LQ' (the lower triangle of OptA,

@@ -132,6 +132,28 @@ def test_matrices_in_lds_or_read_in_place(a_in_lds, g_in_lds, w_in_lds, monkeypa
         assert not bad, (family, bad[:5])
 
 
+def test_bounds_only_qp_in_the_fixed_size_batch():
+    """m = 0 (bounds only) inside a batch of exactly the Herdt size: the fixed 36 x 76 kernel keeps A's rows in registers and
+    clamps the surplus lanes' row index -- with m = 0 that clamp must stay inside the caller's buffers (it read row -1)."""
+    wg = _wg()
+    rng = np.random.default_rng(360)
+    qps = [qpgen.herdt_like(np.random.default_rng(8100 + s), 16, 2) for s in range(6)]
+    for k in (0, 3, 5):                                       # first, middle, last QP of the batch: no general constraint at all
+        q = qps[k]
+        q["m"] = 0
+        q["xl"] = np.full(q["n"], -0.05) if k else q["xl"]    # one of them with bounds that bind, the others effectively free
+        q["xu"] = np.full(q["n"], 0.05) if k else q["xu"]
+        q["A"] = np.asfortranarray(rng.standard_normal(q["A"].shape))   # whatever lies in A must not matter
+        q["b"] = rng.standard_normal(q["b"].shape)
+    pk = wg.pack_qps(qps)
+    assert pk["nmax"] == 36 and pk["mmax"] == 76
+    res = wg.qp_solve_batch(pk, hist_cap=512)
+    bad = _compare(qps, res, "m=0", pk)
+    assert not bad, bad[:5]
+    assert all(int(res["ifail"][k]) == 0 for k in (0, 3, 5))
+    assert int(res["nact"][3]) > 0 and (res["iact"][3, :int(res["nact"][3])] > 0).all()      # the bounds did bind: codes m + i ...
+
+
 def test_two_streams_share_one_context(monkeypatch):
     """Herdt-sized QPs keep wa | b in a slot of global memory per QP (a buffer of the context): a launch that arrives on another
     stream while the slots are in use takes the placement with wa | b in LDS instead -- both batches solve to the oracle's
