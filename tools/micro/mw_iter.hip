@@ -33,7 +33,8 @@ constexpr int kN = 72, kLd = 73, kNact = 41, kRot = kN - 1 - kNact, kM = 149, kS
 struct Lds {
   double Z[kN * kLd];
   double R[kNact * (kNact + 1) / 2];
-  double ww[kN], s[kN], x[kN], chain[kN], ga[kN], gb[kN], lam[kN];   // chain / ga / gb double as the sums' scratch
+  double ww[kN], s[kN], x[kN], chain[kN], ga[kN], gb[kN], lam[kN], bw[kN];   // chain / ga / gb double as the sums' scratch, ga | gb as
+                                                                              // the back substitution's two 64-entry product buffers
   double red[8];
 };
 static_assert(sizeof(Lds) <= 42 * 1280, "three workgroups per CU");
@@ -49,7 +50,7 @@ __global__ __launch_bounds__(64 * W) void mw_iter(double *out, int iters) {
   for (int k = tid; k < kN * kLd; k += 64 * W) { const int i = k % kLd, j = k / kLd; L.Z[k] = (i == j) ? 1.0 : 1e-3 * ((i * 7 + j * 3) % 11 - 5); }
   for (int k = tid; k < kNact * (kNact + 1) / 2; k += 64 * W) L.R[k] = 0.01 * ((k * 5) % 7 - 3);
   for (int k = tid; k < kNact; k += 64 * W) L.R[k * (k + 1) / 2 + k] = 2.0 + 0.01 * k;
-  for (int k = tid; k < kN; k += 64 * W) { L.ww[k] = 0.1 + 0.01 * k; L.x[k] = 0.01 * k; L.lam[k] = 1.0; L.s[k] = 1.0; L.chain[k] = 1.0; L.ga[k] = 1.0; L.gb[k] = 0.0; }
+  for (int k = tid; k < kN; k += 64 * W) { L.ww[k] = 0.1 + 0.01 * k; L.x[k] = 0.01 * k; L.lam[k] = 1.0; L.bw[k] = 0.0; L.s[k] = 1.0; L.chain[k] = 1.0; L.ga[k] = 1.0; L.gb[k] = 0.0; }
   __syncthreads();
   // row / column owner: item c belongs to wave c % W, lane c / W (W = 1: items 64..71 are a second pass of lanes 0..7)
   const bool own0 = (W == 1) ? lane < 64 : lane < (kN + W - 1 - wave) / W;
@@ -79,25 +80,26 @@ __global__ __launch_bounds__(64 * W) void mw_iter(double *out, int iters) {
     __syncthreads();
     // ---- B: the two serial chains
     if (PHASES & 2) {
-      if (wave == 0) {                                       // chain of rotation norms: the solver's own arithmetic
-        double cur = L.s[kN - 1] + 1.0;
+      if (wave == 0 && !(PHASES & 128)) {                    // chain of rotation norms: the solver's own arithmetic and loop shape
+        double cur = L.s[kN - 1] + 1.0;                      // (sweep(): pairs of rotations, the next operand fetched ahead of the chain)
+        double pa = L.s[kN - 2], pb;
+        int iv = kN - 4;
+        asm volatile("" : "+v"(iv));
 #pragma unroll 1
-        for (int c = kN - 1; c > kNact; --c) { cur = wg::givens_norm_fast(L.s[c - 1], cur); L.chain[c - 1] = cur; }
-      }
-      if (wave == (W > 1 ? 1 : 0)) {                         // back substitution, the solver's v_readlane form (nact <= 60)
-        const bool mine = lane < kNact;
-        const double sreg = mine ? L.s[lane] : 0.0, dreg = mine ? L.R[lane * (lane + 1) / 2 + lane] : 1.0;
-        double w = 0.0;
-#pragma unroll 1
-        for (int i = kNact - 1; i >= 0; --i) {
-          const double rrow = (lane > i && mine) ? L.R[lane * (lane + 1) / 2 + i] : 0.0;
-          const double p = rrow * w;
-          double sum = 0.0;
-          for (int j = i + 1; j < kNact; ++j) sum += rlane(p, j);          // ordered
-          const double v = (rlane(sreg, i) - sum) / rlane(dreg, i);
-          if (lane == i) w = v;
+        for (int k = kRot >> 1; k > 0; --k) {
+          pb = L.s[iv + 1];
+          cur = wg::givens_norm_fast(pa, cur); L.chain[iv + 2] = cur;
+          pa = L.s[iv];
+          cur = wg::givens_norm_fast(pb, cur); L.chain[iv + 1] = cur;
+          iv -= 2;
         }
-        if (mine) L.lam[lane] = L.lam[lane] * 0.5 + 1e-3 * w;
+        if (kRot & 1) { cur = wg::givens_norm_fast(pa, cur); L.chain[iv + 2] = cur; }
+      }
+      if (wave == (W > 1 ? 1 : 0) && !(PHASES & 256)) {      // back substitution: the solver's own LDS-pipelined form
+        wg::QlView q;
+        q.R = L.R; q.ww = L.bw;
+        wg::backsub_lds<64>(q, L.s, kNact, lane, L.ga);
+        if (lane < kNact) L.lam[lane] = L.lam[lane] * 0.5 + 1e-3 * L.bw[lane];
       }
     }
     __syncthreads();
@@ -252,12 +254,17 @@ int main() {
     printf("W = %d waves per gait: %9.1f ns = %7.0f cycles per iteration; barriers alone (no phase): %7.1f ns = %5.0f cycles (%d barriers)\n", \
            W, full, full * ghz, none, none * ghz, W > 1 ? 11 : 10); \
     for (int p = 0; p < 7; ++p) printf("      without phase %-40s %9.1f ns -> the phase costs %7.0f cycles\n", names[p], ph[p], (full - ph[p]) * ghz); \
+    { const double nb = ph[1], cn = run<W, 127 + 256>(grid, iters, out), bs = run<W, 127 + 128>(grid, iters, out); \
+      printf("      phase B taken apart: the chain of norms alone %7.0f cycles, the back substitution alone %7.0f cycles, both %7.0f\n", \
+             (cn - nb) * ghz, (bs - nb) * ghz, (full - nb) * ghz); } \
     printf("      => %.3f M ticks/s at 44 iterations per tick with %d gaits resident (optimistic: see the header)\n", grid / (44.0 * full * 1e-9) * 1e-6, grid); \
   } while (0)
   ALL(1);
   ALL(2);
   ALL(4);
-  printf("# shipped wg_mpc_run_xcd_kernel<32>: 12 gaits per CU, 1.31 - 1.33 M ticks/s = 44 x %.0f cycles per gait-iteration per CU slot\n",
-         12.0 * cus / (44.0 * 1.32e6) * ghz * 1e9 / 12.0);
+  const double slot = cus / (44.0 * 1.32e6) * ghz * 1e9;          // cycles per gait-iteration and per resident gait of a CU
+  printf("# shipped wg_mpc_run_xcd_kernel<32>: 12 gaits per CU at 1.31 - 1.33 M ticks/s = an iteration of a gait every %.0f cycles, %.0f per resident gait;\n"
+         "# three gaits per CU must finish an iteration in %.0f cycles to match it, in %.0f for 1.6 M ticks/s\n",
+         12.0 * slot, slot, 3.0 * slot, 3.0 * slot * 1.32 / 1.6);
   return 0;
 }
