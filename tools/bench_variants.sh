@@ -1,5 +1,7 @@
 #!/bin/bash
 # bench.py over experiment builds / launch shapes of the tick kernel (diagnostic; results under gpurun_out/)
+set -eu
+R=${GRAFT_REPO_ROOT:?run this on the GPU box (gpurun sets GRAFT_REPO_ROOT)}
 mkdir -p gpurun_out
 out=gpurun_out/variants.txt
 : > $out

@@ -8,9 +8,9 @@
 #   gramian   tools/probe_gramian.py with the MFMA counters
 #   dimitrov / pldp / preview / zmpdisc   kernel-trace stats + the standard passes
 # gpurun MERGES gpurun_out/ back: remove the local gpurun_out/prof_* first.
-set -u
+set -eu
+R=${GRAFT_REPO_ROOT:?run this on the GPU box (gpurun sets GRAFT_REPO_ROOT)}
 export TMPDIR=/tmp
-R=$GRAFT_REPO_ROOT
 BENCH="bench.py --steps 200 --warmup 50 --no-cpu-baseline --no-parity --no-per-tick-leg --no-config5 --no-kernels --no-outs-leg"
 bash $R/tools/prof.sh tick $BENCH > $R/gpurun_out/prof_tick.log 2>&1
 echo "tick done"
@@ -43,24 +43,24 @@ echo "b1 done"
 $R/jrl-walkgen_amd/bin/latency_b1 > $R/gpurun_out/latency_b1.json 2> $R/gpurun_out/latency_b1.err
 echo "latency done"
 # the Gramian kernel with the matrix-core counters (its own passes)
-OUT=$R/gpurun_out/prof_gramian; rm -rf $OUT; mkdir -p $OUT; cd /tmp
+OUT=$R/gpurun_out/prof_gramian; rm -rf "$OUT"; mkdir -p "$OUT"; cd /tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $R/tools/probe_gramian.py > $OUT/trace.log 2>&1
 rocprofv3 --pmc SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_WAVE_CYCLES --output-format csv -d $OUT/pmc1 -- python3 $R/tools/probe_gramian.py > $OUT/pmc1.log 2>&1
 rocprofv3 --pmc WRITE_SIZE GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc4 -- python3 $R/tools/probe_gramian.py > $OUT/pmc4.log 2>&1
 python3 $R/tools/prof_summary.py $OUT > $OUT/summary.txt 2>&1
 echo "gramian done"
-cd $R
+cd "$R"
 for spec in "dimitrov tools/probe_dimitrov.py" "pldp tools/probe_pldp.py" "preview tools/probe_preview.py" "zmpdisc tools/probe_zmpdisc.py"; do
   set -- $spec
   bash $R/tools/prof.sh $1 $2 > $R/gpurun_out/prof_$1.log 2>&1
   echo "$1 done"
 done
 # in-kernel phase timers of the tick (diagnostic build lib/libwg_mpc_prof.so, one launch per tick)
-PB=4096 python3 $R/tools/probe_tick_phases.py 2>&1 | grep -v amdgpu.ids > $R/gpurun_out/phases_tick.txt
-PN=32 PB=3072 python3 $R/tools/probe_tick_phases.py 2>&1 | grep -v amdgpu.ids > $R/gpurun_out/phases_tick32.txt
+PB=4096 python3 $R/tools/probe_tick_phases.py 2>&1 | { grep -v amdgpu.ids || true; } > $R/gpurun_out/phases_tick.txt
+PN=32 PB=3072 python3 $R/tools/probe_tick_phases.py 2>&1 | { grep -v amdgpu.ids || true; } > $R/gpurun_out/phases_tick32.txt
 echo "phases done"
 # duration of a multi-tick launch against its length: the steady rate and what every launch pays once (ramp + idle tail)
-python3 $R/tools/probe_launch_fit.py 2>&1 | grep -v amdgpu.ids > $R/gpurun_out/launch_fit.txt
-PTS=1,2,4,8,12,20 PN=32 PB=8192 python3 $R/tools/probe_launch_fit.py 2>&1 | grep -v amdgpu.ids >> $R/gpurun_out/launch_fit.txt
+python3 $R/tools/probe_launch_fit.py 2>&1 | { grep -v amdgpu.ids || true; } > $R/gpurun_out/launch_fit.txt
+PTS=1,2,4,8,12,20 PN=32 PB=8192 python3 $R/tools/probe_launch_fit.py 2>&1 | { grep -v amdgpu.ids || true; } >> $R/gpurun_out/launch_fit.txt
 echo "launch fit done"
 tail -25 $R/gpurun_out/prof_tick.log
