@@ -44,6 +44,17 @@ CONFIG5_BATCH = 8192         # BASELINE configs[4]: N = 32 with foot-placement v
 PMC_SUMMARY = os.path.join(ROOT, "profiles", "current_tick_pmc.json")
 
 
+def pmc_file_is_current(pmc):
+    """profiles/current_tick_pmc.json carries the hash of the device sources it was measured on (tools/csrc_hash.py): counters
+    of another kernel than the one being timed are reported as such, not silently scaled"""
+    try:
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        from csrc_hash import csrc_hash
+        return pmc.get("csrc_sha256") == csrc_hash()
+    except Exception:                                                      # noqa: BLE001
+        return False
+
+
 def velocity_table(lo, hi, n_seg):
     """[n_seg, B, 3] references; gait g uses MT19937-64 seeded 20100 + g (global index)."""
     tab = np.empty((n_seg, hi - lo, 3))
@@ -630,6 +641,7 @@ def main():
                          "kernel": "wg_mpc_tick_kernel" if args.per_tick_launch else "wg_mpc_run_xcd_kernel",
                          "kernel_ms": kern_ms, "launches": len(timed), "ticks_per_launch": ticks_per_launch,
                          "algorithmic_bytes_per_launch": alg_bytes_per_launch,
+                         "traffic_is_of_this_kernel": None if pmc is None else pmc_file_is_current(pmc),
                          "traffic_source": None if pmc is None else
                          "%s: %.0f B per gait-tick measured by rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over launches of %s ticks, "
                          "scaled to this run's %.1f ticks per launch" % (os.path.relpath(PMC_SUMMARY, ROOT),

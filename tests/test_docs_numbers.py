@@ -5,11 +5,11 @@ import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+TAG = "round4"          # the profile set that describes HEAD (profiles/README.md)
 
 
 def test_generated_blocks_agree_with_the_filed_profiles():
-    tag = "round4"
-    p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "doc_numbers.py"), tag, "--check"], capture_output=True, text=True)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "doc_numbers.py"), TAG, "--check"], capture_output=True, text=True)
     assert p.returncode == 0, p.stdout + p.stderr
 
 
@@ -24,12 +24,35 @@ def test_every_profile_file_the_documents_cite_exists():
     assert not missing, missing
 
 
+def _csrc_hash():
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from csrc_hash import csrc_hash
+    return csrc_hash()
+
+
+def test_filed_audit_and_counters_describe_the_kernels_at_head():
+    """The resource audit and profiles/current_tick_pmc.json (what bench.py scales roofline.traffic from) carry the hash of the
+    device sources they were made from (tools/csrc_hash.py): a kernel change that is not followed by a fresh audit (tools/isa_audit.py,
+    minutes, no GPU) and a fresh profile set (tools/prof_round.sh on the GPU box) fails here instead of leaving stale figures behind."""
+    import json
+    import re
+    head = _csrc_hash()
+    txt = open(os.path.join(ROOT, "profiles", TAG + "_resource_usage.txt")).read()
+    m = re.search(r"^# csrc sha256: (\w+)", txt, re.M)
+    if m is None and int(TAG[5:]) < 5:
+        import pytest
+        pytest.skip("profile sets before round 5 carry no source hash")
+    assert m and m.group(1) == head, "profiles/%s_resource_usage.txt was made from other device sources: python tools/isa_audit.py --out profiles/%s_resource_usage.txt" % (TAG, TAG)
+    pmc = json.load(open(os.path.join(ROOT, "profiles", "current_tick_pmc.json")))
+    assert pmc.get("csrc_sha256") == head, "profiles/current_tick_pmc.json was measured on other device sources: tools/prof_round.sh + tools/save_round_profiles.py"
+
+
 def test_filed_resource_audit_keeps_the_headline_kernels_budget():
     """VERDICT r3 item 3, as a standing check on the FILED audit (tools/isa_audit.py regenerates it in minutes, without a GPU): the
     multi-tick kernel of the benchmark spills at most 56 B of scratch per lane and none of its scratch traffic sits inside the
     active-set iteration (depth >= 2); the N = 32 instantiation keeps its scratch traffic out of the inner loops (depth >= 3)."""
     import re
-    txt = open(os.path.join(ROOT, "profiles", "round4_resource_usage.txt")).read()
+    txt = open(os.path.join(ROOT, "profiles", TAG + "_resource_usage.txt")).read()
     m = re.search(r"^wg_mpc_run_xcd_kernel<16>\s+(\d+)\s+(\d+)\s+(\d+)\s+(\d+)\s+(\d+)\s+(\d+)\s+(\d+)\s*$", txt, re.M)
     assert m, "no row for wg_mpc_run_xcd_kernel<16>"
     vgpr, agpr, sgpr, vspill, sspill, scratch, occ = (int(x) for x in m.groups())

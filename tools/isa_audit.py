@@ -122,6 +122,9 @@ def main():
     args = ap.parse_args()
     extra = args.extra.split() if args.extra else []
     out = []
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from csrc_hash import csrc_hash
+    out.append("# csrc sha256: %s   (tools/csrc_hash.py: the device sources this audit was made from)" % csrc_hash())
     rows = [] if args.reuse else resource_table(extra)
     names = demangle([r["name"] for r in rows])
     out.append("# kernel resource usage (hipcc -Rpass-analysis=kernel-resource-usage, gfx950%s)" % (", " + args.extra if args.extra else ""))

@@ -11,6 +11,7 @@
 set -eu
 R=${GRAFT_REPO_ROOT:?run this on the GPU box (gpurun sets GRAFT_REPO_ROOT)}
 export TMPDIR=/tmp
+python3 "$R/tools/csrc_hash.py" > "$R/gpurun_out/csrc_hash.txt"       # the sources these profiles describe (filed with them)
 BENCH="bench.py --steps 200 --warmup 50 --no-cpu-baseline --no-parity --no-per-tick-leg --no-config5 --no-kernels --no-outs-leg"
 bash $R/tools/prof.sh tick $BENCH > $R/gpurun_out/prof_tick.log 2>&1
 echo "tick done"

@@ -140,6 +140,9 @@ if "b1" in summ:
         "lds_executing_frac": m_("SQ_ACTIVE_INST_LDS") / m_("SQ_WAVE_CYCLES"), "parked_in_waitcnt_frac": m_("SQ_WAIT_ANY") / m_("SQ_WAVE_CYCLES"),
         "issue_stalled_frac": m_("SQ_WAIT_INST_ANY") / m_("SQ_WAVE_CYCLES"),
         "note": "SQ_WAVE_CYCLES and the SQ_ACTIVE / SQ_WAIT counters are in quad-cycles; fractions are of the wave's lifetime"}
+# the device sources the profiled run was built from: written on the GPU box by tools/prof_round.sh (its copy of the tree)
+hp = os.path.join(ROOT, "gpurun_out", "csrc_hash.txt")
+out["csrc_sha256"] = open(hp).read().split()[0] if os.path.exists(hp) else None
 json.dump(out, open(os.path.join(ROOT, "profiles", "current_tick_pmc.json"), "w"), indent=1)
 lat = os.path.join(ROOT, "gpurun_out", "latency_b1.json")
 if os.path.exists(lat) and os.path.getsize(lat) > 0:
