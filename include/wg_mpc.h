@@ -249,7 +249,7 @@ typedef struct wg_tick_out {
   wg_foot_sample_t lf_back, rf_back;
   /* sizeof == 7808 = 61 cache lines of 128 B (ABI 5; it was 7688, 8 B past 60 lines): in an array of these no line is shared
    * by two gaits' structs -- two waves finishing at different times no longer write the shared line back twice (measured
-   * 10.7 KB written per 7688-B struct stored).  Never written, never read. */
+   * 10.7 KB written per 7688-B struct stored).  The tick writes zeros here (the last line leaves the L2 whole). */
   double pad_[15];
 } wg_tick_out_t;
 

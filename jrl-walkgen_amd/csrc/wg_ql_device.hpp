@@ -1154,7 +1154,7 @@ __device__ __forceinline__ void sweep_flat(const QlView &q, double *s, int nu, i
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------
-// Z in REGISTERS (the N = 32 element view's "Z on chip" form): lane L carries row L of Z in z0[], every access with a
+// Z in REGISTERS (the N = 32 element view's "Z on chip" form, docs/HISTORY.md 3.2): lane L carries row L of Z in z0[], every access with a
 // compile-time column index (fully unrolled loops with wave-uniform predicates), so the array lives in the register file (144
 // of the 256 registers a lane has at one wave per SIMD).  The rows beyond the 64th (n <= 72: at most eight) live in LDS (zt, 8 x
 // NMAX, 4.6 KB): every lane works on tail row 64 + (L & 7) -- eight lanes compute the same values and store them to the same

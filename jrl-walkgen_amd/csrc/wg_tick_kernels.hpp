@@ -35,7 +35,7 @@
 constexpr bool wg_tick_is_elem(int NH) { return NH == -1 || NH == 32; }
 // view 33 (N = 32 with Z in registers): one wave per SIMD, 512 registers
 #define WG_TICK_WAVES(NH) __attribute__((amdgpu_waves_per_eu((NH) == 33 ? WG_ZR_WPS : wg_tick_is_elem(NH) ? WG_TICK32_WPE : WG_TICK_WPE_MIN, (NH) == 33 ? WG_ZR_WPS : wg_tick_is_elem(NH) ? WG_TICK32_WPE : WG_TICK_WPE_MAX)))
-// View 33 (N = 32 with Z in registers, DESIGN 3.2 "Z on chip": measured, slower than view 32) is an EXPERIMENT: its three kernels are
+// View 33 (N = 32 with Z in registers, docs/HISTORY.md 3.2 "Z on chip": measured, slower than view 32) is an EXPERIMENT: its three kernels are
 // only compiled into builds made with -DWG_WITH_REGZ (make lib/libwg_mpc_xregz.so EXTRA=-DWG_WITH_REGZ; tools/regz_probe.sh)
 #ifdef WG_WITH_REGZ
 #define WG_REGZ_KERNEL(KERN, view) (view) == 33 ? reinterpret_cast<const void *>(KERN<33>) :

@@ -128,7 +128,8 @@ def block_current():
     L.append(f"| `kernels.pldp` | {M(k['pldp']['value'])} solves/s | {M(kw['pldp']['value'])} |")
     L.append(f"| `kernels.zmpdisc` / `preview` / `steps_to_com` | {k['zmpdisc']['value'] / 1e9:.2f} G gait-samples/s / {k['preview']['value'] / 1e9:.2f} G gait-steps/s / {k['steps_to_com']['value'] / 1e6:.2f} M walks/s | {kw['zmpdisc']['value'] / 1e9:.2f} / {kw['preview']['value'] / 1e9:.2f} / {kw['steps_to_com']['value'] / 1e6:.2f} |")
     cb = bench["cpu_baseline"]
-    L.append(f"| `cpu_baseline` (`kind: {cb['kind']}`): one host core / all {cb['all_cores']['cores']} | {cb['value'] / 1e3:.1f} k / {cb['all_cores']['value'] / 1e3:.0f} k ticks/s | — |")
+    ac = cb["all_cores"]
+    L.append(f"| `cpu_baseline` (`kind: {cb['kind']}`): one host core / the {ac.get('cores_used', ac['cores'])} usable cores ({ac.get('cores_visible', '?')} visible; parallel efficiency {ac.get('parallel_efficiency', float('nan')):.2f}) | {cb['value'] / 1e3:.1f} k / {ac['value'] / 1e3:.0f} k ticks/s | — |")
     pr = bench["parity"]
     L.append(f"| `parity`: CoM vs the golden file / vs the libm oracle driven by the compiled `ql0001_` | RMSE {pr['com_rmse_m']:.2e} m (the file's print precision) / max {pr['com_max_abs_vs_libm_oracle_m']:.1e} m | same |")
     L.append("")
@@ -195,12 +196,12 @@ def block_headline():
             f"**{M(win['value'])} MPC ticks/s in the driver's window** (`bench.py --steps 20 --warmup 5`: one launch of 20 ticks; the driver's own clock on its own box is "
             f"the number of record — round 3: driver 5.87 M against the builder's 5.98 M); {M(bench['value'])} over the builder's default 200-step run (one launch of 200 "
             f"ticks — the same kernel; a launch pays about half a tick-time once for its ramp and drain, `profiles/{tag}_launch_fit.txt`).  With the tick's deliverable stored "
-            f"(20 CoM / ZMP / feet samples per gait-tick, 7.7 KB): {M(win['outs_on']['value'])} / {M(bench['outs_on']['value'])}.  One launch per tick: "
-            f"{M(win['per_tick_launch']['value'])}.  The reference's compiled solver on one host core: {cb['value'] / 1e3:.1f} k ticks/s, on all {cb['all_cores']['cores']}: "
+            f"(20 CoM / ZMP / feet samples per gait-tick, {bench['outs_on']['out_bytes_per_gait_tick'] / 1e3:.1f} KB): {M(win['outs_on']['value'])} / {M(bench['outs_on']['value'])}.  One launch per tick: "
+            f"{M(win['per_tick_launch']['value'])}.  The reference's compiled solver on one host core: {cb['value'] / 1e3:.1f} k ticks/s, on the {cb['all_cores'].get('cores_used', cb['all_cores']['cores'])} cores the box grants: "
             f"{cb['all_cores']['value'] / 1e3:.0f} k.  {r['hbm_bytes_per_gait_tick'] / 1e3:.1f} KB of HBM traffic per gait-tick; CoM RMSE "
             f"{bench['parity']['com_rmse_m']:.0e} m against the reference's golden file (its print precision), max {bench['parity']['com_max_abs_vs_libm_oracle_m']:.0e} m against "
             f"the libm oracle driven by the compiled `ql0001_`.  N = 32 with foot-placement variables at B = 8192: {M(c5w['value'])} ticks/s "
-            f"({e['hbm_bytes_per_gait_tick'] / 1e6:.1f} MB per gait-tick through the fabric, `DESIGN.md` §3.2).  The other kernels of the path on the same line (`kernels`): "
+            f"({e['hbm_bytes_per_gait_tick'] / 1e6:.1f} MB per gait-tick through the fabric, `DESIGN.md` §4.3).  The other kernels of the path on the same line (`kernels`): "
             f"dense `ql0001_` boundary {M(k['ql0001_dense']['value'])} QPs/s on the workload's real QPs, Dimitrov tick {M(k['dimitrov_tick']['value'])} ticks/s with PLDP and "
             f"{M(k['dimitrov_tick_qldandlq']['value'])} with the in-wave `ql0001_`, PLDP {M(k['pldp']['value'])} hot-started solves/s, step sequences → ZMP queue "
             f"{k['zmpdisc']['value'] / 1e9:.1f} G gait-samples/s → preview control {k['preview']['value'] / 1e9:.1f} G gait-steps/s, {k['steps_to_com']['value'] / 1e6:.2f} M whole "
@@ -219,6 +220,18 @@ def block_latency():
             "(\"one robot\") says with counters why a second wave would not change that.")
 
 
+def wrap_md(text, width=120):
+    """prose at `width` columns; table rows, headings and blank lines as they are"""
+    import textwrap
+    out = []
+    for ln in text.split("\n"):
+        if len(ln) <= width or ln.startswith(("|", "#", "<!--")):
+            out.append(ln)
+        else:
+            out.extend(textwrap.wrap(ln, width, break_long_words=False, break_on_hyphens=False))
+    return "\n".join(out)
+
+
 BLOCKS = {"current": ("DESIGN.md", block_current), "attribution": ("DESIGN.md", block_attribution), "headline": ("README.md", block_headline), "latency": ("INTEGRATION.md", block_latency)}
 rc = 0
 for name, (doc, fn) in BLOCKS.items():
@@ -227,7 +240,7 @@ for name, (doc, fn) in BLOCKS.items():
     a, b = f"<!-- BEGIN GENERATED {name} -->", f"<!-- END GENERATED {name} -->"
     if a not in txt or b not in txt:
         print(f"{doc}: no {name} block"); rc = 1; continue
-    new = txt[:txt.index(a) + len(a)] + "\n" + fn() + "\n" + txt[txt.index(b):]
+    new = txt[:txt.index(a) + len(a)] + "\n" + wrap_md(fn()) + "\n" + txt[txt.index(b):]
     if new != txt:
         if check:
             print(f"{doc}: block `{name}` is stale"); rc = 1

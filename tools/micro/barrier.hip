@@ -1,4 +1,4 @@
-// What does a phase hand-over inside a multi-wave workgroup cost?  (DESIGN 7's estimate for the N = 32 "Z in LDS, several waves
+// What does a phase hand-over inside a multi-wave workgroup cost?  (docs/HISTORY.md 7's estimate for the N = 32 "Z in LDS, several waves
 // per gait" layout rested on an unmeasured s_barrier + LDS hand-over; this measures it at that layout's residency.)
 //
 // One workgroup = one "gait" = W waves (1, 2, 4), 52 KB of LDS each so that exactly THREE workgroups share a CU (Z 41.5 KB + the

@@ -1,4 +1,4 @@
-// Prototype of ONE active-set iteration of ql0002 at N = 32 (n = 72, nact = 41) in the layout DESIGN 7 only estimated: a
+// Prototype of ONE active-set iteration of ql0002 at N = 32 (n = 72, nact = 41) in the layout docs/HISTORY.md 7 only estimated (DESIGN 4.3 has the result): a
 // workgroup of W waves per gait, Z (72 x 72, leading dimension 73: conflict-free column walks) in LDS, three gaits per CU
 // (53 KB of LDS each), the lane-parallel phases split over the waves, the two serial chains on waves 0 and 1 (side by side
 // when W >= 2), a workgroup barrier at every hand-over.  Same instruction shapes as the solver's phases -- the chain of

@@ -1,5 +1,5 @@
 #!/bin/bash
-# The "Z on chip" experiment of DESIGN 3.2 (N = 32, Z's rows in registers, mpc_tick<33>): parity tests, rate and counters of the
+# The "Z on chip" experiment of docs/HISTORY.md 3.2 (N = 32, Z's rows in registers, mpc_tick<33>): parity tests, rate and counters of the
 # experiment build against the default library.  Build first (CPU container):
 #   make -C jrl-walkgen_amd lib/libwg_mpc_xregz.so EXTRA=-DWG_WITH_REGZ
 #   make -C jrl-walkgen_amd lib/libwg_mpc_xregz2.so EXTRA="-DWG_WITH_REGZ -DWG_ZR_TILE=6 -DWG_ZR_WPS=2"      (two waves per SIMD)
