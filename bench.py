@@ -677,7 +677,7 @@ def main():
                 outs_leg["traffic_source"] = "%s: rocprofv3 --pmc WRITE_SIZE / FETCH_SIZE passes of `bench.py --outs-on`" % os.path.relpath(PMC_SUMMARY, ROOT)
             line["outs_on"] = outs_leg
         if world == 1 and not args.no_kernels:
-            line["kernels"] = bench_kernels.run_all(wg, dev, stream, B, sp, model, algorithmic_bytes)
+            line["kernels"] = bench_kernels.run_all(wg, dev, stream, B, states, model, algorithmic_bytes)
             wg.mpc_configure(model)
         if world == 1 and not args.no_config5:
             try:

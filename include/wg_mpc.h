@@ -122,7 +122,9 @@ long long wg_overlap_serialised(void);
  *   nact     B                                               (may be NULL)
  *   hist     B * hist_cap add(+code)/drop(-code) log          (may be NULL)
  *   hist_len B   number of events (can exceed hist_cap)       (NULL iff hist NULL)
- */
+ * With more QPs than the device keeps resident, a batch that follows another one of the same size on the same C array starts
+ * its QPs in the order of decreasing iteration count of that previous batch (an MPC loop: problem k of consecutive calls is
+ * the same robot a tick later).  Scheduling only: no result depends on it; WG_QL_LPT=0 keeps index order. */
 int wg_qp_solve_batch(int B, int nmax, int mmax, const int *n, const int *m,
                       const int *me, const double *C, const double *d,
                       const double *A, const double *b, const double *xl,
@@ -496,7 +498,8 @@ int wg_dimitrov_get_qld_constants(double *Q, double *OptB, double *OptC, double 
 /* polys: B x N polytopes (instant-major per gait); outs may be NULL.  A gait whose solve returns ret != 0 keeps its
  * state (xk not advanced), like the reference which stops there (:1343-1347).  With model.solver == WG_DIMITROV_QLD / _QLDANDLQ the
  * solve is the in-wave ql0002 of wg_qp_solve_batch -- the back-ends of this tick whose CPU counterpart is the reference's own
- * compiled qld.cpp; the PLDP hot-start members of the state are carried along untouched, max_iter is ignored. */
+ * compiled qld.cpp; the PLDP hot-start members of the state are carried along untouched, max_iter is ignored.  With more gaits
+ * than resident waves they start longest-solve-first by the previous tick on the same state array (scheduling only). */
 int wg_dimitrov_tick_batch(int B, const wg_zmp_polytope_t *polys, wg_dimitrov_state_t *states, wg_dimitrov_out_t *outs,
                            int max_iter);
 int wg_dimitrov_tick_batch_dev(int B, const wg_zmp_polytope_t *polys, wg_dimitrov_state_t *states,

@@ -91,6 +91,11 @@ struct wg_ctx {
   DevBuf lpt_buf;                        // [iterations of the last tick (B) | start order (B)]
   const wg_gait_state_t *lpt_states = nullptr;
   int lpt_B = 0;
+  // the same for the dense QP boundary and the Dimitrov tick's QL back-ends: a batch that follows another one of the same size on
+  // the same arrays (an MPC loop: problem k of consecutive calls is the same robot a tick later) starts longest-solve-first
+  DevBuf qlpt_buf, dlpt_buf;
+  const void *qlpt_key = nullptr, *dlpt_key = nullptr;
+  int qlpt_B = 0, dlpt_B = 0;
   // The tick / run kernels keep their queue and per-block solver slots in run_buf / tick_z: launches of one context must
   // not overlap ON THE DEVICE.  Every such launch leaves an event behind; a launch that arrives on ANOTHER stream while that
   // event is still pending is made to wait for it (hipStreamWaitEvent: ordered, not refused -- a double-buffered pipeline that
@@ -135,7 +140,8 @@ struct wg_ctx {
     if (prev_F) (void)hipFree(prev_F);
     tables_dev = nullptr; model_dev = nullptr; pldp_dev = nullptr; dim_dev = nullptr; prev_F = nullptr;
     model_set = false; pldp_N = 0; dim_set = false; prev_set = false;
-    for (DevBuf *b : {&tick_state, &tick_out, &tick_aux, &run_buf, &tick_z, &asm_state, &lpt_buf, &qp_slot, &pldp_buf, &dim_buf, &prev_buf, &in, &out, &gram_buf, &zd_buf})
+    qlpt_key = dlpt_key = nullptr; qlpt_B = dlpt_B = 0;
+    for (DevBuf *b : {&tick_state, &tick_out, &tick_aux, &run_buf, &tick_z, &asm_state, &lpt_buf, &qlpt_buf, &dlpt_buf, &qp_slot, &pldp_buf, &dim_buf, &prev_buf, &in, &out, &gram_buf, &zd_buf})
       b->release();
     for (SlotOrder *o : {&guard_order, &qp_order, &asm_order, &aux_order}) {
       if (o->ev) (void)hipEventDestroy(o->ev);
@@ -263,10 +269,13 @@ __global__ __launch_bounds__(64) WG_QLD_ATTR void wg_ql_dense_kernel(   // never
     const double *__restrict__ A, const double *__restrict__ bvec, const double *__restrict__ xl,
     const double *__restrict__ xu, double eps, double *__restrict__ x, double *__restrict__ u,
     int *__restrict__ ifail, int *__restrict__ n_iter, int *__restrict__ iact, int *__restrict__ nact,
-    int *__restrict__ hist, int hist_cap, int *__restrict__ hist_len, double *__restrict__ wab_slots) {
+    int *__restrict__ hist, int hist_cap, int *__restrict__ hist_len, double *__restrict__ wab_slots,
+    const int *__restrict__ order, int *__restrict__ iters_out) {
   extern __shared__ __attribute__((aligned(16))) double wg_lds[];
   const int lane = threadIdx.x & 63;
-  const int qp = blockIdx.x;                     // one QP per block (grid == B): nothing lane-dependent lives across QPs
+  // one QP per block (grid == B): nothing lane-dependent lives across QPs.  Blocks start in index order: `order`
+  // (wg_lpt_order_kernel) makes that the order of decreasing solve length, as far as the previous batch predicts it
+  const int qp = order ? wg::uni(order[blockIdx.x]) : (int)blockIdx.x;
   const int nmax = kFixN > 0 ? kFixN : nmax_arg, mmax = kFixM > 0 ? kFixM : mmax_arg;   // the host checks the match
   if (qp < B) {
     const int n = n_arr ? n_arr[qp] : nmax;
@@ -332,6 +341,7 @@ __global__ __launch_bounds__(64) WG_QLD_ATTR void wg_ql_dense_kernel(   // never
       if (n_iter) n_iter[qp] = r.n_iter;
       if (nact) nact[qp] = r.nact;
       if (hist_len) hist_len[qp] = r.hist_len;
+      if (iters_out) iters_out[qp] = r.n_iter;
     }
     WG_WSYNC();
   }
@@ -466,13 +476,35 @@ int wg_qp_solve_batch_dev_ctx(wg_ctx_t *ctx, int B, int nmax, int mmax, const in
       lds = lds_now;
     }
   }
+  // more QPs than resident waves: start them longest-solve-first by the iteration counts of the previous batch on the same
+  // arrays (scheduling only; a caller that interleaves unrelated batches merely loses the benefit).  WG_QL_LPT=0: index order
+  int *order = nullptr, *iters_out = nullptr;
+  {
+    size_t per_cu = 128 / ((lds + 1279) / 1280);
+    if (per_cu > 8) per_cu = 8;
+    if (per_cu < 1) per_cu = 1;
+    // the order lives in a buffer of the context: only a launch that also owns the context's wa | b slots uses it (those are
+    // handed to one launch at a time: see above), so no other launch rewrites the order under this one's blocks
+    bool lpt = wab != nullptr && (size_t)B > (size_t)ctx->num_cu * per_cu;
+    if (const char *e = getenv("WG_QL_LPT")) lpt = lpt && atoi(e) != 0;
+    if (lpt) {
+      const bool known = ctx->qlpt_key == C && ctx->qlpt_B == B && ctx->qlpt_buf.p;
+      if (int rc = ctx->qlpt_buf.reserve((size_t)B * 2 * sizeof(int))) return rc;
+      iters_out = static_cast<int *>(ctx->qlpt_buf.p);
+      if (known) {
+        order = iters_out + B;
+        hipLaunchKernelGGL(wg_lpt_order_kernel, dim3(1), dim3(1024), 0, st, B, iters_out, order);
+      }
+      ctx->qlpt_key = C; ctx->qlpt_B = B;
+    }
+  }
   // the Herdt-sized boundary (what QPProblem::solve hands over at N = 16: nmax = 36, mmax = 76) has its own instantiation
   bool fixed36 = wab && nmax == 36 && mmax == 76;
   if (const char *e = getenv("WG_QL_FIXED")) fixed36 = fixed36 && atoi(e) != 0;
   if (fixed36) {
     lds = wg::QlView::fixed_dense_bytes<36>();
     hipLaunchKernelGGL((wg_ql_dense_kernel<false, false, false, 36, 76>), dim3(B), dim3(64), lds, st, B, nmax, mmax, n, m, me, C, d, A, b,
-                       xl, xu, eps, x, u, ifail, n_iter, iact, nact, hist, hist_cap, hist_len, wab);
+                       xl, xu, eps, x, u, ifail, n_iter, iact, nact, hist, hist_cap, hist_len, wab, order, iters_out);
     if (int rc = slot_mark(ctx->qp_order, st)) return rc;
     HIP_TRY(hipGetLastError());
     return WG_OK;
@@ -485,16 +517,16 @@ int wg_qp_solve_batch_dev_ctx(wg_ctx_t *ctx, int B, int nmax, int mmax, const in
   const int grid = B;
   if (a_in_lds)
     hipLaunchKernelGGL((wg_ql_dense_kernel<true, true>), dim3(grid), dim3(64), lds, st, B, nmax, mmax, n, m, me, C, d, A, b,
-                       xl, xu, eps, x, u, ifail, n_iter, iact, nact, hist, hist_cap, hist_len, wab);
+                       xl, xu, eps, x, u, ifail, n_iter, iact, nact, hist, hist_cap, hist_len, wab, order, iters_out);
   else if (g_in_lds)
     hipLaunchKernelGGL((wg_ql_dense_kernel<false, true>), dim3(grid), dim3(64), lds, st, B, nmax, mmax, n, m, me, C, d, A, b,
-                       xl, xu, eps, x, u, ifail, n_iter, iact, nact, hist, hist_cap, hist_len, wab);
+                       xl, xu, eps, x, u, ifail, n_iter, iact, nact, hist, hist_cap, hist_len, wab, order, iters_out);
   else if (!wab)
     hipLaunchKernelGGL((wg_ql_dense_kernel<false, false>), dim3(grid), dim3(64), lds, st, B, nmax, mmax, n, m, me, C, d, A, b,
-                       xl, xu, eps, x, u, ifail, n_iter, iact, nact, hist, hist_cap, hist_len, wab);
+                       xl, xu, eps, x, u, ifail, n_iter, iact, nact, hist, hist_cap, hist_len, wab, order, iters_out);
   else {
     hipLaunchKernelGGL((wg_ql_dense_kernel<false, false, false>), dim3(grid), dim3(64), lds, st, B, nmax, mmax, n, m, me, C, d, A, b,
-                       xl, xu, eps, x, u, ifail, n_iter, iact, nact, hist, hist_cap, hist_len, wab);
+                       xl, xu, eps, x, u, ifail, n_iter, iact, nact, hist, hist_cap, hist_len, wab, order, iters_out);
     if (int rc = slot_mark(ctx->qp_order, st)) return rc;
   }
   HIP_TRY(hipGetLastError());
@@ -1210,11 +1242,15 @@ wg_dimitrov_tick_kernel(int B, const wg::DimitrovConst *__restrict__ K, const wg
 template <bool kLQ>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
 wg_dimitrov_qld_tick_kernel(int B, const wg::DimitrovConst *__restrict__ K, const wg_zmp_polytope_t *__restrict__ polys,
-                            wg_dimitrov_state_t *states, wg_dimitrov_out_t *outs) {
+                            wg_dimitrov_state_t *states, wg_dimitrov_out_t *outs, const int *__restrict__ order,
+                            int *__restrict__ iters_out) {
   extern __shared__ __attribute__((aligned(16))) double dimq_lds[];
   const int N = K->N;
-  const int g = blockIdx.x;
-  if (g < B) wg::dimitrov_qld_tick<kLQ>(*K, dimq_lds, polys + (size_t)g * N, states + g, outs ? outs + g : nullptr);
+  const int g = order ? wg::uni(order[blockIdx.x]) : (int)blockIdx.x;     // longest-solve-first by the previous tick (scheduling only)
+  if (g < B) {
+    const int it = wg::dimitrov_qld_tick<kLQ>(*K, dimq_lds, polys + (size_t)g * N, states + g, outs ? outs + g : nullptr);
+    if (iters_out && (threadIdx.x & 63) == 0) iters_out[g] = it;
+  }
 }
 
 namespace {
@@ -1287,15 +1323,34 @@ int wg_dimitrov_tick_batch_dev_ctx(wg_ctx_t *ctx, int B, const wg_zmp_polytope_t
   if (B == 0) return WG_OK;
   if ((*ctx->dim_host).solver != WG_DIMITROV_PLDP) {
     const size_t ldsq = wg::dimitrov_qld_lds_bytes();
-    if ((*ctx->dim_host).solver == WG_DIMITROV_QLDANDLQ)
-      hipLaunchKernelGGL(wg_dimitrov_qld_tick_kernel<true>, dim3(B), dim3(64), ldsq, reinterpret_cast<hipStream_t>(hip_stream), B,
-                         ctx->dim_dev, polys, states, outs);
-    else
-      hipLaunchKernelGGL(wg_dimitrov_qld_tick_kernel<false>, dim3(B), dim3(64), ldsq, reinterpret_cast<hipStream_t>(hip_stream), B,
-                         ctx->dim_dev, polys, states, outs);
-    HIP_TRY(hipGetLastError());
+    hipStream_t stq = reinterpret_cast<hipStream_t>(hip_stream);
     std::lock_guard<std::mutex> launch_lk(ctx->launch_mu);
-    return slot_mark(ctx->aux_order, reinterpret_cast<hipStream_t>(hip_stream));
+    // more gaits than resident waves (eight per CU): longest-solve-first by the previous tick on the same state array
+    int *order = nullptr, *iters_out = nullptr;
+    {
+      size_t per_cu = 128 / ((ldsq + 1279) / 1280);
+      if (per_cu > 8) per_cu = 8;
+      if (per_cu < 1) per_cu = 1;
+      // the order lives in a buffer of the context: not while another stream's launch of this context may still be reading it
+      bool lpt = (size_t)B > (size_t)ctx->num_cu * per_cu && !slot_pending_elsewhere(ctx->aux_order, stq);
+      if (const char *e = getenv("WG_QL_LPT")) lpt = lpt && atoi(e) != 0;
+      if (lpt) {
+        const bool known = ctx->dlpt_key == states && ctx->dlpt_B == B && ctx->dlpt_buf.p;
+        if (int rc = ctx->dlpt_buf.reserve((size_t)B * 2 * sizeof(int))) return rc;
+        iters_out = static_cast<int *>(ctx->dlpt_buf.p);
+        if (known) {
+          order = iters_out + B;
+          hipLaunchKernelGGL(wg_lpt_order_kernel, dim3(1), dim3(1024), 0, stq, B, iters_out, order);
+        }
+        ctx->dlpt_key = states; ctx->dlpt_B = B;
+      }
+    }
+    if ((*ctx->dim_host).solver == WG_DIMITROV_QLDANDLQ)
+      hipLaunchKernelGGL(wg_dimitrov_qld_tick_kernel<true>, dim3(B), dim3(64), ldsq, stq, B, ctx->dim_dev, polys, states, outs, order, iters_out);
+    else
+      hipLaunchKernelGGL(wg_dimitrov_qld_tick_kernel<false>, dim3(B), dim3(64), ldsq, stq, B, ctx->dim_dev, polys, states, outs, order, iters_out);
+    HIP_TRY(hipGetLastError());
+    return slot_mark(ctx->aux_order, stq);
   }
   const size_t lds = dimitrov_lds_bytes();
   if (lds > 64 * 1024)

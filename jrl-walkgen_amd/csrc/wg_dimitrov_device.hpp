@@ -354,9 +354,9 @@ __host__ __device__ inline size_t dimitrov_qld_lds_bytes() {
          4 * (size_t)(WG_PLDP_MMAX + ((WG_PLDP_N + 2) & ~1)) + 16;
 }
 
-template <bool kLQ>
-__device__ void dimitrov_qld_tick(const DimitrovConst &K, double *lds, const wg_zmp_polytope_t *__restrict__ polys,
-                                  wg_dimitrov_state_t *st, wg_dimitrov_out_t *out) {
+template <bool kLQ>                                          // returns ql0002's iteration count (the launcher's start order, nothing else)
+__device__ int dimitrov_qld_tick(const DimitrovConst &K, double *lds, const wg_zmp_polytope_t *__restrict__ polys,
+                                 wg_dimitrov_state_t *st, wg_dimitrov_out_t *out) {
   const int lane = wg_lane();
   const int N = K.N, n = 2 * N, mcap = WG_PLDP_MMAX;
   double *t = reinterpret_cast<double *>(reinterpret_cast<char *>(lds) + dimitrov_qld_ql_bytes());
@@ -457,6 +457,7 @@ __device__ void dimitrov_qld_tick(const DimitrovConst &K, double *lds, const wg_
     if (out) { out->jerk_x = jx; out->jerk_y = jy; out->ret = r.ifail; out->n_iter = r.n_iter; out->n_active = r.nact; out->m = m; }
   }
   WG_WSYNC();
+  return r.n_iter;
 }
 
 }  // namespace wg

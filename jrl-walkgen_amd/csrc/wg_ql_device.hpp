@@ -1394,10 +1394,75 @@ __device__ __forceinline__ void zr_row_to(const QlView &q, const ZRegs<NMAX> &zr
 }
 
 // qld.cpp:1861-1889.  Returns kdrop (0-based) or -1; ratio updated when found.
+// ---- the two SELECTIONS of an iteration in the reference's own serial form (round 5) ------------------------------------------
+// The violation scan and the ratio test pick a row by a running comparison -- "skip unless strictly better than the best so far" --
+// which the lane-parallel forms below replace by per-lane candidates and a wave arg-max (first index among equals).  The two agree
+// while every compared value is an ordinary number.  Once the iterate holds a NaN they do not: the reference's `if (sumx <= cvmax)
+// goto skip` does NOT skip a NaN, and with cvmax = NaN it skips nothing any more -- the LAST row that passes its other tests wins,
+// which no arg-max reproduces (found on two of 2304 random Herdt-shaped QPs: the reference loops to maxit and reports ifail = 1,
+// the arg-max form "converged" with ifail = 0 and a NaN solution).  So: when x (or the ratio test's operands) is not a number of
+// sane size -- one compare per lane and one ballot per iteration -- the wave takes these loops instead: every lane runs the
+// reference's statements in the reference's order on broadcast operands (wave-uniform control flow; speed is irrelevant, the
+// solve is lost and only has to end the way the reference's does).
+__device__ __forceinline__ bool wg_sane(double v) { return fabs(v) < 1e100; }     // false for NaN, infinities and overflow-bound values
+
+// qld.cpp:1255-1331
+template <class P>
+__device__ __forceinline__ void scan_serial_reference(const QlView &q, const P &prob, double onha, double &cvmax, double &res,
+                                                      double &wsel, int &knext) {
+  const int n = q.n, m = q.m, me = q.me, mn = q.mn;
+  cvmax = 0.0;
+  for (int k = 1; k <= m; ++k) {
+    const double wk = q.wa[k - 1], bk = q.b[k - 1];
+    if (wk <= 0.0) continue;
+    double sum = -bk;
+    for (int i = 0; i < n; ++i) sum += q.x[i] * Am(k - 1, i);
+    double sumx = -sum * wk;
+    if (k <= me) sumx = fabs(sumx);
+    if (sumx <= cvmax) continue;
+    double temp = fabs(bk);
+    for (int i = 0; i < n; ++i) temp += fabs(q.x[i] * Am(k - 1, i));
+    const double tempa = temp + fabs(sum);
+    if (tempa <= temp) continue;
+    temp += onha * fabs(sum);
+    if (temp <= tempa) continue;
+    cvmax = sumx; res = sum; knext = k; wsel = wk;
+  }
+  for (int k = 1; k <= n; ++k) {
+    const double wk = q.wa[m + k - 1];
+    if (wk <= 0.0) continue;
+    bool lower = true;
+    double sum = prob.xl(q, k - 1) - q.x[k - 1];
+    if (sum < 0.0) { sum = q.x[k - 1] - prob.xu(q, k - 1); lower = false; }
+    else if (sum == 0.0) continue;
+    if (sum <= cvmax) continue;
+    cvmax = sum; res = -sum; knext = lower ? k + m : k + mn; wsel = wk;
+  }
+}
+
+// qld.cpp:1861-1889
+__device__ __forceinline__ int pick_drop_serial_reference(const QlView &q, int nact, double res, double &ratio) {
+  int kdrop = -1;
+  for (int k = 0; k < nact; ++k) {
+    if (q.iact[k] <= q.me) continue;
+    const double w = q.ww[k];
+    if (res * w >= 0.0) continue;
+    const double temp = q.lam[k] / w;
+    if (kdrop >= 0 && fabs(temp) >= fabs(ratio)) continue;
+    kdrop = k; ratio = temp;
+  }
+  return kdrop;
+}
+
 template <bool kOnePass = false>                          // kOnePass: nact <= 64 known at compile time (n <= 64)
 __device__ __forceinline__ int pick_drop(const QlView &q, int nact, double res, double &ratio, int lane) {
   double best = 0.0, bestt = 0.0;
   int bidx = -1;
+  {                                                         // operands that are no ordinary numbers: the reference's own loop (see above)
+    bool bad = !wg_sane(res);
+    for (int k = lane; k < nact; k += 64) bad = bad || !wg_sane(q.ww[k]) || !wg_sane(q.lam[k]);
+    if (__ballot(bad) != 0ull) return uni(pick_drop_serial_reference(q, nact, res, ratio));
+  }
   if constexpr (kOnePass) {                                 // one multiplier per lane: selects instead of a lane-dependent loop
     const bool in = lane < nact;
     const int kc = in ? lane : 0;
@@ -2191,6 +2256,19 @@ __device__ __forceinline__ QlResult ql_solve(const QlView &q, P &prob, double vs
       // the critical path is an exposed round trip per iteration (the same value: nothing writes wa between the scan and the add)
       double bestv = 0.0, bestres = 0.0, bestw = 0.0;
       int bidx = -1;
+      bool x_sane;
+      {
+        bool bad = false;
+        for (int i = lane; i < n; i += 64) bad = bad || !wg_sane(q.x[i]);
+        x_sane = __ballot(bad) == 0ull;
+      }
+      if (!x_sane) {                                        // the iterate holds a NaN / an infinity: the reference's own serial loop
+        double cv = 0.0;
+        int kn = knext;
+        scan_serial_reference(q, prob, onha, cv, res, wsel, kn);
+        knext = uni(kn);
+        bestv = uni(cv); bidx = -1;                         // res / knext / wsel are already what the reference leaves
+      } else
       WG_REP(1) {
       bestv = 0.0; bestres = 0.0; bestw = 0.0; bidx = -1;
       if constexpr (P::kCompact) {

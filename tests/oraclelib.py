@@ -174,6 +174,17 @@ def same_bits(a, b):
     return a.shape == b.shape and np.array_equal(a.view(np.uint64), b.view(np.uint64))
 
 
+def same_bits_nan_aware(a, b):
+    """same_bits, except that a NaN matches a NaN whatever its sign / payload bits: an invalid operation gives the negative default
+    NaN on x86-64 SSE (0xFFF8...) and the positive one on gfx950 (0x7FF8...); which of the two is not part of any contract."""
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    b = np.ascontiguousarray(b, dtype=np.float64)
+    if a.shape != b.shape:
+        return False
+    na, nb = np.isnan(a), np.isnan(b)
+    return bool(np.array_equal(na, nb) and np.array_equal(a.view(np.uint64)[~na], b.view(np.uint64)[~nb]))
+
+
 # ---- Dimitrov back-end (oracle/pldp_oracle.c) ------------------------------------------------------------------
 
 PLDP_N = 16

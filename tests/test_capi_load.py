@@ -24,6 +24,17 @@ def test_library_exports_every_declared_symbol():
     assert lib.wg_abi_version() >= 1
 
 
+def test_pod_layouts_of_the_binding_match_the_header():
+    """ABI 5: wg_tick_out_t is 61 whole cache lines (7808 B; the library static_asserts the same), the gait state 1208 B; the ctypes
+    mirrors must agree or every array handed over is mis-strided."""
+    wg = importlib.import_module("jrl-walkgen_amd")
+    assert ctypes.sizeof(wg.TickOut) == 61 * 128 == 7808
+    assert ctypes.sizeof(wg.GaitState) == 1208
+    assert wg.lib().wg_abi_version() == 5
+    hdr = open(os.path.join(ROOT, "include", "wg_mpc.h")).read()
+    assert "double pad_[15];" in hdr and "ABI 5" in hdr
+
+
 def test_lds_footprint_matches_design():
     wg = importlib.import_module("jrl-walkgen_amd")
     # Herdt N=16, two previewed steps: n = 36, m = 75 -> three QPs per 160 KiB CU with A staged in LDS (the launcher

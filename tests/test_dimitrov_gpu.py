@@ -272,6 +272,39 @@ def test_fused_tick_with_the_ql_back_ends_bit_exact(mode, ql):
         wg.dimitrov_configure(wg.dimitrov_defaults())
 
 
+def test_qld_tick_longest_first_start_order_is_scheduling_only(monkeypatch):
+    """More gaits than resident waves through the QL back-end: from the second tick on the gaits start longest-solve-first by the
+    previous tick's iteration counts.  Scheduling only: states and outputs of every tick equal the index-order run (WG_QL_LPT=0)."""
+    model, K, Kq = _qld_setup(2)
+    N = model.N
+    B, T = 2200, 4
+    plans = [dv.plan(np.random.default_rng(700 + g % 37), n_steps=3 + g % 6) for g in range(B)]
+    offs = [(5 * g) % 11 for g in range(B)]
+
+    def run():
+        st = (wg.DimitrovState * B)()
+        for g in range(B):
+            st[g].starting = 1
+            st[g].xk[0] = 0.002 * (g % 50); st[g].xk[4] = 0.001 * (g % 5 - 2)
+        res = []
+        for it in range(T):
+            polys = (wg.ZmpPolytope * (B * N))()
+            for g in range(B):
+                for i, p in enumerate(dv.polys_at(plans[g], it + offs[g], N)):
+                    _fill(polys[g * N + i], p)
+            outs = wg.dimitrov_tick_batch(polys, st)
+            res.append((bytes(st), bytes(outs)))
+        return res, [o.n_iter for o in outs]
+    try:
+        ordered, iters = run()
+        monkeypatch.setenv("WG_QL_LPT", "0")
+        plain, _ = run()
+        assert ordered == plain
+        assert max(iters) > min(iters) + 3                        # there was something to order
+    finally:
+        wg.dimitrov_configure(wg.dimitrov_defaults())
+
+
 def test_qld_tick_with_empty_polytopes():
     """Every polytope of the window without a row (m = 0): the QL back-end's register-row loader has no row to clamp its surplus
     lanes to (it indexed slot[-1]); the tick is the unconstrained minimiser, the same bytes as the oracle tick's."""

@@ -2,7 +2,9 @@
 against the CPU oracle (oracle/ql_oracle.c, itself pinned bit-for-bit to the
 compiled reference qld.cpp).  Bar: bit-exact x, u, ifail, final active set AND
 the full add/drop history."""
+import ctypes as C
 import importlib
+import os
 
 import numpy as np
 import pytest
@@ -152,6 +154,83 @@ def test_bounds_only_qp_in_the_fixed_size_batch():
     assert not bad, bad[:5]
     assert all(int(res["ifail"][k]) == 0 for k in (0, 3, 5))
     assert int(res["nact"][3]) > 0 and (res["iact"][3, :int(res["nact"][3])] > 0).all()      # the bounds did bind: codes m + i ...
+
+
+def test_non_finite_iterates_end_the_way_the_reference_ends_them():
+    """QPs on which ql0002's iterate becomes NaN (7 of 6000 random Herdt-shaped problems, one of the `infeasible` family: found in
+    round 5).  The reference does not notice: its running comparisons never skip a NaN, it adds and drops until maxit = 40 (m + n)
+    and returns ifail = 1 with a NaN solution; the oracle follows it bit for bit.  A wave arg-max does not pick what those serial
+    comparisons pick once NaNs compete -- the solver used to "converge" there with ifail = 0 -- so it takes the reference's own
+    serial loops for the two selections when the iterate is not a number (wg_ql_device.hpp: scan_serial_reference,
+    pick_drop_serial_reference).  Held here: ifail, the NaN solution's bits, the iteration count and the whole add / drop history
+    (8 877 events) against the oracle, alone and inside a batch of ordinary QPs, through the fixed-size and the generic kernel."""
+    wg = _wg()
+    bad = [qpgen.herdt_like(np.random.default_rng(61000 + s), 16, 2) for s in (72, 1732, 3422, 3928, 4265, 5716, 5797)]
+    good = [qpgen.herdt_like(np.random.default_rng(61000 + s), 16, 2) for s in (5, 6, 7)]
+    qps = [good[0]] + bad[:4] + [good[1]] + bad[4:] + [good[2]]
+    for fixed in ("1", "0"):
+        os.environ["WG_QL_FIXED"] = fixed
+        try:
+            pk = wg.pack_qps(qps)
+            res = wg.qp_solve_batch(pk, hist_cap=16384)
+        finally:
+            os.environ.pop("WG_QL_FIXED", None)
+        n_maxit = 0
+        for k, q in enumerate(qps):
+            o = ol.oracle_ql(_padded(pk, qps, k), hist_cap=16384)
+            assert int(res["ifail"][k]) == o["ifail"], (fixed, k, int(res["ifail"][k]), o["ifail"])
+            assert int(res["n_iter"][k]) == o["n_iter"] and int(res["hist_len"][k]) == o["hist_len"], (fixed, k)
+            assert np.array_equal(res["hist"][k, :o["hist_len"]], o["hist"]), (fixed, k)
+            assert ol.same_bits_nan_aware(res["x"][k, :q["n"]], o["x"]), (fixed, k)     # NaN where the reference has NaN
+            if o["ifail"] == 1:
+                n_maxit += 1
+                assert np.isnan(o["x"]).all() and o["n_iter"] == 40 * (q["m"] + q["n"]) + 1
+        assert n_maxit == 7
+    q = qpgen.FAMILIES["infeasible"](np.random.default_rng(5282))
+    pk = wg.pack_qps([q])
+    res = wg.qp_solve_batch(pk, hist_cap=16384)
+    o = ol.oracle_ql(_padded(pk, [q], 0), hist_cap=16384)
+    assert int(res["ifail"][0]) == o["ifail"] == 1 and int(res["n_iter"][0]) == o["n_iter"]
+    assert int(res["hist_len"][0]) == o["hist_len"] and np.array_equal(res["hist"][0, :o["hist_len"]], o["hist"])
+    assert ol.same_bits_nan_aware(res["x"][0, :q["n"]], o["x"])
+
+
+def test_longest_first_start_order_is_scheduling_only(monkeypatch):
+    """More QPs than resident waves: a batch that follows another one of the same size on the same arrays starts its QPs
+    longest-solve-first by the previous batch's iteration counts (wg_lpt_order_kernel, as the tick does).  Scheduling only: the
+    second and third call return the first call's bytes, the oracle's on a sample, and WG_QL_LPT=0 (index order) the same."""
+    import torch
+    wg = _wg()
+    B = 2304                                                   # > 2048 resident waves (eight per CU)
+    qps = [qpgen.herdt_like(np.random.default_rng(61000 + s), 16, 2) for s in range(B)]
+    pk = wg.pack_qps(qps)
+    assert pk["nmax"] == 36 and pk["mmax"] == 76
+    dev = {k: torch.from_numpy(np.ascontiguousarray(pk[k])).cuda() for k in ("C", "d", "A", "b", "xl", "xu")}
+    ints = {k: torch.from_numpy(np.ascontiguousarray(pk[k]).astype(np.int32)).cuda() for k in ("n", "m", "me")}
+
+    def solve():
+        x = torch.zeros(B, 36, dtype=torch.float64, device="cuda"); u = torch.zeros(B, 76 + 72, dtype=torch.float64, device="cuda")
+        ifail = torch.full((B,), -9, dtype=torch.int32, device="cuda"); nit = torch.zeros(B, dtype=torch.int32, device="cuda")
+        iact = torch.zeros(B, 36, dtype=torch.int32, device="cuda"); nact = torch.zeros(B, dtype=torch.int32, device="cuda")
+        p = lambda t: C.c_void_p(t.data_ptr())                 # noqa: E731
+        rc = wg.lib().wg_qp_solve_batch_dev(B, 36, 76, p(ints["n"]), p(ints["m"]), p(ints["me"]), p(dev["C"]), p(dev["d"]), p(dev["A"]),
+                                            p(dev["b"]), p(dev["xl"]), p(dev["xu"]), C.c_double(1e-8), p(x), p(u), p(ifail), p(nit), p(iact),
+                                            p(nact), None, 0, None, None)
+        assert rc == 0, wg.lib().wg_last_error()
+        torch.cuda.synchronize()
+        return [t.cpu().numpy() for t in (x, u, ifail, nit, iact, nact)]
+
+    first = solve()                                            # no prediction yet: index order
+    second = solve()                                           # ordered by the first call's iteration counts
+    third = solve()
+    monkeypatch.setenv("WG_QL_LPT", "0")
+    plain = solve()
+    for other in (second, third, plain):
+        assert all(a.tobytes() == b.tobytes() for a, b in zip(first, other))     # bytes: some of these QPs end in NaN solutions
+    assert first[3].max() > first[3].min() + 5                 # there was something to order
+    for k in (0, 1, B // 2, B - 1):
+        o = ol.oracle_ql(_padded(pk, qps, k))
+        assert int(first[2][k]) == o["ifail"] and ol.same_bits(first[0][k, :36], o["x"]) and int(first[3][k]) == o["n_iter"]
 
 
 def test_two_streams_share_one_context(monkeypatch):

@@ -91,10 +91,18 @@ def audit_kernel(lines):
         args = args.split(";")[0].strip()
         insts.append((parts[0], args)); depth.append(cur)
     loops = [None] * n_loops
-    # SGPR spills: v_writelane_b32 / v_readlane_b32 whose VGPR is one of the reserved spill registers.  The compiler picks the
-    # highest VGPRs for them; the solver's own readlane broadcasts use computed lanes of data registers.  Spill lanes are
-    # immediates (v_writelane_b32 v255, s12, 5): an immediate lane operand marks spill code.
-    hist = {k: collections.Counter() for k in ("scratch", "sgpr_spill_write", "sgpr_spill_read")}
+    # SGPR spills live in lanes of VGPRs the compiler reserves for them: `v_writelane_b32 v237, s12, 5` stores, `v_readlane_b32
+    # s12, v237, 5` reloads -- immediate lanes, and the SAME few VGPRs on both sides.  An immediate lane alone does not mark spill
+    # code: the solver broadcasts with constant lanes too (the register Cholesky's rl(r[k], i): 1 335 v_readlane of the
+    # Herdt-sized dense kernel, which rounds 3 - 4 counted as reloads).  So: the spill registers are the VGPRs that some
+    # v_writelane with an SGPR source and an immediate lane writes; only reads from THOSE are reloads; the other constant-lane
+    # readlanes are listed as what they are.
+    hist = {k: collections.Counter() for k in ("scratch", "sgpr_spill_write", "sgpr_spill_read", "readlane_const_lane_other")}
+    spill_vgprs = set()
+    for op, args in insts:
+        m = re.match(r"^(v\d+), s\d+, \d+\s*$", args) if op == "v_writelane_b32" else None
+        if m:
+            spill_vgprs.add(m.group(1))
     mix = collections.Counter(); salu = collections.Counter(); total = collections.Counter()
     for i, (op, args) in enumerate(insts):
         k = klass(op)
@@ -104,7 +112,8 @@ def audit_kernel(lines):
         if op == "v_writelane_b32" and re.search(r",\s*\d+\s*$", args):
             hist["sgpr_spill_write"][depth[i]] += 1
         if op == "v_readlane_b32" and re.search(r",\s*\d+\s*$", args) and re.match(r"s\d+|s\[", args.strip()):
-            hist["sgpr_spill_read"][depth[i]] += 1
+            src = re.match(r"^s\d+, (v\d+),", args)
+            hist["sgpr_spill_read" if (src and src.group(1) in spill_vgprs) else "readlane_const_lane_other"][depth[i]] += 1
         if depth[i] >= 3:
             mix[k] += 1
             if k == "SALU":
@@ -150,9 +159,9 @@ def main():
         out.append("")
         out.append("%s: %d instructions, %d loops, deepest nesting %d" % (pretty, a["n_insts"], a["n_loops"], a["max_depth"]))
         out.append("   totals: " + ", ".join("%s %d" % kv for kv in sorted(a["total"].items())))
-        for what in ("scratch", "sgpr_spill_write", "sgpr_spill_read"):
+        for what in ("scratch", "sgpr_spill_write", "sgpr_spill_read", "readlane_const_lane_other"):
             h = a["hist"][what]
-            out.append("   %-18s total %4d   by depth: %s" % (what, sum(h.values()), ", ".join("d%d: %d" % kv for kv in sorted(h.items())) or "-"))
+            out.append("   %-25s total %4d   by depth: %s" % (what, sum(h.values()), ", ".join("d%d: %d" % kv for kv in sorted(h.items())) or "-"))
         inner = a["inner_mix"]
         out.append("   inner loops (depth >= 3), static mix: " + ", ".join("%s %d" % kv for kv in sorted(inner.items())))
         if a["inner_salu"]:

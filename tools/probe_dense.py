@@ -1,5 +1,6 @@
 """The ql0001_ boundary on the Herdt workload's real QPs (bench_kernels.ql_dense_on_real_qps) alone: PB QPs, placements by
-WG_QL_A_IN_LDS / WG_QL_G_IN_LDS / WG_QL_W_IN_LDS."""
+WG_QL_A_IN_LDS / WG_QL_G_IN_LDS / WG_QL_W_IN_LDS; WG_QL_LPT=0: index order instead of longest-solve-first; PSAME=1: the same batch
+solved three times (rounds 1 - 4's form) instead of three consecutive ticks' QPs."""
 import importlib, os, sys, numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -17,6 +18,7 @@ wg.mpc_run_batch_dev(B, st.data_ptr(), 120, 20, None, None)
 torch.cuda.synchronize()
 stream = torch.cuda.current_stream()
 alg = lambda n, m: 8.0 * (n * n + n + (m + 1) * n + (m + 1) + 2 * n) + 8.0 * (n + m + 2 * n)
-r = bk.ql_dense_on_real_qps(wg, torch.device("cuda:0"), stream, B, st.data_ptr(), 16, alg)
-print("B=%d: %.0f QPs/s, %.3f ms per launch, %.1f iterations, failed %d (W_IN_LDS=%s)" %
-      (B, r["value"], r["kernel_ms"], r["mean_iterations"], r["failed_qps"], os.environ.get("WG_QL_W_IN_LDS", "default")))
+r = bk.ql_dense_on_real_qps(wg, torch.device("cuda:0"), stream, B, st.data_ptr() if os.environ.get("PSAME") else st, 16, alg)
+print("B=%d: %.0f QPs/s, %.3f ms per launch, %.1f iterations, failed %d (W_IN_LDS=%s, LPT=%s, %s)" %
+      (B, r["value"], r["kernel_ms"], r["mean_iterations"], r["failed_qps"], os.environ.get("WG_QL_W_IN_LDS", "default"),
+       os.environ.get("WG_QL_LPT", "default"), "same batch x 3" if os.environ.get("PSAME") else "three consecutive ticks"))

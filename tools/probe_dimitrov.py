@@ -6,7 +6,7 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 wg = importlib.import_module("jrl-walkgen_amd"); wg.init(0)
 import dimitrov as dv
 B = int(os.environ.get("PB", "4096")); TICKS = int(os.environ.get("PT", "40")); NPLAN = 128
-model = wg.dimitrov_defaults(); wg.dimitrov_configure(model); N = model.N
+model = wg.dimitrov_defaults(); model.solver = int(os.environ.get("PSOLVER", "0")); wg.dimitrov_configure(model); N = model.N   # PSOLVER=2: the QL back-end (QLDANDLQ)
 PT = np.dtype([("nrows", "i4"), ("pad", "i4"), ("similar", "i4", 8), ("A", "f8", (8, 2)), ("B", "f8", 8), ("centre", "f8", 2)])
 assert PT.itemsize == C.sizeof(wg.ZmpPolytope)
 L = 260

@@ -163,7 +163,9 @@ if "run_kernel" in out:
 readme = f"""# profiles/ -- one set, describing HEAD
 
 Everything named `{tag}_*` was produced by ONE run of `tools/prof_round.sh` on an MI355X (gpurun) and filed by
-`tools/save_round_profiles.py {tag}`; older sets are in the git history only.
+`tools/save_round_profiles.py {tag}`.  Older sets (`round4_*`: what `docs/HISTORY.md` cites) stay as the record of their round; they
+do not describe HEAD.  `current_tick_pmc.json` and `{tag}_resource_usage.txt` carry the hash of the device sources they were made
+from (`tools/csrc_hash.py`); `tests/test_docs_numbers.py` fails when that is not HEAD's.
 
 | files | command profiled | what to read there |
 |---|---|---|
@@ -174,8 +176,9 @@ Everything named `{tag}_*` was produced by ONE run of `tools/prof_round.sh` on a
 | `{tag}_elem_*` | `PN=32 PB=8192 PT=50 PR=3 python3 tools/probe_elem.py` | the element-view run kernel `wg_mpc_run_xcd_kernel<32>` alone (what `bench.py`'s `config5` leg times): kernel trace and all PMC passes; `current_tick_pmc.json` -> `elem_run_kernel` holds its HBM-side traffic per gait-tick (FETCH_SIZE x 2 and uncorrected, WRITE_SIZE) |
 | `{tag}_fetchcal_*` | `tools/micro/fetchcal` (plain, then `tools/pmc_traffic.sh`) | FETCH_SIZE / WRITE_SIZE against known byte counts: 4 / 8 / 16 B per lane coalesced, the Z^T a column walk and the sweep's row walk of a 72 x 73 slot |
 | `{tag}_ticko_*` | the same with `--outs-on` | the timed launch stores every gait-tick's `wg_tick_out_t`: WRITE_SIZE of the `outs_on` leg (`current_tick_pmc.json` -> `run_kernel_outs`) |
-| `{tag}_b1_*` | `python3 tools/probe_b1.py` | one robot, one wave alone on a CU: the counters behind DESIGN 4's "one robot" paragraph (`current_tick_pmc.json` -> `one_robot_kernel`) |
-| `{tag}_regz_*` | `bash tools/regz_probe.sh` (experiment builds, `-DWG_WITH_REGZ`) | the "Z on chip" experiment at N = 32 (DESIGN 3.2): parity, rate at four and eight gaits per CU, all counters of the four-per-CU build |
+| `{tag}_b1_*` | `python3 tools/probe_b1.py` | one robot, one wave alone on a CU: the counters behind DESIGN 4.4 / 4.0 ("one robot") (`current_tick_pmc.json` -> `one_robot_kernel`) |
+| `round4_regz_*` | `bash tools/regz_probe.sh` (experiment builds, `-DWG_WITH_REGZ`; round 4) | the "Z on chip" experiment at N = 32 (docs/HISTORY.md 3.2): parity, rate at four and eight gaits per CU, all counters of the four-per-CU build |
+| `round5_mw_barrier.txt`, `round5_mw_iter.txt` | `tools/micro/barrier`, `tools/micro/mw_iter` (round 5) | the multi-wave "Z in LDS" layout at N = 32 measured instead of built (DESIGN 4.3): cost of an `s_barrier` hand-over at three workgroups per CU; cycles per active-set iteration of a W-wave workgroup, per phase, against what the shipped kernel needs |
 | `{tag}_phase_attribution.txt` | `bash tools/phase_attribution.sh` + `python tools/phase_attribution.py`, then the timer table of `{tag}_tick_phase_timers.txt` | per-phase counters of the N = 16 run kernel (phases executed twice, differences against the plain build) and the shader-clock split of everything the counters cannot repeat |
 | `{tag}_phase_attribution_n32.txt` | `ATTR_DIR=attr32 PN=32 PB=8192 PT=50 PR=2 bash tools/phase_attribution.sh` + `... python tools/phase_attribution.py` | the same counter attribution for the N = 32 kernel `wg_mpc_run_xcd_kernel<32>` at the benchmark's residency (back substitution 12.1 %, norm chain 11.6 %, scan 11.0 %, Z^T a 10.4 %) |
 | `{tag}_latency_b1.json` | `jrl-walkgen_amd/bin/latency_b1` | one robot (B = 1): host-pointer call, its split (copy in / launch / kernel / copy out) and the host-mapped call |
