@@ -7,7 +7,9 @@
         add/drop HISTORY: +k = code k added, -k = dropped, in order -- from a throw-away build of the reference's qld.cpp
         with one log call at its add site (qld.cpp:1766) and one at its drop site (:1903), tests/oraclelib.py:ref_hist;
         x, u, ifail and the final set are taken from the UNPATCHED oracle/_ref build and must agree with the patched one)
-        - 24 QPs per family of tests/qpgen.py (branch coverage of ql0002), and
+        - 24 QPs per family of tests/qpgen.py (branch coverage of ql0002),
+        - eight QPs on which the reference's iterate becomes NaN (found in round 5: 7 of 6000 random Herdt-shaped problems, one of
+          the `infeasible` family): it runs to maxit, ifail = 1, a NaN solution, histories of 8 877 / 2 237 events, and
         - the 225 QPs the Herdt oracle assembles while replaying the EmergencyStop scenario.
   preview_control_parameters.npz : the reference's precomputed Kajita gains
         /root/reference/src/data/PreviewControlParameters.ini  (Zc, T, preview time, Kx[3], Ks, F[320]), as data.
@@ -86,6 +88,10 @@ def main():
     for fam in sorted(qpgen.FAMILIES):
         for s in range(24):
             add(fam, qpgen.FAMILIES[fam](np.random.default_rng(424200 + 977 * s)))
+
+    for sd in (72, 1732, 3422, 3928, 4265, 5716, 5797):
+        add("nonfinite_herdt_like", qpgen.herdt_like(np.random.default_rng(61000 + sd), 16, 2))
+    add("nonfinite_infeasible", qpgen.FAMILIES["infeasible"](np.random.default_rng(5282)))
 
     model, state, events = hr.emergency_stop_setup(datref)
 

@@ -78,18 +78,18 @@ def test_golden_vectors_and_reference_history_through_the_gpu():
         qps = [q for _, q, _ in items]
         pk = wg.pack_qps(qps)
         assert pk["nmax"] == n and pk["mmax"] == mmax
-        res = wg.qp_solve_batch(pk, hist_cap=512)
+        res = wg.qp_solve_batch(pk, hist_cap=max(512, max(len(r["hist"]) for _, _, r in items)))
         for k, (tag, q, ref) in enumerate(items):
             m = q["m"]
             assert int(res["ifail"][k]) == ref["ifail"], tag
-            assert ol.same_bits(res["x"][k, :n], ref["x"]), tag
+            assert ol.same_bits_nan_aware(res["x"][k, :n], ref["x"]), tag     # NaN where the reference has NaN (8 such QPs)
             assert int(res["hist_len"][k]) == len(ref["hist"]), tag
             assert np.array_equal(res["hist"][k, :len(ref["hist"])], ref["hist"]), tag
             if ref["ifail"] == 0:
                 assert ol.same_bits(res["u"][k, :m + 2 * n], ref["u"]), tag
                 assert np.array_equal(res["iact"][k, :len(ref["iact"])], ref["iact"]), tag
             n_checked += 1
-    assert n_checked >= 400
+    assert n_checked >= 449
 
 
 def test_herdt_shape_uniform_batch():
