@@ -267,6 +267,7 @@ __device__ void dimitrov_tick(const DimitrovConst &K, unsigned char *lds, const 
 template <bool kLQ>                                       // kLQ: mode QLDANDLQ (identity Hessian, full rows)
 struct DimitrovQldProb {
   static constexpr bool kCompact = false;
+  static constexpr bool kNanExact = false;   // the tick reports a non-finite solve as ifail = 1 at its end (ql_solve, epilogue)
   static constexpr bool kHasFactor = false;
   static constexpr bool kRowOps = false;
   static constexpr bool kWideN = false;

@@ -269,6 +269,7 @@ struct QlView;
 template <bool kGLds, int kNMc = 0>         // where G lives is known at compile time (ds_ or global_ accesses, never flat_)
 struct DenseProbT {
   static constexpr bool kCompact = false;
+  static constexpr bool kNanExact = true;   // the ql0001_ boundary takes anybody's QP: NaN iterates end the way the reference ends them (scan_serial_reference)
   static constexpr bool kHasFactor = false;    // no structure to exploit: ql0002's own Cholesky and inverse
   static constexpr bool kRowOps = false;   // no structured row products: rows are read element by element
   static constexpr int kNM = kNMc;     // 0: no compile-time bound on n; > 0: n <= kNM (the Herdt-sized boundary kernel: the
@@ -1404,7 +1405,13 @@ __device__ __forceinline__ void zr_row_to(const QlView &q, const ZRegs<NMAX> &zr
 // sane size -- one compare per lane and one ballot per iteration -- the wave takes these loops instead: every lane runs the
 // reference's statements in the reference's order on broadcast operands (wave-uniform control flow; speed is irrelevant, the
 // solve is lost and only has to end the way the reference's does).
-__device__ __forceinline__ bool wg_sane(double v) { return fabs(v) < 1e100; }     // false for NaN, infinities and overflow-bound values
+#ifndef WG_NAN_REGIME
+#define WG_NAN_REGIME 1                                    // 0: experiment builds without the NaN-regime tests (A/B of their cost)
+#endif
+// |v| < 2^332 (8.7e99): false for NaN, infinities and overflow-bound values.  On the exponent field of the high word -- an integer
+// mask and a compare against a 32-bit literal: a 64-bit floating-point literal would be hoisted into a scalar register pair and
+// kept alive (or spilled) across the active-set loop, which is what wg_kconst exists to avoid
+__device__ __forceinline__ bool wg_sane(double v) { return ((unsigned)__double2hiint(v) & 0x7fffffffu) < 0x54b00000u; }
 
 // qld.cpp:1255-1331
 template <class P>
@@ -1454,32 +1461,41 @@ __device__ __forceinline__ int pick_drop_serial_reference(const QlView &q, int n
   return kdrop;
 }
 
-template <bool kOnePass = false>                          // kOnePass: nact <= 64 known at compile time (n <= 64)
+template <bool kOnePass = false, bool kNan = false>       // kOnePass: nact <= 64 known at compile time (n <= 64); kNan: see above
 __device__ __forceinline__ int pick_drop(const QlView &q, int nact, double res, double &ratio, int lane) {
   double best = 0.0, bestt = 0.0;
   int bidx = -1;
-  {                                                         // operands that are no ordinary numbers: the reference's own loop (see above)
-    bool bad = !wg_sane(res);
-    for (int k = lane; k < nact; k += 64) bad = bad || !wg_sane(q.ww[k]) || !wg_sane(q.lam[k]);
-    if (__ballot(bad) != 0ull) return uni(pick_drop_serial_reference(q, nact, res, ratio));
-  }
+  // operands that are no ordinary numbers (tested on the values this form loads anyway, consumed after it: nothing waits for
+  // the test): the reference's own loop decides then (see above)
+  bool bad = !wg_sane(res);
   if constexpr (kOnePass) {                                 // one multiplier per lane: selects instead of a lane-dependent loop
     const bool in = lane < nact;
     const int kc = in ? lane : 0;
     const double w = q.ww[kc];
     const int ia = q.iact[kc];
     const bool cand = in & (ia > q.me) & !(res * w >= 0.0);
-    const double temp = q.lam[kc] / w;
+    const double lamv = q.lam[kc];
+    const double temp = lamv / w;
+    if constexpr (kNan) {
+      const bool bw = !wg_sane(w), bl = !wg_sane(lamv);    // plain values: the || below have nothing to short-circuit
+      bad = bad || (in && (bw || bl));
+    }
     best = cand ? -fabs(temp) : 0.0; bestt = cand ? temp : 0.0; bidx = cand ? lane : -1;
   } else
   for (int k = lane; k < nact; k += 64) {
+    const double w = q.ww[k], lamv = q.lam[k];
+    if constexpr (kNan) {
+      const bool bw = !wg_sane(w), bl = !wg_sane(lamv);
+      bad = bad || bw || bl;
+    }
     if (q.iact[k] <= q.me) continue;
-    double w = q.ww[k];
     if (res * w >= 0.0) continue;
-    double temp = q.lam[k] / w;
+    double temp = lamv / w;
     double key = -fabs(temp);          // smaller |temp| wins, first index on ties
     if (bidx < 0 || key > best) { best = key; bestt = temp; bidx = k; }
   }
+  if constexpr (kNan)
+    if (__ballot(bad) != 0ull) return uni(pick_drop_serial_reference(q, nact, res, ratio));
   int idx = bidx;
   double v = best;
   wave_argmax_first(v, idx);
@@ -1913,6 +1929,10 @@ template <class P, class ZR = NoZRegs>
 __device__ __forceinline__ QlResult ql_solve(const QlView &q, P &prob, double vsmall, int *hist, int hist_cap, QlResume *rs = nullptr,
                                              ZR *zr = nullptr) {
   constexpr bool kRegs = !std::is_same<ZR, NoZRegs>::value;   // Z in registers (ZRegs): see zr_* above
+  // NaN iterates followed exactly (the dense boundary), or reported by the caller at the end of the solve (the tick's views: their
+  // kernels sit at their register and instruction-cache limits -- the exact form measured -1.7 % on the benchmark tick, for a regime
+  // its QPs never enter; mpc_tick tests the two jerks it takes from x instead)
+  constexpr bool kNan = P::kNanExact && (WG_NAN_REGIME != 0);
   int lane = wg_lane();
   const int n = q.n, m = q.m, me = q.me, mn = q.mn;
   QlResult out;
@@ -1930,11 +1950,21 @@ __device__ __forceinline__ QlResult ql_solve(const QlView &q, P &prob, double vs
   double *s = q.R + s_tail;
   bool early_exit = false;
   bool cap_hit = false;
+  // Has the iterate left the ordinary numbers (wave-uniform, sticky)?  x only changes in the residual refresh (once or twice per
+  // solve: tested there with one compare per lane) and by `x += step z` (tested on the scalar step: free).  From then on the
+  // reference's own serial loop does the violation scan (see scan_serial_reference) -- exact for any x, merely slow
+  bool x_suspect = false;
+  auto x_has_non_numbers = [&]() {
+    bool b = false;
+    for (int i = lane; i < n; i += 64) { const bool bi = !wg_sane(q.x[i]); b = b || bi; }
+    return __ballot(b) != 0ull;
+  };
   PT_DECL
   if (resuming) {
     nact = rs->nact; info = rs->info; iterc = rs->iterc; itref = rs->itref; iflag = rs->iflag; jfinc = rs->jfinc; knext = rs->knext;
     out.hist_len = rs->hist_len;
     xmag = rs->xmag; vfact = rs->vfact; res = rs->res; ratio = rs->ratio; diag = rs->diag;
+    if constexpr (kNan) x_suspect = x_has_non_numbers();
   }
 
 #define LOG_EVENT(code)                                                   \
@@ -2246,6 +2276,7 @@ __device__ __forceinline__ QlResult ql_solve(const QlView &q, P &prob, double vs
         st = ST_RESID;
         continue;
       }
+      if constexpr (kNan) x_suspect = x_suspect || x_has_non_numbers();       // the refresh rewrote x
       st = ST_SCAN;
     }
 
@@ -2256,18 +2287,14 @@ __device__ __forceinline__ QlResult ql_solve(const QlView &q, P &prob, double vs
       // the critical path is an exposed round trip per iteration (the same value: nothing writes wa between the scan and the add)
       double bestv = 0.0, bestres = 0.0, bestw = 0.0;
       int bidx = -1;
-      bool x_sane;
-      {
-        bool bad = false;
-        for (int i = lane; i < n; i += 64) bad = bad || !wg_sane(q.x[i]);
-        x_sane = __ballot(bad) == 0ull;
-      }
-      if (!x_sane) {                                        // the iterate holds a NaN / an infinity: the reference's own serial loop
-        double cv = 0.0;
-        int kn = knext;
-        scan_serial_reference(q, prob, onha, cv, res, wsel, kn);
-        knext = uni(kn);
-        bestv = uni(cv); bidx = -1;                         // res / knext / wsel are already what the reference leaves
+      if (kNan && x_suspect) {                              // the iterate holds a NaN / an infinity: the reference's own serial loop decides
+        if constexpr (kNan) {
+          double cv = 0.0;
+          int kn = knext;
+          scan_serial_reference(q, prob, onha, cv, res, wsel, kn);
+          knext = uni(kn);
+          bestv = uni(cv); bidx = -1;                       // res / knext / wsel are already what the reference leaves
+        }
       } else
       WG_REP(1) {
       bestv = 0.0; bestres = 0.0; bestw = 0.0; bidx = -1;
@@ -2658,7 +2685,7 @@ __device__ __forceinline__ QlResult ql_solve(const QlView &q, P &prob, double vs
       if (route != 0) PT_COUNT(30);
       if (route != 0) {
         if (route == 1) WG_BACKSUB(q, s, nact, lane);
-        kdrop = pick_drop<(P::kNM > 0)>(q, nact, res, ratio, lane);
+        kdrop = pick_drop<(P::kNM > 0), kNan>(q, nact, res, ratio, lane);
         info = -knext;                                      // :1663
         if (kdrop < 0) { st = ST_CONVERGED; continue; }
         parinc = ratio;
@@ -2677,7 +2704,7 @@ __device__ __forceinline__ QlResult ql_solve(const QlView &q, P &prob, double vs
             PT(14);
             WG_REP(4) WG_BACKSUB(q, s, nact, lane);
             PT(15);
-            WG_REP(7) { kdrop = pick_drop<(P::kNM > 0)>(q, nact, res, ratio, lane); WG_SINK(kdrop); WG_SINK(ratio); }
+            WG_REP(7) { kdrop = pick_drop<(P::kNM > 0), kNan>(q, nact, res, ratio, lane); WG_SINK(kdrop); WG_SINK(ratio); }
             PT(16);
             if (kdrop >= 0) {                               // :1734-1743
               double temp = 1.0 - ratio / parinc;
@@ -2694,6 +2721,7 @@ __device__ __forceinline__ QlResult ql_solve(const QlView &q, P &prob, double vs
           } else
           for (int i = lane; i < n; i += 64) q.x[i] += step * Zm(i, nact);
           parnew += parinc;
+          if constexpr (kNan) x_suspect = x_suspect || WG_UBOOL(!wg_sane(step) || !wg_sane(parinc));
           WG_WSYNC();
           if (nact < 1) break;
         }

@@ -236,6 +236,7 @@ __device__ __forceinline__ void herdt_constant_blocks(const QlView &q, const dou
 template <int NH>
 struct HerdtProb {
   static constexpr bool kCompact = true;
+  static constexpr bool kNanExact = false;   // the tick reports a non-finite solve as ifail = 1 at its end (ql_solve, epilogue)
   static constexpr bool kHasFactor = true;
   static constexpr bool kRowOps = false;       // the compact view has its own register-row paths
   static constexpr int kNM = 2 * NH + 2 * 2;   // n <= 2N + 2*2: at most two previewed steps (checked by wg_mpc_configure)
@@ -661,6 +662,7 @@ constexpr int kGvLdElem = kSMaxQ;
 template <int NHC>
 struct HerdtElemProbT {
   static constexpr bool kCompact = false;
+  static constexpr bool kNanExact = false;   // as in the compact view
   static constexpr bool kHasFactor = true;     // constant factor blocks + structured border (N == 32 only, see factor())
   static constexpr bool kRowOps = true;        // row products walk the row's structure instead of calling A() per element
   static constexpr int kNM = 0;

@@ -1018,6 +1018,11 @@ __device__ __forceinline__ TickDiag mpc_tick(const wg_model_t &m, const TickTabl
     WG_WSYNC();
     if (lane == 0) s->running = 1;
   }
+  // A solve whose iterate left the ordinary numbers must not be reported as a success (found in round 5: the wave arg-max of the
+  // violation scan can "converge" on a NaN iterate where the reference's running comparisons go on to maxit and return ifail = 1,
+  // wg_ql_device.hpp: scan_serial_reference).  The dense boundary follows the reference through that regime exactly; the tick
+  // reports what the reference reports: ifail = 1 after 40 (m + n) iterations, a NaN jerk.
+  if (qr.ifail == 0 && (!wg_sane(q.x[0]) || !wg_sane(q.x[N]))) { qr.ifail = 1; qr.n_iter = 40 * (q.m + q.n) + 1; }
   {
     const double cx[3] = {s->com_x[0], s->com_x[1], s->com_x[2]}, cy[3] = {s->com_y[0], s->com_y[1], s->com_y[2]};
     const double c02 = -s->com_z / 9.81;
