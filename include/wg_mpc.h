@@ -250,8 +250,9 @@ typedef struct wg_tick_out {
    * interpolate_feet_positions rewrites it (OnLineFootTrajectoryGeneration.cpp:333-336, k = 0) */
   wg_foot_sample_t lf_back, rf_back;
   /* sizeof == 7808 = 61 cache lines of 128 B (ABI 5; it was 7688, 8 B past 60 lines): in an array of these no line is shared
-   * by two gaits' structs -- two waves finishing at different times no longer write the shared line back twice (measured
-   * 10.7 KB written per 7688-B struct stored).  The tick writes zeros here (the last line leaves the L2 whole). */
+   * by two gaits' structs.  The tick writes zeros here, so the struct's bytes do not depend on what the buffer held.  (The
+   * write amplification of an outs-on launch -- 11.3 KB leave the L2 per stored struct -- is the strided 8-byte stores of this
+   * array-of-structs layout, not shared lines: DESIGN 2.) */
   double pad_[15];
 } wg_tick_out_t;
 

@@ -5,7 +5,7 @@ import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-TAG = "round4"          # the profile set that describes HEAD (profiles/README.md)
+TAG = "round5"          # the profile set that describes HEAD (profiles/README.md)
 
 
 def test_generated_blocks_agree_with_the_filed_profiles():
