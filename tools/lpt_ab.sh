@@ -1,5 +1,5 @@
 #!/bin/bash
-# round 5: longest-solve-first start order of the dense QP boundary and of the Dimitrov tick's QL back-end: the new tests, then
+# longest-solve-first start order of the dense QP boundary and of the Dimitrov tick's QL back-end: the new tests, then
 # same-box A/B against index order (WG_QL_LPT=0)
 set -eu
 R=${GRAFT_REPO_ROOT:?run this on the GPU box (gpurun sets GRAFT_REPO_ROOT)}
