@@ -1235,7 +1235,9 @@ wg_dimitrov_tick_kernel(int B, const wg::DimitrovConst *__restrict__ K, const wg
   extern __shared__ __attribute__((aligned(16))) unsigned char dim_lds[];
   const int N = K->N;
   const int g = blockIdx.x;                       // one gait per block (grid == B), like the Herdt tick
-  if (g < B) wg::dimitrov_tick(*K, dim_lds, polys + (size_t)g * N, states + g, outs ? outs + g : nullptr, max_iter);
+  // (a longest-solve-first start order as in the QL back-ends below was measured here and gave nothing: 5.19 against 5.20 M
+  // ticks/s -- PLDP's four iterations per tick leave nothing to order)
+  if (g < B) (void)wg::dimitrov_tick(*K, dim_lds, polys + (size_t)g * N, states + g, outs ? outs + g : nullptr, max_iter);
 }
 
 // modes QLD / QLDANDLQ: the same tick with the in-wave ql0002 as its back-end (wg_dimitrov_device.hpp, dimitrov_qld_tick)
@@ -1321,30 +1323,31 @@ int wg_dimitrov_tick_batch_dev_ctx(wg_ctx_t *ctx, int B, const wg_zmp_polytope_t
   if (!ctx->dim_set) return fail(WG_ERR_BAD_ARG, "wg_dimitrov_configure() has not been called on this context");
   if (B < 0 || !polys || !states) return fail(WG_ERR_BAD_ARG, "bad arguments");
   if (B == 0) return WG_OK;
+  hipStream_t stq = reinterpret_cast<hipStream_t>(hip_stream);
+  std::lock_guard<std::mutex> launch_lk(ctx->launch_mu);
+  // more gaits than resident waves: longest-solve-first by the previous tick on the same state array (scheduling only)
+  int *order = nullptr, *iters_out = nullptr;
+  auto lpt_setup = [&](size_t lds_bytes, size_t wave_cap) -> int {
+    size_t per_cu = 128 / ((lds_bytes + 1279) / 1280);
+    if (per_cu > wave_cap) per_cu = wave_cap;
+    if (per_cu < 1) per_cu = 1;
+    // the order lives in a buffer of the context: not while another stream's launch of this context may still be reading it
+    bool lpt = (size_t)B > (size_t)ctx->num_cu * per_cu && !slot_pending_elsewhere(ctx->aux_order, stq);
+    if (const char *e = getenv("WG_QL_LPT")) lpt = lpt && atoi(e) != 0;
+    if (!lpt) return WG_OK;
+    const bool known = ctx->dlpt_key == states && ctx->dlpt_B == B && ctx->dlpt_buf.p;
+    if (int rc = ctx->dlpt_buf.reserve((size_t)B * 2 * sizeof(int))) return rc;
+    iters_out = static_cast<int *>(ctx->dlpt_buf.p);
+    if (known) {
+      order = iters_out + B;
+      hipLaunchKernelGGL(wg_lpt_order_kernel, dim3(1), dim3(1024), 0, stq, B, iters_out, order);
+    }
+    ctx->dlpt_key = states; ctx->dlpt_B = B;
+    return WG_OK;
+  };
   if ((*ctx->dim_host).solver != WG_DIMITROV_PLDP) {
     const size_t ldsq = wg::dimitrov_qld_lds_bytes();
-    hipStream_t stq = reinterpret_cast<hipStream_t>(hip_stream);
-    std::lock_guard<std::mutex> launch_lk(ctx->launch_mu);
-    // more gaits than resident waves (eight per CU): longest-solve-first by the previous tick on the same state array
-    int *order = nullptr, *iters_out = nullptr;
-    {
-      size_t per_cu = 128 / ((ldsq + 1279) / 1280);
-      if (per_cu > 8) per_cu = 8;
-      if (per_cu < 1) per_cu = 1;
-      // the order lives in a buffer of the context: not while another stream's launch of this context may still be reading it
-      bool lpt = (size_t)B > (size_t)ctx->num_cu * per_cu && !slot_pending_elsewhere(ctx->aux_order, stq);
-      if (const char *e = getenv("WG_QL_LPT")) lpt = lpt && atoi(e) != 0;
-      if (lpt) {
-        const bool known = ctx->dlpt_key == states && ctx->dlpt_B == B && ctx->dlpt_buf.p;
-        if (int rc = ctx->dlpt_buf.reserve((size_t)B * 2 * sizeof(int))) return rc;
-        iters_out = static_cast<int *>(ctx->dlpt_buf.p);
-        if (known) {
-          order = iters_out + B;
-          hipLaunchKernelGGL(wg_lpt_order_kernel, dim3(1), dim3(1024), 0, stq, B, iters_out, order);
-        }
-        ctx->dlpt_key = states; ctx->dlpt_B = B;
-      }
-    }
+    if (int rc = lpt_setup(ldsq, 8)) return rc;            // eight gaits per CU (256 registers: two waves per SIMD)
     if ((*ctx->dim_host).solver == WG_DIMITROV_QLDANDLQ)
       hipLaunchKernelGGL(wg_dimitrov_qld_tick_kernel<true>, dim3(B), dim3(64), ldsq, stq, B, ctx->dim_dev, polys, states, outs, order, iters_out);
     else
@@ -1357,11 +1360,9 @@ int wg_dimitrov_tick_batch_dev_ctx(wg_ctx_t *ctx, int B, const wg_zmp_polytope_t
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(wg_dimitrov_tick_kernel),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   const int grid = B;
-  hipLaunchKernelGGL(wg_dimitrov_tick_kernel, dim3(grid), dim3(64), lds, reinterpret_cast<hipStream_t>(hip_stream), B,
-                     ctx->dim_dev, polys, states, outs, max_iter);
+  hipLaunchKernelGGL(wg_dimitrov_tick_kernel, dim3(grid), dim3(64), lds, stq, B, ctx->dim_dev, polys, states, outs, max_iter);
   HIP_TRY(hipGetLastError());
-  std::lock_guard<std::mutex> launch_lk(ctx->launch_mu);
-  return slot_mark(ctx->aux_order, reinterpret_cast<hipStream_t>(hip_stream));
+  return slot_mark(ctx->aux_order, stq);
 }
 
 int wg_dimitrov_tick_batch_ctx(wg_ctx_t *ctx, int B, const wg_zmp_polytope_t *polys, wg_dimitrov_state_t *states, wg_dimitrov_out_t *outs, int max_iter) {

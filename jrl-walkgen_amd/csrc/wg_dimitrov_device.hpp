@@ -155,8 +155,8 @@ struct DimitrovHost {
 constexpr int kDimitrovActiveCap = 40;   // E E' is singular beyond 2N = 32 active rows
 
 // one gait, one tick.  LDS: the structured PLDP work area (mcap = 8N) + 4 * 2N doubles (D, zmpref, NewX, X) + 8 (xk).
-__device__ void dimitrov_tick(const DimitrovConst &K, unsigned char *lds, const wg_zmp_polytope_t *__restrict__ polys,
-                              wg_dimitrov_state_t *st, wg_dimitrov_out_t *out, int max_iter) {
+__device__ int dimitrov_tick(const DimitrovConst &K, unsigned char *lds, const wg_zmp_polytope_t *__restrict__ polys,
+                             wg_dimitrov_state_t *st, wg_dimitrov_out_t *out, int max_iter) {   // returns PLDP's iteration count
   const int lane = threadIdx.x;
   const int N = K.N, n = 2 * N, mcap = WG_POLY_MAX_ROWS * N;
   PldpLds W;
@@ -251,6 +251,7 @@ __device__ void dimitrov_tick(const DimitrovConst &K, unsigned char *lds, const 
     if (out) { out->jerk_x = jx; out->jerk_y = jy; out->ret = rc; out->n_iter = it; out->n_active = S; out->m = m; }
   }
   WG_WSYNC();
+  return it;
 }
 
 // ---- the same tick with ql0001_ as the back-end (m_FastFormulationMode == QLD / QLDANDLQ, :1297-1320) --------------------------

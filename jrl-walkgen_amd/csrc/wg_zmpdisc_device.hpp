@@ -29,6 +29,7 @@ namespace wg {
 #define WG_ZD_WIN_MAX 52                 // (nwin + 2 nwin) x 2 axes x 64 lanes x 8 B = 3 KB x nwin <= 160 KB
 #define WG_ZD_PI 3.14159265358979323846
 
+constexpr int kZdWinStd = 11;            // floor(0.05 / T) + 1 taps at the reference's T = 5 ms (ZMPDiscretization.cpp:240-262)
 struct ZdConst {
   wg_zmpdisc_model_t M;
   int nwin, pad_;
@@ -337,11 +338,25 @@ wg_zmpdisc_kernel(ZdConst K, int B, int smax, const wg_rel_step_t *__restrict__ 
       double l0 = 0.0, l1 = 0.0;
       const int o = nz - 1 - 2;
       if (i + 3 >= K.nwin && i + 2 < nZ) {          // every tap inside the phase: r = i + 2 - j is sample gen - 1 - j
+        if (K.nwin == kZdWinStd) {
+          // the standard window (T = 5 ms: 11 taps): all 22 ring reads requested before the first add -- the loop below waits for
+          // an LDS round trip per tap, which was most of a sample's 2 800 cycles; the same products added in the same order
+          double zx[kZdWinStd], zy[kZdWinStd];
+          int slot = slot_top;
+#pragma unroll
+          for (int j = 0; j < kZdWinStd; j++) {
+            zx[j] = R.Z(slot, 0); zy[j] = R.Z(slot, 1);
+            slot = slot == 0 ? kZdWinStd - 1 : slot - 1;
+          }
+#pragma unroll
+          for (int j = 0; j < kZdWinStd; j++) { const double wj = K.win[j]; l0 += wj * zx[j]; l1 += wj * zy[j]; }
+        } else {
         int slot = slot_top;
         for (int j = 0; j < K.nwin; j++) {
           const double wj = K.win[j];
           l0 += wj * R.Z(slot, 0); l1 += wj * R.Z(slot, 1);
           slot = slot == 0 ? R.nwin - 1 : slot - 1;
+        }
         }
       } else {
         for (int j = 0; j < K.nwin; j++) {

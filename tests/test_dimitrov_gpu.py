@@ -272,12 +272,14 @@ def test_fused_tick_with_the_ql_back_ends_bit_exact(mode, ql):
         wg.dimitrov_configure(wg.dimitrov_defaults())
 
 
-def test_qld_tick_longest_first_start_order_is_scheduling_only(monkeypatch):
-    """More gaits than resident waves through the QL back-end: from the second tick on the gaits start longest-solve-first by the
-    previous tick's iteration counts.  Scheduling only: states and outputs of every tick equal the index-order run (WG_QL_LPT=0)."""
-    model, K, Kq = _qld_setup(2)
+@pytest.mark.parametrize("mode,B", [(2, 2200)])
+def test_tick_longest_first_start_order_is_scheduling_only(mode, B, monkeypatch):
+    """More gaits than resident waves through the QL back-end (eight per CU): from the second tick on the gaits start
+    longest-solve-first by the previous tick's iteration counts.  Scheduling only: states and outputs of every tick equal the
+    index-order run (WG_QL_LPT=0)."""
+    model, K, Kq = _qld_setup(mode)
     N = model.N
-    B, T = 2200, 4
+    T = 4
     plans = [dv.plan(np.random.default_rng(700 + g % 37), n_steps=3 + g % 6) for g in range(B)]
     offs = [(5 * g) % 11 for g in range(B)]
 
@@ -300,7 +302,7 @@ def test_qld_tick_longest_first_start_order_is_scheduling_only(monkeypatch):
         monkeypatch.setenv("WG_QL_LPT", "0")
         plain, _ = run()
         assert ordered == plain
-        assert max(iters) > min(iters) + 3                        # there was something to order
+        assert max(iters) > min(iters) + (3 if mode else 0)       # there was something to order
     finally:
         wg.dimitrov_configure(wg.dimitrov_defaults())
 
