@@ -1000,6 +1000,22 @@ __device__ __forceinline__ TickDiag mpc_tick(const wg_model_t &m, const TickTabl
   tk3 = clock64();
 #endif
   if (hist_len && lane == 0) *hist_len = qr.hist_len;
+  // A solve whose iterate became NaN.  The reference does not notice (its running comparisons never skip a NaN): it adds and drops
+  // until maxit = 40 (m + n), returns ifail = 1 and an x that is NaN in every entry (each x_i took a NaN step), which the tick then
+  // integrates -- the gait is lost.  The dense boundary follows it through that regime iteration by iteration (wg_ql_device.hpp:
+  // scan_serial_reference); the tick's views do not carry that code (-1.7 % on the benchmark tick for a regime its QPs never
+  // enter) and may leave it by another door, with some entries of x still numbers.  So the tick reports what the reference
+  // reports and hands on what the reference hands on: one test per tick, outside the solver (round 5; tools/soak_parity.py with
+  // SOAK_VSCALE=3 runs half a million such ticks against the oracle).
+  {
+    bool has_nan = false;
+    for (int i = lane; i < n; i += 64) { const double xi = q.x[i]; has_nan = has_nan || (xi != xi); }
+    if (__ballot(has_nan) != 0ull) {
+      for (int i = lane; i < n; i += 64) q.x[i] = __builtin_nan("");
+      qr.ifail = 1; qr.n_iter = 40 * (q.m + q.n) + 1;
+      WG_WSYNC();
+    }
+  }
 
   // ---- CoM: jerk, 20 interpolated samples, state step (ZMPVelocityReferencedQP.cpp:405-428) ----
   double jx, jy;
@@ -1018,11 +1034,6 @@ __device__ __forceinline__ TickDiag mpc_tick(const wg_model_t &m, const TickTabl
     WG_WSYNC();
     if (lane == 0) s->running = 1;
   }
-  // A solve whose iterate left the ordinary numbers must not be reported as a success (found in round 5: the wave arg-max of the
-  // violation scan can "converge" on a NaN iterate where the reference's running comparisons go on to maxit and return ifail = 1,
-  // wg_ql_device.hpp: scan_serial_reference).  The dense boundary follows the reference through that regime exactly; the tick
-  // reports what the reference reports: ifail = 1 after 40 (m + n) iterations, a NaN jerk.
-  if (qr.ifail == 0 && (!wg_sane(q.x[0]) || !wg_sane(q.x[N]))) { qr.ifail = 1; qr.n_iter = 40 * (q.m + q.n) + 1; }
   {
     const double cx[3] = {s->com_x[0], s->com_x[1], s->com_x[2]}, cy[3] = {s->com_y[0], s->com_y[1], s->com_y[2]};
     const double c02 = -s->com_z / 9.81;
