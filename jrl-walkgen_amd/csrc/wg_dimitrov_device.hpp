@@ -268,7 +268,7 @@ __device__ int dimitrov_tick(const DimitrovConst &K, unsigned char *lds, const w
 template <bool kLQ>                                       // kLQ: mode QLDANDLQ (identity Hessian, full rows)
 struct DimitrovQldProb {
   static constexpr bool kCompact = false;
-  static constexpr bool kNanExact = false;   // the tick reports a non-finite solve as ifail = 1 at its end (ql_solve, epilogue)
+  static constexpr bool kNanExact = WG_TICK_NAN_EXACT != 0;   // NaN iterates end the way the reference ends them (scan_nan_exact)
   static constexpr bool kHasFactor = false;
   static constexpr bool kRowOps = false;
   static constexpr bool kWideN = false;

@@ -269,7 +269,7 @@ struct QlView;
 template <bool kGLds, int kNMc = 0>         // where G lives is known at compile time (ds_ or global_ accesses, never flat_)
 struct DenseProbT {
   static constexpr bool kCompact = false;
-  static constexpr bool kNanExact = true;   // the ql0001_ boundary takes anybody's QP: NaN iterates end the way the reference ends them (scan_serial_reference)
+  static constexpr bool kNanExact = true;   // the ql0001_ boundary takes anybody's QP: NaN iterates end the way the reference ends them (scan_nan_exact)
   static constexpr bool kHasFactor = false;    // no structure to exploit: ql0002's own Cholesky and inverse
   static constexpr bool kRowOps = false;   // no structured row products: rows are read element by element
   static constexpr int kNM = kNMc;     // 0: no compile-time bound on n; > 0: n <= kNM (the Herdt-sized boundary kernel: the
@@ -414,6 +414,15 @@ __device__ __forceinline__ int wave_min_int(int v) {
   { const int o = dpp_keep<0x118>(v); v = o < v ? o : v; }
   { const int o = dpp_keep<0x142>(v); v = o < v ? o : v; }
   { const int o = dpp_keep<0x143>(v); v = o < v ? o : v; }
+  return __builtin_amdgcn_readlane(v, 63);
+}
+__device__ __forceinline__ int wave_max_int(int v) {
+  { const int o = dpp_keep<0x111>(v); v = o > v ? o : v; }
+  { const int o = dpp_keep<0x112>(v); v = o > v ? o : v; }
+  { const int o = dpp_keep<0x114>(v); v = o > v ? o : v; }
+  { const int o = dpp_keep<0x118>(v); v = o > v ? o : v; }
+  { const int o = dpp_keep<0x142>(v); v = o > v ? o : v; }
+  { const int o = dpp_keep<0x143>(v); v = o > v ? o : v; }
   return __builtin_amdgcn_readlane(v, 63);
 }
 // arg-max over the wave: larger v wins, equal v -> smaller idx.  idx < 0 = no candidate (then idx stays < 0).
@@ -990,10 +999,12 @@ __device__ __forceinline__ void sweep_flat(const QlView &q, double *s, int nu, i
     const bool mine = lane > nact && lane < nu;
     const bool rot = mine && myN != 0.0;
     const double den = rot ? myN : 1.0;
-    const double ga = rot ? myP / den : 1.0;
-    const double gb = rot ? myQ / den : 0.0;                // gb == 0 marks a skipped rotation (q was 0)
+    // ga == 2 marks a skipped rotation (q was 0; a rotation's |ga| = |p| / norm <= 1).  NOT gb == 0: a denormal q under a large p
+    // gives gb = q / norm = 0 by underflow and ga = -1 for p < 0 -- a rotation the reference carries out (both columns change sign)
+    const double ga = rot ? myP / den : 2.0;
+    const double gb = rot ? myQ / den : 0.0;
     // a skipped rotation is rare: when the sweep has none -- one ballot -- phase 3 runs without the selects
-    any_skip = __ballot(mine && gb == 0.0) != 0ull;
+    any_skip = __ballot(mine && !rot) != 0ull;
     const int cl = mine ? lane : nu - 1;                    // lanes without a rotation shadow lane nu-1 ... with ITS values
     const double ga_l = rl(ga, nu - 1), gb_l = rl(gb, nu - 1);
     const double ga_w = mine ? ga : ga_l, gb_w = mine ? gb : gb_l;
@@ -1017,7 +1028,7 @@ __device__ __forceinline__ void sweep_flat(const QlView &q, double *s, int nu, i
       return o;
     };
     auto rotate = [&](const Op &o) {
-      const bool skip = (o.gb == 0.0);
+      const bool skip = (o.ga == 2.0);
       const double t_r = o.ga * o.zl + o.gb * carry;
       const double z_r = o.ga * carry - o.gb * o.zl;
       zp[0] = skip ? carry : z_r;
@@ -1281,7 +1292,7 @@ __device__ __forceinline__ void zr_rows_times(const QlView &q, const ZRegs<NMAX>
   r0 = a0; r1 = a1;
 }
 // Givens sweep (qld.cpp:1992-2030) on register rows.  Phase 1 (the chain of norms) as in sweep(); phase 2: lane c & 63 turns
-// its rotation into (ga, gb) and KEEPS the pair (gb == 0 marks a skipped rotation); phase 3: every lane carries its rows through
+// its rotation into (ga, gb) and KEEPS the pair (ga == 2 marks a skipped rotation); phase 3: every lane carries its rows through
 // the rotations, the coefficients of rotation c read from lane c's registers (v_readlane with a compile-time lane): no global
 // memory access at all in the rotation loop.
 template <int NMAX>
@@ -1332,8 +1343,8 @@ __device__ __forceinline__ void zr_sweep(const QlView &q, ZRegs<NMAX> &zr, doubl
     const double Pb = s[ccb - 1], Qb = (ccb == nu - 1) ? s[nu - 1] : chain[ccb], Nb = (Qb == 0.0) ? 0.0 : chain[ccb - 1];
     const bool ra = ma && Na != 0.0, rb = mb && Nb != 0.0;
     const double da = ra ? Na : 1.0, db = rb ? Nb : 1.0;
-    ga0 = ra ? Pa / da : 1.0; gb0 = ra ? Qa / da : 0.0;
-    ga1 = rb ? Pb / db : 1.0; gb1 = rb ? Qb / db : 0.0;
+    ga0 = ra ? Pa / da : 2.0; gb0 = ra ? Qa / da : 0.0;   // ga == 2: a skipped rotation (see sweep_flat)
+    ga1 = rb ? Pb / db : 2.0; gb1 = rb ? Qb / db : 0.0;
     WG_WSYNC();                                             // every lane has read s[] before any lane rewrites it
     if (ra) s[ca - 1] = Na;
     if (rb) s[cb - 1] = Nb;
@@ -1349,7 +1360,7 @@ __device__ __forceinline__ void zr_sweep(const QlView &q, ZRegs<NMAX> &zr, doubl
       const double ga = (c < 64) ? rl(ga0, c & 63) : rl(ga1, c & 63);
       const double gb = (c < 64) ? rl(gb0, c & 63) : rl(gb1, c & 63);
       const double zl0 = zr.z0[c - 1], zl1 = ztr[c - 1];
-      if (gb == 0.0) {                                      // a skipped rotation (q was 0): wave-uniform
+      if (ga == 2.0) {                                      // a skipped rotation (q was 0): wave-uniform
         zr.z0[c] = carry0; ztr[c] = carry1;
         carry0 = zl0; carry1 = zl1;
       } else {
@@ -1395,16 +1406,21 @@ __device__ __forceinline__ void zr_row_to(const QlView &q, const ZRegs<NMAX> &zr
 }
 
 // qld.cpp:1861-1889.  Returns kdrop (0-based) or -1; ratio updated when found.
-// ---- the two SELECTIONS of an iteration in the reference's own serial form (round 5) ------------------------------------------
+// ---- the two SELECTIONS of an iteration once values stop being ordinary numbers (round 5) ------------------------------------
 // The violation scan and the ratio test pick a row by a running comparison -- "skip unless strictly better than the best so far" --
 // which the lane-parallel forms below replace by per-lane candidates and a wave arg-max (first index among equals).  The two agree
 // while every compared value is an ordinary number.  Once the iterate holds a NaN they do not: the reference's `if (sumx <= cvmax)
 // goto skip` does NOT skip a NaN, and with cvmax = NaN it skips nothing any more -- the LAST row that passes its other tests wins,
 // which no arg-max reproduces (found on two of 2304 random Herdt-shaped QPs: the reference loops to maxit and reports ifail = 1,
 // the arg-max form "converged" with ifail = 0 and a NaN solution).  So: when x (or the ratio test's operands) is not a number of
-// sane size -- one compare per lane and one ballot per iteration -- the wave takes these loops instead: every lane runs the
-// reference's statements in the reference's order on broadcast operands (wave-uniform control flow; speed is irrelevant, the
-// solve is lost and only has to end the way the reference's does).
+// sane size -- one compare per lane and one ballot per iteration -- the wave takes the forms below instead: scan_nan_exact
+// (lane-parallel, with the reference's dense row sums and its NaN semantics) and the ratio test as the reference's own loop.
+// Such a solve is lost and only has to end the way the reference's does -- but it runs maxit = 40 (m + n) iterations on the
+// way, and a fleet waits for its slowest gait: the scan is lane-parallel for that reason (a first, fully serial form took 1 ms
+// per iteration in the compact view, 4.5 s per lost tick).
+#ifndef WG_TICK_NAN_EXACT
+#define WG_TICK_NAN_EXACT 1                                // 0: the tick's views without these forms (A/B of their cost); see mpc_tick
+#endif
 #ifndef WG_NAN_REGIME
 #define WG_NAN_REGIME 1                                    // 0: experiment builds without the NaN-regime tests (A/B of their cost)
 #endif
@@ -1413,38 +1429,100 @@ __device__ __forceinline__ void zr_row_to(const QlView &q, const ZRegs<NMAX> &zr
 // kept alive (or spilled) across the active-set loop, which is what wg_kconst exists to avoid
 __device__ __forceinline__ bool wg_sane(double v) { return ((unsigned)__double2hiint(v) & 0x7fffffffu) < 0x54b00000u; }
 
-// qld.cpp:1255-1331
+// qld.cpp:1255-1331 for an iterate that may hold NaNs and infinities, lane-parallel.  What the reference's loop does, restated:
+// a row (or bound) is a CANDIDATE when it passes every test that does not involve cvmax (weight, significance of the residual;
+// `sum != 0` for a bound) -- written below as the reference's own comparisons, negated, so that a NaN operand passes exactly
+// where it passes there.  Candidates are visited in order (rows 1..m, then the bounds by variable) and taken unless
+// `value <= cvmax`; a taken candidate's value becomes cvmax.  While every value is a number that is the first strict maximum
+// above 0.  A candidate whose value is a NaN is taken (NaN <= cvmax is false) and leaves cvmax = NaN, so the NEXT candidate is
+// taken whatever its value -- and if that value is a number, the running maximum starts again from it.  Hence: with L the last
+// candidate whose value is a NaN, the winner is the first maximum among the candidates BEHIND L (no threshold: the first of them
+// is always taken), or L itself when none follows.  Row sums are the reference's DENSE sums -- every x_i times every
+// coefficient, the structural zeros included: 0 * inf and 0 * NaN are NaN there, which a view that skips its zeros would not
+// produce -- one row per lane, terms in index order.
 template <class P>
-__device__ __forceinline__ void scan_serial_reference(const QlView &q, const P &prob, double onha, double &cvmax, double &res,
-                                                      double &wsel, int &knext) {
+__device__ __forceinline__ void scan_nan_exact(const QlView &q, const P &prob, double onha, double &cvmax, double &res,
+                                               double &wsel, int &knext, int lane) {
   const int n = q.n, m = q.m, me = q.me, mn = q.mn;
+  struct Row { bool cand; double v, r, w; int code; };
+  auto eval = [&](int pos) -> Row {
+    Row o;
+    if (pos < m) {
+      const int k = pos;
+      o.w = q.wa[k];
+      const double bk = q.b[k];
+      double sum = -bk, temp = fabs(bk);
+      for (int i = 0; i < n; ++i) {
+        double aki;
+        if constexpr (P::kCompact) aki = prob.A_own(k, i); else aki = Am(k, i);
+        const double t = q.x[i] * aki; sum += t; temp += fabs(t);
+      }
+      o.v = -sum * o.w;
+      if (k + 1 <= me) o.v = fabs(o.v);
+      const double tempa = temp + fabs(sum);
+      const double temp2 = temp + onha * fabs(sum);
+      o.cand = !(o.w <= 0.0) && !(tempa <= temp) && !(temp2 <= tempa);
+      o.r = sum; o.code = k + 1;
+    } else {
+      const int k = pos - m;
+      o.w = q.wa[m + k];
+      const double xk = q.x[k], s1 = prob.xl(q, k) - xk;
+      const bool upper = s1 < 0.0;
+      o.v = upper ? xk - prob.xu(q, k) : s1;
+      o.cand = !(o.w <= 0.0) && !(s1 == 0.0);
+      o.r = -o.v; o.code = upper ? k + 1 + mn : k + 1 + m;
+    }
+    return o;
+  };
+  // pass 1: the all-numbers answer (running strict maximum above 0 = cvmax's start), and the lane's last NaN candidate
+  double av = 0.0, ar = 0.0, aw = 0.0;
+  int apos = -1, acode = 0;
+  double nr = 0.0, nw = 0.0;
+  int npos = -1, ncode = 0;
+  // the lane's positions in ascending order: pos, pos + 64, ... -- or, in the compact view (whose rows' coefficients live in
+  // their lanes' registers), CoP row lane + 1, foot-placement row 1 + 4N + lane, bound lane (row 0, all zeros, is never a candidate)
+  auto my_positions = [&](auto &&f) {
+    if constexpr (P::kCompact) {
+      if (lane + 1 <= P::kCopRows && lane + 1 < m) f(lane + 1);
+      if (1 + P::kCopRows + lane < m) f(1 + P::kCopRows + lane);
+      if (lane < n) f(m + lane);
+    } else {
+      for (int pos = lane; pos < m + n; pos += 64) f(pos);
+    }
+  };
+  my_positions([&](int pos) {
+    const Row o = eval(pos);
+    if (!o.cand) return;
+    if (o.v != o.v) { npos = pos; nr = o.r; nw = o.w; ncode = o.code; }
+    else if (o.v > av) { av = o.v; ar = o.r; aw = o.w; apos = pos; acode = o.code; }
+  });
+  const int lastnan = uni(wave_max_int(npos));
+  int src;
+  if (lastnan >= 0) {
+    // pass 2: the candidates behind the last NaN (numbers all of them): first maximum, the first one taken unconditionally
+    bool any = false;
+    av = 0.0; apos = -1;
+    my_positions([&](int pos) {
+      if (pos <= lastnan) return;
+      const Row o = eval(pos);
+      if (!o.cand) return;
+      if (!any || o.v > av) { av = o.v; ar = o.r; aw = o.w; apos = pos; acode = o.code; }
+      any = true;
+    });
+    if (__ballot(any) == 0ull) {                             // none follows: the NaN candidate itself, cvmax = NaN
+      src = __ffsll((long long)__ballot(npos == lastnan)) - 1;
+      cvmax = __builtin_nan(""); res = rl(nr, src); wsel = rl(nw, src); knext = __builtin_amdgcn_readlane(ncode, src);
+      return;
+    }
+  }
+  double v = av;
+  int kk = apos;
+  wave_argmax_first(v, kk);
+  kk = uni(kk);
   cvmax = 0.0;
-  for (int k = 1; k <= m; ++k) {
-    const double wk = q.wa[k - 1], bk = q.b[k - 1];
-    if (wk <= 0.0) continue;
-    double sum = -bk;
-    for (int i = 0; i < n; ++i) sum += q.x[i] * Am(k - 1, i);
-    double sumx = -sum * wk;
-    if (k <= me) sumx = fabs(sumx);
-    if (sumx <= cvmax) continue;
-    double temp = fabs(bk);
-    for (int i = 0; i < n; ++i) temp += fabs(q.x[i] * Am(k - 1, i));
-    const double tempa = temp + fabs(sum);
-    if (tempa <= temp) continue;
-    temp += onha * fabs(sum);
-    if (temp <= tempa) continue;
-    cvmax = sumx; res = sum; knext = k; wsel = wk;
-  }
-  for (int k = 1; k <= n; ++k) {
-    const double wk = q.wa[m + k - 1];
-    if (wk <= 0.0) continue;
-    bool lower = true;
-    double sum = prob.xl(q, k - 1) - q.x[k - 1];
-    if (sum < 0.0) { sum = q.x[k - 1] - prob.xu(q, k - 1); lower = false; }
-    else if (sum == 0.0) continue;
-    if (sum <= cvmax) continue;
-    cvmax = sum; res = -sum; knext = lower ? k + m : k + mn; wsel = wk;
-  }
+  if (kk < 0) return;                                        // nothing above 0: knext / res / wsel stay what they were
+  src = __ffsll((long long)__ballot(apos == kk)) - 1;
+  cvmax = rl(av, src); res = rl(ar, src); wsel = rl(aw, src); knext = __builtin_amdgcn_readlane(acode, src);
 }
 
 // qld.cpp:1861-1889
@@ -1929,9 +2007,7 @@ template <class P, class ZR = NoZRegs>
 __device__ __forceinline__ QlResult ql_solve(const QlView &q, P &prob, double vsmall, int *hist, int hist_cap, QlResume *rs = nullptr,
                                              ZR *zr = nullptr) {
   constexpr bool kRegs = !std::is_same<ZR, NoZRegs>::value;   // Z in registers (ZRegs): see zr_* above
-  // NaN iterates followed exactly (the dense boundary), or reported by the caller at the end of the solve (the tick's views: their
-  // kernels sit at their register and instruction-cache limits -- the exact form measured -1.7 % on the benchmark tick, for a regime
-  // its QPs never enter; mpc_tick tests the two jerks it takes from x instead)
+  // NaN iterates followed exactly (every policy of the shipped kernels; a policy may opt out for an A/B of what that costs)
   constexpr bool kNan = P::kNanExact && (WG_NAN_REGIME != 0);
   int lane = wg_lane();
   const int n = q.n, m = q.m, me = q.me, mn = q.mn;
@@ -1952,7 +2028,7 @@ __device__ __forceinline__ QlResult ql_solve(const QlView &q, P &prob, double vs
   bool cap_hit = false;
   // Has the iterate left the ordinary numbers (wave-uniform, sticky)?  x only changes in the residual refresh (once or twice per
   // solve: tested there with one compare per lane) and by `x += step z` (tested on the scalar step: free).  From then on the
-  // reference's own serial loop does the violation scan (see scan_serial_reference) -- exact for any x, merely slow
+  // violation scan is scan_nan_exact's -- the reference's dense row sums and its treatment of NaN values, exact for any x
   bool x_suspect = false;
   auto x_has_non_numbers = [&]() {
     bool b = false;
@@ -1988,7 +2064,7 @@ __device__ __forceinline__ QlResult ql_solve(const QlView &q, P &prob, double vs
         }
         if (sum > 0.0) sum = 1.0 / sqrt(sum);
         else if (q.b[k] == 0.0) {}
-        else if (k + 1 <= me || q.b[k] > 0.0) fatal = k + 1 < fatal ? k + 1 : fatal;
+        else if (k + 1 <= me || !(q.b[k] <= 0.0)) fatal = k + 1 < fatal ? k + 1 : fatal;   // :789, a NaN fails
         q.wa[k] = sum;
       }
     }
@@ -2021,7 +2097,7 @@ __device__ __forceinline__ QlResult ql_solve(const QlView &q, P &prob, double vs
       diag = wave_max(dl);
     }
     diag = uni(diag);
-    bool need_shift = diag > 0.0;
+    bool need_shift = !(diag <= 0.0);                       // :844 `if (diag <= 0) goto L90`: a NaN shifts
     PT(1);
     bool factored = false;
     if constexpr (P::kHasFactor) {
@@ -2265,10 +2341,10 @@ __device__ __forceinline__ QlResult ql_solve(const QlView &q, P &prob, double vs
       { double sm = 0.0; WG_REP(6) { sm = uni(xmag_sum(q, prob, vfact, lane)); WG_SINK(sm); } xmag = maxd(xmag, sm); }
       PT(8);
       if (iflag == itref) { st = ST_RESID; continue; }      // :1226
-      // first inequality with a negative multiplier, :1233-1249
+      // first inequality with a negative multiplier, :1233-1249 (`if (w[kdrop] >= zero) goto next`: a NaN multiplier IS dropped)
       int kd = 0x7fffffff;
       for (int k = lane; k < nact; k += 64)
-        if (q.lam[k] < 0.0 && q.iact[k] > me) { kd = k < kd ? k : kd; }
+        if (!(q.lam[k] >= 0.0) && q.iact[k] > me) { kd = k < kd ? k : kd; }
       kd = uni(wave_min_int(kd));
       if (kd != 0x7fffffff) {
         LOG_EVENT(-q.iact[kd]);
@@ -2291,7 +2367,7 @@ __device__ __forceinline__ QlResult ql_solve(const QlView &q, P &prob, double vs
         if constexpr (kNan) {
           double cv = 0.0;
           int kn = knext;
-          scan_serial_reference(q, prob, onha, cv, res, wsel, kn);
+          scan_nan_exact(q, prob, onha, cv, res, wsel, kn, lane);
           knext = uni(kn);
           bestv = uni(cv); bidx = -1;                       // res / knext / wsel are already what the reference leaves
         }
@@ -2556,7 +2632,6 @@ __device__ __forceinline__ QlResult ql_solve(const QlView &q, P &prob, double vs
         for (int i = lane; i < n; i += 64) q.wx[i] = q.x[i];
         WG_WSYNC();
       }
-
       PT(10);
       ++iterc;                                              // :1415-1420
       if (iterc > maxit) { info = 1; st = ST_FINISH; continue; }

@@ -236,10 +236,11 @@ __device__ __forceinline__ void herdt_constant_blocks(const QlView &q, const dou
 template <int NH>
 struct HerdtProb {
   static constexpr bool kCompact = true;
-  static constexpr bool kNanExact = false;   // the tick reports a non-finite solve as ifail = 1 at its end (ql_solve, epilogue)
+  static constexpr bool kNanExact = WG_TICK_NAN_EXACT != 0;   // NaN iterates end the way the reference ends them (scan_nan_exact)
   static constexpr bool kHasFactor = true;
   static constexpr bool kRowOps = false;       // the compact view has its own register-row paths
   static constexpr int kNM = 2 * NH + 2 * 2;   // n <= 2N + 2*2: at most two previewed steps (checked by wg_mpc_configure)
+  static constexpr int kCopRows = 4 * NH;      // rows 1 .. 4N (lane k - 1 keeps row k's coefficients), then the foot-placement rows
   static constexpr bool kWideN = false;
   static constexpr int kFixedLdz = kNM | 1;    // Z in LDS, leading dimension of carve_fixed<kNM, ...>
   static_assert(4 * NH == 64, "one CoP row per lane needs 4N == 64");
@@ -312,6 +313,15 @@ struct HerdtProb {
     const int src = cop ? k - 1 : k - 1 - 4 * NH;
     const double a = cop ? rl(ra, src) : rl(ga, src), b = cop ? rl(rb, src) : rl(gb, src);
     const int kk = cop ? (k - 1) >> 2 : __builtin_amdgcn_readlane(gk, src);
+    return elem(a, b, kk, k, i);
+  }
+  // the same element of the lane's OWN row -- CoP row k = lane + 1, or foot-placement row k = 1 + 4 NH + lane -- from the lane's
+  // own registers: k differs from lane to lane (scan_nan_exact)
+  __device__ __forceinline__ double A_own(int k, int i) const {
+    const bool cop = k <= 4 * NH;
+    return elem(cop ? ra : ga, cop ? rb : gb, cop ? (k - 1) >> 2 : gk, k, i);
+  }
+  __device__ __forceinline__ double elem(double a, double b, int kk, int k, int i) const {
     if (k <= 4 * NH) {
       const int r = kk;
       if (i < NH) return (i <= r) ? 0.0 + (0.0 + a * u[r - i]) * -1.0 : 0.0;
@@ -400,7 +410,7 @@ struct HerdtProb {
       const int k = lane + 1;
       if (sum > 0.0) sum = 1.0 / sqrt(sum);
       else if (q.b[k] == 0.0) {}
-      else if (q.b[k] > 0.0) fatal = k + 1;
+      else if (!(q.b[k] <= 0.0)) fatal = k + 1;
       q.wa[k] = sum;
     }
     if (lane < 5 * ns) {
@@ -411,7 +421,7 @@ struct HerdtProb {
       const int k = 1 + 4 * NH + lane;
       if (sum > 0.0) sum = 1.0 / sqrt(sum);
       else if (q.b[k] == 0.0) {}
-      else if (q.b[k] > 0.0) fatal = (k + 1 < fatal) ? k + 1 : fatal;
+      else if (!(q.b[k] <= 0.0)) fatal = (k + 1 < fatal) ? k + 1 : fatal;
       q.wa[k] = sum;
     }
     if (lane == 0) q.wa[0] = 0.0;     // the dummy row: zero normal, zero rhs (qp-problem.cpp:428-440)
@@ -662,7 +672,7 @@ constexpr int kGvLdElem = kSMaxQ;
 template <int NHC>
 struct HerdtElemProbT {
   static constexpr bool kCompact = false;
-  static constexpr bool kNanExact = false;   // as in the compact view
+  static constexpr bool kNanExact = WG_TICK_NAN_EXACT != 0;   // as in the compact view
   static constexpr bool kHasFactor = true;     // constant factor blocks + structured border (N == 32 only, see factor())
   static constexpr bool kRowOps = true;        // row products walk the row's structure instead of calling A() per element
   static constexpr int kNM = 0;

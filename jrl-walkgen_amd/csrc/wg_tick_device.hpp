@@ -1000,14 +1000,11 @@ __device__ __forceinline__ TickDiag mpc_tick(const wg_model_t &m, const TickTabl
   tk3 = clock64();
 #endif
   if (hist_len && lane == 0) *hist_len = qr.hist_len;
-  // A solve whose iterate became NaN.  The reference does not notice (its running comparisons never skip a NaN): it adds and drops
-  // until maxit = 40 (m + n), returns ifail = 1 and an x that is NaN in every entry (each x_i took a NaN step), which the tick then
-  // integrates -- the gait is lost.  The dense boundary follows it through that regime iteration by iteration (wg_ql_device.hpp:
-  // scan_serial_reference); the tick's views do not carry that code (-1.7 % on the benchmark tick for a regime its QPs never
-  // enter) and may leave it by another door, with some entries of x still numbers.  So the tick reports what the reference
-  // reports and hands on what the reference hands on: one test per tick, outside the solver (round 5; tools/soak_parity.py with
-  // SOAK_VSCALE=3 runs half a million such ticks against the oracle).
-  {
+  // A solve whose iterate became NaN: the reference does not notice (its running comparisons never skip a NaN), adds and drops until
+  // maxit = 40 (m + n) and returns ifail = 1 with an all-NaN x, which the tick then integrates -- the gait is lost.  The views'
+  // policies follow it there decision by decision (kNanExact, wg_ql_device.hpp: scan_nan_exact); nothing is patched up here.
+#if !WG_TICK_NAN_EXACT
+  {   // experiment builds only: the views without those forms, one test per tick instead (what round 5 shipped at first; -1.6 % less)
     bool has_nan = false;
     for (int i = lane; i < n; i += 64) { const double xi = q.x[i]; has_nan = has_nan || (xi != xi); }
     if (__ballot(has_nan) != 0ull) {
@@ -1016,6 +1013,7 @@ __device__ __forceinline__ TickDiag mpc_tick(const wg_model_t &m, const TickTabl
       WG_WSYNC();
     }
   }
+#endif
 
   // ---- CoM: jerk, 20 interpolated samples, state step (ZMPVelocityReferencedQP.cpp:405-428) ----
   double jx, jy;

@@ -325,7 +325,7 @@ int wgo_ql_solve(int m, int me, int mmax, int n, int nmax,
     else if (binner[k] == 0.0) { /* keep 0 */ }
     else {
       info = -(k + 1);
-      if (k + 1 <= me || binner[k] > 0.0) { done_info_set = 1; break; }
+      if (k + 1 <= me || !(binner[k] <= 0.0)) { done_info_set = 1; break; }   /* :789 `if (b <= 0) ok else fail`: a NaN fails */
     }
     q->wa[k] = sum;
   }
@@ -344,7 +344,7 @@ int wgo_ql_solve(int m, int me, int mmax, int n, int nmax,
     }
   }
   {
-    int need_shift = q->diag > 0.0;
+    int need_shift = !(q->diag <= 0.0);                       /* :844 `if (diag <= 0) goto L90`: a NaN shifts */
     for (;;) {
       if (need_shift) {
         q->diag = diagr * q->diag;
@@ -436,7 +436,8 @@ int wgo_ql_solve(int m, int me, int mmax, int n, int nmax,
       /* delete the first inequality with a negative multiplier, :1233-1249 */
       int kd = -1;
       for (int k = 0; k < q->nact; ++k)
-        if (q->lam[k] < 0.0 && iact[k] > me) { kd = k; break; }
+        /* :1237 `if (w[kdrop] >= zero) goto next`: a NaN multiplier IS dropped */
+        if (!(q->lam[k] >= 0.0) && iact[k] > me) { kd = k; break; }
       if (kd >= 0) { drop_constraint(q, kd, q->nact); st = ST_RESID; continue; }
       st = ST_SCAN;
     }

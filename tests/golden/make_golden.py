@@ -9,7 +9,8 @@
         x, u, ifail and the final set are taken from the UNPATCHED oracle/_ref build and must agree with the patched one)
         - 24 QPs per family of tests/qpgen.py (branch coverage of ql0002),
         - eight QPs on which the reference's iterate becomes NaN (found in round 5: 7 of 6000 random Herdt-shaped problems, one of
-          the `infeasible` family): it runs to maxit, ifail = 1, a NaN solution, histories of 8 877 / 2 237 events, and
+          the `infeasible` family): it runs to maxit, ifail = 1, a NaN solution, histories of 8 877 / 2 237 events,
+        - one QP of an overdriven gait (overdriven_tick_qp below: magnitudes to 1e240 and a rotation with a denormal operand), and
         - the 225 QPs the Herdt oracle assembles while replaying the EmergencyStop scenario.
   preview_control_parameters.npz : the reference's precomputed Kajita gains
         /root/reference/src/data/PreviewControlParameters.ini  (Zc, T, preview time, Kx[3], Ks, F[320]), as data.
@@ -64,6 +65,37 @@ def kajita_datrefs():
     np.savez_compressed(os.path.join(HERE, "kajita_zmpdisc_datref.npz"), **out)
 
 
+def overdriven_tick_qp(gait=18, tick_wanted=87, B=32, scale=3.0):
+    """The QP of tick 87 of gait 18 of tests/test_tick_gpu.py's overdriven scenario (the benchmark's recipe with three times its
+    velocity references; portable-trig oracle): a state near 1e143, b up to 1e160, an iterate that passes 1e230 -- and, after
+    ~600 iterations of the same two bounds going in and out, an entry of Z that has become DENORMAL: the Givens rotation that
+    meets it has gb = q / norm = 0 by underflow and ga = -1, which the reference carries out (two columns change sign)."""
+    import ctypes as C
+    ol.build_oracle()
+    pt = C.CDLL(os.path.join(ol.ORACLE_DIR, "libwg_oracle_ptrig.so"))
+    model = hr.default_model()
+    rng = np.random.default_rng(333)
+    s = hr.init_state(model, [0.0316055, 0.0, 0.7116911], [0.0, 0.09, 0.0], [0.0, -0.09, 0.0])
+    s.nb_steps_left = 2
+    for tick in range(tick_wanted + 1):
+        if tick % 50 == 0:
+            for g in range(B):
+                v = [scale * rng.uniform(-0.1, 0.3), scale * rng.uniform(-0.1, 0.1), scale * rng.uniform(-0.2, 0.2)]
+                if g == gait:
+                    s.vref[0], s.vref[1], s.vref[2] = v
+        c = s.clock
+        for _ in range(1 if tick == 0 else (19 if tick == 1 else 20)):
+            c += model.Tctrl
+        s.clock = c
+        out, dump = hr.TickOut(), hr.QpDump()
+        assert pt.wgo_mpc_tick(C.byref(model), C.byref(s), C.byref(out), C.byref(dump)) == 0
+    n, m, mmax = dump.n, dump.m, dump.mmax
+    assert (out.ifail, out.n_iter) == (1, 40 * (m + n) + 1)
+    return dict(n=n, m=m, me=0, mmax=mmax, nmax=n, C=np.array(dump.C[:n * n]).reshape((n, n), order="F"), d=np.array(dump.d[:n]),
+                A=np.array(dump.A[:mmax * n]).reshape((mmax, n), order="F"), b=np.array(dump.b[:mmax]),
+                xl=np.full(n, -1e8), xu=np.full(n, 1e8))
+
+
 def main():
     preview_ini()
     kajita_datrefs()
@@ -92,6 +124,7 @@ def main():
     for sd in (72, 1732, 3422, 3928, 4265, 5716, 5797):
         add("nonfinite_herdt_like", qpgen.herdt_like(np.random.default_rng(61000 + sd), 16, 2))
     add("nonfinite_infeasible", qpgen.FAMILIES["infeasible"](np.random.default_rng(5282)))
+    add("overdriven_tick_denormal_rotation", overdriven_tick_qp())
 
     model, state, events = hr.emergency_stop_setup(datref)
 

@@ -31,13 +31,13 @@ def test_oracle_matches_reference_golden_vectors_bit_for_bit():
     for tag, q, ref in _golden():
         o = ol.oracle_ql(q)
         assert o["ifail"] == ref["ifail"], tag
-        assert ol.same_bits(o["x"], ref["x"]), tag
+        assert ol.same_bits_nan_aware(o["x"], ref["x"]), tag          # a NaN is a NaN: sign and payload are no contract
         if ref["ifail"] == 0:
             assert ol.same_bits(o["u"], ref["u"]), tag
             assert np.array_equal(o["iact"], ref["iact"]), tag
         fails.add(ref["ifail"] if ref["ifail"] < 3 else 11)
         n_checked += 1
-    assert n_checked >= 449
+    assert n_checked >= 450
     assert {0, 1, 2, 11} <= fails  # success, "maxit" (the iterate went NaN), "accuracy insufficient" and "inconsistent" exits all covered
 
 

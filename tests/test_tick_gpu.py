@@ -181,3 +181,59 @@ def test_pushed_gaits_including_infeasible_qps_bit_exact():
         max_act = max(max_act, int(diag[:, 2].max()))
     assert sizes == {32, 34, 36} and max_act >= 28
     assert any(f > 10 for f in seen_fail) and 0 in seen_fail
+
+
+@pytest.mark.parametrize("N,B,T,scale", [(16, 32, 150, 3.0), (32, 6, 160, 8.0)])
+def test_overdriven_gaits_through_failed_and_nan_solves_end_in_the_oracles_states(N, B, T, scale):
+    """The benchmark's recipe with three times its velocity references (0.9 m/s asked of a 0.7 m robot; eight times at N = 32,
+    whose longer preview copes with three): QPs that QL declares inconsistent, states that grow past 1e140, then solves whose
+    iterate becomes NaN -- the reference runs those to maxit = 40 (m + n) and returns ifail = 1 and an all-NaN x, which the tick
+    integrates: the gait is lost.  The tick's views follow the reference through all of it decision by decision.
+    Every tick: ifail and the iteration count equal the oracle's, the state equals the oracle's (a NaN matches a NaN whatever its
+    sign bit).  (Round 5: this test found a Givens rotation with a DENORMAL second operand -- gb = q / norm underflows to 0,
+    ga = -1 -- that sweep_flat took for a skipped one.)"""
+    wg = _wg()
+    pt = _ptrig()
+    model = wg.model_defaults()
+    model.N = N
+    wg.mpc_configure(model)                                      # (N = 16: the first maxit exit of this seed comes at tick 87)
+    rng = np.random.default_rng(333)
+    states = (wg.GaitState * B)()
+    for g in range(B):
+        s = wg.gait_init(model, [0.0316055, 0.0, 0.7116911], [0.0, 0.09, 0.0], [0.0, -0.09, 0.0])
+        s.nb_steps_left = 2
+        C.memmove(C.byref(states[g]), C.byref(s), C.sizeof(wg.GaitState))
+    ref_states = (wg.GaitState * B)()
+    C.memmove(ref_states, states, C.sizeof(states))
+    sz = C.sizeof(wg.GaitState)
+
+    def same(a, b):
+        if a == b:
+            return True
+        wa, wb = np.frombuffer(a, dtype=np.uint64), np.frombuffer(b, dtype=np.uint64)
+        d = wa != wb
+        nan = lambda w: ((w >> np.uint64(52)) & np.uint64(0x7ff)) == np.uint64(0x7ff)   # noqa: E731
+        return bool((nan(wa[d]) & nan(wb[d])).all())
+    seen = set(); n_maxit = 0
+    for tick in range(T):
+        if tick % 50 == 0:
+            for g in range(B):
+                v = [scale * rng.uniform(-0.1, 0.3), scale * rng.uniform(-0.1, 0.1), scale * rng.uniform(-0.2, 0.2)]
+                for st in (states[g], ref_states[g]):
+                    st.vref[0], st.vref[1], st.vref[2] = v
+        adv = 1 if tick == 0 else (19 if tick == 1 else 20)
+        _, diag, _, _ = wg.mpc_tick_batch(states, want_out=False, advance_calls=adv)
+        got = _bytes(states)
+        for g in range(B):
+            c = ref_states[g].clock
+            for _ in range(adv):
+                c += model.Tctrl
+            ref_states[g].clock = c
+            o = hr.TickOut()
+            assert pt.wgo_mpc_tick(C.byref(model), C.byref(ref_states[g]), C.byref(o), None) == 0
+            assert (o.ifail, o.n_iter) == (int(diag[g, 0]), int(diag[g, 1])), (tick, g, o.ifail, o.n_iter, diag[g])
+            assert same(bytes(ref_states[g]), got[g * sz:(g + 1) * sz]), (tick, g)
+            seen.add(int(o.ifail)); n_maxit += o.ifail == 1
+    wg.mpc_configure(wg.model_defaults())
+    assert 0 in seen and 1 in seen and any(f > 10 for f in seen), seen        # walking, the NaN regime and inconsistent QPs all occurred
+    assert n_maxit >= 20
