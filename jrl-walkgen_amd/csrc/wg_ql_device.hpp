@@ -1474,41 +1474,47 @@ __device__ __forceinline__ void scan_nan_exact(const QlView &q, const P &prob, d
     }
     return o;
   };
+  // the lane's j-th position, ascending in j: lane + 64 j -- or, in the compact view (whose rows' coefficients live in their
+  // lanes' registers), CoP row lane + 1, foot-placement row 1 + 4N + lane, bound lane (row 0, all zeros, is never a
+  // candidate).  -1: the lane has no j-th position
+  auto position = [&](int j) -> int {
+    if constexpr (P::kCompact) {
+      if (j == 0) return (lane + 1 <= P::kCopRows && lane + 1 < m) ? lane + 1 : -1;
+      if (j == 1) return (1 + P::kCopRows + lane < m) ? 1 + P::kCopRows + lane : -1;
+      return lane < n ? m + lane : -1;
+    } else {
+      const int pos = lane + 64 * j;
+      return pos < m + n ? pos : -1;
+    }
+  };
+  const int slots = P::kCompact ? 3 : (m + n + 63) / 64;
   // pass 1: the all-numbers answer (running strict maximum above 0 = cvmax's start), and the lane's last NaN candidate
   double av = 0.0, ar = 0.0, aw = 0.0;
   int apos = -1, acode = 0;
   double nr = 0.0, nw = 0.0;
   int npos = -1, ncode = 0;
-  // the lane's positions in ascending order: pos, pos + 64, ... -- or, in the compact view (whose rows' coefficients live in
-  // their lanes' registers), CoP row lane + 1, foot-placement row 1 + 4N + lane, bound lane (row 0, all zeros, is never a candidate)
-  auto my_positions = [&](auto &&f) {
-    if constexpr (P::kCompact) {
-      if (lane + 1 <= P::kCopRows && lane + 1 < m) f(lane + 1);
-      if (1 + P::kCopRows + lane < m) f(1 + P::kCopRows + lane);
-      if (lane < n) f(m + lane);
-    } else {
-      for (int pos = lane; pos < m + n; pos += 64) f(pos);
-    }
-  };
-  my_positions([&](int pos) {
+  for (int j = 0; j < slots; ++j) {
+    const int pos = position(j);
+    if (pos < 0) continue;
     const Row o = eval(pos);
-    if (!o.cand) return;
+    if (!o.cand) continue;
     if (o.v != o.v) { npos = pos; nr = o.r; nw = o.w; ncode = o.code; }
     else if (o.v > av) { av = o.v; ar = o.r; aw = o.w; apos = pos; acode = o.code; }
-  });
+  }
   const int lastnan = uni(wave_max_int(npos));
   int src;
   if (lastnan >= 0) {
     // pass 2: the candidates behind the last NaN (numbers all of them): first maximum, the first one taken unconditionally
     bool any = false;
     av = 0.0; apos = -1;
-    my_positions([&](int pos) {
-      if (pos <= lastnan) return;
+    for (int j = 0; j < slots; ++j) {
+      const int pos = position(j);
+      if (pos <= lastnan) continue;                          // (covers pos == -1)
       const Row o = eval(pos);
-      if (!o.cand) return;
+      if (!o.cand) continue;
       if (!any || o.v > av) { av = o.v; ar = o.r; aw = o.w; apos = pos; acode = o.code; }
       any = true;
-    });
+    }
     if (__ballot(any) == 0ull) {                             // none follows: the NaN candidate itself, cvmax = NaN
       src = __ffsll((long long)__ballot(npos == lastnan)) - 1;
       cvmax = __builtin_nan(""); res = rl(nr, src); wsel = rl(nw, src); knext = __builtin_amdgcn_readlane(ncode, src);

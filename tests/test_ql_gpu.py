@@ -160,9 +160,8 @@ def test_non_finite_iterates_end_the_way_the_reference_ends_them():
     """QPs on which ql0002's iterate becomes NaN (7 of 6000 random Herdt-shaped problems, one of the `infeasible` family: found in
     round 5).  The reference does not notice: its running comparisons never skip a NaN, it adds and drops until maxit = 40 (m + n)
     and returns ifail = 1 with a NaN solution; the oracle follows it bit for bit.  A wave arg-max does not pick what those serial
-    comparisons pick once NaNs compete -- the solver used to "converge" there with ifail = 0 -- so it takes the reference's own
-    serial loops for the two selections when the iterate is not a number (wg_ql_device.hpp: scan_serial_reference,
-    pick_drop_serial_reference).  Held here: ifail, the NaN solution's bits, the iteration count and the whole add / drop history
+    comparisons pick once NaNs compete -- the solver used to "converge" there with ifail = 0 -- so it takes NaN-exact forms of
+    the two selections when the iterate is not a number (wg_ql_device.hpp: scan_nan_exact, pick_drop_serial_reference).  Held here: ifail, the NaN solution's bits, the iteration count and the whole add / drop history
     (8 877 events) against the oracle, alone and inside a batch of ordinary QPs, through the fixed-size and the generic kernel."""
     wg = _wg()
     bad = [qpgen.herdt_like(np.random.default_rng(61000 + s), 16, 2) for s in (72, 1732, 3422, 3928, 4265, 5716, 5797)]

@@ -31,9 +31,8 @@ if VSCALE != 1.0:
 
 def same_state(a, b):
     """0: bytes equal, or different only in words that are NaNs on both sides (a NaN's sign / payload bits differ between x86 and
-    gfx950); 1: the gait is LOST on both sides -- both states hold numbers of magnitude >= 2^332 (8.7e99), infinities or NaNs: a
-    centre of mass 1e100 m away integrates garbage, sums overflow to inf - inf, and what the two sides make of that is outside any
-    contract (the reference ends such solves at maxit, the tick's views may end them elsewhere: DESIGN 3.3); 2: a real difference"""
+    gfx950); 2: a real difference.  (Until the tick's views followed the reference through non-finite iterates -- DESIGN 3.3 --
+    there was a class 1 here, "lost on both sides", for states beyond 1e100; every gait is compared to the end now.)"""
     if a == b:
         return 0
     wa, wb = np.frombuffer(a, dtype=np.uint64), np.frombuffer(b, dtype=np.uint64)
@@ -41,8 +40,7 @@ def same_state(a, b):
     d = wa != wb
     if bool(((expo(wa[d]) == 0x7ff) & (expo(wb[d]) == 0x7ff)).all()):
         return 0
-    lost = lambda w: bool((expo(w) >= 0x54b).any())                                  # noqa: E731
-    return 1 if lost(wa) and lost(wb) else 2
+    return 2
 
 
 def cpu_chunk(args):
@@ -105,13 +103,14 @@ def soak(N, B, n_ticks, workers):
             if r == 2:
                 bad += 1
                 which.append(g0 + g)
-            lost += r == 1
+            w = np.frombuffer(blob[g * sz:(g + 1) * sz], dtype=np.uint64)
+            lost += bool((((w >> np.uint64(52)) & np.uint64(0x7ff)) == np.uint64(0x7ff)).any())
     if which:
         print("   differing gaits: %s%s" % (sorted(which)[:24], " ..." if len(which) > 24 else ""), flush=True)
     print("N = %d%s: %d gaits x %d ticks = %d MPC ticks; gaits whose final state differs from the CPU checker's: %d%s; "
           "failed QPs %d; QL iterations mean %.1f max %d; n in %s; GPU %.2f s (launch plan %s), CPU checker %.1f s on %d processes"
           % (N, "" if VSCALE == 1.0 else " (references x %g)" % VSCALE, B, n_ticks, B * n_ticks, bad,
-             "" if not lost else " (+ %d lost on both sides: states beyond 1e100, compared no further)" % lost, int((d[..., 0] != 0).sum()), float(d[..., 1].mean()), int(d[..., 1].max()),
+             "" if not lost else " (%d gaits end with NaNs in their state, on both sides)" % lost, int((d[..., 0] != 0).sum()), float(d[..., 1].mean()), int(d[..., 1].max()),
              sorted(set(int(v) for v in np.unique(d[..., 3]))), t_gpu, bench.launch_plan(0, n_ticks), t_cpu, min(workers, len(jobs))), flush=True)
     return bad
 
