@@ -1,6 +1,6 @@
 """Parity fuzz of the QL solver (evidence, not a test): many more seeds than tests/test_ql_gpu.py runs, every family of
 tests/qpgen.py plus magnitude-scaled variants of them (the whole problem scaled by 2^k, the constraints alone, the Hessian
-alone) and config-5-sized problems, through wg_qp_solve_batch (the C ABI) against the CPU oracle -- ifail, iteration count,
+alone; to the edges of the double range in the edge_* families) and config-5-sized problems, through wg_qp_solve_batch (the C ABI) against the CPU oracle -- ifail, iteration count,
 final active set, the complete add / drop history, x bit for bit (NaN where the oracle has NaN), u where the solve succeeded.
 The oracle runs on the host cores beside the product path here, as in tests/: nothing of it is measured or shipped.
 
@@ -41,6 +41,10 @@ def variants():
     out["scaled_down"] = lambda rng: scaled(qpgen.FAMILIES["dependent"](rng), -int(rng.integers(20, 200)), int(rng.integers(-100, 100)))
     out["herdt_scaled"] = lambda rng: scaled(qpgen.herdt_like(rng, 16, int(rng.integers(0, 3))), int(rng.integers(-60, 60)), int(rng.integers(-60, 60)))
     out["config5_sized"] = lambda rng: qpgen.herdt_like(rng, 32, int(rng.integers(0, 5)))
+    # the edges of the double range: overflow, underflow and denormals inside the solver
+    out["edge_up"] = lambda rng: scaled(qpgen.herdt_like(rng, 16, int(rng.integers(0, 3))), int(rng.integers(200, 480)), int(rng.integers(-480, 480)))
+    out["edge_down"] = lambda rng: scaled(qpgen.herdt_like(rng, 16, int(rng.integers(0, 3))), -int(rng.integers(200, 480)), int(rng.integers(-480, 480)))
+    out["edge_random"] = lambda rng: scaled(qpgen.FAMILIES["dependent"](rng), int(rng.integers(-480, 480)), int(rng.integers(-480, 480)))
     return out
 
 

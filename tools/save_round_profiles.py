@@ -189,6 +189,9 @@ from (`tools/csrc_hash.py`); `tests/test_docs_numbers.py` fails when that is not
 | `{tag}_launch_fit.txt` | `python3 tools/probe_launch_fit.py` (N = 16, B = 4096; then N = 32, B = 8192) | duration of a multi-tick launch against its length, least squares: the steady rate and what every launch pays once (ramp and the idle tail in which the last gait-ticks finish) -- the difference between the 200-step figure and the driver's 20-step window |
 | `{tag}_soak_parity.txt` | `python tools/soak_parity.py` | every gait of the benchmark workload (4096 x 250 ticks at N = 16, 8192 x 50 at N = 32) advanced as `bench.py` does it, final states byte for byte against the CPU checker on the host cores |
 | `{tag}_soak_parity_long.txt` | `SOAK_LONG=1 python tools/soak_parity.py` | the same at four times the length (4096 x 1000 ticks at N = 16) and through the element view at N = 20, 24, 28, 32: 5.0 M MPC ticks byte for byte |
+| `{tag}_soak_vscale.txt` | `SOAK_VSCALE=3 python tools/soak_parity.py` | the same workload with its velocity references times three: failed QPs, states beyond 1e140, NaN iterates -- every gait against the oracle to its last tick (DESIGN 3.3) |
+| `{tag}_fuzz_ql.txt` | `python tools/fuzz_ql.py 20000` | the dense boundary against the oracle: 322 000 QPs of seventeen families, ifail / iterations / history / x bit for bit |
+| `{tag}_fuzz_oracle_vs_reference.txt` | `python tools/fuzz_oracle_vs_reference.py 20000` (development container, no GPU) | the oracle's QL restatement against the COMPILED reference qld.cpp on the same 322 000 QPs, histories included |
 | `current_tick_pmc.json` | derived from `{tag}_tick_*`, `{tag}_tickg_*`, `{tag}_pertick_*` | per gait-tick: HBM bytes read / written (FETCH_SIZE x 2 and WRITE_SIZE, KiB units, separate passes), VALU / SALU / LDS / VMEM instructions, VALU busy; `bench.py` scales `roofline.traffic` and its second axis from this file |
 
 {agree}
