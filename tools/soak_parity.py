@@ -86,11 +86,17 @@ def gpu_run(N, B, n_ticks):
 
 
 def soak(N, B, n_ticks, workers):
-    per = (B + workers - 1) // workers
+    per = max(1, (B + 6 * workers - 1) // (6 * workers))            # six chunks per worker: the heartbeat below has something to count
     jobs = [(N, g0, min(per, B - g0), n_ticks) for g0 in range(0, B, per)]
     t0 = time.perf_counter()
     with mp.get_context("spawn").Pool(min(workers, len(jobs))) as pool:
-        cpu = dict(pool.map(cpu_chunk, jobs))
+        cpu = {}
+        t_said = t0
+        for k, v in pool.imap_unordered(cpu_chunk, jobs):
+            cpu[k] = v
+            if time.perf_counter() - t_said > 60:                    # lost gaits run maxit iterations per tick: say that it is alive
+                t_said = time.perf_counter()
+                print("   ... CPU checker: %d of %d chunks" % (len(cpu), len(jobs)), flush=True)
     t_cpu = time.perf_counter() - t0
     got, t_gpu, d = gpu_run(N, B, n_ticks)
     sz = C.sizeof(wg.GaitState)
@@ -120,6 +126,10 @@ if __name__ == "__main__":
     workers = min(os.cpu_count() or 8, 64)
     # SOAK_LONG=1: four times the ticks at N = 16 and other horizons through the element view as well
     long_run = os.environ.get("SOAK_LONG") == "1"
+    if os.environ.get("SOAK_ONLY"):                              # "N:B:T[,N:B:T...]": these runs instead of the standard ones
+        bad = sum(soak(*(int(v) for v in spec.split(":")), workers) for spec in os.environ["SOAK_ONLY"].split(","))
+        print("soak parity: %s" % ("PASS (bit-identical)" if bad == 0 else "FAIL"))
+        sys.exit(1 if bad else 0)
     bad = soak(16, 4096, 1000 if long_run else 250, workers)
     bad += soak(32, 8192, 50, workers)
     if long_run:
