@@ -189,8 +189,8 @@ def test_overdriven_gaits_through_failed_and_nan_solves_end_in_the_oracles_state
     whose longer preview copes with three): QPs that QL declares inconsistent, states that grow past 1e140, then solves whose
     iterate becomes NaN -- the reference runs those to maxit = 40 (m + n) and returns ifail = 1 and an all-NaN x, which the tick
     integrates: the gait is lost.  The tick's views follow the reference through all of it decision by decision.
-    Every tick: ifail and the iteration count equal the oracle's, the state equals the oracle's (a NaN matches a NaN whatever its
-    sign bit).  (Round 5: this test found a Givens rotation with a DENORMAL second operand -- gb = q / norm underflows to 0,
+    Every tick: ifail and the iteration count equal the oracle's, the state and the tick's outputs (wg_tick_out_t: every sample
+    the reference pushes on its deques) equal the oracle's (a NaN matches a NaN whatever its sign bit).  (Round 5: this test found a Givens rotation with a DENORMAL second operand -- gb = q / norm underflows to 0,
     ga = -1 -- that sweep_flat took for a skipped one.)"""
     wg = _wg()
     pt = _ptrig()
@@ -222,8 +222,9 @@ def test_overdriven_gaits_through_failed_and_nan_solves_end_in_the_oracles_state
                 for st in (states[g], ref_states[g]):
                     st.vref[0], st.vref[1], st.vref[2] = v
         adv = 1 if tick == 0 else (19 if tick == 1 else 20)
-        _, diag, _, _ = wg.mpc_tick_batch(states, want_out=False, advance_calls=adv)
+        outs, diag, _, _ = wg.mpc_tick_batch(states, want_out=True, advance_calls=adv)
         got = _bytes(states)
+        got_outs = _bytes(outs); osz = C.sizeof(wg.TickOut)
         for g in range(B):
             c = ref_states[g].clock
             for _ in range(adv):
@@ -233,6 +234,7 @@ def test_overdriven_gaits_through_failed_and_nan_solves_end_in_the_oracles_state
             assert pt.wgo_mpc_tick(C.byref(model), C.byref(ref_states[g]), C.byref(o), None) == 0
             assert (o.ifail, o.n_iter) == (int(diag[g, 0]), int(diag[g, 1])), (tick, g, o.ifail, o.n_iter, diag[g])
             assert same(bytes(ref_states[g]), got[g * sz:(g + 1) * sz]), (tick, g)
+            assert same(bytes(o), got_outs[g * osz:(g + 1) * osz]), (tick, g, "outputs")
             seen.add(int(o.ifail)); n_maxit += o.ifail == 1
     wg.mpc_configure(wg.model_defaults())
     assert 0 in seen and 1 in seen and any(f > 10 for f in seen), seen        # walking, the NaN regime and inconsistent QPs all occurred
