@@ -2369,7 +2369,7 @@ __device__ __forceinline__ QlResult ql_solve(const QlView &q, P &prob, double vs
       // the critical path is an exposed round trip per iteration (the same value: nothing writes wa between the scan and the add)
       double bestv = 0.0, bestres = 0.0, bestw = 0.0;
       int bidx = -1;
-      if (kNan && x_suspect) {                              // the iterate holds a NaN / an infinity: the reference's own serial loop decides
+      if (kNan && x_suspect) {                              // the iterate may hold a NaN / an infinity: the NaN-exact form decides
         if constexpr (kNan) {
           double cv = 0.0;
           int kn = knext;
