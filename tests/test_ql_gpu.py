@@ -196,7 +196,7 @@ def test_non_finite_iterates_end_the_way_the_reference_ends_them():
 
 def test_fuzz_families_scaled_and_config5_sized():
     """A slice of tools/fuzz_ql.py inside the suite: every family, the magnitude-scaled variants (Hessian and constraints scaled by
-    2^k, |k| up to 200) and config-5-sized problems on seeds no other test uses -- ifail, iterations, history, x (NaN-aware), u.
+    2^k, |k| up to 480: the edges of the double range) and config-5-sized problems on seeds no other test uses -- ifail, iterations, history, x (NaN-aware), u.
     The full run (322 000 QPs of seventeen families, 0 mismatches) is filed as profiles/round5_fuzz_ql.txt."""
     import importlib.util
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
