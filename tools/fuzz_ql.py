@@ -65,6 +65,8 @@ def oracle_chunk(args):
                     o["u"].copy()))
     return name, res
 
+SEED0 = int(os.environ.get("FUZZ_SEED0", "910000"))          # another base = another set of problems
+
 
 def main():
     per_family = int(sys.argv[1]) if len(sys.argv) > 1 else 2000
@@ -72,14 +74,14 @@ def main():
     wg.init(0)
     cores = max(1, min(len(os.sched_getaffinity(0)), 16))
     V = variants()
-    print("# QL parity fuzz: %d seeds per family, %d families, oracle on %d host cores" % (per_family, len(V), cores))
+    print("# QL parity fuzz: %d seeds per family from %d, %d families, oracle on %d host cores" % (per_family, SEED0, len(V), cores))
     total = bad_total = 0
     t_all = time.time()
     with mp.get_context("fork").Pool(cores) as pool:
         for name, gen in V.items():
             t0 = time.time()
             n_seeds = per_family if name != "config5_sized" else max(50, per_family // 10)
-            all_seeds = [910000 + 7919 * k for k in range(n_seeds)]
+            all_seeds = [SEED0 + 7919 * k for k in range(n_seeds)]
             bad = []
             fails = {}
             nan_x = longest = 0
